@@ -1,0 +1,207 @@
+"""
+TEST INFRASTRUCTURE ONLY -- generator of tests/golden/*.npz.
+
+Runs the UNTOUCHED reference (/root/reference, python renderer + sampler) on CPU under
+oracle/ref_shim.py on seeded synthetic inputs and stores inputs' seeds + the reference's outputs.
+/root/reference only exists in the authoring container; the fixtures travel, this script is the
+committed provenance.  Usage:   python oracle/make_golden.py [geom] [sampler] [render] [pipeline]
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "3dgs-to-pc_amd"))
+
+from ref_shim import CudaToCpu, load_reference, inject_standard_normal  # noqa: E402
+from np_philox import keyed_normals                                      # noqa: E402
+from g2pc.synth import make_scene, make_cameras                          # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+os.makedirs(GOLD, exist_ok=True)
+torch.set_num_threads(8)
+
+
+def _np(t):
+    return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+class KeyedNoise:
+    """Feeds eps(seed, gid, attempt, k) to the reference's MultivariateNormal draws.
+
+    gid = row of the Gaussian in the array handed to generate_pointcloud; recovered from the
+    active means the reference passes to sample_from_multivariate_normal (gauss_to_pc.py:204)."""
+
+    def __init__(self, g2p, xyz, seed):
+        self.g2p, self.seed = g2p, seed
+        self.lut = {row.tobytes(): i for i, row in enumerate(_np(xyz).astype(np.float32))}
+        assert len(self.lut) == xyz.shape[0], "duplicate means: keyed lookup ambiguous"
+        self.attempt = 0
+        self.gids = None
+        self.orig_create = g2p.create_new_gaussian_points
+        self.orig_sample = g2p.sample_from_multivariate_normal
+
+    def provider(self, shape):
+        n, ga, three = shape
+        assert three == 3 and ga == len(self.gids)
+        eps = keyed_normals(self.seed, self.gids[None, :], self.attempt, np.arange(n)[:, None])
+        return torch.from_numpy(eps)
+
+    def __enter__(self):
+        def create(*a, **k):
+            self.attempt = 0
+            return self.orig_create(*a, **k)
+
+        def sample(means, covs, n, *a, **k):
+            self.gids = np.array([self.lut[r.tobytes()] for r in _np(means).astype(np.float32)],
+                                 dtype=np.int64)
+            out = self.orig_sample(means, covs, n, *a, **k)
+            self.attempt += 1
+            return out
+
+        self.g2p.create_new_gaussian_points = create
+        self.g2p.sample_from_multivariate_normal = sample
+        self.ctx = inject_standard_normal(self.provider)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        self.ctx.__exit__(*exc)
+        self.g2p.create_new_gaussian_points = self.orig_create
+        self.g2p.sample_from_multivariate_normal = self.orig_sample
+
+
+def gen_geom(ref):
+    """Gaussians.__init__ / calculate_normals / validate_covariances / get_gaussian_magnitudes /
+    distribute_points / calculate_bin_sizes on N=4096 (+ a non-PSD and a degenerate case)."""
+    gh, g2p = ref["gauss_handler"], ref["gauss_to_pc"]
+    n, seed = 4096, 1234 + 11
+    sc = make_scene(n, seed)
+    with CudaToCpu():
+        G = gh.Gaussians(sc.xyz.clone(), sc.scales.clone(), sc.rots.clone(), sc.colours.clone(),
+                         sc.opacities.clone())
+        cov0 = G.covariances.clone()
+        G.calculate_normals()
+        nrm = G.normals.clone()
+        mags_op = G.get_gaussian_magnitudes().clone()
+        # make a handful of covariances indefinite / tiny to exercise clamp + cull
+        bad = G.covariances.clone()
+        bad[5] = torch.tensor([[1e-4, 2e-4, 0], [2e-4, 1e-4, 0], [0, 0, 1e-4]])      # indefinite
+        bad[9] = torch.zeros(3, 3)                                                   # zero matrix
+        bad[17] = torch.diag(torch.tensor([1e-4, 1e-4, -3e-6]))                       # negative eig
+        G.covariances = bad.clone()
+        keep = G.validate_covariances().clone()
+        cov_valid = G.covariances.clone()           # filtered (culled rows removed)
+        ppg = g2p.distribute_points(mags_op, 100000).clone()
+        ppg_over = g2p.distribute_points(torch.tensor([1.5] * 4 + [0.01] * 6, dtype=torch.float64), 7)
+        sb, bs = g2p.calculate_bin_sizes(ppg.type(torch.int))
+    np.savez_compressed(os.path.join(GOLD, "geom_n4096.npz"), n=n, seed=seed,
+                        cov=_np(cov0), normals=_np(nrm), mags_opacity=_np(mags_op),
+                        bad_rows=np.array([5, 9, 17]), bad_cov=_np(bad[[5, 9, 17]]),
+                        keep=_np(keep), cov_valid=_np(cov_valid),
+                        ppg_100k=_np(ppg), ppg_overshoot=_np(ppg_over),
+                        start_bin=sb, bin_size=bs)
+    print("geom: cull", int((~keep).sum()), "bins", sb, bs, "sum ppg", float(ppg.sum()))
+
+
+def gen_sampler(ref):
+    """generate_pointcloud with keyed noise, N=3000, non-exact (5 attempts) and exact (100)."""
+    gh, g2p = ref["gauss_handler"], ref["gauss_to_pc"]
+    n, seed, noise_seed = 3000, 1234 + 12, 777
+    for tag, exact, num_points in (("binned", False, 40000), ("exact", True, 12000)):
+        sc = make_scene(n, seed)
+        with CudaToCpu():
+            G = gh.Gaussians(sc.xyz.clone(), sc.scales.clone(), sc.rots.clone(),
+                             (sc.colours * 255).double(), sc.opacities.clone())
+            G.calculate_normals()
+            keep = G.validate_covariances()
+            assert bool(keep.all())
+            with KeyedNoise(g2p, G.xyz, noise_seed):
+                pts, cols, nrms = g2p.generate_pointcloud(
+                    G, num_points, exact_num_points=exact, mahalanobis_distance_std=2.0,
+                    calculate_normals=True, num_sample_attempts=100 if exact else 5,
+                    contributions=None, device="cpu", quiet=True)
+            mags = G.get_gaussian_magnitudes()
+            ppg = g2p.distribute_points(mags, num_points).type(torch.int)
+        np.savez_compressed(os.path.join(GOLD, "sampler_%s_n3000.npz" % tag), n=n, seed=seed,
+                            noise_seed=noise_seed, num_points=num_points, exact=exact,
+                            points=_np(pts), colours=_np(cols).astype(np.float32),
+                            normals=_np(nrms).astype(np.float32), ppg=_np(ppg),
+                            cov_valid=_np(G.covariances))
+        print("sampler", tag, "emitted", pts.shape[0], "of", num_points, pts.dtype, cols.dtype)
+
+
+def gen_render(ref):
+    """GaussPythonRenderer on N=6000, three 320x180 cameras (tile pin 60000/60)."""
+    gh, gr, ch = ref["gauss_handler"], ref["gauss_render"], ref["camera_handler"]
+    n, seed, ncam = 6000, 1234 + 13, 3
+    sc = make_scene(n, seed, scale_lo=0.004, scale_hi=0.04)
+    transforms, intr = make_cameras(ncam, width=320, height=180, focal=275.0)
+    with CudaToCpu():
+        G = gh.Gaussians(sc.xyz.clone(), sc.scales.clone(), sc.rots.clone(), sc.colours.clone(),
+                         sc.opacities.clone())
+        R = gr.get_renderer("python", G.xyz, torch.unsqueeze(torch.clone(G.opacities), 1),
+                            G.colours, G.covariances, visible_gaussian_threshold=0.05)
+        imgs, contribs = [], []
+        for name in transforms:
+            cam = ch.get_camera("python", torch.tensor(transforms[name]), intr[name],
+                                colour_resolution=None)
+            img, _, _, _ = R(cam)
+            imgs.append(_np(img).astype(np.float32))
+            contribs.append(_np(R.gaussian_max_contribution).copy())
+        out = dict(n=n, seed=seed, ncam=ncam, width=320, height=180, focal=275.0,
+                   scale_lo=0.004, scale_hi=0.04,
+                   images=np.stack(imgs), contrib_after_cam=np.stack(contribs),
+                   colours=_np(R.get_gaussian_colours()), visible=_np(R.get_visible_gaussians()),
+                   total=_np(R.get_total_gaussian_contributions()))
+    np.savez_compressed(os.path.join(GOLD, "render_py_n6000.npz"), **out)
+    print("render: visible", int(out["visible"].sum()), "of", n)
+
+
+def gen_pipeline(ref):
+    """Config-1 shaped end-to-end run (10k Gaussians, 1 camera 360x202, 100k points, python
+    renderer, keyed noise): the culling indices / ppg / points the drop-in must reproduce."""
+    gh, gr, ch, g2p = (ref[k] for k in ("gauss_handler", "gauss_render", "camera_handler", "gauss_to_pc"))
+    n, seed, noise_seed, num_points = 10000, 1234 + 1, 4242, 100000
+    sc = make_scene(n, seed, scale_lo=0.004, scale_hi=0.04)
+    transforms, intr = make_cameras(1, width=1280, height=720, focal=1100.0)
+    with CudaToCpu():
+        G = gh.Gaussians(sc.xyz.clone(), sc.scales.clone(), sc.rots.clone(), sc.colours.clone(),
+                         sc.opacities.clone())
+        G.calculate_normals()
+        R = gr.get_renderer("python", G.xyz, torch.unsqueeze(torch.clone(G.opacities), 1),
+                            G.colours, G.covariances, visible_gaussian_threshold=0.05)
+        for name in transforms:
+            cam = ch.get_camera("python", torch.tensor(transforms[name]), intr[name],
+                                colour_resolution=360)
+            R(cam)
+        G.colours = R.get_gaussian_colours()
+        G.add_gaussians_to_cull(R.get_visible_gaussians())
+        G.apply_min_opacity(0.0)
+        G.apply_bounding_box(None, None)
+        culled = G.filter_gaussians()
+        contrib = R.get_total_gaussian_contributions()[culled]
+        keep = G.validate_covariances()
+        contrib = contrib[keep]
+        with KeyedNoise(g2p, G.xyz, noise_seed):
+            pts, cols, nrms = g2p.generate_pointcloud(
+                G, num_points, exact_num_points=False, mahalanobis_distance_std=2.0,
+                calculate_normals=True, num_sample_attempts=5, contributions=contrib,
+                device="cpu", quiet=True)
+    np.savez_compressed(os.path.join(GOLD, "pipeline_cfg1.npz"), n=n, seed=seed,
+                        noise_seed=noise_seed, num_points=num_points,
+                        culled=_np(culled), keep=_np(keep), contrib=_np(contrib),
+                        points=_np(pts), colours=_np(cols).astype(np.float32),
+                        normals=_np(nrms).astype(np.float32))
+    print("pipeline: kept", int(culled.sum()), "points", pts.shape[0])
+
+
+if __name__ == "__main__":
+    ref = load_reference()
+    which = sys.argv[1:] or ["geom", "sampler", "render", "pipeline"]
+    for w in which:
+        {"geom": gen_geom, "sampler": gen_sampler, "render": gen_render, "pipeline": gen_pipeline}[w](ref)

@@ -1,0 +1,79 @@
+"""The oracle (oracle/ref_gauss.py) pinned against fixtures produced by the untouched reference
+(oracle/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import torch
+
+import ref_gauss as RG
+from np_philox import keyed_normals
+from g2pc.synth import make_scene
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_geometry_matches_reference(golden_dir):
+    g = _load(golden_dir, "geom_n4096.npz")
+    sc = make_scene(int(g["n"]), int(g["seed"]))
+    cov = RG.covariances(sc.scales, sc.rots)
+    assert np.array_equal(cov.numpy(), g["cov"])                       # bit-exact on CPU
+    assert np.array_equal(RG.normals(sc.scales, sc.rots).numpy(), g["normals"])
+    mags = RG.magnitudes(cov, sc.opacities)
+    assert np.array_equal(mags.numpy(), g["mags_opacity"])
+    bad = cov.clone()
+    bad[torch.from_numpy(g["bad_rows"])] = torch.from_numpy(g["bad_cov"])
+    valid, keep = RG.validate_covariances(bad)
+    assert np.array_equal(keep.numpy(), g["keep"])
+    np.testing.assert_allclose(valid[keep].numpy(), g["cov_valid"], rtol=0, atol=1e-12)
+
+
+def test_distribute_and_bins_match_reference(golden_dir):
+    g = _load(golden_dir, "geom_n4096.npz")
+    mags = torch.from_numpy(g["mags_opacity"])
+    ppg = RG.distribute_points(mags, 100000)
+    assert np.array_equal(ppg.numpy(), g["ppg_100k"])
+    over = RG.distribute_points(torch.tensor([1.5] * 4 + [0.01] * 6, dtype=torch.float64), 7)
+    assert np.array_equal(over.numpy(), g["ppg_overshoot"])            # negative-slice quirk
+    assert float(over.sum()) == 13.0
+    sb, bs = RG.calculate_bin_sizes(ppg.to(torch.int32))
+    assert (sb, bs) == (int(g["start_bin"]), int(g["bin_size"]))
+
+
+def _run_sampler(g):
+    sc = make_scene(int(g["n"]), int(g["seed"]))
+    cov, keep = RG.validate_covariances(RG.covariances(sc.scales, sc.rots))
+    assert bool(keep.all())
+    seed = int(g["noise_seed"])
+    exact = bool(g["exact"])
+    return RG.generate_pointcloud(
+        sc.xyz, cov, (sc.colours * 255), RG.normals(sc.scales, sc.rots), sc.opacities,
+        int(g["num_points"]), std=2.0, exact=exact, attempts=100 if exact else 5,
+        eps_fn=lambda gids, a, n: keyed_normals(seed, gids[:, None], a, np.arange(n)[None, :]))
+
+
+def test_sampler_binned_matches_reference(golden_dir):
+    g = _load(golden_dir, "sampler_binned_n3000.npz")
+    out = _run_sampler(g)
+    assert np.array_equal(out["ppg"].numpy(), g["ppg"])
+    assert out["points"].shape[0] == g["points"].shape[0]
+    assert np.array_equal(out["points"].numpy(), g["points"])          # same draws, same order
+    np.testing.assert_allclose(out["colours"].numpy(), g["colours"], atol=1e-4)
+    np.testing.assert_allclose(out["normals"].numpy(), g["normals"], atol=1e-6)
+
+
+def test_sampler_exact_matches_reference(golden_dir):
+    g = _load(golden_dir, "sampler_exact_n3000.npz")
+    out = _run_sampler(g)
+    assert np.array_equal(out["ppg"].numpy(), g["ppg"])
+    assert np.array_equal(out["points"].numpy(), g["points"])
+    np.testing.assert_allclose(out["colours"].numpy(), g["colours"], atol=1e-4)
+
+
+def test_keyed_noise_is_standard_normal():
+    z = keyed_normals(5, np.arange(200000)[:, None], 0, np.arange(4)[None, :]).reshape(-1)
+    assert abs(z.mean()) < 5e-3 and abs(z.std() - 1.0) < 5e-3
+    # acceptance rate of a 3-dof chi at radius 2 (SURVEY.md §7 "RNG"): 0.7385
+    r = np.linalg.norm(z.reshape(-1, 3), axis=1)
+    assert abs((r <= 2.0).mean() - 0.7385) < 3e-3
