@@ -1,0 +1,117 @@
+"""
+ctypes binding of libg2pc.so (the C ABI declared in include/g2pc.h).
+
+The library is the product: it is built in-tree by ``__graft_entry__.build()`` /
+``make -C 3dgs-to-pc_amd/g2pc/csrc`` with ``hipcc --offload-arch=gfx950`` and there is NO CPU or
+PyTorch fallback -- ``lib()`` raises if the shared object is missing, and every wrapper refuses
+host tensors.  (tests/ may inject the fiber-emulated build of the same sources through
+``_inject_for_tests``; nothing in the package does.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libg2pc.so")
+ABI_VERSION = 1
+
+_LIB: Optional[C.CDLL] = None
+_EMULATED = False
+
+_vp, _i64, _i32, _f32, _u64, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_uint64, C.c_size_t
+
+_PROTOS = {
+    "g2pc_last_error": (C.c_char_p, []),
+    "g2pc_abi_version": (C.c_int, []),
+    "g2pc_scan_workspace": (_sz, [_i64]),
+    "g2pc_scan_exclusive_u32": (C.c_int, [_vp, _vp, _i64, _vp, _sz, _vp]),
+    "g2pc_sort_workspace": (_sz, [_i64]),
+    "g2pc_sort_pairs_u32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, _vp, _sz, _vp]),
+    "g2pc_build_covariances": (C.c_int, [_vp, _vp, _f32, _i64, _vp, _vp, _vp, _vp]),
+    "g2pc_validate_covariances": (C.c_int, [_vp, _i64, C.c_int, _f32, _f32, _f32, C.c_int, _vp, _vp]),
+    "g2pc_gaussian_magnitudes": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
+    "g2pc_distribute_points_workspace": (_sz, [_i64]),
+    "g2pc_distribute_points": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "g2pc_bincount_i32": (C.c_int, [_vp, _i64, _vp, _i64, _vp]),
+    "g2pc_sampler_plan_workspace": (_sz, [_i64]),
+    "g2pc_sampler_plan": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "g2pc_sampler_count": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _i32, _i32, _u64, _u64, _vp,
+                                     _vp, _vp, _vp]),
+    "g2pc_sampler_emit": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32,
+                                    _u64, _u64, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
+}
+# rasteriser prototypes are appended by g2pc/_native_raster.py style additions below
+_RASTER_PROTOS = {}
+
+
+class G2pcError(RuntimeError):
+    pass
+
+
+def _bind(lib: C.CDLL, optional=()):
+    for name, (res, args) in {**_PROTOS, **_RASTER_PROTOS}.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            if name in optional:
+                continue
+            raise G2pcError("libg2pc.so does not export %s (stale build? run __graft_entry__.build())" % name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def lib() -> C.CDLL:
+    """The loaded HIP library.  Raises (never falls back) when it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.isfile(LIB_PATH):
+            raise G2pcError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+        _LIB = _bind(C.CDLL(LIB_PATH))
+        v = _LIB.g2pc_abi_version()
+        if v != ABI_VERSION:
+            raise G2pcError("libg2pc.so ABI %d != binding ABI %d" % (v, ABI_VERSION))
+    return _LIB
+
+
+def _inject_for_tests(path: str):
+    """tests/ only: route the wrappers to the fiber-emulated build of the same sources."""
+    global _LIB, _EMULATED
+    _LIB = _bind(C.CDLL(path))
+    _EMULATED = True
+
+
+def emulated() -> bool:
+    return _EMULATED
+
+
+def ptr(t: Optional[torch.Tensor]):
+    """Raw device pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise G2pcError("g2pc kernels need contiguous tensors")
+    if t.device.type != "cuda" and not _EMULATED:
+        raise G2pcError("g2pc HIP kernels need tensors resident in HBM (got device %s); no CPU fallback" % t.device)
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_handle(device) -> Optional[C.c_void_p]:
+    if _EMULATED or torch.device(device).type != "cuda":
+        return None
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().g2pc_last_error()
+        raise G2pcError("%s failed (%d): %s" % (what or "g2pc call", rc, msg.decode() if msg else ""))
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    return torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=device)

@@ -1,0 +1,73 @@
+// Device inline implementations for g2pc_internal.h
+#pragma once
+
+namespace g2pc {
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- Philox4x32-10 ------------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3,
+                                             unsigned k0, unsigned k1) {
+    const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    unsigned hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+    unsigned hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    unsigned n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+
+// eps(seed, gid, attempt, k): counter = (k, attempt, gid_lo, gid_hi), key = (seed_lo, seed_hi);
+// u = ((x >> 9) + 0.5) * 2^-23;  z0 = r0 cos(2 pi u1), z1 = r0 sin(2 pi u1), z2 = r1 cos(2 pi u3)
+// with r0 = sqrt(-2 ln u0), r1 = sqrt(-2 ln u2).
+__device__ __forceinline__ Normal3 keyed_normal3(unsigned seed_lo, unsigned seed_hi, unsigned gid_lo,
+                                                 unsigned gid_hi, unsigned attempt, unsigned k) {
+    unsigned c0 = k, c1 = attempt, c2 = gid_lo, c3 = gid_hi;
+    unsigned k0 = seed_lo, k1 = seed_hi;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    const float scale = 1.1920928955078125e-07f;  // 2^-23
+    float u0 = ((float)(c0 >> 9) + 0.5f) * scale;
+    float u1 = ((float)(c1 >> 9) + 0.5f) * scale;
+    float u2 = ((float)(c2 >> 9) + 0.5f) * scale;
+    float u3 = ((float)(c3 >> 9) + 0.5f) * scale;
+    float r0 = sqrtf(-2.0f * logf(u0));
+    float r1 = sqrtf(-2.0f * logf(u2));
+    float s0, cs0;
+    sincospif(2.0f * u1, &s0, &cs0);
+    float cs1 = cospif(2.0f * u3);
+    Normal3 o;
+    o.x = r0 * cs0;
+    o.y = r0 * s0;
+    o.z = r1 * cs1;
+    return o;
+}
+
+// ---- symmetric 3x3 eigenvalues (trigonometric closed form, fp64) --------------------------------
+__device__ __forceinline__ void sym3_eigvals(double a00, double a01, double a02, double a11, double a12,
+                                             double a22, double e[3]) {
+    double p1 = a01 * a01 + a02 * a02 + a12 * a12;
+    double q = (a00 + a11 + a22) / 3.0;
+    double d0 = a00 - q, d1 = a11 - q, d2 = a22 - q;
+    double p2 = d0 * d0 + d1 * d1 + d2 * d2 + 2.0 * p1;
+    if (!(p2 > 0.0)) { e[0] = e[1] = e[2] = q; return; }
+    double p = sqrt(p2 / 6.0);
+    double ip = 1.0 / p;
+    double b00 = d0 * ip, b11 = d1 * ip, b22 = d2 * ip, b01 = a01 * ip, b02 = a02 * ip, b12 = a12 * ip;
+    double det = b00 * (b11 * b22 - b12 * b12) - b01 * (b01 * b22 - b12 * b02) + b02 * (b01 * b12 - b11 * b02);
+    double r = 0.5 * det;
+    r = r < -1.0 ? -1.0 : (r > 1.0 ? 1.0 : r);
+    double phi = acos(r) / 3.0;
+    double hi = q + 2.0 * p * cos(phi);
+    double lo = q + 2.0 * p * cos(phi + 2.0943951023931954923);  // + 2 pi / 3
+    double mid = 3.0 * q - hi - lo;
+    e[0] = lo; e[1] = mid; e[2] = hi;
+}
+
+}  // namespace g2pc

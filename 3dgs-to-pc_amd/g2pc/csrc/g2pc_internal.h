@@ -1,0 +1,97 @@
+// Internal helpers shared by the g2pc HIP translation units (gfx950 / wave64 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../../include/g2pc.h"
+
+namespace g2pc {
+
+constexpr int kWave = 64;
+
+// ---- error plumbing (thread-local message, negative int status) -------------------------------
+void set_error(const char* where, const char* what);
+int check_launch(const char* where);
+
+#define G2PC_REQUIRE(cond, code, msg)                      \
+    do {                                                   \
+        if (!(cond)) {                                     \
+            ::g2pc::set_error(__func__, msg);              \
+            return code;                                   \
+        }                                                  \
+    } while (0)
+
+static inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
+static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// bump allocator over a caller-provided workspace
+struct Arena {
+    char* base;
+    size_t off, cap;
+    Arena(void* p, size_t c) : base((char*)p), off(0), cap(c) {}
+    template <typename T> T* get(size_t n) {
+        size_t o = align_up(off);
+        off = o + n * sizeof(T);
+        return (T*)(base + o);
+    }
+    bool ok() const { return off <= cap; }
+};
+
+// ---- wave-level helpers -------------------------------------------------------------------------
+__device__ __forceinline__ unsigned lane_id() {
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+__device__ __forceinline__ unsigned long long lanemask_lt() {
+    unsigned l = lane_id();
+    return l == 0 ? 0ull : (~0ull >> (64 - l));
+}
+// compiler + LDS ordering point between the lanes of ONE wave (no s_barrier)
+__device__ __forceinline__ void wave_sync();
+
+template <typename T> __device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { unsigned o = __shfl_xor(v, m); v = o > v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { unsigned o = __shfl_xor(v, m); v = o < v ? o : v; }
+    return v;
+}
+// inclusive prefix sum across the 64 lanes
+__device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned v) {
+    unsigned l = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { unsigned o = __shfl_up(v, d); if (l >= (unsigned)d) v += o; }
+    return v;
+}
+
+// ---- device-side primitives implemented in prims.hip -------------------------------------------
+// exclusive scan of n u32 values; out has n+1 entries (out[n] = total).  in may alias out.
+size_t scan_workspace(long n);
+int scan_exclusive_u32(const uint32_t* in, uint32_t* out, long n, void* ws, size_t ws_bytes, hipStream_t s);
+// stable LSD radix sort of (key,value) u32 pairs on bits [bit_lo, bit_hi).  Result ends in
+// keys_out/vals_out (ping-pong buffers keys_tmp/vals_tmp are scratch of n entries each).
+size_t sort_workspace(long n);
+int sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
+                   uint32_t* keys_tmp, uint32_t* vals_tmp, long n, int bit_lo, int bit_hi, void* ws,
+                   size_t ws_bytes, hipStream_t s);
+
+// Philox4x32-10 keyed standard normals (see oracle/np_philox.py for the definition)
+struct Normal3 { float x, y, z; };
+__device__ __forceinline__ Normal3 keyed_normal3(unsigned seed_lo, unsigned seed_hi, unsigned gid_lo,
+                                                 unsigned gid_hi, unsigned attempt, unsigned k);
+
+// closed-form eigenvalues of a symmetric 3x3 (fp64); ascending order e[0] <= e[1] <= e[2]
+__device__ __forceinline__ void sym3_eigvals(double a00, double a01, double a02, double a11, double a12,
+                                             double a22, double e[3]);
+
+}  // namespace g2pc
+
+#include "g2pc_device.inl"

@@ -1,0 +1,217 @@
+// Per-Gaussian geometry kernels (one thread per Gaussian; HBM-bound streaming kernels).
+// Reference behaviour: gauss_handler.py (file:line cited per kernel).
+#include "g2pc_internal.h"
+
+namespace g2pc {
+
+constexpr int GEO_T = 256;
+
+// gauss_handler.py:26-47 (build_rotation, quaternion r,x,y,z, no normalisation),
+// :49-58 (L = R diag(exp(mod*s))), :60-63 (Sigma = L L^T), :12-24 (strip_symmetric),
+// :89-106 (normal = R[:, argmin(log-scale)]).
+__global__ __launch_bounds__(GEO_T) void k_build_cov(const float* __restrict__ ls, const float4* __restrict__ rot,
+                                                    float mod, long n, float* __restrict__ cov9,
+                                                    float* __restrict__ cov6, float* __restrict__ normals) {
+    long i = (long)blockIdx.x * GEO_T + threadIdx.x;
+    if (i >= n) return;
+    float s0 = ls[3 * i + 0], s1 = ls[3 * i + 1], s2 = ls[3 * i + 2];
+    float4 q = rot[i];
+    float r = q.x, x = q.y, y = q.z, z = q.w;
+    float R[3][3];
+    R[0][0] = 1.0f - 2.0f * (y * y + z * z);
+    R[0][1] = 2.0f * (x * y - r * z);
+    R[0][2] = 2.0f * (x * z + r * y);
+    R[1][0] = 2.0f * (x * y + r * z);
+    R[1][1] = 1.0f - 2.0f * (x * x + z * z);
+    R[1][2] = 2.0f * (y * z - r * x);
+    R[2][0] = 2.0f * (x * z - r * y);
+    R[2][1] = 2.0f * (y * z + r * x);
+    R[2][2] = 1.0f - 2.0f * (x * x + y * y);
+    float e[3] = {expf(mod * s0), expf(mod * s1), expf(mod * s2)};
+    float L[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) L[a][b] = R[a][b] * e[b];
+    float C[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) C[a][b] = L[a][0] * L[b][0] + L[a][1] * L[b][1] + L[a][2] * L[b][2];
+    float* o = cov9 + 9 * i;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) o[3 * a + b] = C[a][b];
+    if (cov6) {
+        float* p = cov6 + 6 * i;
+        p[0] = C[0][0]; p[1] = C[0][1]; p[2] = C[0][2]; p[3] = C[1][1]; p[4] = C[1][2]; p[5] = C[2][2];
+    }
+    if (normals) {
+        int ax = 0;
+        float m = s0;
+        if (s1 < m) { m = s1; ax = 1; }
+        if (s2 < m) { m = s2; ax = 2; }
+        normals[3 * i + 0] = R[0][ax];
+        normals[3 * i + 1] = R[1][ax];
+        normals[3 * i + 2] = R[2][ax];
+    }
+}
+
+// unit eigenvector of symmetric A for eigenvalue lam: largest cross product of rows of (A - lam I)
+__device__ __forceinline__ void sym3_eigvec(const double A[6], double lam, double v[3]) {
+    double r0[3] = {A[0] - lam, A[1], A[2]};
+    double r1[3] = {A[1], A[3] - lam, A[4]};
+    double r2[3] = {A[2], A[4], A[5] - lam};
+    double c0[3] = {r0[1] * r1[2] - r0[2] * r1[1], r0[2] * r1[0] - r0[0] * r1[2], r0[0] * r1[1] - r0[1] * r1[0]};
+    double c1[3] = {r0[1] * r2[2] - r0[2] * r2[1], r0[2] * r2[0] - r0[0] * r2[2], r0[0] * r2[1] - r0[1] * r2[0]};
+    double c2[3] = {r1[1] * r2[2] - r1[2] * r2[1], r1[2] * r2[0] - r1[0] * r2[2], r1[0] * r2[1] - r1[1] * r2[0]};
+    double n0 = c0[0] * c0[0] + c0[1] * c0[1] + c0[2] * c0[2];
+    double n1 = c1[0] * c1[0] + c1[1] * c1[1] + c1[2] * c1[2];
+    double n2 = c2[0] * c2[0] + c2[1] * c2[1] + c2[2] * c2[2];
+    const double* c = c0;
+    double nn = n0;
+    if (n1 > nn) { c = c1; nn = n1; }
+    if (n2 > nn) { c = c2; nn = n2; }
+    if (nn > 0.0) {
+        double inv = 1.0 / sqrt(nn);
+        v[0] = c[0] * inv; v[1] = c[1] * inv; v[2] = c[2] * inv;
+    } else {
+        v[0] = 1.0; v[1] = 0.0; v[2] = 0.0;
+    }
+}
+
+// clamp_covariances (gauss_handler.py:114-127): A <- V max(w, eps) V^T, robust to repeated eigenvalues.
+__device__ __forceinline__ void sym3_clamp(double A[6], const double e[3], double eps) {
+    // eigenvector of the best separated eigenvalue first, then deflate in its orthogonal complement
+    double gap_lo = e[1] - e[0], gap_hi = e[2] - e[1];
+    int first = gap_hi >= gap_lo ? 2 : 0;
+    double v0[3];
+    sym3_eigvec(A, e[first], v0);
+    // orthonormal basis (u, w) of the complement
+    double u[3];
+    if (fabs(v0[0]) > fabs(v0[1])) {
+        double inv = 1.0 / sqrt(v0[0] * v0[0] + v0[2] * v0[2]);
+        u[0] = -v0[2] * inv; u[1] = 0.0; u[2] = v0[0] * inv;
+    } else {
+        double inv = 1.0 / sqrt(v0[1] * v0[1] + v0[2] * v0[2]);
+        u[0] = 0.0; u[1] = v0[2] * inv; u[2] = -v0[1] * inv;
+    }
+    double w[3] = {v0[1] * u[2] - v0[2] * u[1], v0[2] * u[0] - v0[0] * u[2], v0[0] * u[1] - v0[1] * u[0]};
+    // 2x2 projected matrix
+    double Au[3] = {A[0] * u[0] + A[1] * u[1] + A[2] * u[2], A[1] * u[0] + A[3] * u[1] + A[4] * u[2],
+                    A[2] * u[0] + A[4] * u[1] + A[5] * u[2]};
+    double Aw[3] = {A[0] * w[0] + A[1] * w[1] + A[2] * w[2], A[1] * w[0] + A[3] * w[1] + A[4] * w[2],
+                    A[2] * w[0] + A[4] * w[1] + A[5] * w[2]};
+    double m00 = u[0] * Au[0] + u[1] * Au[1] + u[2] * Au[2];
+    double m01 = u[0] * Aw[0] + u[1] * Aw[1] + u[2] * Aw[2];
+    double m11 = w[0] * Aw[0] + w[1] * Aw[1] + w[2] * Aw[2];
+    double tr = 0.5 * (m00 + m11), df = 0.5 * (m00 - m11);
+    double rad = sqrt(df * df + m01 * m01);
+    double l1 = tr + rad, l2 = tr - rad;
+    double cs = 1.0, sn = 0.0;   // eigenvector of l1 in (u,w) coordinates
+    if (rad > 0.0) {
+        double a = df + rad, b = m01;
+        if (fabs(a) < fabs(df - rad)) { a = m01; b = -(df - rad); }   // other column, better conditioned
+        double nn = sqrt(a * a + b * b);
+        if (nn > 0.0) { cs = a / nn; sn = b / nn; }
+    }
+    double v1[3] = {cs * u[0] + sn * w[0], cs * u[1] + sn * w[1], cs * u[2] + sn * w[2]};
+    double v2[3] = {-sn * u[0] + cs * w[0], -sn * u[1] + cs * w[1], -sn * u[2] + cs * w[2]};
+    double w0 = e[first] < eps ? eps : e[first];
+    double w1 = l1 < eps ? eps : l1;
+    double w2 = l2 < eps ? eps : l2;
+    A[0] = w0 * v0[0] * v0[0] + w1 * v1[0] * v1[0] + w2 * v2[0] * v2[0];
+    A[1] = w0 * v0[0] * v0[1] + w1 * v1[0] * v1[1] + w2 * v2[0] * v2[1];
+    A[2] = w0 * v0[0] * v0[2] + w1 * v1[0] * v1[2] + w2 * v2[0] * v2[2];
+    A[3] = w0 * v0[1] * v0[1] + w1 * v1[1] * v1[1] + w2 * v2[1] * v2[1];
+    A[4] = w0 * v0[1] * v0[2] + w1 * v1[1] * v1[2] + w2 * v2[1] * v2[2];
+    A[5] = w0 * v0[2] * v0[2] + w1 * v1[2] * v1[2] + w2 * v2[2] * v2[2];
+}
+
+// validate_covariances (gauss_handler.py:142-166) incl. regularise (:129-140), the eigen test (:108-112)
+// and clamp (:114-127).  The reference tests eigvals(cov).real <= eps with a general (non-symmetric)
+// LAPACK solver on the float32 matrix; here: closed-form fp64 eigenvalues of the symmetrised matrix.
+__global__ __launch_bounds__(GEO_T) void k_validate_cov(float* __restrict__ cov9, long n, int regularise,
+                                                       float reg_eps, float eps, float min_eps, int iters,
+                                                       uint8_t* __restrict__ keep) {
+    long i = (long)blockIdx.x * GEO_T + threadIdx.x;
+    if (i >= n) return;
+    float* c = cov9 + 9 * i;
+    float m[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) m[k] = c[k];
+    bool dirty = false;
+    if (regularise) { m[0] += reg_eps; m[4] += reg_eps; m[8] += reg_eps; dirty = true; }
+    double e[3];
+    for (int it = 0; it < iters; ++it) {
+        double A[6] = {(double)m[0], 0.5 * ((double)m[1] + (double)m[3]), 0.5 * ((double)m[2] + (double)m[6]),
+                       (double)m[4], 0.5 * ((double)m[5] + (double)m[7]), (double)m[8]};
+        sym3_eigvals(A[0], A[1], A[2], A[3], A[4], A[5], e);
+        if (!(e[0] <= (double)eps)) break;
+        sym3_clamp(A, e, (double)eps);
+        m[0] = (float)A[0]; m[1] = (float)A[1]; m[2] = (float)A[2];
+        m[3] = (float)A[1]; m[4] = (float)A[3]; m[5] = (float)A[4];
+        m[6] = (float)A[2]; m[7] = (float)A[4]; m[8] = (float)A[5];
+        dirty = true;
+    }
+    sym3_eigvals((double)m[0], 0.5 * ((double)m[1] + (double)m[3]), 0.5 * ((double)m[2] + (double)m[6]),
+                 (double)m[4], 0.5 * ((double)m[5] + (double)m[7]), (double)m[8], e);
+    keep[i] = (e[0] <= (double)min_eps) ? 0 : 1;   // NaN compares false -> kept, as in the reference
+    if (dirty) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) c[k] = m[k];
+    }
+}
+
+// get_gaussian_magnitudes (gauss_handler.py:252-279): fp32 formula on the (fp64-accurate, rounded to
+// fp32) eigenvalues; the result is symmetric in (a,b,c) so the eigenvalue order does not matter.
+__global__ __launch_bounds__(GEO_T) void k_magnitudes(const float* __restrict__ cov9,
+                                                     const float* __restrict__ weights, long n,
+                                                     double* __restrict__ sizes) {
+    long i = (long)blockIdx.x * GEO_T + threadIdx.x;
+    if (i >= n) return;
+    const float* c = cov9 + 9 * i;
+    double e[3];
+    sym3_eigvals((double)c[0], 0.5 * ((double)c[1] + (double)c[3]), 0.5 * ((double)c[2] + (double)c[6]),
+                 (double)c[4], 0.5 * ((double)c[5] + (double)c[7]), (double)c[8], e);
+    const float p = 1.6075f;
+    float a = sqrtf((float)e[0]), b = sqrtf((float)e[1]), cc = sqrtf((float)e[2]);
+    float radicand = (powf(a * b, p) + powf(a * cc, p) + powf(b * cc, p)) / 3.0f;
+    float area = 12.566370614359172f * powf(radicand, (float)(1.0 / 1.6075));
+    float mag = sqrtf(area) * weights[i];
+    sizes[i] = (double)mag;
+}
+
+}  // namespace g2pc
+
+extern "C" {
+int g2pc_build_covariances(const float* log_scales, const float* rots, float scaling_modifier, int64_t n,
+                           float* cov9, float* cov6, float* normals, void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(n >= 0 && (n == 0 || (log_scales && rots && cov9)), G2PC_ERR_ARG, "null input");
+    if (n == 0) return G2PC_OK;
+    hipLaunchKernelGGL(k_build_cov, dim3(cdiv(n, GEO_T)), dim3(GEO_T), 0, (hipStream_t)stream, log_scales,
+                       (const float4*)rots, scaling_modifier, (long)n, cov9, cov6, normals);
+    return check_launch("g2pc_build_covariances");
+}
+
+int g2pc_validate_covariances(float* cov9, int64_t n, int regularise, float reg_eps, float eps, float min_eps,
+                              int iters, uint8_t* keep, void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(n >= 0 && (n == 0 || (cov9 && keep)), G2PC_ERR_ARG, "null input");
+    if (n == 0) return G2PC_OK;
+    hipLaunchKernelGGL(k_validate_cov, dim3(cdiv(n, GEO_T)), dim3(GEO_T), 0, (hipStream_t)stream, cov9, (long)n,
+                       regularise, reg_eps, eps, min_eps, iters, keep);
+    return check_launch("g2pc_validate_covariances");
+}
+
+int g2pc_gaussian_magnitudes(const float* cov9, const float* weights, int64_t n, double* sizes, void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(n >= 0 && (n == 0 || (cov9 && weights && sizes)), G2PC_ERR_ARG, "null input");
+    if (n == 0) return G2PC_OK;
+    hipLaunchKernelGGL(k_magnitudes, dim3(cdiv(n, GEO_T)), dim3(GEO_T), 0, (hipStream_t)stream, cov9, weights,
+                       (long)n, sizes);
+    return check_launch("g2pc_gaussian_magnitudes");
+}
+}

@@ -1,0 +1,247 @@
+// g2pc device primitives for gfx950 (wave64): error plumbing, exclusive scan, stable LSD radix sort.
+//
+// These replace the reference's CUB calls (cub::DeviceScan::InclusiveSum, rasterizer_impl.cu:285;
+// cub::DeviceRadixSort::SortPairs, rasterizer_impl.cu:311-316) and the torch.unique / boolean-index
+// compactions of the sampler (gauss_to_pc.py:225-238,334).  Multi-kernel (histogram -> scan ->
+// scatter) formulations are used on purpose: the per-XCD L2s of MI355X are not coherent, so
+// single-pass look-back schemes would need agent-scope acquire/release per tile.
+#include "g2pc_internal.h"
+
+namespace g2pc {
+
+static thread_local std::string g_err;
+void set_error(const char* where, const char* what) { g_err = std::string(where) + ": " + what; }
+int check_launch(const char* where) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error(where, hipGetErrorString(e)); return G2PC_ERR_LAUNCH; }
+    return G2PC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Exclusive scan.  Block = 256 threads x 4 items.  Recursive over block sums.
+// ------------------------------------------------------------------------------------------------
+constexpr int SCAN_T = 256, SCAN_I = 4, SCAN_TILE = SCAN_T * SCAN_I;
+
+__global__ __launch_bounds__(SCAN_T) void k_scan_tile(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                     long n, uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t wsum[SCAN_T / kWave];
+    const long base = (long)blockIdx.x * SCAN_TILE + (long)threadIdx.x * SCAN_I;
+    uint32_t v[SCAN_I];
+    uint32_t tsum = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_I; ++i) {
+        v[i] = (base + i < n) ? in[base + i] : 0u;
+        tsum += v[i];
+    }
+    const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t incl = wave_incl_scan_u32(tsum);
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    uint32_t woff = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_T / kWave; ++i) {
+        uint32_t s = wsum[i];
+        if (i < (int)w) woff += s;
+        total += s;
+    }
+    uint32_t run = woff + incl - tsum;
+#pragma unroll
+    for (int i = 0; i < SCAN_I; ++i) {
+        if (base + i < n) out[base + i] = run;
+        run += v[i];
+    }
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(SCAN_T) void k_scan_add(uint32_t* __restrict__ out, long n,
+                                                    const uint32_t* __restrict__ block_offs, uint32_t* total_slot) {
+    const uint32_t off = block_offs[blockIdx.x];
+    const long base = (long)blockIdx.x * SCAN_TILE + (long)threadIdx.x * SCAN_I;
+#pragma unroll
+    for (int i = 0; i < SCAN_I; ++i)
+        if (base + i < n) out[base + i] += off;
+    if (total_slot && blockIdx.x == 0 && threadIdx.x == 0) *total_slot = block_offs[gridDim.x];
+}
+
+size_t scan_workspace(long n) {
+    size_t bytes = 0;
+    long m = n;
+    while (true) {
+        long nb = (m + SCAN_TILE - 1) / SCAN_TILE;
+        if (nb < 1) nb = 1;
+        bytes += align_up((size_t)(nb + 1) * sizeof(uint32_t));
+        if (nb == 1) break;
+        m = nb;
+    }
+    return bytes + 256;
+}
+
+static int scan_rec(const uint32_t* in, uint32_t* out, long n, Arena& ar, hipStream_t s) {
+    long nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (nb < 1) nb = 1;
+    uint32_t* sums = ar.get<uint32_t>((size_t)nb + 1);
+    if (!ar.ok()) { set_error("scan", "workspace too small"); return G2PC_ERR_WORKSPACE; }
+    hipLaunchKernelGGL(k_scan_tile, dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, out, n, sums);
+    if (nb == 1) {
+        // out[n] = total: single tile, total is sums[0]
+        hipMemcpyAsync(out + n, sums, sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
+        return check_launch("scan");
+    }
+    int rc = scan_rec(sums, sums, nb, ar, s);   // sums[0..nb] = exclusive offsets (+ total)
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb), dim3(SCAN_T), 0, s, out, n, sums, out + n);
+    return check_launch("scan");
+}
+
+int scan_exclusive_u32(const uint32_t* in, uint32_t* out, long n, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (n <= 0) {
+        hipMemsetAsync(out, 0, sizeof(uint32_t), s);
+        return G2PC_OK;
+    }
+    Arena ar(ws, ws_bytes);
+    return scan_rec(in, out, n, ar, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stable LSD radix sort, up to 8 bits per pass.  Tile = 256 threads x 8 keys; wave w of a block
+// owns the contiguous sub-tile [w*512, (w+1)*512) and walks it in 8 rounds of 64 keys, ranking
+// with wave64 ballots (match-any over the digit bits) against a wave-private LDS histogram row.
+// ------------------------------------------------------------------------------------------------
+constexpr int RS_T = 256, RS_I = 8, RS_TILE = RS_T * RS_I, RS_W = RS_T / kWave, RS_BINS = 256;
+
+__global__ __launch_bounds__(RS_T) void k_radix_hist(const uint32_t* __restrict__ keys, long n, int shift,
+                                                    unsigned mask, uint32_t* __restrict__ ghist, unsigned nb) {
+    __shared__ uint32_t hist[RS_BINS];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const long base = (long)blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int i = 0; i < RS_I; ++i) {
+        long idx = base + (long)i * RS_T + threadIdx.x;
+        if (idx < n) atomicAdd(&hist[(keys[idx] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x <= mask) ghist[(size_t)threadIdx.x * nb + blockIdx.x] = hist[threadIdx.x];
+}
+
+__global__ __launch_bounds__(RS_T) void k_radix_scatter(const uint32_t* __restrict__ keys_in,
+                                                       const uint32_t* __restrict__ vals_in,
+                                                       uint32_t* __restrict__ keys_out,
+                                                       uint32_t* __restrict__ vals_out, long n, int shift,
+                                                       unsigned mask, int nbits,
+                                                       const uint32_t* __restrict__ goffs, unsigned nb) {
+    __shared__ uint32_t whist[RS_W][RS_BINS];   // per-wave running digit counts, then exclusive offsets
+    __shared__ uint32_t gbase[RS_BINS];
+    const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < RS_W * RS_BINS; i += RS_T) (&whist[0][0])[i] = 0;
+    if (threadIdx.x <= mask) gbase[threadIdx.x] = goffs[(size_t)threadIdx.x * nb + blockIdx.x];
+    __syncthreads();
+
+    const long wbase = (long)blockIdx.x * RS_TILE + (long)w * (RS_TILE / RS_W);
+    uint32_t key[RS_I], val[RS_I], rank[RS_I];
+    const unsigned long long lt = lanemask_lt();
+#pragma unroll
+    for (int r = 0; r < RS_I; ++r) {
+        long idx = wbase + (long)r * 64 + lane;
+        bool valid = idx < n;
+        key[r] = valid ? keys_in[idx] : 0xFFFFFFFFu;
+        val[r] = valid ? vals_in[idx] : 0u;
+        unsigned d = (key[r] >> shift) & mask;
+        // match-any: lanes holding the same digit (invalid lanes form their own group via bit 63 trick)
+        unsigned long long peers = __ballot(valid);
+        for (int b = 0; b < nbits; ++b) {
+            unsigned long long bal = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? bal : ~bal;
+        }
+        unsigned cnt = __popcll(peers);
+        unsigned before = __popcll(peers & lt);
+        unsigned basec = valid ? whist[w][d] : 0u;
+        wave_sync();
+        if (valid && before == 0) whist[w][d] = basec + cnt;
+        wave_sync();
+        rank[r] = basec + before;
+    }
+    __syncthreads();
+    // exclusive prefix over waves for every digit (thread d handles digit d)
+    if (threadIdx.x <= mask) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int i = 0; i < RS_W; ++i) { uint32_t c = whist[i][threadIdx.x]; whist[i][threadIdx.x] = run; run += c; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_I; ++r) {
+        long idx = wbase + (long)r * 64 + lane;
+        if (idx < n) {
+            unsigned d = (key[r] >> shift) & mask;
+            uint32_t pos = gbase[d] + whist[w][d] + rank[r];
+            keys_out[pos] = key[r];
+            vals_out[pos] = val[r];
+        }
+    }
+}
+
+size_t sort_workspace(long n) {
+    long nb = (n + RS_TILE - 1) / RS_TILE;
+    if (nb < 1) nb = 1;
+    size_t hist = align_up(((size_t)RS_BINS * nb + 1) * sizeof(uint32_t));
+    return hist + scan_workspace((long)RS_BINS * nb) + 512;
+}
+
+int sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
+                   uint32_t* keys_tmp, uint32_t* vals_tmp, long n, int bit_lo, int bit_hi, void* ws,
+                   size_t ws_bytes, hipStream_t s) {
+    if (n <= 0) return G2PC_OK;
+    int total_bits = bit_hi - bit_lo;
+    int passes = total_bits <= 0 ? 0 : (total_bits + 7) / 8;
+    if (passes == 0) {
+        hipMemcpyAsync(keys_out, keys_in, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
+        hipMemcpyAsync(vals_out, vals_in, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
+        return G2PC_OK;
+    }
+    long nb = (n + RS_TILE - 1) / RS_TILE;
+    Arena ar(ws, ws_bytes);
+    uint32_t* ghist = ar.get<uint32_t>((size_t)RS_BINS * nb + 1);
+    size_t scan_bytes = scan_workspace((long)RS_BINS * nb);
+    char* scan_ws = ar.get<char>(scan_bytes);
+    if (!ar.ok()) { set_error("sort", "workspace too small"); return G2PC_ERR_WORKSPACE; }
+    // choose ping-pong so the last pass lands in *_out
+    const uint32_t* kin = keys_in;
+    const uint32_t* vin = vals_in;
+    int bit = bit_lo;
+    for (int p = 0; p < passes; ++p) {
+        int nbits = total_bits / passes + (p < total_bits % passes ? 1 : 0);
+        unsigned mask = (1u << nbits) - 1u;
+        bool to_out = ((passes - 1 - p) % 2) == 0;
+        uint32_t* kout = to_out ? keys_out : keys_tmp;
+        uint32_t* vout = to_out ? vals_out : vals_tmp;
+        hipLaunchKernelGGL(k_radix_hist, dim3((unsigned)nb), dim3(RS_T), 0, s, kin, n, bit, mask, ghist, (unsigned)nb);
+        int rc = scan_exclusive_u32(ghist, ghist, (long)(mask + 1) * nb, scan_ws, scan_bytes, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_radix_scatter, dim3((unsigned)nb), dim3(RS_T), 0, s, kin, vin, kout, vout, n, bit, mask,
+                           nbits, ghist, (unsigned)nb);
+        kin = kout; vin = vout;
+        bit += nbits;
+    }
+    return check_launch("sort");
+}
+
+}  // namespace g2pc
+
+// ---- C ABI ----------------------------------------------------------------------------------------
+extern "C" {
+const char* g2pc_last_error(void) { return g2pc::g_err.c_str(); }
+int g2pc_abi_version(void) { return G2PC_ABI_VERSION; }
+
+size_t g2pc_scan_workspace(int64_t n) { return g2pc::scan_workspace(n); }
+int g2pc_scan_exclusive_u32(const uint32_t* in, uint32_t* out, int64_t n, void* ws, size_t ws_bytes, void* stream) {
+    return g2pc::scan_exclusive_u32(in, out, n, ws, ws_bytes, (hipStream_t)stream);
+}
+size_t g2pc_sort_workspace(int64_t n) { return g2pc::sort_workspace(n); }
+int g2pc_sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
+                        uint32_t* keys_tmp, uint32_t* vals_tmp, int64_t n, int bit_lo, int bit_hi, void* ws,
+                        size_t ws_bytes, void* stream) {
+    return g2pc::sort_pairs_u32(keys_in, vals_in, keys_out, vals_out, keys_tmp, vals_tmp, n, bit_lo, bit_hi, ws,
+                                ws_bytes, (hipStream_t)stream);
+}
+}

@@ -1,0 +1,246 @@
+"""
+Host-side operators over the g2pc C ABI (include/g2pc.h): thin torch-tensor wrappers, one per entry
+point, plus the stage orchestration of the point sampler.  PyTorch supplies device memory and the
+current HIP stream only; every byte of arithmetic happens in libg2pc.so.
+"""
+from __future__ import annotations
+
+from math import floor
+from typing import List, NamedTuple, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _native as nv
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    return t.to(torch.float32).contiguous()
+
+
+# ------------------------------------------------------------------------------------------ primitives
+def exclusive_scan_u32(values: torch.Tensor) -> torch.Tensor:
+    """int32/uint32 [n] -> int32 [n+1] exclusive prefix sums (last entry = total)."""
+    n = values.numel()
+    out = torch.empty((n + 1,), dtype=torch.int32, device=values.device)
+    ws_bytes = nv.lib().g2pc_scan_workspace(n)
+    ws = nv.workspace(ws_bytes, values.device)
+    nv.check(nv.lib().g2pc_scan_exclusive_u32(nv.ptr(values.contiguous()), nv.ptr(out), n, nv.ptr(ws), ws_bytes,
+                                              nv.stream_handle(values.device)), "scan")
+    return out
+
+
+def sort_pairs_u32(keys: torch.Tensor, vals: torch.Tensor, bit_lo: int = 0, bit_hi: int = 32):
+    """Stable LSD radix sort of int32-typed (bit pattern = u32) key/value pairs."""
+    n = keys.numel()
+    ko, vo, kt, vt = (torch.empty_like(keys) for _ in range(4))
+    ws_bytes = nv.lib().g2pc_sort_workspace(n)
+    ws = nv.workspace(ws_bytes, keys.device)
+    nv.check(nv.lib().g2pc_sort_pairs_u32(nv.ptr(keys.contiguous()), nv.ptr(vals.contiguous()), nv.ptr(ko),
+                                          nv.ptr(vo), nv.ptr(kt), nv.ptr(vt), n, bit_lo, bit_hi, nv.ptr(ws),
+                                          ws_bytes, nv.stream_handle(keys.device)), "sort")
+    return ko, vo
+
+
+# ------------------------------------------------------------------------------------------ geometry
+def build_covariances(log_scales: torch.Tensor, rots: torch.Tensor, scaling_modifier: float = 1.0,
+                      want_cov6: bool = False, want_normals: bool = False):
+    """gauss_handler.py:26-63 (+ :89-106 normals, :12-24 strip_symmetric) in one pass."""
+    s, q = _f32c(log_scales), _f32c(rots)
+    n = s.shape[0]
+    cov = torch.empty((n, 3, 3), dtype=torch.float32, device=s.device)
+    cov6 = torch.empty((n, 6), dtype=torch.float32, device=s.device) if want_cov6 else None
+    nrm = torch.empty((n, 3), dtype=torch.float32, device=s.device) if want_normals else None
+    nv.check(nv.lib().g2pc_build_covariances(nv.ptr(s), nv.ptr(q), float(scaling_modifier), n, nv.ptr(cov),
+                                             nv.ptr(cov6), nv.ptr(nrm), nv.stream_handle(s.device)),
+             "build_covariances")
+    return cov, cov6, nrm
+
+
+def validate_covariances_(cov: torch.Tensor, regularise: bool = True, reg_eps: float = 5e-7, eps: float = 1e-7,
+                          min_eps: float = 1e-8, iters: int = 3) -> torch.Tensor:
+    """In-place gauss_handler.py:142-166; returns the keep mask (bool[n])."""
+    assert cov.dtype == torch.float32 and cov.is_contiguous()
+    n = cov.shape[0]
+    keep = torch.empty((n,), dtype=torch.uint8, device=cov.device)
+    nv.check(nv.lib().g2pc_validate_covariances(nv.ptr(cov), n, int(regularise), reg_eps, eps, min_eps, iters,
+                                                nv.ptr(keep), nv.stream_handle(cov.device)), "validate_covariances")
+    return keep.to(torch.bool)
+
+
+def gaussian_magnitudes(cov: torch.Tensor, weights: torch.Tensor) -> torch.Tensor:
+    """gauss_handler.py:252-279 -> float64 [n]."""
+    c, w = _f32c(cov), _f32c(weights).reshape(-1)
+    n = c.shape[0]
+    out = torch.empty((n,), dtype=torch.float64, device=c.device)
+    nv.check(nv.lib().g2pc_gaussian_magnitudes(nv.ptr(c), nv.ptr(w), n, nv.ptr(out), nv.stream_handle(c.device)),
+             "gaussian_magnitudes")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ allocation
+def distribute_points(sizes: torch.Tensor, num_points: int):
+    """gauss_to_pc.py:73-90.  Returns (ppg float64[n], ppg int32[n], stats int64[4] on device)."""
+    s = sizes.to(torch.float64).contiguous()
+    n = s.shape[0]
+    ppg64 = torch.empty_like(s)
+    ppg32 = torch.empty((n,), dtype=torch.int32, device=s.device)
+    stats = torch.empty((4,), dtype=torch.int64, device=s.device)
+    ws_bytes = nv.lib().g2pc_distribute_points_workspace(n)
+    ws = nv.workspace(ws_bytes, s.device)
+    nv.check(nv.lib().g2pc_distribute_points(nv.ptr(s), n, int(num_points), nv.ptr(ppg64), nv.ptr(ppg32),
+                                             nv.ptr(stats), nv.ptr(ws), ws_bytes, nv.stream_handle(s.device)),
+             "distribute_points")
+    return ppg64, ppg32, stats
+
+
+def bincount(values_i32: torch.Tensor, length: int) -> torch.Tensor:
+    hist = torch.zeros((length,), dtype=torch.int32, device=values_i32.device)
+    nv.check(nv.lib().g2pc_bincount_i32(nv.ptr(values_i32.contiguous()), values_i32.numel(), nv.ptr(hist), length,
+                                        nv.stream_handle(values_i32.device)), "bincount")
+    return hist
+
+
+def calculate_bin_sizes_from_hist(hist: np.ndarray) -> Tuple[int, int]:
+    """gauss_to_pc.py:105-138 on the host-side histogram of points-per-Gaussian."""
+    dist = hist[hist != 0]
+    g2 = np.absolute(np.gradient(np.gradient(dist)))
+    bin_size = max(len(dist) // 100, 1)
+    g2 = g2[:len(g2) - len(g2) % bin_size]
+    sums = g2.reshape(-1, bin_size).sum(axis=1)
+    cut = np.max(sums) // 50
+    peak = int(np.argmax(sums))
+    below = np.nonzero(sums[peak:] < cut)[0]
+    start_bin = int(below[0]) if below.shape[0] != 0 else 1
+    return start_bin, bin_size
+
+
+def bin_table_from_hist(hist: np.ndarray, exact: bool) -> List[Tuple[float, float, int]]:
+    """gauss_to_pc.py:308-337: (start, end, quota) per bin in loop order."""
+    pd = np.nonzero(hist)[0].astype(np.float64)                      # torch.unique(points_per_gaussian)
+    if not exact:
+        start_bin, bin_size = calculate_bin_sizes_from_hist(hist)
+        tail = np.unique(np.ceil(pd[start_bin:] / bin_size)) * bin_size
+        pd = np.concatenate([pd[:start_bin], tail])
+    out = []
+    for i, s in enumerate(pd):
+        e = pd[i + 1] if i != len(pd) - 1 else s + 1
+        out.append((float(s), float(e), floor(s + (e - s) / 2)))
+    return out
+
+
+class SampledCloud(NamedTuple):
+    points: torch.Tensor                 # f32 [m,3]
+    colours: torch.Tensor                # f32 [m,3]
+    normals: Optional[torch.Tensor]      # f32 [m,3]
+    gauss_index: Optional[torch.Tensor]  # i32 [m] (index into the arrays handed in)
+    bins: list
+    emitted_per_attempt: list
+
+
+WAVE_MODE_MIN_DRAWS = 32   # quota-1 at and above which one Gaussian is sampled by a whole wave64
+ATTEMPT_CHUNK = 8
+
+
+def sample_pointcloud(xyz: torch.Tensor, cov: torch.Tensor, colours: torch.Tensor,
+                      normals: Optional[torch.Tensor], ppg_i32: torch.Tensor, max_ppg: int, *, exact: bool,
+                      std: float, attempts: int, seed: int, gid_base: int = 0,
+                      want_index: bool = False) -> SampledCloud:
+    """The bin loop of generate_pointcloud (gauss_to_pc.py:308-371) + create_new_gaussian_points
+    (gauss_to_pc.py:157-275) for all bins at once, in the reference's output order."""
+    L = nv.lib()
+    dev = xyz.device
+    st = nv.stream_handle(dev)
+    xyz, cov, colours = _f32c(xyz), _f32c(cov), _f32c(colours)
+    normals = _f32c(normals) if normals is not None else None
+    G = xyz.shape[0]
+
+    hist = bincount(ppg_i32, int(max_ppg) + 1).cpu().numpy().astype(np.int64)          # sync #1
+    bins = bin_table_from_hist(hist, exact)
+    B = len(bins)
+    lut = np.full((int(max_ppg) + 1,), -1, dtype=np.int32)
+    quota = np.zeros((max(B, 1),), dtype=np.int32)
+    members = np.zeros((max(B, 1),), dtype=np.int64)
+    for b, (s, e, n) in enumerate(bins):
+        quota[b] = n
+        lo, hi = int(np.ceil(s)), int(np.ceil(e))
+        hi = min(hi, int(max_ppg) + 1)
+        if n > 0 and hi > lo:
+            lut[lo:hi] = b
+            members[b] = hist[lo:hi].sum()
+    lut_d = torch.from_numpy(lut).to(dev)
+    quota_d = torch.from_numpy(quota).to(dev)
+
+    perm = torch.empty((G,), dtype=torch.int32, device=dev)
+    pbin = torch.empty((G,), dtype=torch.int32, device=dev)
+    bin_start = torch.empty((B + 2,), dtype=torch.int32, device=dev)
+    ws_bytes = L.g2pc_sampler_plan_workspace(G)
+    ws = nv.workspace(ws_bytes, dev)
+    nv.check(L.g2pc_sampler_plan(nv.ptr(ppg_i32), G, nv.ptr(lut_d), lut.shape[0], B, nv.ptr(perm), nv.ptr(pbin),
+                                 nv.ptr(bin_start), nv.ptr(ws), ws_bytes, st), "sampler_plan")
+    # bin sizes are known on the host from the histogram: no read-back needed
+    bs_host = np.zeros((B + 2,), dtype=np.int64)
+    bs_host[1:B + 1] = np.cumsum(members[:B])
+    gv = int(bs_host[B])
+    wave_bins = [b for b in range(B) if quota[b] - 1 >= WAVE_MODE_MIN_DRAWS and members[b] > 0]
+    p_wave = int(bs_host[wave_bins[0]]) if wave_bins else gv
+
+    added = torch.zeros((max(gv, 1),), dtype=torch.int32, device=dev)
+    remaining = torch.zeros((1,), dtype=torch.int32, device=dev)
+    chunks = []            # (attempt0, count, dcount, dscan)
+    sec_cols = []          # per attempt: int64 [B] section sizes
+    a0 = 0
+    scan_bytes = L.g2pc_scan_workspace(gv)
+    scan_ws = nv.workspace(scan_bytes, dev)
+    any_sampling = bool(np.any((quota[:B] > 1) & (members[:B] > 0))) if B else False
+    bs_idx = torch.from_numpy(bs_host[:B + 1]).to(dev)
+    while any_sampling and a0 < attempts:
+        na = min(ATTEMPT_CHUNK, attempts - a0)
+        dcount = torch.empty((na, gv), dtype=torch.int32, device=dev)
+        dscan = torch.empty((na, gv + 1), dtype=torch.int32, device=dev)
+        remaining.zero_()
+        nv.check(L.g2pc_sampler_count(nv.ptr(xyz), nv.ptr(cov), nv.ptr(perm), nv.ptr(pbin), nv.ptr(quota_d), gv,
+                                      p_wave, float(std), a0, na, int(seed), int(gid_base), nv.ptr(added),
+                                      nv.ptr(dcount), nv.ptr(remaining), st), "sampler_count")
+        for a in range(na):
+            nv.check(L.g2pc_scan_exclusive_u32(nv.ptr(dcount[a]), nv.ptr(dscan[a]), gv, nv.ptr(scan_ws), scan_bytes,
+                                               st), "scan")
+        edge = dscan[:, bs_idx].to(torch.int64)                     # [na, B+1] scan values at bin boundaries
+        host = torch.cat([edge.reshape(-1), remaining.to(torch.int64)]).cpu().numpy()     # sync
+        edge_h = host[:-1].reshape(na, B + 1)
+        for a in range(na):
+            sec_cols.append(edge_h[a, 1:] - edge_h[a, :-1])
+        chunks.append((a0, na, dcount, dscan))
+        a0 += na
+        if int(host[-1]) == 0:
+            break
+    # trailing attempts that emitted nothing are dropped (the reference's loop would have stopped)
+    A_used = len(sec_cols)
+    sec_sizes = np.zeros((max(B, 1), 1 + A_used), dtype=np.int64)
+    for b in range(B):
+        sec_sizes[b, 0] = members[b] if quota[b] > 0 else 0
+    for a in range(A_used):
+        sec_sizes[:B, 1 + a] = sec_cols[a]
+    flat = sec_sizes[:B].reshape(-1)
+    base = np.zeros_like(flat)
+    if flat.size:
+        base[1:] = np.cumsum(flat)[:-1]
+    M = int(flat.sum())
+    sec_base = torch.from_numpy(base.reshape(max(B, 0), 1 + A_used).copy() if B else np.zeros((1, 1), np.int64)).to(dev)
+
+    pts = torch.empty((M, 3), dtype=torch.float32, device=dev)
+    cols = torch.empty((M, 3), dtype=torch.float32, device=dev)
+    nrm = torch.empty((M, 3), dtype=torch.float32, device=dev) if normals is not None else None
+    gidx = torch.empty((M,), dtype=torch.int32, device=dev) if want_index else None
+    if M > 0 and gv > 0:
+        common = (nv.ptr(xyz), nv.ptr(cov), nv.ptr(colours), nv.ptr(normals), nv.ptr(perm), nv.ptr(pbin),
+                  nv.ptr(bin_start), nv.ptr(quota_d), gv, p_wave, B)
+        if not chunks:
+            nv.check(L.g2pc_sampler_emit(*common, 0, 0, 1 + A_used, int(seed), int(gid_base), None, None,
+                                         nv.ptr(sec_base), 1, nv.ptr(pts), nv.ptr(cols), nv.ptr(nrm), nv.ptr(gidx),
+                                         st), "sampler_emit")
+        for ci, (c0, na, dcount, dscan) in enumerate(chunks):
+            nv.check(L.g2pc_sampler_emit(*common, c0, na, 1 + A_used, int(seed), int(gid_base), nv.ptr(dcount),
+                                         nv.ptr(dscan), nv.ptr(sec_base), 1 if ci == 0 else 0, nv.ptr(pts),
+                                         nv.ptr(cols), nv.ptr(nrm), nv.ptr(gidx), st), "sampler_emit")
+    return SampledCloud(pts, cols, nrm, gidx, bins, [int(c.sum()) for c in sec_cols])

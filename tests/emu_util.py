@@ -1,0 +1,24 @@
+"""TEST INFRASTRUCTURE: builds tests/hipemu/libg2pc_emu.so (the product .hip sources compiled by g++
+against the fiber emulator) and routes g2pc._native to it for the duration of a test module."""
+import os
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def build_emu() -> str:
+    out = subprocess.run(["bash", os.path.join(HERE, "hipemu", "build_emu.sh")], capture_output=True, text=True)
+    if out.returncode != 0:
+        raise RuntimeError("emulator build failed:\n" + out.stdout + out.stderr)
+    return os.path.join(HERE, "hipemu", "libg2pc_emu.so")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    from g2pc import _native as nv
+    saved = (nv._LIB, nv._EMULATED)
+    nv._inject_for_tests(build_emu())
+    yield nv
+    nv._LIB, nv._EMULATED = saved

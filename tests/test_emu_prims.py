@@ -1,0 +1,71 @@
+"""Kernel LOGIC of the scan / radix sort / geometry / allocation kernels, run through the fiber emulator on
+CPU (no GPU here).  The same assertions run on the real MI355X in tests/test_gpu_*.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from emu_util import emu  # noqa: F401
+import ref_gauss as RG
+from g2pc import ops
+from g2pc.synth import make_scene
+
+
+@pytest.mark.parametrize("n", [1, 63, 1024, 1025, 5000, 1024 * 1024 + 7])
+def test_scan(emu, n):
+    rng = np.random.default_rng(n)
+    v = rng.integers(0, 5, size=n).astype(np.int32)
+    out = ops.exclusive_scan_u32(torch.from_numpy(v)).numpy()
+    ref = np.concatenate([[0], np.cumsum(v)]).astype(np.int64)
+    assert np.array_equal(out.astype(np.int64), ref)
+
+
+@pytest.mark.parametrize("n,lo,hi", [(1, 0, 32), (777, 0, 8), (5000, 0, 13), (20000, 0, 32), (6000, 4, 11), (3000, 0, 3)])
+def test_radix_sort_stable(emu, n, lo, hi):
+    rng = np.random.default_rng(n + hi)
+    keys = rng.integers(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32)
+    if hi <= 13:
+        keys = (keys % (1 << hi)).astype(np.uint32)
+    vals = np.arange(n, dtype=np.uint32)
+    ko, vo = ops.sort_pairs_u32(torch.from_numpy(keys.view(np.int32)), torch.from_numpy(vals.view(np.int32)), lo, hi)
+    ko, vo = ko.numpy().view(np.uint32), vo.numpy().view(np.uint32)
+    digit = (keys >> lo) & ((1 << (hi - lo)) - 1)
+    order = np.argsort(digit, kind="stable")
+    assert np.array_equal(vo, vals[order])
+    assert np.array_equal(ko, keys[order])
+
+
+def test_geometry_matches_oracle(emu, golden_dir):
+    g = np.load(os.path.join(golden_dir, "geom_n4096.npz"))
+    sc = make_scene(int(g["n"]), int(g["seed"]))
+    cov, cov6, nrm = ops.build_covariances(sc.scales, sc.rots, 1.0, want_cov6=True, want_normals=True)
+    np.testing.assert_allclose(cov.numpy(), g["cov"], rtol=2e-6, atol=5e-11)   # entries ~1e-4: 5e-7 of scale
+    np.testing.assert_array_equal(cov6.numpy(), RG.strip_symmetric(cov).numpy())
+    np.testing.assert_allclose(nrm.numpy(), g["normals"], rtol=0, atol=1e-6)
+    mags = ops.gaussian_magnitudes(cov, sc.opacities)
+    np.testing.assert_allclose(mags.numpy(), g["mags_opacity"], rtol=5e-6)
+    bad = torch.from_numpy(g["cov"]).clone()
+    bad[torch.from_numpy(g["bad_rows"])] = torch.from_numpy(g["bad_cov"])
+    keep = ops.validate_covariances_(bad)
+    assert np.array_equal(keep.numpy(), g["keep"])
+    np.testing.assert_allclose(bad[keep].numpy(), g["cov_valid"], rtol=1e-6, atol=2e-10)
+
+
+def test_distribute_points_matches_reference(emu, golden_dir):
+    g = np.load(os.path.join(golden_dir, "geom_n4096.npz"))
+    mags = torch.from_numpy(g["mags_opacity"])
+    ppg64, ppg32, stats = ops.distribute_points(mags, 100000)
+    assert np.array_equal(ppg64.numpy(), g["ppg_100k"])
+    assert np.array_equal(ppg32.numpy(), g["ppg_100k"].astype(np.int32))
+    assert int(stats[3]) == int(g["ppg_100k"].max())
+    over, over32, st = ops.distribute_points(torch.tensor([1.5] * 4 + [0.01] * 6, dtype=torch.float64), 7)
+    assert np.array_equal(over.numpy(), g["ppg_overshoot"])            # negative-slice quirk
+    assert int(st[2]) == -1 and int(st[1]) == 6
+    hist = ops.bincount(ppg32, int(stats[3]) + 1).numpy()
+    assert np.array_equal(hist, np.bincount(g["ppg_100k"].astype(np.int64)))
+    assert ops.calculate_bin_sizes_from_hist(hist) == (int(g["start_bin"]), int(g["bin_size"]))
+    # underfill: every zero entry gets a point while the budget lasts, in index order
+    sizes = torch.tensor([10.0, 0.001, 0.001, 10.0, 0.001], dtype=torch.float64)
+    p, _, st = ops.distribute_points(sizes, 22)
+    assert p.tolist() == RG.distribute_points(sizes, 22).tolist()
