@@ -31,7 +31,11 @@ _PROTOS = {
     "g2pc_scan_exclusive_u32": (C.c_int, [_vp, _vp, _i64, _vp, _sz, _vp]),
     "g2pc_sort_workspace": (_sz, [_i64]),
     "g2pc_sort_pairs_u32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, _vp, _sz, _vp]),
-    "g2pc_build_covariances": (C.c_int, [_vp, _vp, _f32, _i64, _vp, _vp, _vp, _vp]),
+    "g2pc_build_covariances": (C.c_int, [_vp, _vp, _f32, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "g2pc_cull_mask": (C.c_int, [_vp, _vp, _i64, C.c_int, _f32, _vp, _vp, _vp, _vp]),
+    "g2pc_compact_workspace": (_sz, [_i64]),
+    "g2pc_compact_index": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "g2pc_gather_rows": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "g2pc_validate_covariances": (C.c_int, [_vp, _i64, C.c_int, _f32, _f32, _f32, C.c_int, _vp, _vp]),
     "g2pc_gaussian_magnitudes": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "g2pc_distribute_points_workspace": (_sz, [_i64]),
@@ -44,6 +48,8 @@ _PROTOS = {
     "g2pc_sampler_emit": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32,
                                     _u64, _u64, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
 }
+_PROTOS["g2pc_mahalanobis"] = (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp])
+_PROTOS["g2pc_sample_mvn"] = (C.c_int, [_vp, _vp, _i64, _i32, _u64, _u64, _i32, _vp, _vp])
 # rasteriser prototypes are appended by g2pc/_native_raster.py style additions below
 _RASTER_PROTOS = {}
 
@@ -115,3 +121,32 @@ def check(rc: int, what: str = ""):
 
 def workspace(nbytes: int, device) -> torch.Tensor:
     return torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=device)
+
+
+# ---- optional per-region device timing (bench.py only): HIP events on the stream the kernels run on --------
+import contextlib
+
+PROFILE = None   # dict name -> list of (start_event, end_event) when enabled
+
+
+@contextlib.contextmanager
+def region(name: str, device=None):
+    if PROFILE is None or _EMULATED:
+        yield
+        return
+    a = torch.cuda.Event(enable_timing=True)
+    b = torch.cuda.Event(enable_timing=True)
+    a.record(torch.cuda.current_stream(device))
+    try:
+        yield
+    finally:
+        b.record(torch.cuda.current_stream(device))
+        PROFILE.setdefault(name, []).append((a, b))
+
+
+def profile_summary():
+    """name -> (launch count, total ms); call after torch.cuda.synchronize()."""
+    out = {}
+    for name, evs in (PROFILE or {}).items():
+        out[name] = (len(evs), sum(a.elapsed_time(b) for a, b in evs))
+    return out

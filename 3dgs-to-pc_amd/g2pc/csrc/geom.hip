@@ -11,7 +11,8 @@ constexpr int GEO_T = 256;
 // :89-106 (normal = R[:, argmin(log-scale)]).
 __global__ __launch_bounds__(GEO_T) void k_build_cov(const float* __restrict__ ls, const float4* __restrict__ rot,
                                                     float mod, long n, float* __restrict__ cov9,
-                                                    float* __restrict__ cov6, float* __restrict__ normals) {
+                                                    float* __restrict__ cov6, float* __restrict__ normals,
+                                                    float* __restrict__ rotmat) {
     long i = (long)blockIdx.x * GEO_T + threadIdx.x;
     if (i >= n) return;
     float s0 = ls[3 * i + 0], s1 = ls[3 * i + 1], s2 = ls[3 * i + 2];
@@ -27,6 +28,12 @@ __global__ __launch_bounds__(GEO_T) void k_build_cov(const float* __restrict__ l
     R[2][0] = 2.0f * (x * z - r * y);
     R[2][1] = 2.0f * (y * z + r * x);
     R[2][2] = 1.0f - 2.0f * (x * x + y * y);
+    if (rotmat) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) rotmat[9 * i + 3 * a + b] = R[a][b];
+    }
     float e[3] = {expf(mod * s0), expf(mod * s1), expf(mod * s2)};
     float L[3][3];
 #pragma unroll
@@ -183,16 +190,59 @@ __global__ __launch_bounds__(GEO_T) void k_magnitudes(const float* __restrict__ 
     sizes[i] = (double)mag;
 }
 
+
+// apply_min_opacity / apply_bounding_box (gauss_handler.py:195-224): mask &= tests (strict inequalities)
+__global__ __launch_bounds__(GEO_T) void k_cull_mask(const float* __restrict__ xyz, const float* __restrict__ opac,
+                                                    long n, int use_opacity, float min_opacity, int use_min,
+                                                    float3 bmin, int use_max, float3 bmax,
+                                                    uint8_t* __restrict__ mask) {
+    long i = (long)blockIdx.x * GEO_T + threadIdx.x;
+    if (i >= n) return;
+    bool ok = mask[i] != 0;
+    if (use_opacity) ok = ok && (opac[i] > min_opacity);
+    if (use_min | use_max) {
+        float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        if (use_min) ok = ok && (x > bmin.x) && (y > bmin.y) && (z > bmin.z);
+        if (use_max) ok = ok && (x < bmax.x) && (y < bmax.y) && (z < bmax.z);
+    }
+    mask[i] = ok ? 1 : 0;
+}
+
+__global__ __launch_bounds__(GEO_T) void k_mask_to_u32(const uint8_t* __restrict__ mask, long n,
+                                                      uint32_t* __restrict__ flag) {
+    long i = (long)blockIdx.x * GEO_T + threadIdx.x;
+    if (i < n) flag[i] = mask[i] ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(GEO_T) void k_compact_index(const uint8_t* __restrict__ mask,
+                                                        const uint32_t* __restrict__ rank, long n,
+                                                        uint32_t* __restrict__ index) {
+    long i = (long)blockIdx.x * GEO_T + threadIdx.x;
+    if (i < n && mask[i]) index[rank[i]] = (uint32_t)i;
+}
+
+// boolean-index gather of rows (filter_gaussians, gauss_handler.py:171-193): dst[j,:] = src[index[j],:]
+__global__ __launch_bounds__(GEO_T) void k_gather_rows(const uint32_t* __restrict__ src,
+                                                      const uint32_t* __restrict__ index, long m, int row_words,
+                                                      uint32_t* __restrict__ dst) {
+    long t = (long)blockIdx.x * GEO_T + threadIdx.x;
+    long total = m * row_words;
+    if (t >= total) return;
+    long j = t / row_words;
+    int w = (int)(t - j * row_words);
+    dst[t] = src[(size_t)index[j] * row_words + w];
+}
+
 }  // namespace g2pc
 
 extern "C" {
 int g2pc_build_covariances(const float* log_scales, const float* rots, float scaling_modifier, int64_t n,
-                           float* cov9, float* cov6, float* normals, void* stream) {
+                           float* cov9, float* cov6, float* normals, float* rotmat, void* stream) {
     using namespace g2pc;
     G2PC_REQUIRE(n >= 0 && (n == 0 || (log_scales && rots && cov9)), G2PC_ERR_ARG, "null input");
     if (n == 0) return G2PC_OK;
     hipLaunchKernelGGL(k_build_cov, dim3(cdiv(n, GEO_T)), dim3(GEO_T), 0, (hipStream_t)stream, log_scales,
-                       (const float4*)rots, scaling_modifier, (long)n, cov9, cov6, normals);
+                       (const float4*)rots, scaling_modifier, (long)n, cov9, cov6, normals, rotmat);
     return check_launch("g2pc_build_covariances");
 }
 
@@ -213,5 +263,56 @@ int g2pc_gaussian_magnitudes(const float* cov9, const float* weights, int64_t n,
     hipLaunchKernelGGL(k_magnitudes, dim3(cdiv(n, GEO_T)), dim3(GEO_T), 0, (hipStream_t)stream, cov9, weights,
                        (long)n, sizes);
     return check_launch("g2pc_gaussian_magnitudes");
+}
+}
+
+extern "C" {
+int g2pc_cull_mask(const float* xyz, const float* opacities, int64_t n, int use_min_opacity, float min_opacity,
+                   const float* bbox_min, const float* bbox_max, uint8_t* mask, void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(n >= 0 && mask, G2PC_ERR_ARG, "null mask");
+    G2PC_REQUIRE(!use_min_opacity || opacities, G2PC_ERR_ARG, "opacities missing");
+    G2PC_REQUIRE((!bbox_min && !bbox_max) || xyz, G2PC_ERR_ARG, "xyz missing");
+    if (n == 0) return G2PC_OK;
+    float3 a = bbox_min ? make_float3(bbox_min[0], bbox_min[1], bbox_min[2]) : make_float3(0, 0, 0);
+    float3 b = bbox_max ? make_float3(bbox_max[0], bbox_max[1], bbox_max[2]) : make_float3(0, 0, 0);
+    hipLaunchKernelGGL(k_cull_mask, dim3(cdiv(n, GEO_T)), dim3(GEO_T), 0, (hipStream_t)stream, xyz, opacities,
+                       (long)n, use_min_opacity, min_opacity, bbox_min ? 1 : 0, a, bbox_max ? 1 : 0, b, mask);
+    return check_launch("g2pc_cull_mask");
+}
+
+size_t g2pc_compact_workspace(int64_t n) {
+    return g2pc::align_up((size_t)(n + 1) * 4) * 2 + g2pc::scan_workspace(n) + 1024;
+}
+
+int g2pc_compact_index(const uint8_t* mask, int64_t n, uint32_t* index, uint32_t* count, void* ws, size_t ws_bytes,
+                       void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(n >= 0 && mask && index && count && ws, G2PC_ERR_ARG, "bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) { hipMemsetAsync(count, 0, 4, s); return G2PC_OK; }
+    Arena ar(ws, ws_bytes);
+    uint32_t* flag = ar.get<uint32_t>((size_t)n + 1);
+    uint32_t* rank = ar.get<uint32_t>((size_t)n + 1);
+    size_t sb = scan_workspace(n);
+    char* sw = ar.get<char>(sb);
+    G2PC_REQUIRE(ar.ok(), G2PC_ERR_WORKSPACE, "workspace too small");
+    hipLaunchKernelGGL(k_mask_to_u32, dim3(cdiv(n, GEO_T)), dim3(GEO_T), 0, s, mask, (long)n, flag);
+    int rc = scan_exclusive_u32(flag, rank, n, sw, sb, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_compact_index, dim3(cdiv(n, GEO_T)), dim3(GEO_T), 0, s, mask, rank, (long)n, index);
+    hipMemcpyAsync(count, rank + n, 4, hipMemcpyDeviceToDevice, s);
+    return check_launch("g2pc_compact_index");
+}
+
+int g2pc_gather_rows(const void* src, const uint32_t* index, int64_t m, int32_t row_bytes, void* dst, void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(m >= 0 && row_bytes > 0 && row_bytes % 4 == 0, G2PC_ERR_ARG, "row_bytes must be a multiple of 4");
+    if (m == 0) return G2PC_OK;
+    G2PC_REQUIRE(src && index && dst, G2PC_ERR_ARG, "null pointer");
+    long total = (long)m * (row_bytes / 4);
+    hipLaunchKernelGGL(k_gather_rows, dim3(cdiv(total, GEO_T)), dim3(GEO_T), 0, (hipStream_t)stream,
+                       (const uint32_t*)src, index, (long)m, (int)(row_bytes / 4), (uint32_t*)dst);
+    return check_launch("g2pc_gather_rows");
 }
 }

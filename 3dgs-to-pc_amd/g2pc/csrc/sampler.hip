@@ -276,6 +276,39 @@ __global__ __launch_bounds__(SM_T) void k_emit_wave(
     }
 }
 
+// standalone mahalanobis() of the reference API (gauss_to_pc.py:92-103): one thread per (mean, sample, cov) row
+__global__ __launch_bounds__(SM_T) void k_mahalanobis(const float* __restrict__ means,
+                                                     const float* __restrict__ samples,
+                                                     const float* __restrict__ cov9, long n,
+                                                     float* __restrict__ out) {
+    long i = (long)blockIdx.x * SM_T + threadIdx.x;
+    if (i >= n) return;
+    GaussSample s;
+    load_gauss(means, cov9, (unsigned)i, s);
+    float dx = s.mx - samples[3 * i], dy = s.my - samples[3 * i + 1], dz = s.mz - samples[3 * i + 2];
+    float yx = s.i00 * dx + s.i01 * dy + s.i02 * dz;
+    float yy = s.i01 * dx + s.i11 * dy + s.i12 * dz;
+    float yz = s.i02 * dx + s.i12 * dy + s.i22 * dz;
+    out[i] = sqrtf(dx * yx + dy * yy + dz * yz);
+}
+
+// standalone sample_from_multivariate_normal (gauss_to_pc.py:140-155): out[k, g, :] = mean_g + chol(cov_g) eps
+__global__ __launch_bounds__(SM_T) void k_sample_mvn(const float* __restrict__ means,
+                                                    const float* __restrict__ cov9, long g_count, int n,
+                                                    unsigned seed_lo, unsigned seed_hi, uint64_t gid_base,
+                                                    unsigned attempt, float* __restrict__ out) {
+    long g = (long)blockIdx.x * SM_T + threadIdx.x;
+    if (g >= g_count) return;
+    GaussSample s;
+    load_gauss(means, cov9, (unsigned)g, s);
+    const uint64_t gid = gid_base + (uint64_t)g;
+    for (int k = 0; k < n; ++k) {
+        float x, y, z;
+        draw(s, seed_lo, seed_hi, (unsigned)gid, (unsigned)(gid >> 32), attempt, (unsigned)k, 0.f, x, y, z);
+        put3(out, (size_t)k * g_count + g, x, y, z);
+    }
+}
+
 static int bits_for(unsigned v) { int b = 0; while ((1u << b) <= v && b < 31) ++b; return b < 1 ? 1 : b; }
 
 }  // namespace g2pc
@@ -372,5 +405,29 @@ int g2pc_sampler_emit(const float* means, const float* cov9, const float* colour
                                out_points, out_colours, out_normals, out_gauss);
     }
     return check_launch("g2pc_sampler_emit");
+}
+}
+
+extern "C" {
+int g2pc_mahalanobis(const float* means, const float* samples, const float* cov9, int64_t n, float* out,
+                     void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(n >= 0, G2PC_ERR_ARG, "negative n");
+    if (n == 0) return G2PC_OK;
+    G2PC_REQUIRE(means && samples && cov9 && out, G2PC_ERR_ARG, "null pointer");
+    hipLaunchKernelGGL(k_mahalanobis, dim3(cdiv(n, SM_T)), dim3(SM_T), 0, (hipStream_t)stream, means, samples, cov9,
+                       (long)n, out);
+    return check_launch("g2pc_mahalanobis");
+}
+
+int g2pc_sample_mvn(const float* means, const float* cov9, int64_t g, int32_t n, uint64_t seed, uint64_t gid_base,
+                    int32_t attempt, float* out, void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(g >= 0 && n >= 0, G2PC_ERR_ARG, "negative size");
+    if (g == 0 || n == 0) return G2PC_OK;
+    G2PC_REQUIRE(means && cov9 && out, G2PC_ERR_ARG, "null pointer");
+    hipLaunchKernelGGL(k_sample_mvn, dim3(cdiv(g, SM_T)), dim3(SM_T), 0, (hipStream_t)stream, means, cov9, (long)g,
+                       (int)n, (unsigned)seed, (unsigned)(seed >> 32), gid_base, (unsigned)attempt, out);
+    return check_launch("g2pc_sample_mvn");
 }
 }

@@ -44,17 +44,64 @@ def sort_pairs_u32(keys: torch.Tensor, vals: torch.Tensor, bit_lo: int = 0, bit_
 
 # ------------------------------------------------------------------------------------------ geometry
 def build_covariances(log_scales: torch.Tensor, rots: torch.Tensor, scaling_modifier: float = 1.0,
-                      want_cov6: bool = False, want_normals: bool = False):
+                      want_cov6: bool = False, want_normals: bool = False, want_rotmat: bool = False):
     """gauss_handler.py:26-63 (+ :89-106 normals, :12-24 strip_symmetric) in one pass."""
     s, q = _f32c(log_scales), _f32c(rots)
     n = s.shape[0]
     cov = torch.empty((n, 3, 3), dtype=torch.float32, device=s.device)
     cov6 = torch.empty((n, 6), dtype=torch.float32, device=s.device) if want_cov6 else None
     nrm = torch.empty((n, 3), dtype=torch.float32, device=s.device) if want_normals else None
+    rm = torch.empty((n, 3, 3), dtype=torch.float32, device=s.device) if want_rotmat else None
     nv.check(nv.lib().g2pc_build_covariances(nv.ptr(s), nv.ptr(q), float(scaling_modifier), n, nv.ptr(cov),
-                                             nv.ptr(cov6), nv.ptr(nrm), nv.stream_handle(s.device)),
+                                             nv.ptr(cov6), nv.ptr(nrm), nv.ptr(rm), nv.stream_handle(s.device)),
              "build_covariances")
+    if want_rotmat:
+        return cov, cov6, nrm, rm
     return cov, cov6, nrm
+
+
+def cull_mask_(mask_u8: torch.Tensor, xyz: Optional[torch.Tensor], opacities: Optional[torch.Tensor],
+               min_opacity: Optional[float], bbox_min, bbox_max) -> torch.Tensor:
+    """In-place gauss_handler.py:195-224 on a uint8 mask."""
+    import ctypes as C
+    n = mask_u8.numel()
+    bmin = (C.c_float * 3)(*[float(v) for v in bbox_min]) if bbox_min is not None else None
+    bmax = (C.c_float * 3)(*[float(v) for v in bbox_max]) if bbox_max is not None else None
+    x = _f32c(xyz) if xyz is not None else None
+    o = _f32c(opacities).reshape(-1) if opacities is not None else None
+    nv.check(nv.lib().g2pc_cull_mask(nv.ptr(x), nv.ptr(o), n, 1 if min_opacity is not None else 0,
+                                     float(min_opacity or 0.0), C.cast(bmin, C.c_void_p) if bmin else None,
+                                     C.cast(bmax, C.c_void_p) if bmax else None, nv.ptr(mask_u8),
+                                     nv.stream_handle(mask_u8.device)), "cull_mask")
+    return mask_u8
+
+
+def compact_index(mask: torch.Tensor) -> torch.Tensor:
+    """Ascending indices (int32) of the set entries of a bool/uint8 mask (one host read-back for the count)."""
+    m8 = mask.to(torch.uint8).contiguous()
+    n = m8.numel()
+    index = torch.empty((max(n, 1),), dtype=torch.int32, device=m8.device)
+    count = torch.zeros((1,), dtype=torch.int32, device=m8.device)
+    ws_bytes = nv.lib().g2pc_compact_workspace(n)
+    ws = nv.workspace(ws_bytes, m8.device)
+    nv.check(nv.lib().g2pc_compact_index(nv.ptr(m8), n, nv.ptr(index), nv.ptr(count), nv.ptr(ws), ws_bytes,
+                                         nv.stream_handle(m8.device)), "compact_index")
+    return index[:int(count.item())]
+
+
+def gather_rows(src: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
+    """src[index] for a contiguous tensor whose rows are a multiple of 4 bytes."""
+    src = src.contiguous()
+    m = index.numel()
+    row_bytes = (src.numel() // max(src.shape[0], 1)) * src.element_size() if src.shape[0] else 0
+    out = torch.empty((m,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    if m == 0:
+        return out
+    if row_bytes % 4 != 0:            # bool / uint8 rows: widen, gather, narrow
+        return gather_rows(src.to(torch.int32), index).to(src.dtype)
+    nv.check(nv.lib().g2pc_gather_rows(nv.ptr(src), nv.ptr(index.contiguous()), m, row_bytes, nv.ptr(out),
+                                       nv.stream_handle(src.device)), "gather_rows")
+    return out
 
 
 def validate_covariances_(cov: torch.Tensor, regularise: bool = True, reg_eps: float = 5e-7, eps: float = 1e-7,
@@ -142,12 +189,31 @@ WAVE_MODE_MIN_DRAWS = 32   # quota-1 at and above which one Gaussian is sampled 
 ATTEMPT_CHUNK = 8
 
 
+def mahalanobis(means: torch.Tensor, samples: torch.Tensor, covs: torch.Tensor) -> torch.Tensor:
+    m, s_, c = _f32c(means), _f32c(samples), _f32c(covs)
+    out = torch.empty((m.shape[0],), dtype=torch.float32, device=m.device)
+    nv.check(nv.lib().g2pc_mahalanobis(nv.ptr(m), nv.ptr(s_), nv.ptr(c), m.shape[0], nv.ptr(out),
+                                       nv.stream_handle(m.device)), "mahalanobis")
+    return out
+
+
+def sample_mvn(means: torch.Tensor, covs: torch.Tensor, n: int, seed: int, gid_base: int = 0,
+               attempt: int = 0) -> torch.Tensor:
+    m, c = _f32c(means), _f32c(covs)
+    out = torch.empty((n, m.shape[0], 3), dtype=torch.float32, device=m.device)
+    nv.check(nv.lib().g2pc_sample_mvn(nv.ptr(m), nv.ptr(c), m.shape[0], int(n), int(seed), int(gid_base),
+                                      int(attempt), nv.ptr(out), nv.stream_handle(m.device)), "sample_mvn")
+    return out
+
+
 def sample_pointcloud(xyz: torch.Tensor, cov: torch.Tensor, colours: torch.Tensor,
                       normals: Optional[torch.Tensor], ppg_i32: torch.Tensor, max_ppg: int, *, exact: bool,
-                      std: float, attempts: int, seed: int, gid_base: int = 0,
-                      want_index: bool = False) -> SampledCloud:
+                      std: float, attempts: int, seed: int, gid_base: int = 0, want_index: bool = False,
+                      bins: Optional[list] = None, emit_means: bool = True) -> SampledCloud:
     """The bin loop of generate_pointcloud (gauss_to_pc.py:308-371) + create_new_gaussian_points
-    (gauss_to_pc.py:157-275) for all bins at once, in the reference's output order."""
+    (gauss_to_pc.py:157-275) for all bins at once, in the reference's output order.
+    `bins` overrides the bin table ((start, end, quota) triples); emit_means=False drops the centre points
+    (create_new_gaussian_points on its own)."""
     L = nv.lib()
     dev = xyz.device
     st = nv.stream_handle(dev)
@@ -156,7 +222,8 @@ def sample_pointcloud(xyz: torch.Tensor, cov: torch.Tensor, colours: torch.Tenso
     G = xyz.shape[0]
 
     hist = bincount(ppg_i32, int(max_ppg) + 1).cpu().numpy().astype(np.int64)          # sync #1
-    bins = bin_table_from_hist(hist, exact)
+    if bins is None:
+        bins = bin_table_from_hist(hist, exact)
     B = len(bins)
     lut = np.full((int(max_ppg) + 1,), -1, dtype=np.int32)
     quota = np.zeros((max(B, 1),), dtype=np.int32)
@@ -199,9 +266,10 @@ def sample_pointcloud(xyz: torch.Tensor, cov: torch.Tensor, colours: torch.Tenso
         dcount = torch.empty((na, gv), dtype=torch.int32, device=dev)
         dscan = torch.empty((na, gv + 1), dtype=torch.int32, device=dev)
         remaining.zero_()
-        nv.check(L.g2pc_sampler_count(nv.ptr(xyz), nv.ptr(cov), nv.ptr(perm), nv.ptr(pbin), nv.ptr(quota_d), gv,
-                                      p_wave, float(std), a0, na, int(seed), int(gid_base), nv.ptr(added),
-                                      nv.ptr(dcount), nv.ptr(remaining), st), "sampler_count")
+        with nv.region("sampler_count", dev):
+            nv.check(L.g2pc_sampler_count(nv.ptr(xyz), nv.ptr(cov), nv.ptr(perm), nv.ptr(pbin), nv.ptr(quota_d), gv,
+                                          p_wave, float(std), a0, na, int(seed), int(gid_base), nv.ptr(added),
+                                          nv.ptr(dcount), nv.ptr(remaining), st), "sampler_count")
         for a in range(na):
             nv.check(L.g2pc_scan_exclusive_u32(nv.ptr(dcount[a]), nv.ptr(dscan[a]), gv, nv.ptr(scan_ws), scan_bytes,
                                                st), "scan")
@@ -218,7 +286,7 @@ def sample_pointcloud(xyz: torch.Tensor, cov: torch.Tensor, colours: torch.Tenso
     A_used = len(sec_cols)
     sec_sizes = np.zeros((max(B, 1), 1 + A_used), dtype=np.int64)
     for b in range(B):
-        sec_sizes[b, 0] = members[b] if quota[b] > 0 else 0
+        sec_sizes[b, 0] = members[b] if (quota[b] > 0 and emit_means) else 0
     for a in range(A_used):
         sec_sizes[:B, 1 + a] = sec_cols[a]
     flat = sec_sizes[:B].reshape(-1)
@@ -237,10 +305,11 @@ def sample_pointcloud(xyz: torch.Tensor, cov: torch.Tensor, colours: torch.Tenso
                   nv.ptr(bin_start), nv.ptr(quota_d), gv, p_wave, B)
         if not chunks:
             nv.check(L.g2pc_sampler_emit(*common, 0, 0, 1 + A_used, int(seed), int(gid_base), None, None,
-                                         nv.ptr(sec_base), 1, nv.ptr(pts), nv.ptr(cols), nv.ptr(nrm), nv.ptr(gidx),
-                                         st), "sampler_emit")
+                                         nv.ptr(sec_base), 1 if emit_means else 0, nv.ptr(pts), nv.ptr(cols),
+                                         nv.ptr(nrm), nv.ptr(gidx), st), "sampler_emit")
         for ci, (c0, na, dcount, dscan) in enumerate(chunks):
-            nv.check(L.g2pc_sampler_emit(*common, c0, na, 1 + A_used, int(seed), int(gid_base), nv.ptr(dcount),
-                                         nv.ptr(dscan), nv.ptr(sec_base), 1 if ci == 0 else 0, nv.ptr(pts),
-                                         nv.ptr(cols), nv.ptr(nrm), nv.ptr(gidx), st), "sampler_emit")
+            with nv.region("sampler_emit", dev):
+                nv.check(L.g2pc_sampler_emit(*common, c0, na, 1 + A_used, int(seed), int(gid_base), nv.ptr(dcount),
+                                             nv.ptr(dscan), nv.ptr(sec_base), 1 if (ci == 0 and emit_means) else 0,
+                                             nv.ptr(pts), nv.ptr(cols), nv.ptr(nrm), nv.ptr(gidx), st), "sampler_emit")
     return SampledCloud(pts, cols, nrm, gidx, bins, [int(c.sum()) for c in sec_cols])

@@ -1,0 +1,170 @@
+"""
+Drop-in mirror of the reference's ``gauss_handler.py`` (same public names, arguments and results) whose
+arithmetic runs in libg2pc.so on the MI355X.  Reference lines are cited per function
+(``gauss_handler.py:NN`` = /root/reference/gauss_handler.py).
+
+Differences that are deliberate and documented in DESIGN.md:
+  * device-agnostic (tensors stay on the device they arrive on; the reference hard-codes "cuda");
+  * eigen tests use closed-form fp64 eigenvalues instead of LAPACK's general ``eigvals``;
+  * ``cull_large_gaussians`` implements the documented intent (keep the smallest fraction); the
+    reference's version ANDs a bool mask with an index tensor (gauss_handler.py:248-250) and cannot run.
+"""
+from math import floor
+
+import torch
+
+from g2pc import ops
+
+
+def strip_lowerdiag(L):
+    """gauss_handler.py:12-21 -- (xx, xy, xz, yy, yz, zz) of a batch of 3x3 matrices (pure data movement)."""
+    idx = torch.tensor([0, 1, 2, 4, 5, 8], device=L.device)
+    return L.reshape(L.shape[0], 9).index_select(1, idx).to(torch.float)
+
+
+def strip_symmetric(sym):
+    """gauss_handler.py:23-24."""
+    return strip_lowerdiag(sym)
+
+
+def build_rotation(q):
+    """gauss_handler.py:26-47 -- quaternion (r,x,y,z), used as given (no normalisation)."""
+    zeros = torch.zeros((q.shape[0], 3), dtype=torch.float32, device=q.device)
+    return ops.build_covariances(zeros, q, 1.0, want_rotmat=True)[3]
+
+
+def build_scaling_rotation(s, r):
+    """gauss_handler.py:49-58 -- L = R diag(exp(s)); the reference's scales are log-space."""
+    R = build_rotation(r)
+    return R * torch.exp(s.to(torch.float32)).unsqueeze(1)
+
+
+def build_covariance_from_scaling_rotation(scaling, scaling_modifier, rotation):
+    """gauss_handler.py:60-63 -- Sigma = L L^T in one fused HIP pass."""
+    return ops.build_covariances(scaling, rotation, scaling_modifier)[0]
+
+
+class Gaussians():
+    """
+    Manages all loaded gaussians in the renderer (gauss_handler.py:65-279)
+    """
+
+    def __init__(self, xyz, scales, rots, colours, opacities, shs=None):
+        self.xyz = xyz
+        self.scales = scales
+        self.rots = rots
+        self.opacities = opacities
+        self.colours = colours
+        self.shs = shs
+        self.normals = None
+
+        self.scaling_modifier = 1.0
+
+        # 3D covariance matrices and (same pass, kept for calculate_normals) the normals
+        self.covariances, _, self._normals_from_build = ops.build_covariances(
+            scales, rots, self.scaling_modifier, want_normals=True)
+
+        self.set_default_filter()
+
+    def set_default_filter(self):
+        self.filter_indices = torch.full((self.xyz.shape[0],), True, dtype=torch.bool, device=self.xyz.device)
+
+    def calculate_normals(self):
+        """gauss_handler.py:89-106 -- the axis of the smallest scale, rotated by R."""
+        if self._normals_from_build is None or self._normals_from_build.shape[0] != self.xyz.shape[0]:
+            self._normals_from_build = ops.build_covariances(self.scales, self.rots, 1.0, want_normals=True)[2]
+        self.normals = self._normals_from_build
+
+    def non_posdef_covariances(self, covariances, epsilon: float = 1e-10):
+        """gauss_handler.py:108-112 -- mask of matrices with an eigenvalue <= epsilon."""
+        probe = covariances.to(torch.float32).contiguous().clone()
+        keep = ops.validate_covariances_(probe, regularise=False, eps=epsilon, min_eps=epsilon, iters=0)
+        return ~keep
+
+    def clamp_covariances(self, covariances, mask=None, epsilon=1e-6):
+        """gauss_handler.py:114-127 -- clamp eigenvalues to >= epsilon (one round), in place on the masked rows."""
+        work = covariances.to(torch.float32).contiguous().clone()
+        ops.validate_covariances_(work, regularise=False, eps=epsilon, min_eps=epsilon, iters=1)
+        if mask is None:
+            covariances[:] = work
+        else:
+            covariances[mask] = work[mask]
+        return covariances
+
+    def regularise_covariances(self, covariances, mask=None, epsilon=5e-7):
+        """gauss_handler.py:129-140 -- Sigma += epsilon * I."""
+        eye = epsilon * torch.eye(3, device=covariances.device, dtype=covariances.dtype)
+        if mask is None:
+            covariances += eye
+        else:
+            covariances[mask] += eye
+        return covariances
+
+    def validate_covariances(self, regularise=True, epsilon=1e-7, min_ps_epsilon=1e-8, num_clamp_iters=3):
+        """gauss_handler.py:142-166 -- one fused kernel: regularise, up to num_clamp_iters clamp rounds,
+        final test; culls what is still not positive definite and returns the keep mask."""
+        cov = self.covariances.to(torch.float32).contiguous()
+        keep = ops.validate_covariances_(cov, regularise=regularise, reg_eps=5e-7, eps=epsilon,
+                                         min_eps=min_ps_epsilon, iters=num_clamp_iters)
+        self.covariances = cov
+        if bool((~keep).any()):
+            self.add_gaussians_to_cull(keep)
+            self.filter_gaussians()
+        return keep
+
+    def add_gaussians_to_cull(self, indices_to_cull):
+        self.filter_indices = self.filter_indices & indices_to_cull
+
+    def filter_gaussians(self):
+        """gauss_handler.py:171-193 -- stream compaction (scan + row gathers in HIP)."""
+        filter_indices = torch.clone(self.filter_indices)
+        index = ops.compact_index(filter_indices)
+
+        self.xyz = ops.gather_rows(self.xyz, index)
+        self.scales = ops.gather_rows(self.scales, index)
+        self.rots = ops.gather_rows(self.rots, index)
+        self.colours = ops.gather_rows(self.colours, index)
+        self.opacities = ops.gather_rows(self.opacities, index)
+        self.covariances = ops.gather_rows(self.covariances, index)
+
+        if self.shs is not None:
+            self.shs = ops.gather_rows(self.shs, index)
+
+        if self.normals is not None:
+            self.normals = ops.gather_rows(self.normals, index)
+        self._normals_from_build = self.normals
+
+        self.set_default_filter()
+
+        return filter_indices
+
+    def apply_min_opacity(self, min_opacity):
+        """gauss_handler.py:195-204."""
+        if min_opacity > 0.0:
+            m = self.filter_indices.to(torch.uint8)
+            ops.cull_mask_(m, None, self.opacities, min_opacity, None, None)
+            self.filter_indices = m.to(torch.bool)
+
+    def apply_bounding_box(self, bounding_box_min, bounding_box_max):
+        """gauss_handler.py:206-224 -- strict inequalities on xyz."""
+        if bounding_box_min is None and bounding_box_max is None:
+            return
+        m = self.filter_indices.to(torch.uint8)
+        ops.cull_mask_(m, self.xyz, None, None, bounding_box_min, bounding_box_max)
+        self.filter_indices = m.to(torch.bool)
+
+    def cull_large_gaussians(self, cull_gauss_size_percent):
+        """gauss_handler.py:235-250 (intent: drop the largest `cull_gauss_size_percent` of the Gaussians)."""
+        if cull_gauss_size_percent > 0.0:
+            gaussian_sizes = self.get_gaussian_magnitudes()
+            cull_index = floor(gaussian_sizes.shape[0] * (1 - cull_gauss_size_percent))
+            sorted_sizes, sorted_indices = torch.sort(gaussian_sizes)
+            keep = torch.zeros_like(self.filter_indices)
+            keep[sorted_indices[:cull_index]] = True
+            self.filter_indices = self.filter_indices & keep
+
+    def get_gaussian_magnitudes(self, contributions=None):
+        """gauss_handler.py:252-279 -- sqrt(ellipsoid area) x (contributions or opacities), float64."""
+        if contributions is None:
+            contributions = self.opacities
+        return ops.gaussian_magnitudes(self.covariances, contributions)

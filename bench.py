@@ -1,0 +1,192 @@
+#!/usr/bin/env python
+"""
+bench.py -- coloured points / second of the 3DGS -> point-cloud hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload render|sample] [--no-cpu-baseline]
+
+A "step" is one whole pass of the hot path over one synthetic scene whose inputs (xyz, log-scales, rotations,
+opacities, colours) are already resident in HBM when the timed region starts:
+  render (BASELINE.json configs[2], the configuration the metric is quoted on):
+      covariances+normals -> 50 cameras x (preprocess, depth sort, tile binning, blend + visibility) ->
+      colours / cull / filter -> validate -> magnitudes -> distribute -> sample 10M points
+  sample (configs[1]): covariances+normals -> validate -> magnitudes(opacity) -> distribute -> sample 10M points
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), launched by torch.distributed.run.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "3dgs-to-pc_amd"), os.path.join(ROOT, "oracle"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=None, choices=[None, "render", "sample"])
+    ap.add_argument("--gaussians", type=int, default=1_000_000)
+    ap.add_argument("--points", type=int, default=10_000_000)
+    ap.add_argument("--cameras", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def have_renderer():
+    try:
+        import gauss_render
+        return hasattr(gauss_render, "GaussHipRenderer")
+    except Exception:
+        return False
+
+
+def settings(workload, num_points, device):
+    from gauss_to_pc import GaussPointCloudSettings
+    return GaussPointCloudSettings(
+        renderer_type="python", num_points=num_points, prioritise_visible_gaussians=True,
+        mahalanobis_distance_std=2.0, camera_skip_rate=0, render_colours=(workload == "render"), min_opacity=0.0,
+        bounding_box_min=None, bounding_box_max=None, calculate_normals=True, cull_large_percentage=0.0,
+        remove_unrendered_gaussians=True, colour_resolution=1280, max_sh_degree=3, exact_num_points=False,
+        visibility_threshold=0.05, surface_distance_std=None, generate_mesh=False, quiet=True, device=str(device))
+
+
+def one_step(scene, cams, workload, num_points, device, seed):
+    """One pass of the hot path; returns the number of coloured points produced."""
+    from gauss_handler import Gaussians
+    from gauss_to_pc import convert_gaussians_to_pc
+    g = Gaussians(scene.xyz, scene.scales, scene.rots, scene.colours.clone(), scene.opacities)
+    transforms, intr = cams if cams is not None else (None, None)
+    cloud, _ = convert_gaussians_to_pc(g, transforms, intr, None, settings(workload, num_points, device), seed=seed)
+    return cloud.points.shape[0]
+
+
+def algorithmic_bytes(workload, n, n_kept, m, cams, stats):
+    """B_geom = 116 N; B_samp = 56 N_kept + 36 M; B_cam = 156 N + (76 + 24 p) L + 32 W H."""
+    b = 116.0 * n + 56.0 * n_kept + 36.0 * m
+    if workload == "render":
+        for (L, p, wh) in stats:
+            b += 156.0 * n + (76.0 + 24.0 * p) * L + 32.0 * wh
+    return b
+
+
+def cpu_baseline(workload):
+    """The oracle (CPU restatement of the reference, `kind: port`) on a bounded sample of the same workload."""
+    import ref_gauss as RG
+    from np_philox import keyed_normals
+    from g2pc.synth import make_scene
+    n, pts = 20_000, 200_000
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    sc = make_scene(n, 1234 + 2)
+    t0 = time.perf_counter()
+    cov = RG.covariances(sc.scales, sc.rots)
+    nrm = RG.normals(sc.scales, sc.rots)
+    cov, keep = RG.validate_covariances(cov)
+    out = RG.generate_pointcloud(sc.xyz, cov, sc.colours * 255, nrm, sc.opacities, pts, std=2.0, exact=False,
+                                 attempts=5,
+                                 eps_fn=lambda gids, a, k: keyed_normals(7, gids[:, None], a, np.arange(k)[None, :]))
+    dt = time.perf_counter() - t0
+    return {"value": out["points"].shape[0] / dt, "unit": "points/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": "oracle/ref_gauss.py sampler pipeline (cov, validate, magnitudes, distribute, sample) on "
+                      "%d Gaussians -> %d points, no rendering, %.1f s" % (n, out["points"].shape[0], dt)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (run it through gpurun)"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+    from g2pc import _native as nv
+    from g2pc.synth import make_scene, make_cameras
+    nv.lib()
+    workload = a.workload or ("render" if have_renderer() else "sample")
+
+    # weak scaling: every rank owns a full configs[1]/[2] sized shard (its own Gaussians and point budget)
+    scene = make_scene(a.gaussians, 1234 + 3 + rank, device=device)
+    cams = make_cameras(a.cameras) if workload == "render" else None
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(a.warmup):
+        one_step(scene, cams, workload, a.points, device, seed=100 + w)
+    nv.PROFILE = {}
+    sync()
+    t0 = time.perf_counter()
+    points = 0
+    for k in range(a.steps):
+        points += one_step(scene, cams, workload, a.points, device, seed=200 + k)
+    sync()
+    dt = time.perf_counter() - t0
+    prof = nv.profile_summary()
+    nv.PROFILE = None
+
+    tot = torch.tensor([float(points), dt], dtype=torch.float64, device=device)
+    if world > 1:
+        import torch.distributed as dist
+        pts_all = tot[0:1].clone()
+        dist.all_reduce(pts_all, op=dist.ReduceOp.SUM)
+        t_all = tot[1:2].clone()
+        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+        points_all, dt_all = float(pts_all), float(t_all)
+    else:
+        points_all, dt_all = float(points), dt
+
+    if rank != 0:
+        return
+    # dominant kernel: the region with the largest device time
+    dom = max(prof.items(), key=lambda kv: kv[1][1]) if prof else None
+    roof = None
+    if dom is not None:
+        name, (launches, ms) = dom
+        m_step = points / max(a.steps, 1)
+        per_launch = {"sampler_emit": 56.0 * a.gaussians + 36.0 * m_step,          # read Gaussians, write the cloud
+                      "sampler_count": 56.0 * a.gaussians + 4.0 * 5 * a.gaussians}.get(name)
+        extra = getattr(nv, "REGION_BYTES", {}).get(name)
+        if extra is not None:
+            per_launch = extra
+        if per_launch is not None and ms > 0:
+            ach = per_launch / (ms / launches * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ms / launches,
+                    "algorithmic_bytes_per_launch": per_launch}
+    out = {
+        "metric": "coloured points/sec", "value": points_all / dt_all, "unit": "points/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt_all / a.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": ("configs[2]: 1M Gaussians, 50 cameras 1280x720, 10M points, python-renderer semantics"
+                                if workload == "render" else
+                                "configs[1]: 1M Gaussians, no_render_colours, 10M points (sampling pipeline)"),
+                   "gaussians_per_gpu": a.gaussians, "points_per_gpu": a.points,
+                   "cameras": a.cameras if workload == "render" else 0, "parallelism": "shard-by-gaussian x%d" % world},
+        "roofline": roof,
+        "regions_ms_per_step": {k: v[1] / a.steps for k, v in sorted(prof.items())},
+    }
+    if not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(workload)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

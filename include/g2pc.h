@@ -53,9 +53,9 @@ int g2pc_sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32
 /* build_covariance_from_scaling_rotation (gauss_handler.py:26-63) fused with calculate_normals
  * (gauss_handler.py:89-106).  log_scales f32[n,3], rots f32[n,4] (r,x,y,z; NOT normalised, as in the
  * reference).  cov9 f32[n,3,3] out; cov6 f32[n,6] (xx,xy,xz,yy,yz,zz; strip_symmetric
- * gauss_handler.py:12-24) and normals f32[n,3] are optional (NULL to skip). */
+ * gauss_handler.py:12-24), normals f32[n,3] and rotmat f32[n,3,3] (build_rotation) are optional (NULL to skip). */
 int g2pc_build_covariances(const float* log_scales, const float* rots, float scaling_modifier, int64_t n,
-                           float* cov9, float* cov6, float* normals, void* stream);
+                           float* cov9, float* cov6, float* normals, float* rotmat, void* stream);
 
 /* validate_covariances (gauss_handler.py:108-166): in-place regularise (+reg_eps*I when regularise),
  * `iters` rounds of {min eig <= eps -> clamp eigenvalues to eps and recompose}, then
@@ -66,6 +66,18 @@ int g2pc_validate_covariances(float* cov9, int64_t n, int regularise, float reg_
 /* get_gaussian_magnitudes (gauss_handler.py:252-279): Knud-Thomsen ellipsoid area from the eigenvalues,
  * sqrt, times weights (contributions or opacities) -> f64[n]. */
 int g2pc_gaussian_magnitudes(const float* cov9, const float* weights, int64_t n, double* sizes, void* stream);
+
+/* apply_min_opacity + apply_bounding_box (gauss_handler.py:195-224): mask[i] &= opacity > min (when
+ * use_min_opacity) & strict box tests (bbox_min / bbox_max are HOST float[3] or NULL).  mask u8[n] in/out. */
+int g2pc_cull_mask(const float* xyz, const float* opacities, int64_t n, int use_min_opacity, float min_opacity,
+                   const float* bbox_min, const float* bbox_max, uint8_t* mask, void* stream);
+
+/* filter_gaussians (gauss_handler.py:171-193) = stream compaction: index u32[<=n] of the set mask entries in
+ * ascending order, count u32[1] (device); then gather whole rows (row_bytes multiple of 4) per tensor. */
+size_t g2pc_compact_workspace(int64_t n);
+int g2pc_compact_index(const uint8_t* mask, int64_t n, uint32_t* index, uint32_t* count, void* ws, size_t ws_bytes,
+                       void* stream);
+int g2pc_gather_rows(const void* src, const uint32_t* index, int64_t m, int32_t row_bytes, void* dst, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Point allocation (gauss_to_pc.py:73-138)
@@ -117,6 +129,15 @@ int g2pc_sampler_emit(const float* means, const float* cov9, const float* colour
                       int32_t sec_stride, uint64_t seed, uint64_t gid_base, const uint32_t* dcount,
                       const uint32_t* dscan, const int64_t* sec_base, int emit_means, float* out_points,
                       float* out_colours, float* out_normals, int32_t* out_gauss, void* stream);
+
+/* mahalanobis() (gauss_to_pc.py:92-103): out[i] = sqrt(d^T inv(cov_i) d), d = means_i - samples_i; NaN when the
+ * quadratic form is negative (the caller's `<=` then rejects, as in the reference). */
+int g2pc_mahalanobis(const float* means, const float* samples, const float* cov9, int64_t n, float* out,
+                     void* stream);
+/* sample_from_multivariate_normal (gauss_to_pc.py:140-155): out f32[n, g, 3] (sample-major like
+ * MultivariateNormal.sample((n,))) = mean + chol(cov) eps(seed, gid_base + g, attempt, k). */
+int g2pc_sample_mvn(const float* means, const float* cov9, int64_t g, int32_t n, uint64_t seed, uint64_t gid_base,
+                    int32_t attempt, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -182,11 +182,12 @@ def sample_bin(gids, means, covs, n, std, attempts, eps_fn):
 
 
 def generate_pointcloud(xyz, covs, colours, normals_, weights, num_points, std=2.0, exact=False,
-                        attempts=5, eps_fn=None):
+                        attempts=5, eps_fn=None, ppg=None):
     """gauss_to_pc.py:277-371.  Returns dict(points f32, colours, normals, gauss_index int64,
     ppg int32, bins)."""
-    sizes = magnitudes(covs, weights)
-    ppg = distribute_points(sizes, num_points).to(torch.int32)
+    if ppg is None:          # `ppg` given: check the sampling alone on a fixed allocation
+        sizes = magnitudes(covs, weights)
+        ppg = distribute_points(sizes, num_points).to(torch.int32)
     bins = bin_table(ppg, exact)
     P, C, Nn, I = [], [], [], []
     for (s, e, n) in bins:
