@@ -1,0 +1,462 @@
+// Tile-binned splat rasteriser with per-Gaussian visibility accumulation (gfx950, wave64).
+//
+// Semantics "PY" = the reference's pure-torch renderer (the parity target named by BASELINE north_star):
+//   gauss_render.py:101-148 build_covariance_2d, :151-168 projection_ndc, :171-193 get_radius/get_rect,
+//   :266-402 GaussPythonRenderer.render (quad-tree leaf tiles, strict rect overlap, depth order, alpha
+//   clip 0.99 with NO cut-offs, T = cumprod, per-Gaussian max of T*alpha over a tile and arg-max pixel,
+//   strict-> running update of the contribution and of the colour = that tile's pixel colour).
+// Kernel structure = the reference's native rasteriser re-designed for CDNA4:
+//   preprocess (forward.cu:153-271) -> DEPTH sort of the N Gaussians (4 radix passes over N) -> duplicate in
+//   depth order (rasterizer_impl.cu:69-110) -> stable sort of the L instances by TILE id only (2 passes over L,
+//   instead of the reference's 6 passes over 64-bit keys, rasterizer_impl.cu:311-316) -> per-tile ranges ->
+//   blend (forward.cu:303-497) with LDS-staged batches, 4 pixels per lane and wave64 reductions feeding a
+//   packed 64-bit (contribution bits << 32 | ~order) atomicMax, which makes the cross-tile / cross-camera
+//   arg-max exact and deterministic (the reference's CUDA kernel races here, SURVEY.md §2.2 defect 3).
+#include "g2pc_internal.h"
+
+namespace g2pc {
+
+constexpr int RA_T = 256;
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct Cam {            // device copy of G2pcCamera (passed by value as kernel argument)
+    float V[16];
+    float P[16];
+    float tan_fovx, tan_fovy, focal_x, focal_y;
+    int W, H;
+    float bg[3];
+};
+
+struct Layout {         // device pointers of G2pcTileLayout
+    int nx, ny;
+    const int32_t *xs, *ws, *ys, *hs;
+    const int32_t *tile_seq, *seq_tile, *tile_pix_off;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// K1 (PY): per Gaussian projection, EWA covariance, conic, radius, pixel rect -> tile index ranges.
+// Writes the depth-sort input in REVERSED index order so that the stable ascending radix sort leaves equal
+// depths in descending index order = torch.sort (stable on CPU) followed by flip (gauss_render.py:340-342).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void interval_range(const int32_t* __restrict__ start, const int32_t* __restrict__ size,
+                                               int n, float rmin, float rmax, int& i0, int& i1) {
+    i0 = n; i1 = -1;
+    for (int i = 0; i < n; ++i) {
+        float lo = (float)start[i], hi = (float)(start[i] + size[i] - 1);
+        float tl = rmin > lo ? rmin : lo;        // rect_min.clip(min = tile start)
+        float br = rmax < hi ? rmax : hi;        // rect_max.clip(max = tile end)
+        if (br > tl) { if (i < i0) i0 = i; i1 = i; }
+    }
+}
+
+__global__ __launch_bounds__(RA_T) void k_preprocess_py(Cam cam, Layout lay, const float* __restrict__ means3D,
+                                                       const float* __restrict__ cov9,
+                                                       const float* __restrict__ opacity, long n,
+                                                       uint32_t* __restrict__ depth_key_rev,
+                                                       uint32_t* __restrict__ index_rev,
+                                                       uint32_t* __restrict__ tiles_touched,
+                                                       float4* __restrict__ p0, float4* __restrict__ p1,
+                                                       uint32_t* __restrict__ rect) {
+    long i = (long)blockIdx.x * RA_T + threadIdx.x;
+    if (i >= n) return;
+    const float x = means3D[3 * i], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
+    const float* V = cam.V;
+    // p_view = [x,1] @ V  (gauss_render.py:163)
+    float pv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pv[j] = x * V[0 + j] + y * V[4 + j] + z * V[8 + j] + V[12 + j];
+    const bool in_mask = pv[2] <= -0.000001f;                       // :167
+    uint32_t key = 0xFFFFFFFFu, touched = 0, rc = 0;
+    if (in_mask) {
+        // t = mean @ V[:3,:3] + V[3,:3]  (:125)
+        float t0 = (x * V[0] + y * V[4] + z * V[8]) + V[12];
+        float t1 = (x * V[1] + y * V[5] + z * V[9]) + V[13];
+        float t2 = (x * V[2] + y * V[6] + z * V[10]) + V[14];
+        float limx = cam.tan_fovx * 1.3f, limy = cam.tan_fovy * 1.3f;
+        float qx = t0 / t2, qy = t1 / t2;
+        qx = qx < -limx ? -limx : (qx > limx ? limx : qx);
+        qy = qy < -limy ? -limy : (qy > limy ? limy : qy);
+        float tx = qx * t2, ty = qy * t2, tz = t2;
+        // J (:134-138), W = V[:3,:3]^T; cov2d = J W S W^T J^T evaluated left to right (:144)
+        float j00 = 1.0f / tz * cam.focal_x, j02 = -tx / (tz * tz) * cam.focal_x;
+        float j11 = 1.0f / tz * cam.focal_y, j12 = -ty / (tz * tz) * cam.focal_y;
+        // M = J @ W : rows 0,1 (W[k][c] = V[c][k] -> W row k = column k of V)
+        float M0[3], M1[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            M0[c] = j00 * V[4 * c + 0] + j02 * V[4 * c + 2];
+            M1[c] = j11 * V[4 * c + 1] + j12 * V[4 * c + 2];
+        }
+        const float* S = cov9 + 9 * i;
+        float A0[3], A1[3];                                          // (J W) @ Sigma
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            A0[c] = M0[0] * S[0 + c] + M0[1] * S[3 + c] + M0[2] * S[6 + c];
+            A1[c] = M1[0] * S[0 + c] + M1[1] * S[3 + c] + M1[2] * S[6 + c];
+        }
+        float B0[3], B1[3];                                          // ... @ W^T  (W^T[k][c] = V[k][c])
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            B0[c] = A0[0] * V[0 + c] + A0[1] * V[4 + c] + A0[2] * V[8 + c];
+            B1[c] = A1[0] * V[0 + c] + A1[1] * V[4 + c] + A1[2] * V[8 + c];
+        }
+        // ... @ J^T : J^T[k][c] = J[c][k]
+        float c00 = B0[0] * j00 + B0[2] * j02 + 0.3f;
+        float c01 = B0[1] * j11 + B0[2] * j12;
+        float c10 = B1[0] * j00 + B1[2] * j02;
+        float c11 = B1[1] * j11 + B1[2] * j12 + 0.3f;
+        // projection (:160-163)
+        const float* P = cam.P;
+        float ph0 = pv[0] * P[0] + pv[1] * P[4] + pv[2] * P[8] + pv[3] * P[12];
+        float ph1 = pv[0] * P[1] + pv[1] * P[5] + pv[2] * P[9] + pv[3] * P[13];
+        float ph3 = pv[0] * P[3] + pv[1] * P[7] + pv[2] * P[11] + pv[3] * P[15];
+        float pw = 1.0f / (ph3 + 0.000001f);
+        float ndx = ph0 * pw, ndy = ph1 * pw;
+        float mx = ((ndx + 1.0f) * (float)cam.W - 1.0f) * 0.5f;        // gauss_render.py:435-436
+        float my = ((ndy + 1.0f) * (float)cam.H - 1.0f) * 0.5f;
+        // radius (:171-180) and rect (:182-193)
+        float det = c00 * c11 - c01 * c10;
+        float mid = 0.5f * (c00 + c11);
+        float disc = mid * mid - det;
+        disc = disc < 0.1f ? 0.1f : disc;
+        float sq = sqrtf(disc);
+        float l1 = mid + sq, l2 = mid - sq;
+        float radius = 3.0f * ceilf(sqrtf(l1 > l2 ? l1 : l2));
+        float wmax = (float)cam.W - 1.0f, hmax = (float)cam.H - 1.0f;
+        float rminx = fminf(fmaxf(mx - radius, 0.0f), wmax), rmaxx = fminf(fmaxf(mx + radius, 0.0f), wmax);
+        float rminy = fminf(fmaxf(my - radius, 0.0f), hmax), rmaxy = fminf(fmaxf(my + radius, 0.0f), hmax);
+        int ix0, ix1, iy0, iy1;
+        interval_range(lay.xs, lay.ws, lay.nx, rminx, rmaxx, ix0, ix1);
+        interval_range(lay.ys, lay.hs, lay.ny, rminy, rmaxy, iy0, iy1);
+        // conic = inverse(cov2d) (:349); exponent pre-scaled for exp2:  w = exp(-0.5 q) = exp2(A dx^2 + C dy^2 + B dx dy)
+        float idet = 1.0f / det;
+        float k00 = c11 * idet, k11 = c00 * idet, k01 = -c01 * idet, k10 = -c10 * idet;
+        const float sc = -0.5f * LOG2E;
+        bool ok = (ix1 >= ix0) && (iy1 >= iy0) && (mx == mx) && (my == my) && (det == det);
+        if (ok) {
+            touched = (uint32_t)((ix1 - ix0 + 1) * (iy1 - iy0 + 1));
+            rc = (uint32_t)ix0 | ((uint32_t)ix1 << 8) | ((uint32_t)iy0 << 16) | ((uint32_t)iy1 << 24);
+            key = __float_as_uint(-pv[2]);                          // ascending = nearest first
+        }
+        p0[i] = make_float4(mx, my, sc * k00, sc * (k01 + k10));
+        p1[i] = make_float4(sc * k11, opacity[i], pv[2], radius);
+    }
+    const long r = n - 1 - i;
+    depth_key_rev[r] = key;
+    index_rev[r] = (uint32_t)i;
+    tiles_touched[i] = touched;
+    rect[i] = rc;
+}
+
+__global__ __launch_bounds__(RA_T) void k_gather_u32(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx,
+                                                    long n, uint32_t* __restrict__ dst) {
+    long i = (long)blockIdx.x * RA_T + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+
+// K3: one (tile, gaussian) instance per overlapped tile, emitted in depth order (rasterizer_impl.cu:69-110)
+__global__ __launch_bounds__(RA_T) void k_duplicate(const uint32_t* __restrict__ sorted_idx,
+                                                   const uint32_t* __restrict__ offsets,
+                                                   const uint32_t* __restrict__ rect, long n, int nx,
+                                                   uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ inst_g) {
+    long p = (long)blockIdx.x * RA_T + threadIdx.x;
+    if (p >= n) return;
+    uint32_t off = offsets[p], end = offsets[p + 1];
+    if (end == off) return;
+    uint32_t g = sorted_idx[p];
+    uint32_t rc = rect[g];
+    int ix0 = rc & 255, ix1 = (rc >> 8) & 255, iy0 = (rc >> 16) & 255, iy1 = rc >> 24;
+    for (int iy = iy0; iy <= iy1; ++iy)
+        for (int ix = ix0; ix <= ix1; ++ix) {
+            inst_tile[off] = (uint32_t)(iy * nx + ix);
+            inst_g[off] = g;
+            ++off;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K6 (PY): blend.  One block per (tile, 1024-pixel chunk); 256 lanes x 4 pixels; Gaussians staged through LDS
+// in batches of 256.  For every Gaussian the wave reduces (max T*alpha, lowest pixel among the maxima) and
+// lane 0 publishes  key = contribution_bits << 32 | ~(slot << 24 | tile_seq << 12 | pixel)  with one 64-bit
+// atomicMax -- but only when some lane can beat the value staged from the running maximum.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int BL_PPT = 4, BL_BATCH = 256;
+
+__global__ __launch_bounds__(RA_T) void k_blend_py(Layout lay, const int32_t* __restrict__ chunk_tile,
+                                                  const int32_t* __restrict__ chunk_pix0,
+                                                  const uint32_t* __restrict__ tile_start,
+                                                  const uint32_t* __restrict__ inst_g,
+                                                  const float4* __restrict__ p0, const float4* __restrict__ p1,
+                                                  const float* __restrict__ colours,
+                                                  unsigned long long* __restrict__ best_key, uint32_t order_base,
+                                                  float t_floor, float bg, float* __restrict__ tilebuf) {
+    __shared__ float4 s_p0[BL_BATCH];
+    __shared__ float4 s_p1[BL_BATCH];
+    __shared__ float4 s_p2[BL_BATCH];
+    __shared__ uint32_t s_g[BL_BATCH];
+    const int tile = chunk_tile[blockIdx.x];
+    const int pix0 = chunk_pix0[blockIdx.x];
+    const int ix = tile % lay.nx, iy = tile / lay.nx;
+    const int x0 = lay.xs[ix], w = lay.ws[ix], y0 = lay.ys[iy], h = lay.hs[iy];
+    const int npix = w * h;
+    const uint32_t order_tile = order_base | ((uint32_t)lay.tile_seq[tile] << 12);
+    const unsigned lane = threadIdx.x & 63;
+
+    int pix[BL_PPT];
+    float px[BL_PPT], py[BL_PPT], T[BL_PPT], cr[BL_PPT], cg[BL_PPT], cb[BL_PPT];
+#pragma unroll
+    for (int j = 0; j < BL_PPT; ++j) {
+        pix[j] = pix0 + j * RA_T + (int)threadIdx.x;
+        bool valid = pix[j] < npix;
+        int lx = valid ? pix[j] % w : 0, ly = valid ? pix[j] / w : 0;
+        px[j] = (float)(x0 + lx);
+        py[j] = (float)(y0 + ly);
+        T[j] = valid ? 1.0f : 0.0f;             // invalid slots never contribute (contribution = T * alpha = 0)
+        cr[j] = cg[j] = cb[j] = 0.0f;
+    }
+    const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
+    for (uint32_t b = start; b < end; b += BL_BATCH) {
+        __syncthreads();
+        if (b + threadIdx.x < end) {
+            uint32_t g = inst_g[b + threadIdx.x];
+            s_p0[threadIdx.x] = p0[g];
+            s_p1[threadIdx.x] = p1[g];
+            float gm = __uint_as_float((uint32_t)(best_key[g] >> 32));
+            s_p2[threadIdx.x] = make_float4(colours[3 * (size_t)g], colours[3 * (size_t)g + 1], colours[3 * (size_t)g + 2], gm);
+            s_g[threadIdx.x] = g;
+        }
+        __syncthreads();
+        const int cnt = (end - b) < (uint32_t)BL_BATCH ? (int)(end - b) : BL_BATCH;
+        for (int k = 0; k < cnt; ++k) {
+            const float4 a = s_p0[k], q = s_p1[k], c = s_p2[k];
+            float best = 0.0f;
+            uint32_t bestpix = 0xFFFFFFFFu;
+#pragma unroll
+            for (int j = 0; j < BL_PPT; ++j) {
+                float dx = px[j] - a.x, dy = py[j] - a.y;
+                float power = fmaf(a.z * dx, dx, fmaf(q.x * dy, dy, a.w * dx * dy));
+                float wgt = exp2f(power);
+                float alpha = fminf(wgt * q.y, 0.99f);
+                float contrib = T[j] * alpha;
+                cr[j] = fmaf(contrib, c.x, cr[j]);
+                cg[j] = fmaf(contrib, c.y, cg[j]);
+                cb[j] = fmaf(contrib, c.z, cb[j]);
+                T[j] -= contrib;
+                if (contrib > best) { best = contrib; bestpix = (uint32_t)pix[j]; }
+            }
+            const bool cand = (best > 0.0f) && (best >= c.w);
+            if (__any(cand)) {
+                uint32_t bits = __float_as_uint(best);
+                uint32_t m = wave_max_u32(bits);
+                uint32_t pm = wave_min_u32(bits == m ? bestpix : 0xFFFFFFFFu);
+                if (lane == 0) {
+                    unsigned long long key = ((unsigned long long)m << 32) | (unsigned long long)(uint32_t)(~(order_tile | pm));
+                    atomicMax(&best_key[s_g[k]], key);
+                }
+            }
+        }
+        if (t_floor > 0.0f) {
+            bool done = true;
+#pragma unroll
+            for (int j = 0; j < BL_PPT; ++j) done = done && (T[j] < t_floor);
+            if (__syncthreads_and(done ? 1 : 0)) break;
+        }
+    }
+    float* out = tilebuf + 3 * (size_t)lay.tile_pix_off[tile];
+#pragma unroll
+    for (int j = 0; j < BL_PPT; ++j) {
+        if (pix[j] < npix && pix[j] < pix0 + BL_PPT * RA_T) {
+            out[3 * (size_t)pix[j] + 0] = fmaf(T[j], bg, cr[j]);
+            out[3 * (size_t)pix[j] + 1] = fmaf(T[j], bg, cg[j]);
+            out[3 * (size_t)pix[j] + 2] = fmaf(T[j], bg, cb[j]);
+        }
+    }
+}
+
+// K7 (PY): running update of the per-Gaussian colour: Gaussians whose best key was set by this camera slot take
+// the colour of the winning (tile, pixel) from that tile's own rendered colours (gauss_render.py:387-395).
+__global__ __launch_bounds__(RA_T) void k_update_colours_py(Layout lay, const unsigned long long* __restrict__ best_key,
+                                                           long n, uint32_t slot, const float* __restrict__ tilebuf,
+                                                           float* __restrict__ colours_out) {
+    long i = (long)blockIdx.x * RA_T + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long key = best_key[i];
+    if ((key >> 32) == 0ull) return;
+    uint32_t order = ~(uint32_t)key;
+    if ((order >> 24) != slot) return;
+    int seq = (order >> 12) & 0xFFF, pix = order & 0xFFF;
+    int tile = lay.seq_tile[seq];
+    const float* src = tilebuf + 3 * ((size_t)lay.tile_pix_off[tile] + pix);
+    colours_out[3 * i + 0] = src[0];
+    colours_out[3 * i + 1] = src[1];
+    colours_out[3 * i + 2] = src[2];
+}
+
+// keys older than the current epoch: forget their order (order 0 = "earliest possible") but keep the value
+__global__ __launch_bounds__(RA_T) void k_rebase_keys(unsigned long long* __restrict__ best_key, long n) {
+    long i = (long)blockIdx.x * RA_T + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long key = best_key[i];
+    if ((key >> 32) != 0ull) best_key[i] = key | 0xFFFFFFFFull;
+}
+
+__global__ __launch_bounds__(RA_T) void k_contributions(const unsigned long long* __restrict__ best_key, long n,
+                                                       float* __restrict__ out) {
+    long i = (long)blockIdx.x * RA_T + threadIdx.x;
+    if (i < n) out[i] = __uint_as_float((uint32_t)(best_key[i] >> 32));
+}
+
+// image[y][W-1-x] = colour of the LAST tile (processing order) that covers pixel (x,y); flip = gauss_render.py:402
+__global__ __launch_bounds__(RA_T) void k_assemble_image_py(Layout lay, int W, int H, const float* __restrict__ tilebuf,
+                                                           float* __restrict__ image) {
+    long t = (long)blockIdx.x * RA_T + threadIdx.x;
+    if (t >= (long)W * H) return;
+    int x = (int)(t % W), y = (int)(t / W);
+    int bx[2], by[2], nbx = 0, nby = 0;
+    for (int i = 0; i < lay.nx && nbx < 2; ++i) if (x >= lay.xs[i] && x < lay.xs[i] + lay.ws[i]) bx[nbx++] = i;
+    for (int i = 0; i < lay.ny && nby < 2; ++i) if (y >= lay.ys[i] && y < lay.ys[i] + lay.hs[i]) by[nby++] = i;
+    int best_seq = -1, best_tile = -1;
+    for (int a = 0; a < nby; ++a)
+        for (int b = 0; b < nbx; ++b) {
+            int tile = by[a] * lay.nx + bx[b];
+            int s = lay.tile_seq[tile];
+            if (s > best_seq) { best_seq = s; best_tile = tile; }
+        }
+    float r = 1.0f, g = 1.0f, bl = 1.0f;          // torch.ones init (gauss_render.py:287)
+    if (best_tile >= 0) {
+        int ix = best_tile % lay.nx, iy = best_tile / lay.nx;
+        int lp = (y - lay.ys[iy]) * lay.ws[ix] + (x - lay.xs[ix]);
+        const float* src = tilebuf + 3 * ((size_t)lay.tile_pix_off[best_tile] + lp);
+        r = src[0]; g = src[1]; bl = src[2];
+    }
+    float* dst = image + 3 * ((size_t)y * W + (W - 1 - x));
+    dst[0] = r; dst[1] = g; dst[2] = bl;
+}
+
+static Cam to_cam(const G2pcCamera* c) {
+    Cam k;
+    for (int i = 0; i < 16; ++i) { k.V[i] = c->view[i]; k.P[i] = c->proj[i]; }
+    k.tan_fovx = c->tan_fovx; k.tan_fovy = c->tan_fovy; k.focal_x = c->focal_x; k.focal_y = c->focal_y;
+    k.W = c->width; k.H = c->height;
+    k.bg[0] = c->bg[0]; k.bg[1] = c->bg[1]; k.bg[2] = c->bg[2];
+    return k;
+}
+static Layout to_layout(const G2pcTileLayout* l) {
+    Layout k;
+    k.nx = l->nx; k.ny = l->ny; k.xs = l->xs; k.ws = l->ws; k.ys = l->ys; k.hs = l->hs;
+    k.tile_seq = l->tile_seq; k.seq_tile = l->seq_tile; k.tile_pix_off = l->tile_pix_off;
+    return k;
+}
+static int bits_for_tiles(unsigned t) { int b = 1; while ((1u << b) < t && b < 31) ++b; return b; }
+
+}  // namespace g2pc
+
+extern "C" {
+
+size_t g2pc_raster_front_workspace(int64_t n) {
+    using namespace g2pc;
+    return align_up((size_t)n * 4) * 6 + sort_workspace(n) + scan_workspace(n) + 4096;
+}
+
+// Front half of one camera: preprocess -> depth sort -> tiles-touched scan.  Leaves sorted_idx u32[n] and
+// offsets u32[n+1] (offsets[n] = L, the number of (tile, Gaussian) instances) for the back half.
+int g2pc_raster_front_py(const G2pcCamera* cam, const G2pcTileLayout* layout, const float* means3D, const float* cov9,
+                         const float* opacity, int64_t n, float* p0, float* p1, uint32_t* rect, uint32_t* sorted_idx,
+                         uint32_t* offsets, void* ws, size_t ws_bytes, void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(cam && layout && means3D && cov9 && opacity && p0 && p1 && rect && sorted_idx && offsets && ws && n > 0,
+                 G2PC_ERR_ARG, "bad arguments");
+    G2PC_REQUIRE(layout->nx <= 256 && layout->ny <= 256, G2PC_ERR_UNSUPPORTED, "more than 256 tile intervals per axis");
+    hipStream_t s = (hipStream_t)stream;
+    Arena ar(ws, ws_bytes);
+    uint32_t* key_rev = ar.get<uint32_t>((size_t)n);
+    uint32_t* idx_rev = ar.get<uint32_t>((size_t)n);
+    uint32_t* key_sorted = ar.get<uint32_t>((size_t)n);
+    uint32_t* ktmp = ar.get<uint32_t>((size_t)n);
+    uint32_t* vtmp = ar.get<uint32_t>((size_t)n);
+    uint32_t* touched = ar.get<uint32_t>((size_t)n);
+    size_t sort_bytes = sort_workspace(n), scan_bytes = scan_workspace(n);
+    char* sort_ws = ar.get<char>(sort_bytes);
+    char* scan_ws = ar.get<char>(scan_bytes);
+    G2PC_REQUIRE(ar.ok(), G2PC_ERR_WORKSPACE, "workspace too small");
+    hipLaunchKernelGGL(k_preprocess_py, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, to_cam(cam), to_layout(layout), means3D,
+                       cov9, opacity, (long)n, key_rev, idx_rev, touched, (float4*)p0, (float4*)p1, rect);
+    int rc = sort_pairs_u32(key_rev, idx_rev, key_sorted, sorted_idx, ktmp, vtmp, n, 0, 32, sort_ws, sort_bytes, s);
+    if (rc) return rc;
+    // tiles touched in depth order (ktmp reused as the gathered array)
+    hipLaunchKernelGGL(k_gather_u32, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, touched, sorted_idx, (long)n, ktmp);
+    rc = scan_exclusive_u32(ktmp, offsets, n, scan_ws, scan_bytes, s);
+    if (rc) return rc;
+    return check_launch("g2pc_raster_front_py");
+}
+
+size_t g2pc_raster_back_workspace(int64_t num_instances, int32_t num_tiles) {
+    using namespace g2pc;
+    return align_up((size_t)(num_instances + 1) * 4) * 4 + sort_workspace(num_instances) + scan_workspace(num_tiles + 1) +
+           align_up((size_t)(num_tiles + 2) * 4) + 4096;
+}
+
+// Back half: duplicate -> stable sort by tile id -> tile ranges -> blend + visibility -> colour update.
+int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, const float* colours, int64_t n,
+                        int64_t num_instances, const float* p0, const float* p1, const uint32_t* rect,
+                        const uint32_t* sorted_idx, const uint32_t* offsets, uint32_t camera_slot, float t_floor,
+                        unsigned long long* best_key, float* colours_out, float* tilebuf, float* image, void* ws,
+                        size_t ws_bytes, void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(cam && layout && colours && p0 && p1 && rect && sorted_idx && offsets && best_key && colours_out &&
+                     tilebuf && ws && n > 0,
+                 G2PC_ERR_ARG, "bad arguments");
+    G2PC_REQUIRE(camera_slot >= 1 && camera_slot <= 255, G2PC_ERR_ARG, "camera_slot must be in [1,255]");
+    const int T = layout->nx * layout->ny;
+    G2PC_REQUIRE(T <= 4096, G2PC_ERR_UNSUPPORTED, "more than 4096 tiles");
+    hipStream_t s = (hipStream_t)stream;
+    const long L = num_instances;
+    Arena ar(ws, ws_bytes);
+    uint32_t* inst_tile = ar.get<uint32_t>((size_t)L + 1);
+    uint32_t* inst_g = ar.get<uint32_t>((size_t)L + 1);
+    uint32_t* tile_sorted = ar.get<uint32_t>((size_t)L + 1);
+    uint32_t* g_sorted = ar.get<uint32_t>((size_t)L + 1);
+    uint32_t* tile_start = ar.get<uint32_t>((size_t)T + 2);
+    size_t sort_bytes = sort_workspace(L), scan_bytes = scan_workspace(T + 1);
+    char* sort_ws = ar.get<char>(sort_bytes);
+    char* scan_ws = ar.get<char>(scan_bytes);
+    G2PC_REQUIRE(ar.ok(), G2PC_ERR_WORKSPACE, "workspace too small");
+    Layout lay = to_layout(layout);
+    hipMemsetAsync(tile_start, 0, (size_t)(T + 2) * 4, s);
+    if (L > 0) {
+        hipLaunchKernelGGL(k_duplicate, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, sorted_idx, offsets, rect, (long)n, lay.nx,
+                           inst_tile, inst_g);
+        // the sort needs scratch ping-pong buffers: reuse inst_* as temporaries of the 2nd pass
+        int rc = sort_pairs_u32(inst_tile, inst_g, tile_sorted, g_sorted, inst_tile, inst_g, L, 0, bits_for_tiles((unsigned)T),
+                                sort_ws, sort_bytes, s);
+        if (rc) return rc;
+        rc = g2pc_bincount_i32((const int32_t*)tile_sorted, L, tile_start, T, stream);
+        if (rc) return rc;
+    }
+    int rc = scan_exclusive_u32(tile_start, tile_start, T, scan_ws, scan_bytes, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_blend_py, dim3((unsigned)layout->num_chunks), dim3(RA_T), 0, s, lay, layout->chunk_tile,
+                       layout->chunk_pix0, tile_start, g_sorted, (const float4*)p0, (const float4*)p1, colours, best_key,
+                       camera_slot << 24, t_floor, cam->bg[0], tilebuf);
+    hipLaunchKernelGGL(k_update_colours_py, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, lay, best_key, (long)n, camera_slot,
+                       tilebuf, colours_out);
+    if (image)
+        hipLaunchKernelGGL(k_assemble_image_py, dim3(cdiv((long)cam->width * cam->height, RA_T)), dim3(RA_T), 0, s, lay,
+                           cam->width, cam->height, tilebuf, image);
+    return check_launch("g2pc_raster_back_py");
+}
+
+int g2pc_raster_rebase_keys(unsigned long long* best_key, int64_t n, void* stream) {
+    using namespace g2pc;
+    if (n <= 0) return G2PC_OK;
+    hipLaunchKernelGGL(k_rebase_keys, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, (hipStream_t)stream, best_key, (long)n);
+    return check_launch("g2pc_raster_rebase_keys");
+}
+
+int g2pc_raster_contributions(const unsigned long long* best_key, int64_t n, float* out, void* stream) {
+    using namespace g2pc;
+    if (n <= 0) return G2PC_OK;
+    hipLaunchKernelGGL(k_contributions, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, (hipStream_t)stream, best_key, (long)n, out);
+    return check_launch("g2pc_raster_contributions");
+}
+}

@@ -1,0 +1,91 @@
+"""
+Tile layouts of the rasteriser.
+
+`python_quadtree_layout` replays the FIFO quad-tree of the reference's pure-torch renderer
+(gauss_render.py:290-335) for an image size and tile limit.  When no tile overflows
+`max_gaussians_per_tile`, the split rule (`w > max_tile_size or h > max_tile_size` halves BOTH sides,
+children = ceil(size/2), second child starts at floor(ceil(size/2)) and is clipped to the IMAGE, not the
+parent) produces leaves of uniform depth that are the cartesian product of two 1-D interval families, with
+1-pixel overlaps where a size was odd.  The leaves' FIFO order (top-left, bottom-left, top-right,
+bottom-right per split) is kept as `tile_seq`; it decides which tile wins ties of the running maximum and
+which tile's colour an overlapped pixel finally shows.
+
+`grid_layout` is the regular 16x16 grid of the native rasteriser (config.h:15-17, auxiliary.h:45-55).
+"""
+from __future__ import annotations
+
+from math import ceil, floor
+from typing import Dict
+
+import numpy as np
+
+CHUNK_PIXELS = 1024          # pixels per blend block (256 lanes x 4 pixels)
+
+
+def _finish(xs, ws, ys, hs, seq_of) -> Dict[str, np.ndarray]:
+    nx, ny = len(xs), len(ys)
+    T = nx * ny
+    tile_seq = np.zeros((T,), dtype=np.int32)
+    for iy in range(ny):
+        for ix in range(nx):
+            tile_seq[iy * nx + ix] = seq_of[(xs[ix], ys[iy])]
+    order = np.argsort(tile_seq, kind="stable")
+    # compress the FIFO sequence numbers to 0..T-1 (only their order matters)
+    rank = np.empty((T,), dtype=np.int32)
+    rank[order] = np.arange(T, dtype=np.int32)
+    seq_tile = order.astype(np.int32)
+    pix = np.array([ws[t % nx] * hs[t // nx] for t in range(T)], dtype=np.int64)
+    off = np.zeros((T + 1,), dtype=np.int64)
+    off[1:] = np.cumsum(pix)
+    chunk_tile, chunk_pix0 = [], []
+    for t in range(T):
+        for p0 in range(0, int(pix[t]), CHUNK_PIXELS):
+            chunk_tile.append(t)
+            chunk_pix0.append(p0)
+    return dict(nx=nx, ny=ny, xs=np.asarray(xs, np.int32), ws=np.asarray(ws, np.int32),
+                ys=np.asarray(ys, np.int32), hs=np.asarray(hs, np.int32), tile_seq=rank, seq_tile=seq_tile,
+                tile_pix_off=off.astype(np.int32), chunk_tile=np.asarray(chunk_tile, np.int32),
+                chunk_pix0=np.asarray(chunk_pix0, np.int32), total_pixels=int(off[-1]))
+
+
+def python_quadtree_layout(width: int, height: int, max_tile_size: int = 60) -> Dict[str, np.ndarray]:
+    queue = [([0, 0], [width, height])]          # ([row, col], [w, h]) as in the reference
+    leaves = []
+    while queue:
+        start, size = queue.pop(0)
+        if size[0] <= 1 or size[1] <= 1:          # gauss_render.py:301
+            continue
+        size = [min(size[0], width - start[1]), min(size[1], height - start[0])]
+        if size[0] > max_tile_size or size[1] > max_tile_size:
+            size = [ceil(size[0] / 2), ceil(size[1] / 2)]
+            s = list(start)
+            queue.append((list(s), list(size)))
+            s[0] += floor(size[1])
+            queue.append((list(s), list(size)))
+            s[0] -= floor(size[1])
+            s[1] += floor(size[0])
+            queue.append((list(s), list(size)))
+            s[0] += floor(size[1])
+            queue.append((list(s), list(size)))
+            continue
+        leaves.append((start[1], start[0], size[0], size[1]))       # x0, y0, w, h in FIFO order
+    xs = sorted({(l[0], l[2]) for l in leaves})
+    ys = sorted({(l[1], l[3]) for l in leaves})
+    if len({x for x, _ in xs}) != len(xs) or len({y for y, _ in ys}) != len(ys) or len(xs) * len(ys) != len(leaves):
+        raise NotImplementedError("quad-tree leaves are not a product of intervals for %dx%d / %d" % (width, height, max_tile_size))
+    wof, hof = dict(xs), dict(ys)
+    seq_of = {}
+    for s, (x0, y0, w, h) in enumerate(leaves):
+        if wof[x0] != w or hof[y0] != h:
+            raise NotImplementedError("non-uniform quad-tree leaves")
+        seq_of[(x0, y0)] = s
+    return _finish([x for x, _ in xs], [w for _, w in xs], [y for y, _ in ys], [h for _, h in ys], seq_of)
+
+
+def grid_layout(width: int, height: int, block: int = 16) -> Dict[str, np.ndarray]:
+    xs = list(range(0, width, block))
+    ys = list(range(0, height, block))
+    ws = [min(block, width - x) for x in xs]
+    hs = [min(block, height - y) for y in ys]
+    seq_of = {(x, y): iy * len(xs) + ix for iy, y in enumerate(ys) for ix, x in enumerate(xs)}
+    return _finish(xs, ws, ys, hs, seq_of)

@@ -139,6 +139,60 @@ int g2pc_mahalanobis(const float* means, const float* samples, const float* cov9
 int g2pc_sample_mvn(const float* means, const float* cov9, int64_t g, int32_t n, uint64_t seed, uint64_t gid_base,
                     int32_t attempt, float* out, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Rasteriser (replaces _C.rasterize_gaussians, rasterize_points.h:18-41 / rasterizer_impl.cu:197-352, and
+ * the pure-torch GaussPythonRenderer, gauss_render.py:266-465).  One camera = front half, ONE 4-byte read-back
+ * by the caller (offsets[n] = number of (tile, Gaussian) instances; the reference has the same hidden
+ * read-back at rasterizer_impl.cu:289), back half.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct G2pcCamera {          /* HOST struct, passed by value to the kernels */
+    float view[16];                  /* world_view_transform / viewmatrix, row-major (row-vector convention) */
+    float proj[16];                  /* PY: projection_matrix (P^T);  CUDA semantics: full projmatrix = view @ P^T */
+    float tan_fovx, tan_fovy;        /* tan(fov/2) */
+    float focal_x, focal_y;
+    int32_t width, height;
+    float bg[3];
+} G2pcCamera;
+
+typedef struct G2pcTileLayout {      /* HOST struct of DEVICE pointers: tiles = x-intervals times y-intervals */
+    int32_t nx, ny;
+    const int32_t* xs;               /* [nx] first pixel column of interval i */
+    const int32_t* ws;               /* [nx] width */
+    const int32_t* ys;               /* [ny] */
+    const int32_t* hs;               /* [ny] */
+    const int32_t* tile_seq;         /* [ny*nx] processing order of tile iy*nx+ix (python renderer: FIFO quad-tree order) */
+    const int32_t* seq_tile;         /* [ny*nx] inverse of tile_seq */
+    const int32_t* tile_pix_off;     /* [ny*nx+1] pixel offset of every tile inside the per-tile colour buffer */
+    int32_t num_chunks;              /* blend work list: one block per (tile, first pixel) chunk of <= 1024 pixels */
+    const int32_t* chunk_tile;       /* [num_chunks] */
+    const int32_t* chunk_pix0;       /* [num_chunks] */
+} G2pcTileLayout;
+
+size_t g2pc_raster_front_workspace(int64_t n);
+/* PY semantics front half (gauss_render.py:101-193,404-437): projection, EWA covariance, conic, radius, rect ->
+ * tile ranges; depth sort (nearest first, ties in descending index = torch.sort + flip); tiles-touched scan.
+ * means3D f32[n,3], cov9 f32[n,3,3], opacity f32[n].  Out: p0/p1 f32[n,4] blend parameters, rect u32[n],
+ * sorted_idx u32[n] (Gaussian indices in depth order), offsets u32[n+1]. */
+int g2pc_raster_front_py(const G2pcCamera* cam, const G2pcTileLayout* layout, const float* means3D, const float* cov9,
+                         const float* opacity, int64_t n, float* p0, float* p1, uint32_t* rect, uint32_t* sorted_idx,
+                         uint32_t* offsets, void* ws, size_t ws_bytes, void* stream);
+size_t g2pc_raster_back_workspace(int64_t num_instances, int32_t num_tiles);
+/* PY semantics back half (gauss_render.py:290-402): duplicate, stable tile sort, ranges, blend with per-Gaussian
+ * max-contribution / arg-max pixel, colour update, optional image (f32[H,W,3], already flipped as the reference
+ * returns it).  colours f32[n,3] input colours; best_key u64[n] and colours_out f32[n,3] are the renderer's
+ * running state (zero-initialised by the caller); tilebuf f32[tile_pix_off[T],3] scratch.  camera_slot in
+ * [1,255] must increase from camera to camera (call g2pc_raster_rebase_keys before wrapping around).
+ * t_floor: 0 = exact python semantics; > 0 stops a pixel chunk once every pixel's transmittance is below it
+ * (all later contributions and colour terms are then < t_floor). */
+int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, const float* colours, int64_t n,
+                        int64_t num_instances, const float* p0, const float* p1, const uint32_t* rect,
+                        const uint32_t* sorted_idx, const uint32_t* offsets, uint32_t camera_slot, float t_floor,
+                        unsigned long long* best_key, float* colours_out, float* tilebuf, float* image, void* ws,
+                        size_t ws_bytes, void* stream);
+int g2pc_raster_rebase_keys(unsigned long long* best_key, int64_t n, void* stream);
+/* gaussian_max_contribution f32[n] out of the packed keys (gauss_render.py:243-264 getters read this) */
+int g2pc_raster_contributions(const unsigned long long* best_key, int64_t n, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -142,7 +142,9 @@ def gen_render(ref):
     sc = make_scene(n, seed, scale_lo=0.004, scale_hi=0.04)
     transforms, intr = make_cameras(ncam, width=320, height=180, focal=275.0)
     with CudaToCpu():
-        G = gh.Gaussians(sc.xyz.clone(), sc.scales.clone(), sc.rots.clone(), sc.colours.clone(),
+        # colours are float64 in the reference's python-renderer path (its loader yields doubles and
+        # gauss_render.py:395 index-puts tile colours into a float64 state tensor)
+        G = gh.Gaussians(sc.xyz.clone(), sc.scales.clone(), sc.rots.clone(), sc.colours.double(),
                          sc.opacities.clone())
         R = gr.get_renderer("python", G.xyz, torch.unsqueeze(torch.clone(G.opacities), 1),
                             G.colours, G.covariances, visible_gaussian_threshold=0.05)
@@ -170,7 +172,7 @@ def gen_pipeline(ref):
     sc = make_scene(n, seed, scale_lo=0.004, scale_hi=0.04)
     transforms, intr = make_cameras(1, width=1280, height=720, focal=1100.0)
     with CudaToCpu():
-        G = gh.Gaussians(sc.xyz.clone(), sc.scales.clone(), sc.rots.clone(), sc.colours.clone(),
+        G = gh.Gaussians(sc.xyz.clone(), sc.scales.clone(), sc.rots.clone(), sc.colours.double(),
                          sc.opacities.clone())
         G.calculate_normals()
         R = gr.get_renderer("python", G.xyz, torch.unsqueeze(torch.clone(G.opacities), 1),

@@ -1,0 +1,50 @@
+"""Shared renderer parity assertions against the reference python renderer's golden outputs
+(tests/golden/render_py_n6000.npz, written by oracle/make_golden.py from the untouched reference)."""
+import os
+
+import numpy as np
+import torch
+
+from g2pc.synth import make_scene, make_cameras
+
+
+def run_render_case(golden_dir, device="cpu", t_floor=0.0):
+    import gauss_render
+    import camera_handler
+    from gauss_handler import Gaussians
+    g = np.load(os.path.join(golden_dir, "render_py_n6000.npz"))
+    dev = torch.device(device)
+    sc = make_scene(int(g["n"]), int(g["seed"]), scale_lo=float(g["scale_lo"]), scale_hi=float(g["scale_hi"]))
+    transforms, intr = make_cameras(int(g["ncam"]), width=int(g["width"]), height=int(g["height"]), focal=float(g["focal"]))
+    G = Gaussians(sc.xyz.to(dev), sc.scales.to(dev), sc.rots.to(dev), sc.colours.to(dev), sc.opacities.to(dev))
+    R = gauss_render.get_renderer("python", G.xyz, torch.unsqueeze(torch.clone(G.opacities), 1), G.colours,
+                                  G.covariances, visible_gaussian_threshold=0.05)
+    R.t_floor = t_floor
+    images, contribs = [], []
+    for name in transforms:
+        cam = camera_handler.get_camera("python", torch.tensor(transforms[name]), intr[name], colour_resolution=None)
+        img, _, _, _ = R(cam)
+        images.append(img.cpu().numpy())
+        contribs.append(R.gaussian_max_contribution.cpu().numpy())
+    return g, R, np.stack(images), np.stack(contribs)
+
+
+def assert_render_matches(g, R, images, contribs, tol=1e-4, allow_mask_flips=0):
+    # images within tol
+    d_img = np.abs(images - g["images"]).max()
+    assert d_img < tol, "image max abs diff %g" % d_img
+    # running max contribution after every camera
+    d_c = np.abs(contribs - g["contrib_after_cam"]).max()
+    assert d_c < tol, "contribution max abs diff %g" % d_c
+    # per-Gaussian colours (0..255 scale in the API -> compare in 0..1)
+    cols = R.get_gaussian_colours().cpu().numpy() / 255.0
+    ref_cols = g["colours"] / 255.0
+    d_col = np.abs(cols - ref_cols).max()
+    assert d_col < tol, "colour max abs diff %g" % d_col
+    # culling mask: exact, report the margin of anything that flips
+    vis = R.get_visible_gaussians().cpu().numpy()
+    flips = np.nonzero(vis != g["visible"])[0]
+    margins = np.abs(g["contrib_after_cam"][-1][flips] - 0.05)
+    assert len(flips) <= allow_mask_flips, "visible-mask flips: %d, margins %s" % (len(flips), margins)
+    np.testing.assert_allclose(R.get_total_gaussian_contributions().cpu().numpy(), g["total"], atol=tol)
+    return dict(image=d_img, contribution=d_c, colour=d_col, flips=len(flips))

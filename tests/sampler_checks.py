@@ -16,7 +16,7 @@ def run_sampler_case(golden_dir, name, device="cpu"):
     cov, _, nrm = ops.build_covariances(sc.scales.to(dev), sc.rots.to(dev), 1.0, want_normals=True)
     keep = ops.validate_covariances_(cov)
     assert bool(keep.all())
-    np.testing.assert_allclose(cov.cpu().numpy(), g["cov_valid"], rtol=2e-6, atol=5e-11)
+    np.testing.assert_allclose(cov.cpu().numpy(), g["cov_valid"], rtol=2e-6, atol=5e-10)
     # the allocation is checked bit-exactly on the reference's own covariances (isolates sampling
     # from 1-ulp differences of the covariance build)
     cov_ref = torch.from_numpy(g["cov_valid"]).to(dev)

@@ -1,0 +1,17 @@
+"""Rasteriser kernels (python-renderer semantics) through the fiber emulator against the reference's outputs."""
+import numpy as np
+import pytest
+
+from emu_util import emu  # noqa: F401
+from render_checks import run_render_case, assert_render_matches
+
+
+def test_render_matches_reference_python_renderer(emu, golden_dir):
+    g, R, images, contribs = run_render_case(golden_dir)
+    stats = assert_render_matches(g, R, images, contribs)
+    print(stats)
+
+
+def test_render_with_transmittance_floor_is_within_floor(emu, golden_dir):
+    g, R, images, contribs = run_render_case(golden_dir, t_floor=1e-6)
+    assert_render_matches(g, R, images, contribs)
