@@ -400,8 +400,8 @@ size_t g2pc_raster_back_workspace(int64_t num_instances, int32_t num_tiles) {
 int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, const float* colours, int64_t n,
                         int64_t num_instances, const float* p0, const float* p1, const uint32_t* rect,
                         const uint32_t* sorted_idx, const uint32_t* offsets, uint32_t camera_slot, float t_floor,
-                        unsigned long long* best_key, float* colours_out, float* tilebuf, float* image, void* ws,
-                        size_t ws_bytes, void* stream) {
+                        unsigned long long* best_key, float* colours_out, float* tilebuf, float* image, int phases,
+                        void* ws, size_t ws_bytes, void* stream) {
     using namespace g2pc;
     G2PC_REQUIRE(cam && layout && colours && p0 && p1 && rect && sorted_idx && offsets && best_key && colours_out &&
                      tilebuf && ws && n > 0,
@@ -422,6 +422,7 @@ int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, con
     char* scan_ws = ar.get<char>(scan_bytes);
     G2PC_REQUIRE(ar.ok(), G2PC_ERR_WORKSPACE, "workspace too small");
     Layout lay = to_layout(layout);
+    if (phases & 1) {
     hipMemsetAsync(tile_start, 0, (size_t)(T + 2) * 4, s);
     if (L > 0) {
         hipLaunchKernelGGL(k_duplicate, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, sorted_idx, offsets, rect, (long)n, lay.nx,
@@ -435,6 +436,8 @@ int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, con
     }
     int rc = scan_exclusive_u32(tile_start, tile_start, T, scan_ws, scan_bytes, s);
     if (rc) return rc;
+    }
+    if (phases & 2) {
     hipLaunchKernelGGL(k_blend_py, dim3((unsigned)layout->num_chunks), dim3(RA_T), 0, s, lay, layout->chunk_tile,
                        layout->chunk_pix0, tile_start, g_sorted, (const float4*)p0, (const float4*)p1, colours, best_key,
                        camera_slot << 24, t_floor, cam->bg[0], tilebuf);
@@ -443,6 +446,7 @@ int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, con
     if (image)
         hipLaunchKernelGGL(k_assemble_image_py, dim3(cdiv((long)cam->width * cam->height, RA_T)), dim3(RA_T), 0, s, lay,
                            cam->width, cam->height, tilebuf, image);
+    }
     return check_launch("g2pc_raster_back_py");
 }
 

@@ -30,6 +30,7 @@ C3 = [-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.37317633259
 
 # transmittance floor of the blend (see include/g2pc.h g2pc_raster_back_py).  0.0 = exact reference semantics.
 DEFAULT_T_FLOOR = 0.0
+RENDER_STATS = []          # (instances L, tile-sort passes, W*H) of every camera rendered (bench.py reads this)
 
 
 class _Camera(C.Structure):
@@ -50,7 +51,7 @@ nv._RASTER_PROTOS.update({
                              [C.c_void_p] * 6 + [C.c_size_t, C.c_void_p]),
     "g2pc_raster_back_workspace": (C.c_size_t, [C.c_int64, C.c_int32]),
     "g2pc_raster_back_py": (C.c_int, [C.POINTER(_Camera), C.POINTER(_Layout), C.c_void_p, C.c_int64, C.c_int64] +
-                            [C.c_void_p] * 5 + [C.c_uint32, C.c_float] + [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p]),
+                            [C.c_void_p] * 5 + [C.c_uint32, C.c_float] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "g2pc_raster_rebase_keys": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "g2pc_raster_contributions": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
 })
@@ -190,14 +191,17 @@ class GaussHipRenderer():
             self.camera_slot = 0
         self.camera_slot += 1
         image = torch.empty((H, W, 3), dtype=torch.float32, device=self.device) if return_image else None
-        with nv.region("raster_back", self.device):
-            nv.check(L.g2pc_raster_back_py(C.byref(cam), C.byref(lay.c), nv.ptr(self.colour), self.n, num_inst,
-                                           nv.ptr(self.p0), nv.ptr(self.p1), nv.ptr(self.rect), nv.ptr(self.sorted_idx),
-                                           nv.ptr(self.offsets), self.camera_slot, self.t_floor, nv.ptr(self.best_key),
-                                           nv.ptr(self.gaussian_colours), nv.ptr(self.tilebuf), nv.ptr(image),
-                                           nv.ptr(self.back_ws), self.back_ws_bytes, st), "raster_back_py")
+        for phase, name in ((1, "raster_bin"), (2, "raster_blend")):
+            with nv.region(name, self.device):
+                nv.check(L.g2pc_raster_back_py(C.byref(cam), C.byref(lay.c), nv.ptr(self.colour), self.n, num_inst,
+                                               nv.ptr(self.p0), nv.ptr(self.p1), nv.ptr(self.rect),
+                                               nv.ptr(self.sorted_idx), nv.ptr(self.offsets), self.camera_slot,
+                                               self.t_floor, nv.ptr(self.best_key), nv.ptr(self.gaussian_colours),
+                                               nv.ptr(self.tilebuf), nv.ptr(image), phase, nv.ptr(self.back_ws),
+                                               self.back_ws_bytes, st), "raster_back_py")
         bits = max(1, int(np.ceil(np.log2(max(lay.num_tiles, 2)))))
         self.last_stats.append((num_inst, (bits + 7) // 8, W * H))
+        RENDER_STATS.append((num_inst, (bits + 7) // 8, W * H))
         return image, None, None, None
 
 

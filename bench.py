@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--points", type=int, default=10_000_000)
     ap.add_argument("--cameras", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--t-floor", type=float, default=None, help="blend transmittance floor (default: gauss_render.DEFAULT_T_FLOOR)")
     return ap.parse_args()
 
 
@@ -81,25 +82,40 @@ def algorithmic_bytes(workload, n, n_kept, m, cams, stats):
 
 
 def cpu_baseline(workload):
-    """The oracle (CPU restatement of the reference, `kind: port`) on a bounded sample of the same workload."""
+    """The oracle (CPU restatement of the reference, `kind: port`; pinned bit-exactly to the reference's own
+    outputs by tests/test_oracle_*.py) on a bounded sample of the same workload, on this box's host cores."""
     import ref_gauss as RG
+    import ref_render as RR
     from np_philox import keyed_normals
-    from g2pc.synth import make_scene
-    n, pts = 20_000, 200_000
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    from g2pc.synth import make_scene, make_cameras
+    n, pts, ncam = 10_000, 100_000, 2
+    torch.set_num_threads(min(16, max(1, os.cpu_count() or 1)))     # torch CPU ops on 3x3 batches do not scale past this
     sc = make_scene(n, 1234 + 2)
     t0 = time.perf_counter()
     cov = RG.covariances(sc.scales, sc.rots)
     nrm = RG.normals(sc.scales, sc.rots)
+    xyz, colours, weights = sc.xyz, sc.colours * 255, sc.opacities
+    t_render = 0.0
+    if workload == "render":
+        tr, intr = make_cameras(ncam)
+        R = RR.PythonRendererOracle(sc.xyz, sc.opacities.unsqueeze(1), sc.colours.double(), cov, threshold=0.05)
+        for name in tr:
+            R(RR.get_camera(torch.tensor(tr[name]), intr[name], colour_resolution=1280))
+        vis = R.get_visible_gaussians()
+        xyz, cov, nrm = xyz[vis], cov[vis], nrm[vis]
+        colours, weights = R.get_gaussian_colours()[vis].float(), R.max_contribution[vis]
+        t_render = time.perf_counter() - t0
     cov, keep = RG.validate_covariances(cov)
-    out = RG.generate_pointcloud(sc.xyz, cov, sc.colours * 255, nrm, sc.opacities, pts, std=2.0, exact=False,
-                                 attempts=5,
+    out = RG.generate_pointcloud(xyz[keep], cov[keep], colours[keep], nrm[keep], weights[keep], pts, std=2.0,
+                                 exact=False, attempts=5,
                                  eps_fn=lambda gids, a, k: keyed_normals(7, gids[:, None], a, np.arange(k)[None, :]))
     dt = time.perf_counter() - t0
+    what = ("%d cameras 1280x720 (%.1f s) + " % (ncam, t_render)) if workload == "render" else ""
     return {"value": out["points"].shape[0] / dt, "unit": "points/s", "cores": torch.get_num_threads(),
             "kind": "port",
-            "sample": "oracle/ref_gauss.py sampler pipeline (cov, validate, magnitudes, distribute, sample) on "
-                      "%d Gaussians -> %d points, no rendering, %.1f s" % (n, out["points"].shape[0], dt)}
+            "sample": "oracle (ref_render.py + ref_gauss.py): %d Gaussians, %scov/validate/magnitudes/distribute/sample "
+                      "-> %d points, %.1f s wall; the full workload has 100x the Gaussians, %sx the cameras and 100x "
+                      "the points" % (n, what, out["points"].shape[0], dt, "25" if workload == "render" else "0")}
 
 
 def main():
@@ -117,6 +133,9 @@ def main():
     from g2pc.synth import make_scene, make_cameras
     nv.lib()
     workload = a.workload or ("render" if have_renderer() else "sample")
+    import gauss_render
+    if a.t_floor is not None:
+        gauss_render.DEFAULT_T_FLOOR = a.t_floor
 
     # weak scaling: every rank owns a full configs[1]/[2] sized shard (its own Gaussians and point budget)
     scene = make_scene(a.gaussians, 1234 + 3 + rank, device=device)
@@ -132,6 +151,9 @@ def main():
     for w in range(a.warmup):
         one_step(scene, cams, workload, a.points, device, seed=100 + w)
     nv.PROFILE = {}
+    if workload == "render":
+        import gauss_render
+        gauss_render.RENDER_STATS.clear()
     sync()
     t0 = time.perf_counter()
     points = 0
@@ -163,9 +185,15 @@ def main():
         m_step = points / max(a.steps, 1)
         per_launch = {"sampler_emit": 56.0 * a.gaussians + 36.0 * m_step,          # read Gaussians, write the cloud
                       "sampler_count": 56.0 * a.gaussians + 4.0 * 5 * a.gaussians}.get(name)
-        extra = getattr(nv, "REGION_BYTES", {}).get(name)
-        if extra is not None:
-            per_launch = extra
+        if name in ("raster_blend", "raster_bin", "raster_front"):
+            import gauss_render
+            st = gauss_render.RENDER_STATS[-launches:]
+            L_avg = float(np.mean([x[0] for x in st]))
+            wh = float(np.mean([x[2] for x in st]))
+            passes = float(np.mean([x[1] for x in st]))
+            per_launch = {"raster_blend": 56.0 * L_avg + 32.0 * wh + 40.0 * a.gaussians,     # K6 + visibility update
+                          "raster_bin": (20.0 * a.gaussians + 12.0 * L_avg) + 24.0 * passes * L_avg + 8.0 * L_avg,
+                          "raster_front": 88.0 * a.gaussians + 8.0 * a.gaussians + 4 * 24.0 * a.gaussians}[name]
         if per_launch is not None and ms > 0:
             ach = per_launch / (ms / launches * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -179,7 +207,8 @@ def main():
                                 if workload == "render" else
                                 "configs[1]: 1M Gaussians, no_render_colours, 10M points (sampling pipeline)"),
                    "gaussians_per_gpu": a.gaussians, "points_per_gpu": a.points,
-                   "cameras": a.cameras if workload == "render" else 0, "parallelism": "shard-by-gaussian x%d" % world},
+                   "cameras": a.cameras if workload == "render" else 0,
+                   "blend_transmittance_floor": gauss_render.DEFAULT_T_FLOOR, "parallelism": "shard-by-gaussian x%d" % world},
         "roofline": roof,
         "regions_ms_per_step": {k: v[1] / a.steps for k, v in sorted(prof.items())},
     }

@@ -183,12 +183,14 @@ size_t g2pc_raster_back_workspace(int64_t num_instances, int32_t num_tiles);
  * running state (zero-initialised by the caller); tilebuf f32[tile_pix_off[T],3] scratch.  camera_slot in
  * [1,255] must increase from camera to camera (call g2pc_raster_rebase_keys before wrapping around).
  * t_floor: 0 = exact python semantics; > 0 stops a pixel chunk once every pixel's transmittance is below it
- * (all later contributions and colour terms are then < t_floor). */
+ * (all later contributions and colour terms are then < t_floor).
+ * phases: bit 0 = binning (duplicate, tile sort, ranges), bit 1 = blend + colour update + image; 3 = both
+ * (the two halves share `ws`; bench.py times them separately). */
 int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, const float* colours, int64_t n,
                         int64_t num_instances, const float* p0, const float* p1, const uint32_t* rect,
                         const uint32_t* sorted_idx, const uint32_t* offsets, uint32_t camera_slot, float t_floor,
-                        unsigned long long* best_key, float* colours_out, float* tilebuf, float* image, void* ws,
-                        size_t ws_bytes, void* stream);
+                        unsigned long long* best_key, float* colours_out, float* tilebuf, float* image, int phases,
+                        void* ws, size_t ws_bytes, void* stream);
 int g2pc_raster_rebase_keys(unsigned long long* best_key, int64_t n, void* stream);
 /* gaussian_max_contribution f32[n] out of the packed keys (gauss_render.py:243-264 getters read this) */
 int g2pc_raster_contributions(const unsigned long long* best_key, int64_t n, float* out, void* stream);
