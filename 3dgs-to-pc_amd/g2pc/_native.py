@@ -27,6 +27,7 @@ _vp, _i64, _i32, _f32, _u64, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, 
 _PROTOS = {
     "g2pc_last_error": (C.c_char_p, []),
     "g2pc_abi_version": (C.c_int, []),
+    "g2pc_selftest_wave_reduce": (C.c_int, [_vp, _vp, _i64, _vp]),
     "g2pc_scan_workspace": (_sz, [_i64]),
     "g2pc_scan_exclusive_u32": (C.c_int, [_vp, _vp, _i64, _vp, _sz, _vp]),
     "g2pc_sort_workspace": (_sz, [_i64]),

@@ -9,6 +9,38 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ---- wave64 reductions on the DPP crossbar (no LDS traffic, unlike ds_bpermute based __shfl) ----------------
+// row_shr:1,2,4,8 give every lane 15 of a 16-lane row the row result; row_bcast:15 / row_bcast:31 fold the four
+// rows into lane 63; v_readlane broadcasts it.  `identity` fills lanes that have no source.
+#define G2PC_DPP_STEP(OP, CTRL, ROWMASK)                                                              \
+    {                                                                                                 \
+        unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROWMASK, 0xF, false); \
+        v = OP(v, o);                                                                                 \
+    }
+__device__ __forceinline__ unsigned umax_(unsigned a, unsigned b) { return a > b ? a : b; }
+__device__ __forceinline__ unsigned umin_(unsigned a, unsigned b) { return a < b ? a : b; }
+__device__ __forceinline__ unsigned wave_max_u32_dpp(unsigned v) {
+    const unsigned identity = 0u;
+    G2PC_DPP_STEP(umax_, 0x111, 0xF)   // row_shr:1
+    G2PC_DPP_STEP(umax_, 0x112, 0xF)   // row_shr:2
+    G2PC_DPP_STEP(umax_, 0x114, 0xF)   // row_shr:4
+    G2PC_DPP_STEP(umax_, 0x118, 0xF)   // row_shr:8
+    G2PC_DPP_STEP(umax_, 0x142, 0xA)   // row_bcast:15 -> rows 1,3
+    G2PC_DPP_STEP(umax_, 0x143, 0xC)   // row_bcast:31 -> rows 2,3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned wave_min_u32_dpp(unsigned v) {
+    const unsigned identity = 0xFFFFFFFFu;
+    G2PC_DPP_STEP(umin_, 0x111, 0xF)
+    G2PC_DPP_STEP(umin_, 0x112, 0xF)
+    G2PC_DPP_STEP(umin_, 0x114, 0xF)
+    G2PC_DPP_STEP(umin_, 0x118, 0xF)
+    G2PC_DPP_STEP(umin_, 0x142, 0xA)
+    G2PC_DPP_STEP(umin_, 0x143, 0xC)
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+#undef G2PC_DPP_STEP
+
 // ---- Philox4x32-10 ------------------------------------------------------------------------------
 __device__ __forceinline__ void philox_round(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3,
                                              unsigned k0, unsigned k1) {

@@ -192,6 +192,11 @@ int sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* k
                    uint32_t* keys_tmp, uint32_t* vals_tmp, long n, int bit_lo, int bit_hi, void* ws,
                    size_t ws_bytes, hipStream_t s) {
     if (n <= 0) return G2PC_OK;
+    if (keys_tmp == keys_in || vals_tmp == vals_in || keys_tmp == keys_out || vals_tmp == vals_out ||
+        keys_out == keys_in || vals_out == vals_in) {
+        set_error("sort", "in / out / tmp buffers must be distinct");
+        return G2PC_ERR_ARG;
+    }
     int total_bits = bit_hi - bit_lo;
     int passes = total_bits <= 0 ? 0 : (total_bits + 7) / 8;
     if (passes == 0) {
@@ -226,6 +231,13 @@ int sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* k
     return check_launch("sort");
 }
 
+// self-test of the DPP reductions against the shuffle based ones (tests only)
+__global__ __launch_bounds__(64) void k_selftest_wave_reduce(const uint32_t* __restrict__ in, uint32_t* __restrict__ out) {
+    uint32_t v = in[blockIdx.x * 64 + threadIdx.x];
+    uint32_t a = wave_max_u32_dpp(v), b = wave_min_u32_dpp(v), c = wave_max_u32(v), d = wave_min_u32(v);
+    if (threadIdx.x == 0) { out[4 * blockIdx.x] = a; out[4 * blockIdx.x + 1] = b; out[4 * blockIdx.x + 2] = c; out[4 * blockIdx.x + 3] = d; }
+}
+
 }  // namespace g2pc
 
 // ---- C ABI ----------------------------------------------------------------------------------------
@@ -233,6 +245,10 @@ extern "C" {
 const char* g2pc_last_error(void) { return g2pc::g_err.c_str(); }
 int g2pc_abi_version(void) { return G2PC_ABI_VERSION; }
 
+int g2pc_selftest_wave_reduce(const uint32_t* in, uint32_t* out, int64_t waves, void* stream) {
+    hipLaunchKernelGGL(g2pc::k_selftest_wave_reduce, dim3((unsigned)waves), dim3(64), 0, (hipStream_t)stream, in, out);
+    return g2pc::check_launch("selftest");
+}
 size_t g2pc_scan_workspace(int64_t n) { return g2pc::scan_workspace(n); }
 int g2pc_scan_exclusive_u32(const uint32_t* in, uint32_t* out, int64_t n, void* ws, size_t ws_bytes, void* stream) {
     return g2pc::scan_exclusive_u32(in, out, n, ws, ws_bytes, (hipStream_t)stream);

@@ -175,14 +175,14 @@ __global__ __launch_bounds__(RA_T) void k_duplicate(const uint32_t* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// K6 (PY): blend.  One block per (tile, 1024-pixel chunk); 256 lanes x 4 pixels; Gaussians staged through LDS
-// in batches of 256.  For every Gaussian the wave reduces (max T*alpha, lowest pixel among the maxima) and
+// K6 (PY): blend.  One single-wave block per (tile, 256-pixel chunk); 64 lanes x 4 pixels; Gaussians staged through
+// wave-private LDS in batches of 64 (no s_barrier: 32 independent waves per CU, fine-grained early exit).  For every Gaussian the wave reduces (max T*alpha, lowest pixel among the maxima) and
 // lane 0 publishes  key = contribution_bits << 32 | ~(slot << 24 | tile_seq << 12 | pixel)  with one 64-bit
 // atomicMax -- but only when some lane can beat the value staged from the running maximum.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int BL_PPT = 4, BL_BATCH = 256;
+constexpr int BL_T = 64, BL_PPT = 4, BL_BATCH = 64, BL_CHUNK = BL_T * BL_PPT;
 
-__global__ __launch_bounds__(RA_T) void k_blend_py(Layout lay, const int32_t* __restrict__ chunk_tile,
+__global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __restrict__ chunk_tile,
                                                   const int32_t* __restrict__ chunk_pix0,
                                                   const uint32_t* __restrict__ tile_start,
                                                   const uint32_t* __restrict__ inst_g,
@@ -190,6 +190,7 @@ __global__ __launch_bounds__(RA_T) void k_blend_py(Layout lay, const int32_t* __
                                                   const float* __restrict__ colours,
                                                   unsigned long long* __restrict__ best_key, uint32_t order_base,
                                                   float t_floor, float bg, float* __restrict__ tilebuf) {
+    // one wave64 per block: the LDS stage is wave-private, no s_barrier anywhere
     __shared__ float4 s_p0[BL_BATCH];
     __shared__ float4 s_p1[BL_BATCH];
     __shared__ float4 s_p2[BL_BATCH];
@@ -200,13 +201,13 @@ __global__ __launch_bounds__(RA_T) void k_blend_py(Layout lay, const int32_t* __
     const int x0 = lay.xs[ix], w = lay.ws[ix], y0 = lay.ys[iy], h = lay.hs[iy];
     const int npix = w * h;
     const uint32_t order_tile = order_base | ((uint32_t)lay.tile_seq[tile] << 12);
-    const unsigned lane = threadIdx.x & 63;
+    const unsigned lane = threadIdx.x;
 
     int pix[BL_PPT];
     float px[BL_PPT], py[BL_PPT], T[BL_PPT], cr[BL_PPT], cg[BL_PPT], cb[BL_PPT];
 #pragma unroll
     for (int j = 0; j < BL_PPT; ++j) {
-        pix[j] = pix0 + j * RA_T + (int)threadIdx.x;
+        pix[j] = pix0 + j * BL_T + (int)lane;
         bool valid = pix[j] < npix;
         int lx = valid ? pix[j] % w : 0, ly = valid ? pix[j] / w : 0;
         px[j] = (float)(x0 + lx);
@@ -216,16 +217,16 @@ __global__ __launch_bounds__(RA_T) void k_blend_py(Layout lay, const int32_t* __
     }
     const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
     for (uint32_t b = start; b < end; b += BL_BATCH) {
-        __syncthreads();
-        if (b + threadIdx.x < end) {
-            uint32_t g = inst_g[b + threadIdx.x];
-            s_p0[threadIdx.x] = p0[g];
-            s_p1[threadIdx.x] = p1[g];
+        wave_sync();                            // everyone is done reading the previous batch
+        if (b + lane < end) {
+            uint32_t g = inst_g[b + lane];
+            s_p0[lane] = p0[g];
+            s_p1[lane] = p1[g];
             float gm = __uint_as_float((uint32_t)(best_key[g] >> 32));
-            s_p2[threadIdx.x] = make_float4(colours[3 * (size_t)g], colours[3 * (size_t)g + 1], colours[3 * (size_t)g + 2], gm);
-            s_g[threadIdx.x] = g;
+            s_p2[lane] = make_float4(colours[3 * (size_t)g], colours[3 * (size_t)g + 1], colours[3 * (size_t)g + 2], gm);
+            s_g[lane] = g;
         }
-        __syncthreads();
+        wave_sync();
         const int cnt = (end - b) < (uint32_t)BL_BATCH ? (int)(end - b) : BL_BATCH;
         for (int k = 0; k < cnt; ++k) {
             const float4 a = s_p0[k], q = s_p1[k], c = s_p2[k];
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(RA_T) void k_blend_py(Layout lay, const int32_t* __
             for (int j = 0; j < BL_PPT; ++j) {
                 float dx = px[j] - a.x, dy = py[j] - a.y;
                 float power = fmaf(a.z * dx, dx, fmaf(q.x * dy, dy, a.w * dx * dy));
-                float wgt = exp2f(power);
+                float wgt = __builtin_amdgcn_exp2f(power);          // raw v_exp_f32 (results below 2^-126 flush to 0)
                 float alpha = fminf(wgt * q.y, 0.99f);
                 float contrib = T[j] * alpha;
                 cr[j] = fmaf(contrib, c.x, cr[j]);
@@ -247,8 +248,8 @@ __global__ __launch_bounds__(RA_T) void k_blend_py(Layout lay, const int32_t* __
             const bool cand = (best > 0.0f) && (best >= c.w);
             if (__any(cand)) {
                 uint32_t bits = __float_as_uint(best);
-                uint32_t m = wave_max_u32(bits);
-                uint32_t pm = wave_min_u32(bits == m ? bestpix : 0xFFFFFFFFu);
+                uint32_t m = wave_max_u32_dpp(bits);
+                uint32_t pm = wave_min_u32_dpp(bits == m ? bestpix : 0xFFFFFFFFu);
                 if (lane == 0) {
                     unsigned long long key = ((unsigned long long)m << 32) | (unsigned long long)(uint32_t)(~(order_tile | pm));
                     atomicMax(&best_key[s_g[k]], key);
@@ -259,13 +260,13 @@ __global__ __launch_bounds__(RA_T) void k_blend_py(Layout lay, const int32_t* __
             bool done = true;
 #pragma unroll
             for (int j = 0; j < BL_PPT; ++j) done = done && (T[j] < t_floor);
-            if (__syncthreads_and(done ? 1 : 0)) break;
+            if (__all(done ? 1 : 0)) break;
         }
     }
     float* out = tilebuf + 3 * (size_t)lay.tile_pix_off[tile];
 #pragma unroll
     for (int j = 0; j < BL_PPT; ++j) {
-        if (pix[j] < npix && pix[j] < pix0 + BL_PPT * RA_T) {
+        if (pix[j] < npix) {
             out[3 * (size_t)pix[j] + 0] = fmaf(T[j], bg, cr[j]);
             out[3 * (size_t)pix[j] + 1] = fmaf(T[j], bg, cg[j]);
             out[3 * (size_t)pix[j] + 2] = fmaf(T[j], bg, cb[j]);
@@ -298,6 +299,19 @@ __global__ __launch_bounds__(RA_T) void k_rebase_keys(unsigned long long* __rest
     if (i >= n) return;
     unsigned long long key = best_key[i];
     if ((key >> 32) != 0ull) best_key[i] = key | 0xFFFFFFFFull;
+}
+
+// multi-GPU winner selection: after the all-reduce(MAX) of the packed keys, a rank keeps its colour only where it
+// owns the winning key; the all-reduce(SUM) of the colours then has exactly one non-zero term per Gaussian.
+__global__ __launch_bounds__(RA_T) void k_keep_winner_colours(const unsigned long long* __restrict__ local_key,
+                                                             const unsigned long long* __restrict__ global_key,
+                                                             long n, float* __restrict__ colours) {
+    long i = (long)blockIdx.x * RA_T + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long g = global_key[i];
+    if ((g >> 32) == 0ull || local_key[i] != g) {
+        colours[3 * i + 0] = 0.0f; colours[3 * i + 1] = 0.0f; colours[3 * i + 2] = 0.0f;
+    }
 }
 
 __global__ __launch_bounds__(RA_T) void k_contributions(const unsigned long long* __restrict__ best_key, long n,
@@ -392,7 +406,7 @@ int g2pc_raster_front_py(const G2pcCamera* cam, const G2pcTileLayout* layout, co
 
 size_t g2pc_raster_back_workspace(int64_t num_instances, int32_t num_tiles) {
     using namespace g2pc;
-    return align_up((size_t)(num_instances + 1) * 4) * 4 + sort_workspace(num_instances) + scan_workspace(num_tiles + 1) +
+    return align_up((size_t)(num_instances + 1) * 4) * 6 + sort_workspace(num_instances) + scan_workspace(num_tiles + 1) +
            align_up((size_t)(num_tiles + 2) * 4) + 4096;
 }
 
@@ -416,6 +430,8 @@ int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, con
     uint32_t* inst_g = ar.get<uint32_t>((size_t)L + 1);
     uint32_t* tile_sorted = ar.get<uint32_t>((size_t)L + 1);
     uint32_t* g_sorted = ar.get<uint32_t>((size_t)L + 1);
+    uint32_t* tile_tmp = ar.get<uint32_t>((size_t)L + 1);       // ping-pong scratch of the multi-pass sort: must NOT
+    uint32_t* g_tmp = ar.get<uint32_t>((size_t)L + 1);          // alias its input (pass 0 writes here when #passes is even)
     uint32_t* tile_start = ar.get<uint32_t>((size_t)T + 2);
     size_t sort_bytes = sort_workspace(L), scan_bytes = scan_workspace(T + 1);
     char* sort_ws = ar.get<char>(sort_bytes);
@@ -427,8 +443,7 @@ int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, con
     if (L > 0) {
         hipLaunchKernelGGL(k_duplicate, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, sorted_idx, offsets, rect, (long)n, lay.nx,
                            inst_tile, inst_g);
-        // the sort needs scratch ping-pong buffers: reuse inst_* as temporaries of the 2nd pass
-        int rc = sort_pairs_u32(inst_tile, inst_g, tile_sorted, g_sorted, inst_tile, inst_g, L, 0, bits_for_tiles((unsigned)T),
+        int rc = sort_pairs_u32(inst_tile, inst_g, tile_sorted, g_sorted, tile_tmp, g_tmp, L, 0, bits_for_tiles((unsigned)T),
                                 sort_ws, sort_bytes, s);
         if (rc) return rc;
         rc = g2pc_bincount_i32((const int32_t*)tile_sorted, L, tile_start, T, stream);
@@ -438,7 +453,7 @@ int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, con
     if (rc) return rc;
     }
     if (phases & 2) {
-    hipLaunchKernelGGL(k_blend_py, dim3((unsigned)layout->num_chunks), dim3(RA_T), 0, s, lay, layout->chunk_tile,
+    hipLaunchKernelGGL(k_blend_py, dim3((unsigned)layout->num_chunks), dim3(BL_T), 0, s, lay, layout->chunk_tile,
                        layout->chunk_pix0, tile_start, g_sorted, (const float4*)p0, (const float4*)p1, colours, best_key,
                        camera_slot << 24, t_floor, cam->bg[0], tilebuf);
     hipLaunchKernelGGL(k_update_colours_py, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, lay, best_key, (long)n, camera_slot,
@@ -455,6 +470,16 @@ int g2pc_raster_rebase_keys(unsigned long long* best_key, int64_t n, void* strea
     if (n <= 0) return G2PC_OK;
     hipLaunchKernelGGL(k_rebase_keys, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, (hipStream_t)stream, best_key, (long)n);
     return check_launch("g2pc_raster_rebase_keys");
+}
+
+int g2pc_raster_keep_winner_colours(const unsigned long long* local_key, const unsigned long long* global_key,
+                                    int64_t n, float* colours, void* stream) {
+    using namespace g2pc;
+    if (n <= 0) return G2PC_OK;
+    G2PC_REQUIRE(local_key && global_key && colours, G2PC_ERR_ARG, "null pointer");
+    hipLaunchKernelGGL(k_keep_winner_colours, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, (hipStream_t)stream, local_key,
+                       global_key, (long)n, colours);
+    return check_launch("g2pc_raster_keep_winner_colours");
 }
 
 int g2pc_raster_contributions(const unsigned long long* best_key, int64_t n, float* out, void* stream) {

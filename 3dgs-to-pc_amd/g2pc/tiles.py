@@ -19,7 +19,7 @@ from typing import Dict
 
 import numpy as np
 
-CHUNK_PIXELS = 1024          # pixels per blend block (256 lanes x 4 pixels)
+CHUNK_PIXELS = 256           # pixels per blend block (one wave64 x 4 pixels)
 
 
 def _finish(xs, ws, ys, hs, seq_of) -> Dict[str, np.ndarray]:

@@ -28,8 +28,11 @@ C2 = [1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.092548430
 C3 = [-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658,
       1.445305721320277, -0.5900435899266435]
 
-# transmittance floor of the blend (see include/g2pc.h g2pc_raster_back_py).  0.0 = exact reference semantics.
-DEFAULT_T_FLOOR = 0.0
+# Transmittance floor of the blend (include/g2pc.h, g2pc_raster_back_py).  0.0 = the reference's semantics to the
+# letter (every Gaussian of a tile is blended into every pixel).  With a floor t a 256-pixel chunk stops once all
+# its pixels have T < t: every contribution >= t is still computed bit-identically (so the visibility mask, the
+# culled index set and the point allocation are unchanged for thresholds > t) and pixel colours move by < t.
+DEFAULT_T_FLOOR = 1e-6
 RENDER_STATS = []          # (instances L, tile-sort passes, W*H) of every camera rendered (bench.py reads this)
 
 
@@ -53,6 +56,7 @@ nv._RASTER_PROTOS.update({
     "g2pc_raster_back_py": (C.c_int, [C.POINTER(_Camera), C.POINTER(_Layout), C.c_void_p, C.c_int64, C.c_int64] +
                             [C.c_void_p] * 5 + [C.c_uint32, C.c_float] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "g2pc_raster_rebase_keys": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    "g2pc_raster_keep_winner_colours": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "g2pc_raster_contributions": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
 })
 if nv._LIB is not None:
@@ -162,7 +166,22 @@ class GaussHipRenderer():
             self.tilebuf = torch.empty((need,), dtype=torch.float32, device=self.device)
         return lay
 
-    def __call__(self, camera, return_image=True, **kwargs):
+    def all_reduce_visibility(self, group=None):
+        """Multi-GPU (cameras sharded over ranks): combine the running state of all ranks.  all-reduce MAX of the
+        packed (contribution, ~order) keys -- exact and order-free -- then every rank zeroes the colours it did
+        not win and an all-reduce SUM delivers the winners' colours (one non-zero term per Gaussian)."""
+        import torch.distributed as dist
+        if not dist.is_initialized() or dist.get_world_size(group) == 1:
+            return
+        global_key = self.best_key.clone()
+        dist.all_reduce(global_key, op=dist.ReduceOp.MAX, group=group)
+        nv.check(nv.lib().g2pc_raster_keep_winner_colours(nv.ptr(self.best_key), nv.ptr(global_key), self.n,
+                                                          nv.ptr(self.gaussian_colours), nv.stream_handle(self.device)),
+                 "keep_winner_colours")
+        dist.all_reduce(self.gaussian_colours, op=dist.ReduceOp.SUM, group=group)
+        self.best_key = global_key
+
+    def __call__(self, camera, return_image=True, slot=None, **kwargs):
         L = nv.lib()
         st = nv.stream_handle(self.device)
         W, H = int(camera.image_width), int(camera.image_height)
@@ -186,10 +205,15 @@ class GaussHipRenderer():
         if need > self.back_ws_bytes:
             self.back_ws_bytes = int(need * 1.25)
             self.back_ws = nv.workspace(self.back_ws_bytes, self.device)
-        if self.camera_slot >= 255:
-            nv.check(L.g2pc_raster_rebase_keys(nv.ptr(self.best_key), self.n, st), "rebase")
-            self.camera_slot = 0
-        self.camera_slot += 1
+        if slot is not None:                       # caller-assigned global camera order (multi-GPU camera sharding)
+            if not (1 <= slot <= 255):
+                raise ValueError("camera slot must be in [1, 255]")
+            self.camera_slot = int(slot)
+        else:
+            if self.camera_slot >= 255:
+                nv.check(L.g2pc_raster_rebase_keys(nv.ptr(self.best_key), self.n, st), "rebase")
+                self.camera_slot = 0
+            self.camera_slot += 1
         image = torch.empty((H, W, 3), dtype=torch.float32, device=self.device) if return_image else None
         for phase, name in ((1, "raster_bin"), (2, "raster_blend")):
             with nv.region(name, self.device):

@@ -120,8 +120,10 @@ def create_new_gaussian_points(num_points_to_sample, means, covariances, colours
 
 def generate_pointcloud(gaussians, num_points, contributions=None, mahalanobis_distance_std=2, exact_num_points=False,
                         calculate_normals=True, num_sample_attempts=5, device="cuda:0", quiet=False, seed=None,
-                        gid_base=0):
-    """gauss_to_pc.py:277-371."""
+                        gid_base=0, shard=None):
+    """gauss_to_pc.py:277-371.  `shard=(rank, world)`: the allocation (sizes, points per Gaussian, bins) is computed
+    for ALL Gaussians -- identical on every rank -- and only the Gaussians of this rank's contiguous index range are
+    sampled; the union over ranks is exactly the single-GPU cloud (noise is keyed by the global Gaussian index)."""
     seed = SAMPLER_SEED if seed is None else seed
 
     # Calculate Gaussian sizes
@@ -135,13 +137,26 @@ def generate_pointcloud(gaussians, num_points, contributions=None, mahalanobis_d
     _, points_per_gaussian, stats = ops.distribute_points(gaussian_sizes, num_points)
     max_ppg = int(stats[3].item())
 
+    bins = None
+    if shard is not None and shard[1] > 1:
+        rank, world = shard
+        g_total = points_per_gaussian.shape[0]
+        lo, hi = (g_total * rank) // world, (g_total * (rank + 1)) // world
+        hist = ops.bincount(points_per_gaussian, max_ppg + 1).cpu().numpy().astype(np.int64)
+        bins = ops.bin_table_from_hist(hist, bool(exact_num_points))          # global bin table
+        local = torch.zeros_like(points_per_gaussian)
+        local[lo:hi] = points_per_gaussian[lo:hi]
+        # Gaussians outside the shard get the (unused) value -1 -> no bin
+        points_per_gaussian = torch.where(local > 0, local, torch.full_like(local, -1)) if lo > 0 or hi < g_total else local
+        points_per_gaussian[lo:hi] = local[lo:hi]
+
     if not quiet:
         print(f"Starting Point Cloud Generation")
 
     out = ops.sample_pointcloud(gaussians.xyz, gaussians.covariances, gaussians.colours,
                                 gaussians.normals if calculate_normals else None, points_per_gaussian, max_ppg,
                                 exact=bool(exact_num_points), std=mahalanobis_distance_std,
-                                attempts=num_sample_attempts, seed=seed, gid_base=gid_base)
+                                attempts=num_sample_attempts, seed=seed, gid_base=gid_base, bins=bins)
     return _finish_dtypes(out.points, out.colours, out.normals)
 
 

@@ -210,6 +210,7 @@ def main():
                    "cameras": a.cameras if workload == "render" else 0,
                    "blend_transmittance_floor": gauss_render.DEFAULT_T_FLOOR, "parallelism": "shard-by-gaussian x%d" % world},
         "roofline": roof,
+        "instances_per_camera": (float(np.mean([x[0] for x in gauss_render.RENDER_STATS])) if gauss_render.RENDER_STATS else None),
         "regions_ms_per_step": {k: v[1] / a.steps for k, v in sorted(prof.items())},
     }
     if not a.no_cpu_baseline:

@@ -38,6 +38,8 @@ int g2pc_abi_version(void);
  * cub::DeviceRadixSort::SortPairs rasterizer_impl.cu:311-316, and the torch.unique / boolean
  * index compactions of gauss_to_pc.py:225-238,334).
  * ------------------------------------------------------------------------------------------- */
+/* diagnostic: out[4w..4w+3] = {dpp max, dpp min, shuffle max, shuffle min} of the 64 values of wave w */
+int g2pc_selftest_wave_reduce(const uint32_t* in, uint32_t* out, int64_t waves, void* stream);
 size_t g2pc_scan_workspace(int64_t n);
 /* out[0..n] = exclusive prefix sums of in[0..n-1]; out[n] = total.  in may alias out. */
 int g2pc_scan_exclusive_u32(const uint32_t* in, uint32_t* out, int64_t n, void* ws, size_t ws_bytes, void* stream);
@@ -163,7 +165,7 @@ typedef struct G2pcTileLayout {      /* HOST struct of DEVICE pointers: tiles = 
     const int32_t* tile_seq;         /* [ny*nx] processing order of tile iy*nx+ix (python renderer: FIFO quad-tree order) */
     const int32_t* seq_tile;         /* [ny*nx] inverse of tile_seq */
     const int32_t* tile_pix_off;     /* [ny*nx+1] pixel offset of every tile inside the per-tile colour buffer */
-    int32_t num_chunks;              /* blend work list: one block per (tile, first pixel) chunk of <= 1024 pixels */
+    int32_t num_chunks;              /* blend work list: one block per (tile, first pixel) chunk of <= 256 pixels */
     const int32_t* chunk_tile;       /* [num_chunks] */
     const int32_t* chunk_pix0;       /* [num_chunks] */
 } G2pcTileLayout;
@@ -192,6 +194,10 @@ int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, con
                         unsigned long long* best_key, float* colours_out, float* tilebuf, float* image, int phases,
                         void* ws, size_t ws_bytes, void* stream);
 int g2pc_raster_rebase_keys(unsigned long long* best_key, int64_t n, void* stream);
+/* multi-GPU (no counterpart in the reference): zero colours[i,:] unless local_key[i] == global_key[i] != 0, so that an
+ * all-reduce(SUM) over ranks after an all-reduce(MAX) of the keys reproduces "earliest camera wins" exactly. */
+int g2pc_raster_keep_winner_colours(const unsigned long long* local_key, const unsigned long long* global_key,
+                                    int64_t n, float* colours, void* stream);
 /* gaussian_max_contribution f32[n] out of the packed keys (gauss_render.py:243-264 getters read this) */
 int g2pc_raster_contributions(const unsigned long long* best_key, int64_t n, float* out, void* stream);
 

@@ -314,3 +314,23 @@ using std::min;
 // amdgcn builtins used by g2pc_device.inl
 static inline void __builtin_amdgcn_fence(int, const char*) {}
 static inline void __builtin_amdgcn_wave_barrier() { hipemu::wave_barrier(); }
+
+// DPP / readlane emulation (only the controls g2pc uses: row_shr:n, row_bcast:15, row_bcast:31)
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    unsigned l = hipemu::S().cur & 63;
+    uint64_t act = 0;
+    const uint64_t* t = hipemu::exchange((uint64_t)(uint32_t)src, &act);
+    unsigned row = l >> 4, bank = (l & 15) >> 2;
+    if (!((row_mask >> row) & 1) || !((bank_mask >> bank) & 1)) return old;
+    int j = -1;
+    if (ctrl >= 0x111 && ctrl <= 0x11F) { int n = ctrl - 0x110; if ((int)(l & 15) >= n) j = (int)l - n; }
+    else if (ctrl == 0x142) { if (row >= 1) j = (int)(16 * (row - 1) + 15); }
+    else if (ctrl == 0x143) { if (row >= 2) j = 31; }
+    else { fprintf(stderr, "hipemu: unsupported dpp ctrl 0x%x\n", ctrl); abort(); }
+    if (j < 0 || !((act >> j) & 1)) return bound_ctrl ? 0 : old;
+    return (int)(uint32_t)t[j];
+}
+static inline int __builtin_amdgcn_readlane(int v, int lane) {
+    const uint64_t* t = hipemu::exchange((uint64_t)(uint32_t)v);
+    return (int)(uint32_t)t[lane & 63];
+}

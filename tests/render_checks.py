@@ -48,3 +48,36 @@ def assert_render_matches(g, R, images, contribs, tol=1e-4, allow_mask_flips=0):
     assert len(flips) <= allow_mask_flips, "visible-mask flips: %d, margins %s" % (len(flips), margins)
     np.testing.assert_allclose(R.get_total_gaussian_contributions().cpu().numpy(), g["total"], atol=tol)
     return dict(image=d_img, contribution=d_c, colour=d_col, flips=len(flips))
+
+
+def run_vs_oracle(n, seed, width, height, focal, ncam, device="cpu", scale=(0.004, 0.04), colour_resolution=None,
+                  t_floor=0.0):
+    """HIP renderer vs oracle/ref_render.py (itself bit-pinned to the reference) on a seeded synthetic scene."""
+    import gauss_render
+    import camera_handler
+    import ref_gauss as RG
+    import ref_render as RR
+    from gauss_handler import Gaussians
+    dev = torch.device(device)
+    sc = make_scene(n, seed, scale_lo=scale[0], scale_hi=scale[1])
+    transforms, intr = make_cameras(ncam, width=width, height=height, focal=focal)
+    G = Gaussians(sc.xyz.to(dev), sc.scales.to(dev), sc.rots.to(dev), sc.colours.to(dev), sc.opacities.to(dev))
+    R = gauss_render.get_renderer("python", G.xyz, G.opacities.unsqueeze(1), G.colours, G.covariances,
+                                  visible_gaussian_threshold=0.05)
+    R.t_floor = t_floor
+    O = RR.PythonRendererOracle(sc.xyz, sc.opacities.unsqueeze(1), sc.colours.double(), RG.covariances(sc.scales, sc.rots),
+                                threshold=0.05)
+    worst = dict(image=0.0, contribution=0.0, colour=0.0, flips=0, near_threshold=0)
+    for name in transforms:
+        cam = camera_handler.get_camera("python", torch.tensor(transforms[name]), intr[name], colour_resolution=colour_resolution)
+        img = R(cam)[0].cpu()
+        ref = O(RR.get_camera(torch.tensor(transforms[name]), intr[name], colour_resolution=colour_resolution))
+        worst["image"] = max(worst["image"], float((img - ref).abs().max()))
+    c = R.gaussian_max_contribution.cpu()
+    worst["contribution"] = float((c - O.max_contribution).abs().max())
+    worst["colour"] = float((R.get_gaussian_colours().cpu().double() - O.get_gaussian_colours()).abs().max() / 255.0)
+    flips = (R.get_visible_gaussians().cpu() != O.get_visible_gaussians())
+    worst["flips"] = int(flips.sum())
+    worst["near_threshold"] = int(((O.max_contribution - 0.05).abs() < 1e-5).sum())
+    worst["flip_margins"] = (O.max_contribution[flips] - 0.05).abs().tolist()
+    return worst

@@ -69,3 +69,18 @@ def test_distribute_points_matches_reference(emu, golden_dir):
     sizes = torch.tensor([10.0, 0.001, 0.001, 10.0, 0.001], dtype=torch.float64)
     p, _, st = ops.distribute_points(sizes, 22)
     assert p.tolist() == RG.distribute_points(sizes, 22).tolist()
+
+
+def test_dpp_wave_reductions(emu):
+    import ctypes
+    from g2pc import _native as nv
+    rng = np.random.default_rng(3)
+    v = rng.integers(0, 2 ** 32, size=64 * 37, dtype=np.uint64).astype(np.uint32)
+    v[64:128] = 7
+    t = torch.from_numpy(v.view(np.int32))
+    out = torch.zeros(4 * 37, dtype=torch.int32)
+    nv.check(nv.lib().g2pc_selftest_wave_reduce(nv.ptr(t), nv.ptr(out), 37, None), "selftest")
+    o = out.numpy().view(np.uint32).reshape(37, 4)
+    r = v.reshape(37, 64)
+    assert np.array_equal(o[:, 0], r.max(1)) and np.array_equal(o[:, 1], r.min(1))
+    assert np.array_equal(o[:, 2], r.max(1)) and np.array_equal(o[:, 3], r.min(1))

@@ -59,3 +59,13 @@ def test_render_full_size_properties():
     assert torch.equal(v0, v1)                                   # visibility mask at threshold 0.05 is identical
     assert float((col0 - col1).abs().max()) < 255e-5
     assert 0.01 < float(v0.float().mean()) < 0.9
+
+
+@pytest.mark.parametrize("n,w,h,f,res", [(20_000, 1280, 720, 1100.0, None), (5_000, 1920, 1080, 1650.0, None),
+                                         (8_000, 1280, 720, 1100.0, 360)])
+def test_render_vs_oracle_other_sizes(n, w, h, f, res):
+    from render_checks import run_vs_oracle
+    r = run_vs_oracle(n, 31 + n, w, h, f, 2, device=DEV, colour_resolution=res)
+    print(r)
+    assert r["image"] < 1e-4 and r["contribution"] < 1e-4 and r["colour"] < 1e-4
+    assert r["flips"] <= r["near_threshold"], r       # a mask may only flip where the oracle sits within 1e-5 of 0.05
