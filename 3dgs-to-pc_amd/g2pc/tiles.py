@@ -37,11 +37,27 @@ def _finish(xs, ws, ys, hs, seq_of) -> Dict[str, np.ndarray]:
     pix = np.array([ws[t % nx] * hs[t // nx] for t in range(T)], dtype=np.int64)
     off = np.zeros((T + 1,), dtype=np.int64)
     off[1:] = np.cumsum(pix)
+    # Blend work list.  Dispatch order = block index, and block b runs on XCD b % 8 (observed, speed only):
+    #  * tiles are visited from the image centre outwards, so the long-running (dense) tiles start first and the
+    #    cheap border tiles fill the tail of the launch;
+    #  * tiles are taken 8 at a time and their chunks interleaved with stride 8, so all chunks of one tile land on
+    #    the same XCD and re-read the tile's Gaussian list from that XCD's L2.
+    W = max(x + w_ for x, w_ in zip(xs, ws))
+    H = max(y + h_ for y, h_ in zip(ys, hs))
+    def dist(t):
+        ix, iy = t % nx, t // nx
+        cx, cy = xs[ix] + ws[ix] / 2.0, ys[iy] + hs[iy] / 2.0
+        return ((cx - W / 2.0) / W) ** 2 + ((cy - H / 2.0) / H) ** 2
+    order_t = sorted(range(T), key=dist)
     chunk_tile, chunk_pix0 = [], []
-    for t in range(T):
-        for p0 in range(0, int(pix[t]), CHUNK_PIXELS):
-            chunk_tile.append(t)
-            chunk_pix0.append(p0)
+    for g0 in range(0, T, 8):
+        group = order_t[g0:g0 + 8]
+        per_tile = [list(range(0, int(pix[t]), CHUNK_PIXELS)) for t in group]
+        for c in range(max(len(p) for p in per_tile)):
+            for k, t in enumerate(group):
+                if c < len(per_tile[k]):
+                    chunk_tile.append(t)
+                    chunk_pix0.append(per_tile[k][c])
     return dict(nx=nx, ny=ny, xs=np.asarray(xs, np.int32), ws=np.asarray(ws, np.int32),
                 ys=np.asarray(ys, np.int32), hs=np.asarray(hs, np.int32), tile_seq=rank, seq_tile=seq_tile,
                 tile_pix_off=off.astype(np.int32), chunk_tile=np.asarray(chunk_tile, np.int32),

@@ -181,6 +181,11 @@ class GaussHipRenderer():
         dist.all_reduce(self.gaussian_colours, op=dist.ReduceOp.SUM, group=group)
         self.best_key = global_key
 
+    def rebase_keys(self):
+        """Forget the camera order of the current keys (they become "earliest"), freeing the 8-bit order field."""
+        nv.check(nv.lib().g2pc_raster_rebase_keys(nv.ptr(self.best_key), self.n, nv.stream_handle(self.device)), "rebase")
+        self.camera_slot = 0
+
     def __call__(self, camera, return_image=True, slot=None, **kwargs):
         L = nv.lib()
         st = nv.stream_handle(self.device)

@@ -144,11 +144,9 @@ def generate_pointcloud(gaussians, num_points, contributions=None, mahalanobis_d
         lo, hi = (g_total * rank) // world, (g_total * (rank + 1)) // world
         hist = ops.bincount(points_per_gaussian, max_ppg + 1).cpu().numpy().astype(np.int64)
         bins = ops.bin_table_from_hist(hist, bool(exact_num_points))          # global bin table
-        local = torch.zeros_like(points_per_gaussian)
+        local = torch.full_like(points_per_gaussian, -1)                      # -1: not a member of any bin
         local[lo:hi] = points_per_gaussian[lo:hi]
-        # Gaussians outside the shard get the (unused) value -1 -> no bin
-        points_per_gaussian = torch.where(local > 0, local, torch.full_like(local, -1)) if lo > 0 or hi < g_total else local
-        points_per_gaussian[lo:hi] = local[lo:hi]
+        points_per_gaussian = local
 
     if not quiet:
         print(f"Starting Point Cloud Generation")
@@ -160,11 +158,17 @@ def generate_pointcloud(gaussians, num_points, contributions=None, mahalanobis_d
     return _finish_dtypes(out.points, out.colours, out.normals)
 
 
-def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, pointcloud_settings, seed=None):
+def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, pointcloud_settings, seed=None,
+                            group=None):
     """The body of convert_3dgs_to_pc (gauss_to_pc.py:414-601) on already-loaded data:
-    `gaussians` is a gauss_handler.Gaussians, transforms / intrinsics are name -> 4x4 c2w / [w, h, fx, fy]."""
+    `gaussians` is a gauss_handler.Gaussians, transforms / intrinsics are name -> 4x4 c2w / [w, h, fx, fy].
+    Under torch.distributed (one process per GPU) the cameras are split over the ranks, the per-Gaussian
+    visibility state is all-reduced once, and every rank returns the points of its Gaussian-index shard
+    (g2pc.dist.gather_pointcloud assembles them); see g2pc/dist.py."""
+    from g2pc.dist import rank_world
     s = pointcloud_settings
     device = gaussians.xyz.device
+    rank, world = rank_world(group)
 
     # Calculate Gaussian Normals
     if s.calculate_normals:
@@ -185,15 +189,26 @@ def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, poin
         if transforms is None:
             raise Exception("Transforms are required to render colours")
 
-        for img_name, transform in transforms.items():
-            transform = torch.tensor(list(transform), device=device)
+        for cam_index, (img_name, transform) in enumerate(transforms.items()):
+            if world > 1:
+                if cam_index > 0 and cam_index % 255 == 0:           # camera-order field of the keys is 8 bits wide
+                    gaussian_renderer.all_reduce_visibility(group)
+                    gaussian_renderer.rebase_keys()
+                if cam_index % world != rank:
+                    continue
+            transform = torch.tensor(list(transform))
             mask = None
             if mask_images is not None and img_name in mask_images.keys():
                 mask = mask_images[img_name].to(device)
             camera = get_camera(s.renderer_type, transform, intrinsics[img_name], colour_resolution=s.colour_resolution,
                                 sh_degree=s.max_sh_degree, white_bkgd=True, mask=mask)
-            # Render new image and Gaussian contributions
-            gaussian_renderer(camera)
+            # Render new image and Gaussian contributions (the image itself is not used by the pipeline)
+            if world > 1:
+                gaussian_renderer(camera, return_image=False, slot=cam_index % 255 + 1)
+            else:
+                gaussian_renderer(camera, return_image=False)
+        if world > 1:
+            gaussian_renderer.all_reduce_visibility(group)
 
         if not s.quiet:
             print()
@@ -260,7 +275,8 @@ def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, poin
                                                    calculate_normals=s.calculate_normals,
                                                    num_sample_attempts=num_sample_attempts,
                                                    contributions=total_gaussian_contributions,
-                                                   device=s.device, quiet=s.quiet, seed=seed)
+                                                   device=s.device, quiet=s.quiet, seed=seed,
+                                                   shard=(rank, world))
 
     total_point_cloud = PointCloudData(points=points, colours=colours, normals=normals)
 
@@ -282,7 +298,7 @@ def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, poin
         points, colours, normals = generate_pointcloud(gaussians, total_mesh_points, exact_num_points=s.exact_num_points,
                                                        num_sample_attempts=num_sample_attempts,
                                                        contributions=total_gaussian_contributions[surface_gaussian_idxs],
-                                                       device=s.device, quiet=s.quiet, seed=seed)
+                                                       device=s.device, quiet=s.quiet, seed=seed, shard=(rank, world))
 
         surface_point_cloud = PointCloudData(points=points, colours=colours, normals=normals)
 

@@ -67,15 +67,22 @@ def run_vs_oracle(n, seed, width, height, focal, ncam, device="cpu", scale=(0.00
     R.t_floor = t_floor
     O = RR.PythonRendererOracle(sc.xyz, sc.opacities.unsqueeze(1), sc.colours.double(), RG.covariances(sc.scales, sc.rots),
                                 threshold=0.05)
-    worst = dict(image=0.0, contribution=0.0, colour=0.0, flips=0, near_threshold=0)
+    worst = dict(image=0.0, contribution=0.0, colour=0.0, flips=0, near_threshold=0, image_frac_off=0.0)
     for name in transforms:
         cam = camera_handler.get_camera("python", torch.tensor(transforms[name]), intr[name], colour_resolution=colour_resolution)
         img = R(cam)[0].cpu()
         ref = O(RR.get_camera(torch.tensor(transforms[name]), intr[name], colour_resolution=colour_resolution))
-        worst["image"] = max(worst["image"], float((img - ref).abs().max()))
+        d = (img - ref).abs()
+        worst["image"] = max(worst["image"], float(d.max()))
+        worst["image_frac_off"] = max(worst["image_frac_off"], float((d > 1e-4).float().mean()))
     c = R.gaussian_max_contribution.cpu()
-    worst["contribution"] = float((c - O.max_contribution).abs().max())
-    worst["colour"] = float((R.get_gaussian_colours().cpu().double() - O.get_gaussian_colours()).abs().max() / 255.0)
+    dc = (c - O.max_contribution).abs()
+    worst["contribution"] = float(dc.max())
+    worst["contribution_frac_off"] = float((dc > 1e-4).float().mean())
+    dcol = (R.get_gaussian_colours().cpu().double() - O.get_gaussian_colours()).abs() / 255.0
+    seen = O.max_contribution > (t_floor if t_floor > 0 else -1.0)
+    worst["colour"] = float(dcol[seen].max())
+    worst["colour_frac_off"] = float((dcol[seen] > 1e-4).float().mean())
     flips = (R.get_visible_gaussians().cpu() != O.get_visible_gaussians())
     worst["flips"] = int(flips.sum())
     worst["near_threshold"] = int(((O.max_contribution - 0.05).abs() < 1e-5).sum())

@@ -20,6 +20,6 @@ def test_render_with_transmittance_floor_is_within_floor(emu, golden_dir):
 def test_render_1024_tiles_two_pass_tile_sort_vs_oracle(emu):
     """1280x720 = 1024 quad-tree leaves -> 10-bit tile ids -> two radix passes (ping-pong buffers)."""
     from render_checks import run_vs_oracle
-    w = run_vs_oracle(400, 21, 1280, 720, 1100.0, 1, scale=(0.01, 0.08))
+    w = run_vs_oracle(400, 21, 1280, 720, 1100.0, 1, scale=(0.01, 0.08), t_floor=0.0)
     print(w)
     assert w["image"] < 1e-4 and w["contribution"] < 1e-4 and w["colour"] < 1e-4 and w["flips"] == 0
