@@ -7,8 +7,6 @@ render call launches no set-up kernels and needs no device read-back.
 Reference lines: camera_handler.py:8-50 (maths + Camera), :53-108 (get_camera).
 """
 import math
-from typing import NamedTuple, Optional
-
 import torch
 
 
@@ -65,24 +63,6 @@ class Camera():
         self.full_proj_transform = self.world_view_transform @ self.projection_matrix
 
 
-class GaussianRasterizationSettings(NamedTuple):
-    """gaussian_pointcloud_rasterization/__init__.py:21-35 (same 14 fields, same order)."""
-    image_height: int
-    image_width: int
-    tanfovx: float
-    tanfovy: float
-    bg: torch.Tensor
-    scale_modifier: float
-    viewmatrix: torch.Tensor
-    projmatrix: torch.Tensor
-    sh_degree: int
-    campos: torch.Tensor
-    mask: Optional[torch.Tensor]
-    prefiltered: bool
-    debug: bool
-    antialiasing: bool
-
-
 def get_camera(renderer_type, transform, cam_intrinsic, colour_resolution=None, sh_degree=3, white_bkgd=True, mask=None):
     """camera_handler.py:53-108.  'hip' is accepted as the native spelling of the reference's 'cuda'."""
 
@@ -103,6 +83,8 @@ def get_camera(renderer_type, transform, cam_intrinsic, colour_resolution=None, 
         return Camera(img_width, img_height, focal_x, focal_y, transform)
 
     elif renderer_type in ("cuda", "hip"):
+        from gaussian_pointcloud_rasterization import GaussianRasterizationSettings
+
         transform = transform.detach().to("cpu", torch.float32).clone()
         transform[:, 1:3] = -transform[:, 1:3]
 

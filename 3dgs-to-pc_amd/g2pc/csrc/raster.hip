@@ -180,7 +180,7 @@ __global__ __launch_bounds__(RA_T) void k_duplicate(const uint32_t* __restrict__
 // lane 0 publishes  key = contribution_bits << 32 | ~(slot << 24 | tile_seq << 12 | pixel)  with one 64-bit
 // atomicMax -- but only when some lane can beat the value staged from the running maximum.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int BL_T = 64, BL_PPT = 4, BL_BATCH = 64, BL_CHUNK = BL_T * BL_PPT;
+constexpr int BL_T = 64, BL_PPT = 4, BL_BATCH = 64;
 
 __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __restrict__ chunk_tile,
                                                   const int32_t* __restrict__ chunk_pix0,
@@ -347,6 +347,293 @@ __global__ __launch_bounds__(RA_T) void k_assemble_image_py(Layout lay, int W, i
     dst[0] = r; dst[1] = g; dst[2] = bl;
 }
 
+// =========================================================================================================
+// Semantics "CU" = the reference's native rasteriser (renderer_type="cuda"), deterministic spec of SURVEY §8(a.5).
+// =========================================================================================================
+__constant__ float kSH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f,
+                                0.5462742152960396f};
+__constant__ float kSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                                -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+
+// forward.cu:153-271 (preprocessCUDA) + :22-73 (computeColorFromSH) + :76-111 (computeCov2D); 16x16 tile rect of
+// auxiliary.h:45-55.  Depth-sort input is written in ASCENDING index order: the reference's stable radix sort of
+// (tile << 32 | depth bits) keeps equal depths in ascending Gaussian index.
+__global__ __launch_bounds__(RA_T) void k_preprocess_cu(Cam cam, int grid_x, int grid_y,
+                                                       const float* __restrict__ means3D,
+                                                       const float* __restrict__ cov6,
+                                                       const float* __restrict__ opacity,
+                                                       const float* __restrict__ colours_precomp,
+                                                       const float* __restrict__ shs, int sh_degree, int sh_coeffs,
+                                                       float3 campos, long n, uint32_t* __restrict__ depth_key,
+                                                       uint32_t* __restrict__ index, uint32_t* __restrict__ tiles_touched,
+                                                       float4* __restrict__ p0, float4* __restrict__ p1,
+                                                       uint32_t* __restrict__ rect, float* __restrict__ rgb,
+                                                       int32_t* __restrict__ radii) {
+    long i = (long)blockIdx.x * RA_T + threadIdx.x;
+    if (i >= n) return;
+    const float x = means3D[3 * i], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
+    const float* V = cam.V;
+    const float* P = cam.P;
+    uint32_t key = 0xFFFFFFFFu, touched = 0, rc = 0;
+    int rad = 0;
+    const float tz0 = V[2] * x + V[6] * y + V[10] * z + V[14];
+    if (tz0 > 0.2f) {                                                   // in_frustum (auxiliary.h:166)
+        float hx = P[0] * x + P[4] * y + P[8] * z + P[12];
+        float hy = P[1] * x + P[5] * y + P[9] * z + P[13];
+        float hw = P[3] * x + P[7] * y + P[11] * z + P[15];
+        float pw = 1.0f / (hw + 0.0000001f);
+        const float focal_x = (float)cam.W / (2.0f * cam.tan_fovx), focal_y = (float)cam.H / (2.0f * cam.tan_fovy);
+        float tx = V[0] * x + V[4] * y + V[8] * z + V[12];
+        float ty = V[1] * x + V[5] * y + V[9] * z + V[13];
+        float tz = tz0;
+        float limx = 1.3f * cam.tan_fovx, limy = 1.3f * cam.tan_fovy;
+        tx = fminf(limx, fmaxf(-limx, tx / tz)) * tz;
+        ty = fminf(limy, fmaxf(-limy, ty / tz)) * tz;
+        // T = W J (math convention, see oracle/cuda_raster_ref.c): only columns 0 and 1 of T are non-zero
+        float j00 = focal_x / tz, j11 = focal_y / tz, j20 = -(focal_x * tx) / (tz * tz), j21 = -(focal_y * ty) / (tz * tz);
+        float T0[3], T1[3];                                              // columns 0 and 1 of T, indexed by row
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            T0[r] = V[4 * r + 0] * j00 + V[4 * r + 2] * j20;
+            T1[r] = V[4 * r + 1] * j11 + V[4 * r + 2] * j21;
+        }
+        const float* c = cov6 + 6 * i;
+        float S[3][3] = {{c[0], c[1], c[2]}, {c[1], c[3], c[4]}, {c[2], c[4], c[5]}};
+        float a0[3], a1[3];                                              // rows 0,1 of T^T Vrk^T
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            a0[k] = T0[0] * S[k][0] + T0[1] * S[k][1] + T0[2] * S[k][2];
+            a1[k] = T1[0] * S[k][0] + T1[1] * S[k][1] + T1[2] * S[k][2];
+        }
+        float cxx = a0[0] * T0[0] + a0[1] * T0[1] + a0[2] * T0[2] + 0.3f;
+        float cxy = a1[0] * T0[0] + a1[1] * T0[1] + a1[2] * T0[2];
+        float cyy = a1[0] * T1[0] + a1[1] * T1[1] + a1[2] * T1[2] + 0.3f;
+        float det = cxx * cyy - cxy * cxy;
+        if (det != 0.0f) {
+            float di = 1.0f / det;
+            float kx = cyy * di, ky = -cxy * di, kz = cxx * di;
+            float mid = 0.5f * (cxx + cyy);
+            float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+            float l1 = mid + sq, l2 = mid - sq;
+            float my_radius = ceilf(3.0f * sqrtf(fmaxf(l1, l2)));
+            float px = (float)((((double)(hx * pw) + 1.0) * cam.W - 1.0) * 0.5);     // ndc2Pix in double (auxiliary.h:40-43)
+            float py = (float)((((double)(hy * pw) + 1.0) * cam.H - 1.0) * 0.5);
+            int r = (int)my_radius;
+            int x0 = (int)((px - r) / 16), y0 = (int)((py - r) / 16);
+            int x1 = (int)((px + r + 15) / 16), y1 = (int)((py + r + 15) / 16);
+            x0 = min(grid_x, max(0, x0)); y0 = min(grid_y, max(0, y0));
+            x1 = min(grid_x, max(0, x1)); y1 = min(grid_y, max(0, y1));
+            if ((x1 - x0) * (y1 - y0) != 0) {
+                touched = (uint32_t)((x1 - x0) * (y1 - y0));
+                rc = (uint32_t)x0 | ((uint32_t)(x1 - 1) << 8) | ((uint32_t)y0 << 16) | ((uint32_t)(y1 - 1) << 24);
+                key = __float_as_uint(tz0);
+                rad = r;
+                const float sc = LOG2E;
+                p0[i] = make_float4(px, py, -0.5f * sc * kx, -sc * ky);
+                p1[i] = make_float4(-0.5f * sc * kz, opacity[i], tz0, my_radius);
+                float cr, cg, cb;
+                if (colours_precomp) {
+                    cr = colours_precomp[3 * i]; cg = colours_precomp[3 * i + 1]; cb = colours_precomp[3 * i + 2];
+                } else {
+                    float dx = x - campos.x, dy = y - campos.y, dz = z - campos.z;
+                    float len = sqrtf(dx * dx + dy * dy + dz * dz);
+                    dx /= len; dy /= len; dz /= len;
+                    const float* sh = shs + (size_t)i * sh_coeffs * 3;
+                    float res[3];
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        float v = 0.28209479177387814f * sh[ch];
+                        if (sh_degree > 0) {
+                            v = v - 0.4886025119029199f * dy * sh[3 + ch] + 0.4886025119029199f * dz * sh[6 + ch] -
+                                0.4886025119029199f * dx * sh[9 + ch];
+                            if (sh_degree > 1) {
+                                float xx = dx * dx, yy = dy * dy, zz = dz * dz, xy = dx * dy, yz = dy * dz, xz = dx * dz;
+                                v = v + kSH_C2[0] * xy * sh[12 + ch] + kSH_C2[1] * yz * sh[15 + ch] +
+                                    kSH_C2[2] * (2.0f * zz - xx - yy) * sh[18 + ch] + kSH_C2[3] * xz * sh[21 + ch] +
+                                    kSH_C2[4] * (xx - yy) * sh[24 + ch];
+                                if (sh_degree > 2) {
+                                    v = v + kSH_C3[0] * dy * (3.0f * xx - yy) * sh[27 + ch] + kSH_C3[1] * xy * dz * sh[30 + ch] +
+                                        kSH_C3[2] * dy * (4.0f * zz - xx - yy) * sh[33 + ch] +
+                                        kSH_C3[3] * dz * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[36 + ch] +
+                                        kSH_C3[4] * dx * (4.0f * zz - xx - yy) * sh[39 + ch] +
+                                        kSH_C3[5] * dz * (xx - yy) * sh[42 + ch] + kSH_C3[6] * dx * (xx - 3.0f * yy) * sh[45 + ch];
+                                }
+                            }
+                        }
+                        v += 0.5f;
+                        res[ch] = v < 0.0f ? 0.0f : v;
+                    }
+                    cr = res[0]; cg = res[1]; cb = res[2];
+                }
+                rgb[3 * i] = cr; rgb[3 * i + 1] = cg; rgb[3 * i + 2] = cb;
+            }
+        }
+    }
+    depth_key[i] = key;
+    index[i] = (uint32_t)i;
+    tiles_touched[i] = touched;
+    rect[i] = rc;
+    radii[i] = rad;
+}
+
+// forward.cu:303-497 (renderCUDA).  One wave64 per 16x16 tile, 4 pixels per lane (thread rank t = lane + 64 j,
+// pixel (t % 16, t / 16) of the tile).  The reference's 256-instance batches are kept as the unit of the
+// "everyone done" test and of the surface-distance pass; inside a batch the list is staged 64 at a time.
+__global__ __launch_bounds__(BL_T) void k_blend_cu(int W, int H, int grid_x, const uint32_t* __restrict__ tile_start,
+                                                  const uint32_t* __restrict__ inst_g, const float4* __restrict__ p0,
+                                                  const float4* __restrict__ p1, const float* __restrict__ rgb,
+                                                  const int32_t* __restrict__ mask, float3 bg, int calc_surf,
+                                                  unsigned long long* __restrict__ cam_key,
+                                                  uint32_t* __restrict__ cam_surf, float* __restrict__ out_color,
+                                                  float* __restrict__ out_depth, float* __restrict__ out_invdepth) {
+    __shared__ float4 s_p0[BL_BATCH];
+    __shared__ float4 s_p1[BL_BATCH];
+    __shared__ float4 s_p2[BL_BATCH];
+    __shared__ uint32_t s_g[256];
+    __shared__ float s_depth[256];
+    const int tile = blockIdx.x;
+    const int tx = tile % grid_x, ty = tile / grid_x;
+    const unsigned lane = threadIdx.x;
+    float px[BL_PPT], py[BL_PPT], T[BL_PPT], cr[BL_PPT], cg[BL_PPT], cb[BL_PPT], E[BL_PPT], Ei[BL_PPT];
+    uint32_t pixid[BL_PPT];
+    bool done[BL_PPT], part[BL_PPT], inside[BL_PPT];
+#pragma unroll
+    for (int j = 0; j < BL_PPT; ++j) {
+        int t = (int)lane + 64 * j;
+        int x = tx * 16 + (t & 15), y = ty * 16 + (t >> 4);
+        inside[j] = (x < W) && (y < H);
+        bool masked = inside[j] && mask && (mask[(size_t)W * y + x] == 0);
+        part[j] = inside[j] && !masked;              // takes part in blending
+        done[j] = !part[j];
+        px[j] = (float)x; py[j] = (float)y;
+        pixid[j] = (uint32_t)(W * y + x);
+        T[j] = 1.0f; cr[j] = cg[j] = cb[j] = 0.0f; E[j] = 0.0f; Ei[j] = 0.0f;
+    }
+    const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
+    for (uint32_t b256 = start; b256 < end; b256 += 256) {
+        bool all_done = true;
+#pragma unroll
+        for (int j = 0; j < BL_PPT; ++j) all_done = all_done && done[j];
+        if (__all(all_done ? 1 : 0)) break;                               // forward.cu:373-375
+        const uint32_t bend = (end - b256) < 256u ? end : b256 + 256;
+        for (uint32_t b = b256; b < bend; b += BL_BATCH) {
+            wave_sync();
+            if (b + lane < bend) {
+                uint32_t g = inst_g[b + lane];
+                float4 q = p1[g];
+                s_p0[lane] = p0[g];
+                s_p1[lane] = q;
+                float gm = __uint_as_float((uint32_t)(cam_key[g] >> 32));
+                s_p2[lane] = make_float4(rgb[3 * (size_t)g], rgb[3 * (size_t)g + 1], rgb[3 * (size_t)g + 2], gm);
+                s_g[b - b256 + lane] = g;
+                s_depth[b - b256 + lane] = q.z;
+            }
+            wave_sync();
+            const int cnt = (bend - b) < (uint32_t)BL_BATCH ? (int)(bend - b) : BL_BATCH;
+            for (int k = 0; k < cnt; ++k) {
+                const float4 a = s_p0[k], q = s_p1[k], c = s_p2[k];
+                const float depth = q.z, inv_depth = 1.0f / q.z;
+                float best = 0.0f;
+                uint32_t bestpix = 0xFFFFFFFFu;
+#pragma unroll
+                for (int j = 0; j < BL_PPT; ++j) {
+                    float dx = a.x - px[j], dy = a.y - py[j];
+                    float power = fmaf(a.z * dx, dx, fmaf(q.x * dy, dy, a.w * dx * dy));
+                    float alpha = fminf(0.99f, q.y * __builtin_amdgcn_exp2f(power));
+                    float test_T = T[j] * (1.0f - alpha);
+                    bool live = !done[j] && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                    bool stop = live && (test_T < 0.0001f);
+                    done[j] = done[j] || stop;
+                    bool blend = live && !stop;
+                    float contrib = blend ? alpha * T[j] : 0.0f;
+                    cr[j] = fmaf(c.x, contrib, cr[j]);
+                    cg[j] = fmaf(c.y, contrib, cg[j]);
+                    cb[j] = fmaf(c.z, contrib, cb[j]);
+                    Ei[j] = fmaf(inv_depth, contrib, Ei[j]);
+                    E[j] = fmaf(depth, contrib, E[j]);
+                    T[j] = blend ? test_T : T[j];
+                    if (contrib > best) { best = contrib; bestpix = pixid[j]; }      // pixel ids ascend with j
+                }
+                const bool cand = (best > 0.0f) && (best >= c.w);
+                if (__any(cand)) {
+                    uint32_t bits = __float_as_uint(best);
+                    uint32_t m = wave_max_u32_dpp(bits);
+                    uint32_t pm = wave_min_u32_dpp(bits == m ? bestpix : 0xFFFFFFFFu);
+                    if (lane == 0) {
+                        unsigned long long key = ((unsigned long long)m << 32) | (unsigned long long)(uint32_t)(~pm);
+                        atomicMax(&cam_key[s_g[b - b256 + k]], key);
+                    }
+                }
+            }
+        }
+        if (calc_surf) {                                                   // forward.cu:460-477
+            wave_sync();
+            const int cnt256 = (int)(bend - b256);
+            for (int k = 0; k < cnt256; ++k) {
+                const float depth = s_depth[k];
+                float dmin = 3.402823466e+38f;
+#pragma unroll
+                for (int j = 0; j < BL_PPT; ++j) {
+                    // out-of-image threads take part with expected depth 0, masked pixels do not
+                    bool takes_part = !inside[j] || part[j];
+                    float d = fabsf(depth - E[j]);
+                    dmin = (takes_part && d < dmin) ? d : dmin;
+                }
+                uint32_t m = wave_min_u32_dpp(__float_as_uint(dmin));
+                if (lane == 0) atomicMin(&cam_surf[s_g[k]], m);
+            }
+        }
+    }
+    const size_t plane = (size_t)W * H;
+#pragma unroll
+    for (int j = 0; j < BL_PPT; ++j) {
+        if (part[j]) {
+            out_color[pixid[j]] = fmaf(T[j], bg.x, cr[j]);
+            out_color[plane + pixid[j]] = fmaf(T[j], bg.y, cg[j]);
+            out_color[2 * plane + pixid[j]] = fmaf(T[j], bg.z, cb[j]);
+            out_invdepth[pixid[j]] = Ei[j];
+            out_depth[pixid[j]] = E[j];
+        }
+    }
+}
+
+// binding-side reductions (gaussian_pointcloud_rasterization/__init__.py:128-158): gather the colour of the arg-max
+// pixel from the final image, strict-> running max (earliest camera wins ties), running SUM of the per-camera
+// maxima, running min of the surface distance.
+__global__ __launch_bounds__(RA_T) void k_update_cu(const unsigned long long* __restrict__ cam_key,
+                                                   const uint32_t* __restrict__ cam_surf, long n, int W, int H,
+                                                   const float* __restrict__ out_color,
+                                                   float* __restrict__ max_contrib, float* __restrict__ total_contrib,
+                                                   float* __restrict__ colours, float* __restrict__ min_surf,
+                                                   int32_t* __restrict__ winner_cam, int32_t cam_index,
+                                                   float* __restrict__ cur_contrib, int32_t* __restrict__ cur_pixels,
+                                                   float* __restrict__ cur_surf) {
+    long i = (long)blockIdx.x * RA_T + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long key = cam_key[i];
+    float c = __uint_as_float((uint32_t)(key >> 32));
+    uint32_t pix = c > 0.0f ? ~(uint32_t)key : 0u;                      // never blended: pixel 0, contribution 0
+    if (c > max_contrib[i]) {
+        const size_t plane = (size_t)W * H;
+        max_contrib[i] = c;
+        if (winner_cam) winner_cam[i] = cam_index;
+        colours[3 * i + 0] = out_color[pix];
+        colours[3 * i + 1] = out_color[plane + pix];
+        colours[3 * i + 2] = out_color[2 * plane + pix];
+    }
+    total_contrib[i] += c;
+    float sd = __uint_as_float(cam_surf[i]);
+    if (sd < min_surf[i]) min_surf[i] = sd;
+    if (cur_contrib) cur_contrib[i] = c;
+    if (cur_pixels) cur_pixels[i] = (int32_t)pix;
+    if (cur_surf) cur_surf[i] = sd;
+}
+
+__global__ __launch_bounds__(RA_T) void k_fill_u32(uint32_t* __restrict__ p, long n, uint32_t v) {
+    long i = (long)blockIdx.x * RA_T + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
 static Cam to_cam(const G2pcCamera* c) {
     Cam k;
     for (int i = 0; i < 16; ++i) { k.V[i] = c->view[i]; k.P[i] = c->proj[i]; }
@@ -487,5 +774,101 @@ int g2pc_raster_contributions(const unsigned long long* best_key, int64_t n, flo
     if (n <= 0) return G2PC_OK;
     hipLaunchKernelGGL(k_contributions, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, (hipStream_t)stream, best_key, (long)n, out);
     return check_launch("g2pc_raster_contributions");
+}
+}
+
+extern "C" {
+// CU semantics, front half: preprocess (+SH) -> depth sort (ascending index on ties) -> tiles-touched scan.
+int g2pc_raster_front_cu(const G2pcCamera* cam, const float* means3D, const float* cov6, const float* opacity,
+                         const float* colours_precomp, const float* shs, int32_t sh_degree, int32_t sh_coeffs,
+                         const float* campos, int64_t n, float* p0, float* p1, uint32_t* rect, float* rgb,
+                         int32_t* radii, uint32_t* sorted_idx, uint32_t* offsets, void* ws, size_t ws_bytes,
+                         void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(cam && means3D && cov6 && opacity && campos && p0 && p1 && rect && rgb && radii && sorted_idx &&
+                     offsets && ws && n > 0,
+                 G2PC_ERR_ARG, "bad arguments");
+    G2PC_REQUIRE((colours_precomp != nullptr) != (shs != nullptr), G2PC_ERR_ARG,
+                 "provide exactly one of precomputed colours or SHs");       // __init__.py:42-43
+    G2PC_REQUIRE(!shs || (sh_degree >= 0 && sh_degree <= 3 && sh_coeffs >= (sh_degree + 1) * (sh_degree + 1)), G2PC_ERR_ARG,
+                 "SH degree / coefficient count mismatch");
+    const int gx = (cam->width + 15) / 16, gy = (cam->height + 15) / 16;
+    G2PC_REQUIRE(gx <= 256 && gy <= 256, G2PC_ERR_UNSUPPORTED, "image larger than 4096 pixels per side");
+    hipStream_t s = (hipStream_t)stream;
+    Arena ar(ws, ws_bytes);
+    uint32_t* key = ar.get<uint32_t>((size_t)n);
+    uint32_t* idx = ar.get<uint32_t>((size_t)n);
+    uint32_t* key_sorted = ar.get<uint32_t>((size_t)n);
+    uint32_t* ktmp = ar.get<uint32_t>((size_t)n);
+    uint32_t* vtmp = ar.get<uint32_t>((size_t)n);
+    uint32_t* touched = ar.get<uint32_t>((size_t)n);
+    size_t sort_bytes = sort_workspace(n), scan_bytes = scan_workspace(n);
+    char* sort_ws = ar.get<char>(sort_bytes);
+    char* scan_ws = ar.get<char>(scan_bytes);
+    G2PC_REQUIRE(ar.ok(), G2PC_ERR_WORKSPACE, "workspace too small");
+    hipLaunchKernelGGL(k_preprocess_cu, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, to_cam(cam), gx, gy, means3D, cov6, opacity,
+                       colours_precomp, shs, (int)sh_degree, (int)sh_coeffs, make_float3(campos[0], campos[1], campos[2]),
+                       (long)n, key, idx, touched, (float4*)p0, (float4*)p1, rect, rgb, radii);
+    int rc = sort_pairs_u32(key, idx, key_sorted, sorted_idx, ktmp, vtmp, n, 0, 32, sort_ws, sort_bytes, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_gather_u32, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, touched, sorted_idx, (long)n, ktmp);
+    rc = scan_exclusive_u32(ktmp, offsets, n, scan_ws, scan_bytes, s);
+    if (rc) return rc;
+    return check_launch("g2pc_raster_front_cu");
+}
+
+// CU semantics, back half: duplicate -> tile sort -> ranges -> blend -> running-state update.
+// out_color f32[3,H,W], out_depth / out_invdepth f32[H,W] are zero-filled here.  cam_key u64[n], cam_surf u32[n] are
+// per-camera scratch.  cur_* (optional) receive this camera's gauss_contributions / gauss_pixels / surface distances.
+int g2pc_raster_back_cu(const G2pcCamera* cam, const int32_t* mask, int64_t n, int64_t num_instances, const float* p0,
+                        const float* p1, const uint32_t* rect, const float* rgb, const uint32_t* sorted_idx,
+                        const uint32_t* offsets, int calculate_surface_distance, unsigned long long* cam_key,
+                        uint32_t* cam_surf, float* out_color, float* out_depth, float* out_invdepth,
+                        float* max_contrib, float* total_contrib, float* colours, float* min_surf,
+                        int32_t* winner_cam, int32_t cam_index, float* cur_contrib, int32_t* cur_pixels, float* cur_surf,
+                        void* ws, size_t ws_bytes, void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(cam && p0 && p1 && rect && rgb && sorted_idx && offsets && cam_key && cam_surf && out_color &&
+                     out_depth && out_invdepth && max_contrib && total_contrib && colours && min_surf && ws && n > 0,
+                 G2PC_ERR_ARG, "bad arguments");
+    const int W = cam->width, H = cam->height;
+    const int gx = (W + 15) / 16, gy = (H + 15) / 16, T = gx * gy;
+    hipStream_t s = (hipStream_t)stream;
+    const long L = num_instances;
+    Arena ar(ws, ws_bytes);
+    uint32_t* inst_tile = ar.get<uint32_t>((size_t)L + 1);
+    uint32_t* inst_g = ar.get<uint32_t>((size_t)L + 1);
+    uint32_t* tile_sorted = ar.get<uint32_t>((size_t)L + 1);
+    uint32_t* g_sorted = ar.get<uint32_t>((size_t)L + 1);
+    uint32_t* tile_tmp = ar.get<uint32_t>((size_t)L + 1);
+    uint32_t* g_tmp = ar.get<uint32_t>((size_t)L + 1);
+    uint32_t* tile_start = ar.get<uint32_t>((size_t)T + 2);
+    size_t sort_bytes = sort_workspace(L), scan_bytes = scan_workspace(T + 1);
+    char* sort_ws = ar.get<char>(sort_bytes);
+    char* scan_ws = ar.get<char>(scan_bytes);
+    G2PC_REQUIRE(ar.ok(), G2PC_ERR_WORKSPACE, "workspace too small");
+    hipMemsetAsync(tile_start, 0, (size_t)(T + 2) * 4, s);
+    hipMemsetAsync(cam_key, 0, (size_t)n * 8, s);
+    hipMemsetAsync(out_color, 0, (size_t)3 * W * H * 4, s);
+    hipMemsetAsync(out_depth, 0, (size_t)W * H * 4, s);
+    hipMemsetAsync(out_invdepth, 0, (size_t)W * H * 4, s);
+    hipLaunchKernelGGL(k_fill_u32, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, cam_surf, (long)n, 0x7F7FFFFFu);   // FLT_MAX
+    if (L > 0) {
+        hipLaunchKernelGGL(k_duplicate, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, sorted_idx, offsets, rect, (long)n, gx,
+                           inst_tile, inst_g);
+        int rc = sort_pairs_u32(inst_tile, inst_g, tile_sorted, g_sorted, tile_tmp, g_tmp, L, 0, bits_for_tiles((unsigned)T),
+                                sort_ws, sort_bytes, s);
+        if (rc) return rc;
+        rc = g2pc_bincount_i32((const int32_t*)tile_sorted, L, tile_start, T, stream);
+        if (rc) return rc;
+    }
+    int rc = scan_exclusive_u32(tile_start, tile_start, T, scan_ws, scan_bytes, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_blend_cu, dim3((unsigned)T), dim3(BL_T), 0, s, W, H, gx, tile_start, g_sorted, (const float4*)p0,
+                       (const float4*)p1, rgb, mask, make_float3(cam->bg[0], cam->bg[1], cam->bg[2]),
+                       calculate_surface_distance, cam_key, cam_surf, out_color, out_depth, out_invdepth);
+    hipLaunchKernelGGL(k_update_cu, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, cam_key, cam_surf, (long)n, W, H, out_color,
+                       max_contrib, total_contrib, colours, min_surf, winner_cam, cam_index, cur_contrib, cur_pixels, cur_surf);
+    return check_launch("g2pc_raster_back_cu");
 }
 }

@@ -238,8 +238,21 @@ def get_renderer(renderer_type: str, xyz, opacities, colours, covariances, shs=N
                  surface_distance_std=None, calculate_surface_distance=False):
     """gauss_render.py:467-493."""
     if renderer_type in ("cuda", "hip"):
-        return GaussHipRenderer(xyz, opacities, colours, covariances, semantics="cuda",
-                                visible_gaussian_threshold=visible_gaussian_threshold)
+        from gaussian_pointcloud_rasterization import GaussianRasterizer as GaussianPCRasterizer
+
+        means2D = torch.zeros_like(xyz, dtype=xyz.dtype) + 0
+
+        if shs is None:
+            return GaussianPCRasterizer(xyz.to(torch.float), means2D, opacities.type(torch.float),
+                                        colors_precomp=colours.to(torch.float), cov3D_precomp=strip_symmetric(covariances).to(torch.float),
+                                        visible_gaussian_threshold=visible_gaussian_threshold, surface_distance_std=surface_distance_std,
+                                        calculate_surface_distance=calculate_surface_distance)
+        else:
+            return GaussianPCRasterizer(xyz.to(torch.float), means2D, opacities.type(torch.float),
+                                        shs=shs.to(torch.float), cov3D_precomp=strip_symmetric(covariances).to(torch.float),
+                                        visible_gaussian_threshold=visible_gaussian_threshold, surface_distance_std=surface_distance_std,
+                                        calculate_surface_distance=calculate_surface_distance)
+
     elif renderer_type == "python":
         return GaussHipRenderer(xyz, opacities, colours, covariances, semantics="python",
                                 visible_gaussian_threshold=visible_gaussian_threshold)

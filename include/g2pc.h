@@ -194,6 +194,32 @@ int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, con
                         unsigned long long* best_key, float* colours_out, float* tilebuf, float* image, int phases,
                         void* ws, size_t ws_bytes, void* stream);
 int g2pc_raster_rebase_keys(unsigned long long* best_key, int64_t n, void* stream);
+/* --- native-rasteriser ("cuda") semantics: _C.rasterize_gaussians (rasterize_points.h:18-41) ----------------------
+ * Deterministic spec of SURVEY.md §8(a.5): 16x16 tiles, near cull z_view <= 0.2, radius ceil(3 sqrt(lambda_max)),
+ * stable (tile, depth) order, alpha rules (power > 0 skip, min(0.99, .), alpha < 1/255 skip, T(1-alpha) < 1e-4 stop),
+ * per-Gaussian max contribution + arg-max pixel (ties -> lowest pixel id), surface distance against the expected
+ * depth at the end of every 256-instance batch, optional mask (i32[H*W], 0 = skip the pixel) and SH colours
+ * (sh f32[n, sh_coeffs, 3], degree <= 3, forward.cu:22-73).  cam->view = viewmatrix, cam->proj = FULL projmatrix
+ * (view @ proj), cam->tan_fovx/y; focal = W / (2 tan_fovx) (rasterizer_impl.cu:229-230).
+ * front: p0/p1 f32[n,4], rect u32[n], rgb f32[n,3], radii i32[n], sorted_idx u32[n], offsets u32[n+1] out. */
+int g2pc_raster_front_cu(const G2pcCamera* cam, const float* means3D, const float* cov6, const float* opacity,
+                         const float* colours_precomp, const float* shs, int32_t sh_degree, int32_t sh_coeffs,
+                         const float* campos, int64_t n, float* p0, float* p1, uint32_t* rect, float* rgb,
+                         int32_t* radii, uint32_t* sorted_idx, uint32_t* offsets, void* ws, size_t ws_bytes,
+                         void* stream);
+/* back: out_color f32[3,H,W], out_depth / out_invdepth f32[H,W] (zero-filled here, masked pixels stay 0);
+ * running state max_contrib / total_contrib / min_surf f32[n], colours f32[n,3] updated as the reference's binding does
+ * (gaussian_pointcloud_rasterization/__init__.py:128-158); winner_cam i32[n] (optional) records cam_index of the camera
+ * that set the running maximum (multi-GPU tie-break); cur_* (optional) = this camera's gauss_contributions,
+ * gauss_pixels, gauss_surface_distances.  Workspace size: g2pc_raster_back_workspace(num_instances, tiles). */
+int g2pc_raster_back_cu(const G2pcCamera* cam, const int32_t* mask, int64_t n, int64_t num_instances, const float* p0,
+                        const float* p1, const uint32_t* rect, const float* rgb, const uint32_t* sorted_idx,
+                        const uint32_t* offsets, int calculate_surface_distance, unsigned long long* cam_key,
+                        uint32_t* cam_surf, float* out_color, float* out_depth, float* out_invdepth,
+                        float* max_contrib, float* total_contrib, float* colours, float* min_surf,
+                        int32_t* winner_cam, int32_t cam_index, float* cur_contrib, int32_t* cur_pixels, float* cur_surf,
+                        void* ws, size_t ws_bytes, void* stream);
+
 /* multi-GPU (no counterpart in the reference): zero colours[i,:] unless local_key[i] == global_key[i] != 0, so that an
  * all-reduce(SUM) over ranks after an all-reduce(MAX) of the keys reproduces "earliest camera wins" exactly. */
 int g2pc_raster_keep_winner_colours(const unsigned long long* local_key, const unsigned long long* global_key,

@@ -1,0 +1,79 @@
+"""Shared parity assertions for the native-rasteriser ("cuda") semantics: HIP GaussianRasterizer vs the C restatement
+oracle/cuda_raster_ref.c (parity UNPINNED against the CUDA reference itself -- it cannot be run here)."""
+import numpy as np
+import torch
+
+import ref_cuda
+import ref_gauss as RG
+from g2pc.synth import make_scene, make_cameras
+
+
+def run_cuda_case(n, seed, width, height, focal, ncam, device="cpu", with_sh=False, surf=True, scale=(0.004, 0.04),
+                  use_mask=False, colour_resolution=None):
+    import camera_handler
+    import gauss_render
+    from gauss_handler import Gaussians
+    dev = torch.device(device)
+    sc = make_scene(n, seed, with_sh=with_sh, scale_lo=scale[0], scale_hi=scale[1])
+    transforms, intr = make_cameras(ncam, width=width, height=height, focal=focal)
+    G = Gaussians(sc.xyz.to(dev), sc.scales.to(dev), sc.rots.to(dev), sc.colours.to(dev), sc.opacities.to(dev))
+    R = gauss_render.get_renderer("cuda", G.xyz, G.opacities.unsqueeze(1), G.colours, G.covariances,
+                                  shs=sc.shs.to(dev) if with_sh else None, visible_gaussian_threshold=0.05,
+                                  surface_distance_std=2.0 if surf else None, calculate_surface_distance=surf)
+    cov6 = RG.strip_symmetric(RG.covariances(sc.scales, sc.rots)).numpy()
+    O = ref_cuda.CudaRasterizerOracle(sc.xyz.numpy(), sc.opacities.numpy(), cov6,
+                                      colors_precomp=None if with_sh else sc.colours.numpy(),
+                                      shs=sc.shs.numpy() if with_sh else None, sh_degree=3, threshold=0.05,
+                                      surface_distance_std=2.0 if surf else None, calculate_surface_distance=surf)
+    rep = dict(image=0.0, depth=0.0, invdepth=0.0, contrib=0.0, surf_frac_off=0.0, radii_mismatch=0, pix_mismatch=0,
+               num_rendered=[])
+    rng = np.random.default_rng(seed)
+    for name in transforms:
+        mask = None
+        if use_mask:
+            mask = torch.from_numpy((rng.random((height, width)) > 0.3).astype(np.int32))
+        cam = camera_handler.get_camera("cuda", torch.tensor(transforms[name]), intr[name],
+                                        colour_resolution=colour_resolution, sh_degree=3, mask=mask)
+        colour, radii, invd, dep = R.forward(cam, return_per_camera=True)
+        o = O.forward(ref_cuda.camera_settings(transforms[name], intr[name], colour_resolution if not use_mask else None),
+                      mask=None if mask is None else mask.numpy().reshape(-1))
+        rep["num_rendered"].append((R.last["num_rendered"], o["num_rendered"]))
+        di = np.abs(colour.cpu().numpy() - o["colour"])
+        rep["image"] = max(rep["image"], float(di.max()))
+        rep["image_frac_off"] = max(rep.get("image_frac_off", 0.0), float((di > 2e-4).mean()))
+        rep["depth"] = max(rep["depth"], float(np.abs(dep.cpu().numpy() - o["depth"]).max()))
+        rep["invdepth"] = max(rep["invdepth"], float(np.abs(invd.cpu().numpy() - o["invdepth"]).max()))
+        rep["radii_mismatch"] += int((radii.cpu().numpy() != o["radii"]).sum())
+        c = R.last["contributions"].cpu().numpy()
+        rep["contrib"] = max(rep["contrib"], float(np.abs(c - o["contrib"]).max()))
+        same = np.abs(c - o["contrib"]) < 1e-6
+        rep["pix_mismatch"] += int(((R.last["pixels"].cpu().numpy() != o["pixels"]) & same & (o["contrib"] > 0)).sum())
+        if surf:
+            s, so = R.last["surface_distances"].cpu().numpy(), o["surf"]
+            fin = (so < 3e38) | (s < 3e38)
+            off = np.abs(np.where(fin, s, 0) - np.where(fin, so, 0)) > 1e-4 * np.maximum(1.0, np.abs(np.where(fin, so, 0)))
+            rep["surf_frac_off"] = max(rep["surf_frac_off"], float(off.mean()))
+    rep["state_max"] = float(np.abs(R.gaussian_max_contribution.cpu().numpy() - O.max_contribution).max())
+    rep["state_total"] = float(np.abs(R.get_total_gaussian_contributions().cpu().numpy() - O.total).max())
+    rep["state_colour"] = float(np.abs(R.get_gaussian_colours().cpu().numpy() - O.get_gaussian_colours()).max() / 255.0)
+    rep["visible_flips"] = int((R.get_visible_gaussians().cpu().numpy() != O.get_visible_gaussians()).sum())
+    if surf:
+        rep["surface_mask_flips"] = int((R.get_gaussians_with_low_surface_distance().cpu().numpy() !=
+                                         O.get_surface_gaussians_below_distance_threshold(2.0)).sum())
+    return rep
+
+
+def assert_cuda_matches(rep, n):
+    for a, b in rep["num_rendered"]:
+        assert abs(a - b) <= max(2, 1e-4 * b), rep["num_rendered"]       # instance counts (tile rect is integer maths)
+    assert rep["radii_mismatch"] <= max(1, n // 20000), rep
+    # the alpha < 1/255 and T(1-alpha) < 1e-4 cut-offs are threshold decisions on fp32 values: a last-bit difference
+    # (v_exp_f32 vs expf) flips a whole term of up to ~alpha*T*c at an isolated pixel; the bulk agrees to ~1e-6
+    assert rep["image_frac_off"] < 2e-3 and rep["image"] < 2e-2 and rep["depth"] < 0.1 and rep["invdepth"] < 2e-2, rep
+    assert rep["contrib"] < 1e-4 and rep["state_max"] < 1e-4 and rep["state_colour"] < 2e-4, rep
+    assert rep["state_total"] < 1e-3, rep
+    assert rep["pix_mismatch"] <= max(2, n // 2000), rep
+    assert rep["visible_flips"] <= 1, rep
+    if "surface_mask_flips" in rep:
+        assert rep["surf_frac_off"] < 2e-3, rep
+        assert rep["surface_mask_flips"] <= max(2, n // 2000), rep

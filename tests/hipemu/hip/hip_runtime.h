@@ -26,6 +26,7 @@
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __shared__ static
+#define __constant__ static const
 #define __launch_bounds__(...)
 #define __restrict__ __restrict
 
