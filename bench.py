@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--points", type=int, default=10_000_000)
     ap.add_argument("--cameras", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--camera-subset", type=int, default=0, help="profiling aid: render only the first k cameras of the rig")
     ap.add_argument("--t-floor", type=float, default=None, help="blend transmittance floor (default: gauss_render.DEFAULT_T_FLOOR)")
     return ap.parse_args()
 
@@ -145,6 +146,9 @@ def main():
     # the visibility state is all-reduced, sampling is sharded by Gaussian index, the points are gathered on rank 0
     scene = make_scene(a.gaussians, 1234 + 3, device=device)
     cams = make_cameras(a.cameras) if workload == "render" else None
+    if cams is not None and a.camera_subset:
+        keep = sorted(cams[0])[:a.camera_subset]              # profiling aid: first k of the SAME 50-camera rig
+        cams = ({k: cams[0][k] for k in keep}, {k: cams[1][k] for k in keep})
 
     def sync():
         torch.cuda.synchronize()
