@@ -182,6 +182,11 @@ __global__ __launch_bounds__(RA_T) void k_duplicate(const uint32_t* __restrict__
 // ---------------------------------------------------------------------------------------------------------
 constexpr int BL_T = 64, BL_PPT = 4, BL_BATCH = 64;
 
+// Pixels of a tile are grouped in 8x8 sub-blocks (row-major inside the tile); a chunk = PPT consecutive sub-blocks,
+// lane l owns pixel (l % 8, l / 8) of each of them.  Compact blocks saturate together (early exit) and the PPT
+// template trades instruction count per (pixel, Gaussian) pair against the length of the serial chain a single
+// wave has to walk through a tile's list (the launch's critical path).
+template <int PPT>
 __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __restrict__ chunk_tile,
                                                   const int32_t* __restrict__ chunk_pix0,
                                                   const uint32_t* __restrict__ tile_start,
@@ -196,22 +201,24 @@ __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __
     __shared__ float4 s_p2[BL_BATCH];
     __shared__ uint32_t s_g[BL_BATCH];
     const int tile = chunk_tile[blockIdx.x];
-    const int pix0 = chunk_pix0[blockIdx.x];
+    const int sb0 = chunk_pix0[blockIdx.x];                 // first 8x8 sub-block of this chunk
     const int ix = tile % lay.nx, iy = tile / lay.nx;
     const int x0 = lay.xs[ix], w = lay.ws[ix], y0 = lay.ys[iy], h = lay.hs[iy];
-    const int npix = w * h;
+    const int nsbx = (w + 7) >> 3;
     const uint32_t order_tile = order_base | ((uint32_t)lay.tile_seq[tile] << 12);
     const unsigned lane = threadIdx.x;
+    const int lx = lane & 7, ly = lane >> 3;
 
-    int pix[BL_PPT];
-    float px[BL_PPT], py[BL_PPT], T[BL_PPT], cr[BL_PPT], cg[BL_PPT], cb[BL_PPT];
+    int pix[PPT];
+    float px[PPT], py[PPT], T[PPT], cr[PPT], cg[PPT], cb[PPT];
 #pragma unroll
-    for (int j = 0; j < BL_PPT; ++j) {
-        pix[j] = pix0 + j * BL_T + (int)lane;
-        bool valid = pix[j] < npix;
-        int lx = valid ? pix[j] % w : 0, ly = valid ? pix[j] / w : 0;
-        px[j] = (float)(x0 + lx);
-        py[j] = (float)(y0 + ly);
+    for (int j = 0; j < PPT; ++j) {
+        int sb = sb0 + j;
+        int x = (sb % nsbx) * 8 + lx, y = (sb / nsbx) * 8 + ly;
+        bool valid = (x < w) && (y < h);
+        pix[j] = valid ? y * w + x : -1;        // row-major pixel index inside the tile (the reference's arg-max order)
+        px[j] = (float)(x0 + x);
+        py[j] = (float)(y0 + y);
         T[j] = valid ? 1.0f : 0.0f;             // invalid slots never contribute (contribution = T * alpha = 0)
         cr[j] = cg[j] = cb[j] = 0.0f;
     }
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __
             float best = 0.0f;
             uint32_t bestpix = 0xFFFFFFFFu;
 #pragma unroll
-            for (int j = 0; j < BL_PPT; ++j) {
+            for (int j = 0; j < PPT; ++j) {
                 float dx = px[j] - a.x, dy = py[j] - a.y;
                 float power = fmaf(a.z * dx, dx, fmaf(q.x * dy, dy, a.w * dx * dy));
                 float wgt = __builtin_amdgcn_exp2f(power);          // raw v_exp_f32 (results below 2^-126 flush to 0)
@@ -243,7 +250,8 @@ __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __
                 cg[j] = fmaf(contrib, c.y, cg[j]);
                 cb[j] = fmaf(contrib, c.z, cb[j]);
                 T[j] -= contrib;
-                if (contrib > best) { best = contrib; bestpix = (uint32_t)pix[j]; }
+                // sub-blocks of one lane are not ordered by pixel index: explicit tie-break to the lowest index
+                if (contrib > best || (contrib == best && contrib > 0.0f && (uint32_t)pix[j] < bestpix)) { best = contrib; bestpix = (uint32_t)pix[j]; }
             }
             const bool cand = (best > 0.0f) && (best >= c.w);
             if (__any(cand)) {
@@ -259,14 +267,14 @@ __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __
         if (t_floor > 0.0f) {
             bool done = true;
 #pragma unroll
-            for (int j = 0; j < BL_PPT; ++j) done = done && (T[j] < t_floor);
+            for (int j = 0; j < PPT; ++j) done = done && (T[j] < t_floor);
             if (__all(done ? 1 : 0)) break;
         }
     }
     float* out = tilebuf + 3 * (size_t)lay.tile_pix_off[tile];
 #pragma unroll
-    for (int j = 0; j < BL_PPT; ++j) {
-        if (pix[j] < npix) {
+    for (int j = 0; j < PPT; ++j) {
+        if (pix[j] >= 0) {
             out[3 * (size_t)pix[j] + 0] = fmaf(T[j], bg, cr[j]);
             out[3 * (size_t)pix[j] + 1] = fmaf(T[j], bg, cg[j]);
             out[3 * (size_t)pix[j] + 2] = fmaf(T[j], bg, cb[j]);
@@ -740,9 +748,17 @@ int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, con
     if (rc) return rc;
     }
     if (phases & 2) {
-    hipLaunchKernelGGL(k_blend_py, dim3((unsigned)layout->num_chunks), dim3(BL_T), 0, s, lay, layout->chunk_tile,
-                       layout->chunk_pix0, tile_start, g_sorted, (const float4*)p0, (const float4*)p1, colours, best_key,
-                       camera_slot << 24, t_floor, cam->bg[0], tilebuf);
+#define G2PC_BLEND(PPT)                                                                                              \
+    hipLaunchKernelGGL((k_blend_py<PPT>), dim3((unsigned)layout->num_chunks), dim3(BL_T), 0, s, lay, layout->chunk_tile, \
+                       layout->chunk_pix0, tile_start, g_sorted, (const float4*)p0, (const float4*)p1, colours, best_key, \
+                       camera_slot << 24, t_floor, cam->bg[0], tilebuf)
+    switch (layout->chunk_subblocks) {
+        case 1: G2PC_BLEND(1); break;
+        case 2: G2PC_BLEND(2); break;
+        case 4: G2PC_BLEND(4); break;
+        default: set_error("g2pc_raster_back_py", "chunk_subblocks must be 1, 2 or 4"); return G2PC_ERR_ARG;
+    }
+#undef G2PC_BLEND
     hipLaunchKernelGGL(k_update_colours_py, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, lay, best_key, (long)n, camera_slot,
                        tilebuf, colours_out);
     if (image)

@@ -19,10 +19,11 @@ from typing import Dict
 
 import numpy as np
 
-CHUNK_PIXELS = 256           # pixels per blend block (one wave64 x 4 pixels)
+SUBBLOCKS_PER_CHUNK = 1      # 8x8-pixel sub-blocks per blend wave (1, 2 or 4 pixels per lane)
 
 
-def _finish(xs, ws, ys, hs, seq_of) -> Dict[str, np.ndarray]:
+def _finish(xs, ws, ys, hs, seq_of, subblocks=None) -> Dict[str, np.ndarray]:
+    subblocks = SUBBLOCKS_PER_CHUNK if subblocks is None else subblocks
     nx, ny = len(xs), len(ys)
     T = nx * ny
     tile_seq = np.zeros((T,), dtype=np.int32)
@@ -52,7 +53,7 @@ def _finish(xs, ws, ys, hs, seq_of) -> Dict[str, np.ndarray]:
     chunk_tile, chunk_pix0 = [], []
     for g0 in range(0, T, 8):
         group = order_t[g0:g0 + 8]
-        per_tile = [list(range(0, int(pix[t]), CHUNK_PIXELS)) for t in group]
+        per_tile = [list(range(0, ((ws[t % nx] + 7) // 8) * ((hs[t // nx] + 7) // 8), subblocks)) for t in group]
         for c in range(max(len(p) for p in per_tile)):
             for k, t in enumerate(group):
                 if c < len(per_tile[k]):
@@ -61,10 +62,10 @@ def _finish(xs, ws, ys, hs, seq_of) -> Dict[str, np.ndarray]:
     return dict(nx=nx, ny=ny, xs=np.asarray(xs, np.int32), ws=np.asarray(ws, np.int32),
                 ys=np.asarray(ys, np.int32), hs=np.asarray(hs, np.int32), tile_seq=rank, seq_tile=seq_tile,
                 tile_pix_off=off.astype(np.int32), chunk_tile=np.asarray(chunk_tile, np.int32),
-                chunk_pix0=np.asarray(chunk_pix0, np.int32), total_pixels=int(off[-1]))
+                chunk_pix0=np.asarray(chunk_pix0, np.int32), total_pixels=int(off[-1]), chunk_subblocks=int(subblocks))
 
 
-def python_quadtree_layout(width: int, height: int, max_tile_size: int = 60) -> Dict[str, np.ndarray]:
+def python_quadtree_layout(width: int, height: int, max_tile_size: int = 60, subblocks=None) -> Dict[str, np.ndarray]:
     queue = [([0, 0], [width, height])]          # ([row, col], [w, h]) as in the reference
     leaves = []
     while queue:
@@ -95,7 +96,7 @@ def python_quadtree_layout(width: int, height: int, max_tile_size: int = 60) -> 
         if wof[x0] != w or hof[y0] != h:
             raise NotImplementedError("non-uniform quad-tree leaves")
         seq_of[(x0, y0)] = s
-    return _finish([x for x, _ in xs], [w for _, w in xs], [y for y, _ in ys], [h for _, h in ys], seq_of)
+    return _finish([x for x, _ in xs], [w for _, w in xs], [y for y, _ in ys], [h for _, h in ys], seq_of, subblocks)
 
 
 def grid_layout(width: int, height: int, block: int = 16) -> Dict[str, np.ndarray]:

@@ -33,6 +33,7 @@ C3 = [-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.37317633259
 # its pixels have T < t: every contribution >= t is still computed bit-identically (so the visibility mask, the
 # culled index set and the point allocation are unchanged for thresholds > t) and pixel colours move by < t.
 DEFAULT_T_FLOOR = 1e-6
+BLEND_SUBBLOCKS = None     # 8x8 sub-blocks per blend wave (None -> g2pc.tiles.SUBBLOCKS_PER_CHUNK)
 RENDER_STATS = []          # (instances L, tile-sort passes, W*H) of every camera rendered (bench.py reads this)
 
 
@@ -45,7 +46,8 @@ class _Camera(C.Structure):
 class _Layout(C.Structure):
     _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("xs", C.c_void_p), ("ws", C.c_void_p), ("ys", C.c_void_p),
                 ("hs", C.c_void_p), ("tile_seq", C.c_void_p), ("seq_tile", C.c_void_p), ("tile_pix_off", C.c_void_p),
-                ("num_chunks", C.c_int32), ("chunk_tile", C.c_void_p), ("chunk_pix0", C.c_void_p)]
+                ("num_chunks", C.c_int32), ("chunk_tile", C.c_void_p), ("chunk_pix0", C.c_void_p),
+                ("chunk_subblocks", C.c_int32)]
 
 
 nv._RASTER_PROTOS.update({
@@ -81,6 +83,7 @@ class _DeviceLayout:
         self.t = {k: torch.from_numpy(lay[k]).to(device) for k in
                   ("xs", "ws", "ys", "hs", "tile_seq", "seq_tile", "tile_pix_off", "chunk_tile", "chunk_pix0")}
         self.c = _Layout(nx=lay["nx"], ny=lay["ny"], num_chunks=len(lay["chunk_tile"]),
+                         chunk_subblocks=lay["chunk_subblocks"],
                          **{k: v.data_ptr() for k, v in self.t.items()})
         self.num_tiles = lay["nx"] * lay["ny"]
         self.total_pixels = lay["total_pixels"]
@@ -159,7 +162,7 @@ class GaussHipRenderer():
     def _layout(self, width, height):
         key = (width, height)
         if key not in self.layouts:
-            self.layouts[key] = _DeviceLayout(tiles.python_quadtree_layout(width, height, self.MAX_TILE_SIZE), self.device)
+            self.layouts[key] = _DeviceLayout(tiles.python_quadtree_layout(width, height, self.MAX_TILE_SIZE, BLEND_SUBBLOCKS), self.device)
         lay = self.layouts[key]
         need = lay.total_pixels * 3
         if self.tilebuf is None or self.tilebuf.numel() < need:

@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--points", type=int, default=10_000_000)
     ap.add_argument("--cameras", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--blend-subblocks", type=int, default=0, help="tuning aid: 8x8 sub-blocks per blend wave (1, 2, 4)")
     ap.add_argument("--camera-subset", type=int, default=0, help="profiling aid: render only the first k cameras of the rig")
     ap.add_argument("--t-floor", type=float, default=None, help="blend transmittance floor (default: gauss_render.DEFAULT_T_FLOOR)")
     return ap.parse_args()
@@ -141,6 +142,8 @@ def main():
     import gauss_render
     if a.t_floor is not None:
         gauss_render.DEFAULT_T_FLOOR = a.t_floor
+    if a.blend_subblocks:
+        gauss_render.BLEND_SUBBLOCKS = a.blend_subblocks
 
     # strong scaling: ONE scene (same seed on every rank, replicated read-only); cameras are split over the ranks,
     # the visibility state is all-reduced, sampling is sharded by Gaussian index, the points are gathered on rank 0

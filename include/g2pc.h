@@ -165,9 +165,10 @@ typedef struct G2pcTileLayout {      /* HOST struct of DEVICE pointers: tiles = 
     const int32_t* tile_seq;         /* [ny*nx] processing order of tile iy*nx+ix (python renderer: FIFO quad-tree order) */
     const int32_t* seq_tile;         /* [ny*nx] inverse of tile_seq */
     const int32_t* tile_pix_off;     /* [ny*nx+1] pixel offset of every tile inside the per-tile colour buffer */
-    int32_t num_chunks;              /* blend work list: one block per (tile, first pixel) chunk of <= 256 pixels */
-    const int32_t* chunk_tile;       /* [num_chunks] */
-    const int32_t* chunk_pix0;       /* [num_chunks] */
+    int32_t num_chunks;              /* blend work list: one wave64 per chunk = chunk_subblocks consecutive 8x8 pixel */
+    const int32_t* chunk_tile;       /* [num_chunks]    sub-blocks of a tile (sub-blocks row-major inside the tile)   */
+    const int32_t* chunk_pix0;       /* [num_chunks] first sub-block of the chunk */
+    int32_t chunk_subblocks;         /* 1, 2 or 4 (pixels per lane) */
 } G2pcTileLayout;
 
 size_t g2pc_raster_front_workspace(int64_t n);

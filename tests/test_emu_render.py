@@ -23,3 +23,12 @@ def test_render_1024_tiles_two_pass_tile_sort_vs_oracle(emu):
     w = run_vs_oracle(400, 21, 1280, 720, 1100.0, 1, scale=(0.01, 0.08), t_floor=0.0)
     print(w)
     assert w["image"] < 1e-4 and w["contribution"] < 1e-4 and w["colour"] < 1e-4 and w["flips"] == 0
+
+
+@pytest.mark.parametrize("sub", [2, 4])
+def test_render_other_pixels_per_lane_vs_oracle(emu, sub, monkeypatch):
+    import gauss_render
+    from render_checks import run_vs_oracle
+    monkeypatch.setattr(gauss_render, "BLEND_SUBBLOCKS", sub)
+    w = run_vs_oracle(500, 23, 320, 180, 275.0, 1, scale=(0.01, 0.08), t_floor=1e-6)
+    assert w["image"] < 1e-4 and w["contribution"] < 1e-4 and w["colour"] < 1e-4 and w["flips"] == 0
