@@ -1,6 +1,12 @@
 // Device inline implementations for g2pc_internal.h
 #pragma once
 
+// Pins a value in a VGPR at this program point: stops LLVM from sinking independent work (e.g. exp chains) past
+// later branches, i.e. keeps hand-scheduled instruction-level parallelism.
+#ifndef G2PC_PIN
+#define G2PC_PIN(x) asm volatile("" : "+v"(x))
+#endif
+
 namespace g2pc {
 
 __device__ __forceinline__ void wave_sync() {

@@ -186,7 +186,7 @@ constexpr int BL_T = 64, BL_PPT = 4, BL_BATCH = 64;
 // lane l owns pixel (l % 8, l / 8) of each of them.  Compact blocks saturate together (early exit) and the PPT
 // template trades instruction count per (pixel, Gaussian) pair against the length of the serial chain a single
 // wave has to walk through a tile's list (the launch's critical path).
-template <int PPT>
+template <int PPT, int U>
 __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __restrict__ chunk_tile,
                                                   const int32_t* __restrict__ chunk_pix0,
                                                   const uint32_t* __restrict__ tile_start,
@@ -196,8 +196,8 @@ __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __
                                                   unsigned long long* __restrict__ best_key, uint32_t order_base,
                                                   float t_floor, float bg, float* __restrict__ tilebuf) {
     // one wave64 per block: the LDS stage is wave-private, no s_barrier anywhere
-    __shared__ float4 s_p0[BL_BATCH];
-    __shared__ float4 s_p1[BL_BATCH];
+    __shared__ float4 s_p0[BL_BATCH + 4];
+    __shared__ float4 s_p1[BL_BATCH + 4];
     __shared__ float4 s_p2[BL_BATCH];
     __shared__ uint32_t s_g[BL_BATCH];
     const int tile = chunk_tile[blockIdx.x];
@@ -230,37 +230,63 @@ __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __
             s_p0[lane] = p0[g];
             s_p1[lane] = p1[g];
             float gm = __uint_as_float((uint32_t)(best_key[g] >> 32));
+            gm = fmaxf(gm, 1.17549435e-38f);                       // a zero contribution never updates anything
             s_p2[lane] = make_float4(colours[3 * (size_t)g], colours[3 * (size_t)g + 1], colours[3 * (size_t)g + 2], gm);
             s_g[lane] = g;
+        } else {                                // padding: opacity 0 -> alpha 0 -> no effect, never a candidate
+            s_p0[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+            s_p1[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+            s_p2[lane] = make_float4(0.f, 0.f, 0.f, 3.0e38f);
+            s_g[lane] = 0;
         }
         wave_sync();
         const int cnt = (end - b) < (uint32_t)BL_BATCH ? (int)(end - b) : BL_BATCH;
-        for (int k = 0; k < cnt; ++k) {
-            const float4 a = s_p0[k], q = s_p1[k], c = s_p2[k];
-            float best = 0.0f;
-            uint32_t bestpix = 0xFFFFFFFFu;
+        // U Gaussians per trip: their weights (position only) are independent -> U exp chains in flight; the
+        // transmittance recurrence and the visibility bookkeeping then run in depth order.
+        for (int k0 = 0; k0 < cnt; k0 += U) {
+            float alpha[U][PPT];
 #pragma unroll
-            for (int j = 0; j < PPT; ++j) {
-                float dx = px[j] - a.x, dy = py[j] - a.y;
-                float power = fmaf(a.z * dx, dx, fmaf(q.x * dy, dy, a.w * dx * dy));
-                float wgt = __builtin_amdgcn_exp2f(power);          // raw v_exp_f32 (results below 2^-126 flush to 0)
-                float alpha = fminf(wgt * q.y, 0.99f);
-                float contrib = T[j] * alpha;
-                cr[j] = fmaf(contrib, c.x, cr[j]);
-                cg[j] = fmaf(contrib, c.y, cg[j]);
-                cb[j] = fmaf(contrib, c.z, cb[j]);
-                T[j] -= contrib;
-                // sub-blocks of one lane are not ordered by pixel index: explicit tie-break to the lowest index
-                if (contrib > best || (contrib == best && contrib > 0.0f && (uint32_t)pix[j] < bestpix)) { best = contrib; bestpix = (uint32_t)pix[j]; }
+            for (int u = 0; u < U; ++u) {
+                const float4 a = s_p0[k0 + u], q = s_p1[k0 + u];       // entries past cnt are zero-opacity padding
+#pragma unroll
+                for (int j = 0; j < PPT; ++j) {
+                    float dx = px[j] - a.x, dy = py[j] - a.y;
+                    float power = fmaf(a.z * dx, dx, fmaf(q.x * dy, dy, a.w * dx * dy));
+                    float wgt = __builtin_amdgcn_exp2f(power);      // raw v_exp_f32 (results below 2^-126 flush to 0)
+                    alpha[u][j] = fminf(wgt * q.y, 0.99f);
+                }
             }
-            const bool cand = (best > 0.0f) && (best >= c.w);
-            if (__any(cand)) {
-                uint32_t bits = __float_as_uint(best);
-                uint32_t m = wave_max_u32_dpp(bits);
-                uint32_t pm = wave_min_u32_dpp(bits == m ? bestpix : 0xFFFFFFFFu);
-                if (lane == 0) {
-                    unsigned long long key = ((unsigned long long)m << 32) | (unsigned long long)(uint32_t)(~(order_tile | pm));
-                    atomicMax(&best_key[s_g[k]], key);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < PPT; ++j) G2PC_PIN(alpha[u][j]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                {
+                    const float4 c = s_p2[k0 + u];
+                    float best = 0.0f;
+                    uint32_t bestpix = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int j = 0; j < PPT; ++j) {
+                        float contrib = T[j] * alpha[u][j];
+                        cr[j] = fmaf(contrib, c.x, cr[j]);
+                        cg[j] = fmaf(contrib, c.y, cg[j]);
+                        cb[j] = fmaf(contrib, c.z, cb[j]);
+                        T[j] -= contrib;
+                        if (PPT == 1) { best = contrib; bestpix = (uint32_t)pix[j]; }
+                        // sub-blocks of one lane are not ordered by pixel index: explicit tie-break to the lowest index
+                        else if (contrib > best || (contrib == best && contrib > 0.0f && (uint32_t)pix[j] < bestpix)) { best = contrib; bestpix = (uint32_t)pix[j]; }
+                    }
+                    const bool cand = best >= c.w;                   // c.w = max(running maximum, FLT_MIN)
+                    if (__any(cand)) {
+                        uint32_t bits = __float_as_uint(best);
+                        uint32_t m = wave_max_u32_dpp(bits);
+                        uint32_t pm = wave_min_u32_dpp(bits == m ? bestpix : 0xFFFFFFFFu);
+                        if (lane == 0) {
+                            unsigned long long key = ((unsigned long long)m << 32) | (unsigned long long)(uint32_t)(~(order_tile | pm));
+                            atomicMax(&best_key[s_g[k0 + u]], key);
+                        }
+                    }
                 }
             }
         }
@@ -748,14 +774,14 @@ int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, con
     if (rc) return rc;
     }
     if (phases & 2) {
-#define G2PC_BLEND(PPT)                                                                                              \
-    hipLaunchKernelGGL((k_blend_py<PPT>), dim3((unsigned)layout->num_chunks), dim3(BL_T), 0, s, lay, layout->chunk_tile, \
+#define G2PC_BLEND(PPT, U)                                                                                            \
+    hipLaunchKernelGGL((k_blend_py<PPT, U>), dim3((unsigned)layout->num_chunks), dim3(BL_T), 0, s, lay, layout->chunk_tile, \
                        layout->chunk_pix0, tile_start, g_sorted, (const float4*)p0, (const float4*)p1, colours, best_key, \
                        camera_slot << 24, t_floor, cam->bg[0], tilebuf)
     switch (layout->chunk_subblocks) {
-        case 1: G2PC_BLEND(1); break;
-        case 2: G2PC_BLEND(2); break;
-        case 4: G2PC_BLEND(4); break;
+        case 1: G2PC_BLEND(1, 4); break;
+        case 2: G2PC_BLEND(2, 2); break;
+        case 4: G2PC_BLEND(4, 1); break;
         default: set_error("g2pc_raster_back_py", "chunk_subblocks must be 1, 2 or 4"); return G2PC_ERR_ARG;
     }
 #undef G2PC_BLEND

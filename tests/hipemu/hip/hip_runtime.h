@@ -27,6 +27,7 @@
 #define __forceinline__ inline __attribute__((always_inline))
 #define __shared__ static
 #define __constant__ static const
+#define G2PC_PIN(x) ((void)0)
 #define __launch_bounds__(...)
 #define __restrict__ __restrict
 
