@@ -50,7 +50,30 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_tile(const uint32_t* __restrict
         if (base + i < n) out[base + i] = run;
         run += v[i];
     }
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+    if (threadIdx.x == 0) {
+        block_sums[blockIdx.x] = total;
+        if (gridDim.x == 1) out[n] = total;                 // single tile: the scan is complete
+    }
+}
+
+// second (and last) kernel of the 2-kernel scan: every block sums the block totals in front of it by itself
+// (nb <= 2048 values, L2 resident) instead of a separate scan-of-sums launch; the last block also writes the total.
+__global__ __launch_bounds__(SCAN_T) void k_scan_add_self(uint32_t* __restrict__ out, long n,
+                                                         const uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t wsum[SCAN_T / kWave];
+    uint32_t acc = 0;
+    for (unsigned i = threadIdx.x; i < blockIdx.x; i += SCAN_T) acc += block_sums[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    uint32_t off = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_T / kWave; ++i) off += wsum[i];
+    const long base = (long)blockIdx.x * SCAN_TILE + (long)threadIdx.x * SCAN_I;
+#pragma unroll
+    for (int i = 0; i < SCAN_I; ++i)
+        if (base + i < n) out[base + i] += off;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = off + block_sums[blockIdx.x];
 }
 
 __global__ __launch_bounds__(SCAN_T) void k_scan_add(uint32_t* __restrict__ out, long n,
@@ -82,9 +105,9 @@ static int scan_rec(const uint32_t* in, uint32_t* out, long n, Arena& ar, hipStr
     uint32_t* sums = ar.get<uint32_t>((size_t)nb + 1);
     if (!ar.ok()) { set_error("scan", "workspace too small"); return G2PC_ERR_WORKSPACE; }
     hipLaunchKernelGGL(k_scan_tile, dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, out, n, sums);
-    if (nb == 1) {
-        // out[n] = total: single tile, total is sums[0]
-        hipMemcpyAsync(out + n, sums, sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
+    if (nb == 1) return check_launch("scan");
+    if (nb <= 2048) {
+        hipLaunchKernelGGL(k_scan_add_self, dim3((unsigned)nb), dim3(SCAN_T), 0, s, out, n, sums);
         return check_launch("scan");
     }
     int rc = scan_rec(sums, sums, nb, ar, s);   // sums[0..nb] = exclusive offsets (+ total)
@@ -103,51 +126,55 @@ int scan_exclusive_u32(const uint32_t* in, uint32_t* out, long n, void* ws, size
 }
 
 // ------------------------------------------------------------------------------------------------
-// Stable LSD radix sort, up to 8 bits per pass.  Tile = 256 threads x 8 keys; wave w of a block
-// owns the contiguous sub-tile [w*512, (w+1)*512) and walks it in 8 rounds of 64 keys, ranking
+// Stable LSD radix sort, digits of up to 8 or up to 11 bits.  Tile = 256 threads x ITEMS keys; wave w of a block
+// owns a contiguous quarter of the tile and walks it in ITEMS rounds of 64 keys, ranking
 // with wave64 ballots (match-any over the digit bits) against a wave-private LDS histogram row.
 // ------------------------------------------------------------------------------------------------
-constexpr int RS_T = 256, RS_I = 8, RS_TILE = RS_T * RS_I, RS_W = RS_T / kWave, RS_BINS = 256;
+constexpr int RS_T = 256, RS_W = RS_T / kWave;
 
+template <int BITS, int ITEMS>
 __global__ __launch_bounds__(RS_T) void k_radix_hist(const uint32_t* __restrict__ keys, long n, int shift,
                                                     unsigned mask, uint32_t* __restrict__ ghist, unsigned nb) {
-    __shared__ uint32_t hist[RS_BINS];
-    hist[threadIdx.x] = 0;
+    constexpr int BINS = 1 << BITS, TILE = RS_T * ITEMS;
+    __shared__ uint32_t hist[BINS];
+    for (int i = threadIdx.x; i < BINS; i += RS_T) hist[i] = 0;
     __syncthreads();
-    const long base = (long)blockIdx.x * RS_TILE;
+    const long base = (long)blockIdx.x * TILE;
 #pragma unroll
-    for (int i = 0; i < RS_I; ++i) {
+    for (int i = 0; i < ITEMS; ++i) {
         long idx = base + (long)i * RS_T + threadIdx.x;
         if (idx < n) atomicAdd(&hist[(keys[idx] >> shift) & mask], 1u);
     }
     __syncthreads();
-    if (threadIdx.x <= mask) ghist[(size_t)threadIdx.x * nb + blockIdx.x] = hist[threadIdx.x];
+    for (unsigned d = threadIdx.x; d <= mask; d += RS_T) ghist[(size_t)d * nb + blockIdx.x] = hist[d];
 }
 
+template <int BITS, int ITEMS>
 __global__ __launch_bounds__(RS_T) void k_radix_scatter(const uint32_t* __restrict__ keys_in,
                                                        const uint32_t* __restrict__ vals_in,
                                                        uint32_t* __restrict__ keys_out,
                                                        uint32_t* __restrict__ vals_out, long n, int shift,
                                                        unsigned mask, int nbits,
                                                        const uint32_t* __restrict__ goffs, unsigned nb) {
-    __shared__ uint32_t whist[RS_W][RS_BINS];   // per-wave running digit counts, then exclusive offsets
-    __shared__ uint32_t gbase[RS_BINS];
+    constexpr int BINS = 1 << BITS, TILE = RS_T * ITEMS;
+    __shared__ uint32_t whist[RS_W][BINS];      // per-wave running digit counts, then exclusive offsets
+    __shared__ uint32_t gbase[BINS];
     const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < RS_W * RS_BINS; i += RS_T) (&whist[0][0])[i] = 0;
-    if (threadIdx.x <= mask) gbase[threadIdx.x] = goffs[(size_t)threadIdx.x * nb + blockIdx.x];
+    for (int i = threadIdx.x; i < RS_W * BINS; i += RS_T) (&whist[0][0])[i] = 0;
+    for (unsigned d = threadIdx.x; d <= mask; d += RS_T) gbase[d] = goffs[(size_t)d * nb + blockIdx.x];
     __syncthreads();
 
-    const long wbase = (long)blockIdx.x * RS_TILE + (long)w * (RS_TILE / RS_W);
-    uint32_t key[RS_I], val[RS_I], rank[RS_I];
+    const long wbase = (long)blockIdx.x * TILE + (long)w * (TILE / RS_W);
+    uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
     const unsigned long long lt = lanemask_lt();
 #pragma unroll
-    for (int r = 0; r < RS_I; ++r) {
+    for (int r = 0; r < ITEMS; ++r) {
         long idx = wbase + (long)r * 64 + lane;
         bool valid = idx < n;
         key[r] = valid ? keys_in[idx] : 0xFFFFFFFFu;
         val[r] = valid ? vals_in[idx] : 0u;
         unsigned d = (key[r] >> shift) & mask;
-        // match-any: lanes holding the same digit (invalid lanes form their own group via bit 63 trick)
+        // match-any: lanes holding the same digit
         unsigned long long peers = __ballot(valid);
         for (int b = 0; b < nbits; ++b) {
             unsigned long long bal = __ballot((d >> b) & 1u);
@@ -162,15 +189,15 @@ __global__ __launch_bounds__(RS_T) void k_radix_scatter(const uint32_t* __restri
         rank[r] = basec + before;
     }
     __syncthreads();
-    // exclusive prefix over waves for every digit (thread d handles digit d)
-    if (threadIdx.x <= mask) {
+    // exclusive prefix over waves for every digit
+    for (unsigned d = threadIdx.x; d <= mask; d += RS_T) {
         uint32_t run = 0;
 #pragma unroll
-        for (int i = 0; i < RS_W; ++i) { uint32_t c = whist[i][threadIdx.x]; whist[i][threadIdx.x] = run; run += c; }
+        for (int i = 0; i < RS_W; ++i) { uint32_t c = whist[i][d]; whist[i][d] = run; run += c; }
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < RS_I; ++r) {
+    for (int r = 0; r < ITEMS; ++r) {
         long idx = wbase + (long)r * 64 + lane;
         if (idx < n) {
             unsigned d = (key[r] >> shift) & mask;
@@ -181,11 +208,27 @@ __global__ __launch_bounds__(RS_T) void k_radix_scatter(const uint32_t* __restri
     }
 }
 
+// pass geometry: digits of up to 11 bits (2048 LDS bins) when more than 8 bits have to be sorted, 4 keys per
+// thread for inputs that would otherwise leave CUs idle (<= 2M keys), else 8
+static inline int radix_items(long n) { return n <= (2L << 20) ? 4 : 8; }
+static inline int radix_maxbits(int total_bits) { return total_bits <= 8 ? 8 : 11; }
+
 size_t sort_workspace(long n) {
-    long nb = (n + RS_TILE - 1) / RS_TILE;
+    long nb = (n + RS_T * 4 - 1) / (RS_T * 4);
     if (nb < 1) nb = 1;
-    size_t hist = align_up(((size_t)RS_BINS * nb + 1) * sizeof(uint32_t));
-    return hist + scan_workspace((long)RS_BINS * nb) + 512;
+    size_t entries = (size_t)2048 * nb + 1;
+    return align_up(entries * sizeof(uint32_t)) + scan_workspace((long)entries) + 512;
+}
+
+template <int BITS, int ITEMS>
+static void radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, long n, int bit,
+                       int nbits, uint32_t* ghist, unsigned nb, char* scan_ws, size_t scan_bytes, hipStream_t s, int& rc) {
+    unsigned mask = (1u << nbits) - 1u;
+    hipLaunchKernelGGL((k_radix_hist<BITS, ITEMS>), dim3(nb), dim3(RS_T), 0, s, kin, n, bit, mask, ghist, nb);
+    rc = scan_exclusive_u32(ghist, ghist, (long)(mask + 1) * nb, scan_ws, scan_bytes, s);
+    if (rc) return;
+    hipLaunchKernelGGL((k_radix_scatter<BITS, ITEMS>), dim3(nb), dim3(RS_T), 0, s, kin, vin, kout, vout, n, bit, mask, nbits,
+                       ghist, nb);
 }
 
 int sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
@@ -198,33 +241,38 @@ int sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* k
         return G2PC_ERR_ARG;
     }
     int total_bits = bit_hi - bit_lo;
-    int passes = total_bits <= 0 ? 0 : (total_bits + 7) / 8;
-    if (passes == 0) {
+    if (total_bits <= 0) {
         hipMemcpyAsync(keys_out, keys_in, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
         hipMemcpyAsync(vals_out, vals_in, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
         return G2PC_OK;
     }
-    long nb = (n + RS_TILE - 1) / RS_TILE;
+    const int maxbits = radix_maxbits(total_bits), items = radix_items(n);
+    const int passes = (total_bits + maxbits - 1) / maxbits;
+    const long tile = (long)RS_T * items;
+    const unsigned nb = (unsigned)((n + tile - 1) / tile);
     Arena ar(ws, ws_bytes);
-    uint32_t* ghist = ar.get<uint32_t>((size_t)RS_BINS * nb + 1);
-    size_t scan_bytes = scan_workspace((long)RS_BINS * nb);
+    size_t entries = ((size_t)1 << maxbits) * nb + 1;
+    uint32_t* ghist = ar.get<uint32_t>(entries);
+    size_t scan_bytes = scan_workspace((long)entries);
     char* scan_ws = ar.get<char>(scan_bytes);
     if (!ar.ok()) { set_error("sort", "workspace too small"); return G2PC_ERR_WORKSPACE; }
-    // choose ping-pong so the last pass lands in *_out
+    // ping-pong so that the last pass lands in *_out
     const uint32_t* kin = keys_in;
     const uint32_t* vin = vals_in;
-    int bit = bit_lo;
+    int bit = bit_lo, rc = G2PC_OK;
     for (int p = 0; p < passes; ++p) {
         int nbits = total_bits / passes + (p < total_bits % passes ? 1 : 0);
-        unsigned mask = (1u << nbits) - 1u;
         bool to_out = ((passes - 1 - p) % 2) == 0;
         uint32_t* kout = to_out ? keys_out : keys_tmp;
         uint32_t* vout = to_out ? vals_out : vals_tmp;
-        hipLaunchKernelGGL(k_radix_hist, dim3((unsigned)nb), dim3(RS_T), 0, s, kin, n, bit, mask, ghist, (unsigned)nb);
-        int rc = scan_exclusive_u32(ghist, ghist, (long)(mask + 1) * nb, scan_ws, scan_bytes, s);
+        if (maxbits == 8) {
+            if (items == 4) radix_pass<8, 4>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc);
+            else radix_pass<8, 8>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc);
+        } else {
+            if (items == 4) radix_pass<11, 4>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc);
+            else radix_pass<11, 8>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc);
+        }
         if (rc) return rc;
-        hipLaunchKernelGGL(k_radix_scatter, dim3((unsigned)nb), dim3(RS_T), 0, s, kin, vin, kout, vout, n, bit, mask,
-                           nbits, ghist, (unsigned)nb);
         kin = kout; vin = vout;
         bit += nbits;
     }
