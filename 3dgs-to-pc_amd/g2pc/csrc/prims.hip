@@ -210,8 +210,10 @@ __global__ __launch_bounds__(RS_T) void k_radix_scatter(const uint32_t* __restri
 
 // pass geometry: digits of up to 11 bits (2048 LDS bins) when more than 8 bits have to be sorted, 4 keys per
 // thread for inputs that would otherwise leave CUs idle (<= 2M keys), else 8
-static inline int radix_items(long n) { return n <= (2L << 20) ? 4 : 8; }
-static inline int radix_maxbits(int total_bits) { return total_bits <= 8 ? 8 : 11; }
+static int g_radix_wide_bits = 8;          // 8 or 11: digit width used when more than 8 bits are sorted (tuning knob)
+static long g_radix_small_n = 2L << 20;    // inputs up to this size use 4 keys per thread
+static inline int radix_items(long n) { return n <= g_radix_small_n ? 4 : 8; }
+static inline int radix_maxbits(int total_bits) { return total_bits <= 8 ? 8 : g_radix_wide_bits; }
 
 size_t sort_workspace(long n) {
     long nb = (n + RS_T * 4 - 1) / (RS_T * 4);
@@ -293,6 +295,12 @@ extern "C" {
 const char* g2pc_last_error(void) { return g2pc::g_err.c_str(); }
 int g2pc_abi_version(void) { return G2PC_ABI_VERSION; }
 
+int g2pc_set_sort_tuning(int wide_digit_bits, int64_t small_input_keys) {
+    if (wide_digit_bits != 8 && wide_digit_bits != 11) return G2PC_ERR_ARG;
+    g2pc::g_radix_wide_bits = wide_digit_bits;
+    g2pc::g_radix_small_n = small_input_keys;
+    return G2PC_OK;
+}
 int g2pc_selftest_wave_reduce(const uint32_t* in, uint32_t* out, int64_t waves, void* stream) {
     hipLaunchKernelGGL(g2pc::k_selftest_wave_reduce, dim3((unsigned)waves), dim3(64), 0, (hipStream_t)stream, in, out);
     return g2pc::check_launch("selftest");

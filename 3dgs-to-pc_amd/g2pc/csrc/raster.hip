@@ -223,21 +223,42 @@ __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __
         cr[j] = cg[j] = cb[j] = 0.0f;
     }
     const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
+    // Software pipeline of the list staging (the gathers are two dependent HBM/L2 round trips and sit on the
+    // critical path of the waves that never saturate): ids run two batches ahead, parameters one batch ahead.
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t g_cur = 0, g_nxt = 0;
+    bool v_cur = (start + lane) < end, v_nxt = (start + BL_BATCH + lane) < end;
+    if (v_cur) g_cur = inst_g[start + lane];
+    if (v_nxt) g_nxt = inst_g[start + BL_BATCH + lane];
+    // raw loads only (no arithmetic on them before the LDS write, or the compiler waits for the load right here)
+    float4 r0 = zero4, r1 = zero4;                       // zero opacity = padding
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    uint32_t gmb = 0x7F000000u;                          // huge running maximum: padding is never a candidate
+    const uint32_t* key_hi = (const uint32_t*)best_key + 1;     // high word = contribution bits (little endian)
+    if (v_cur) {
+        r0 = p0[g_cur];
+        r1 = p1[g_cur];
+        gmb = key_hi[2 * (size_t)g_cur];
+        c0 = colours[3 * (size_t)g_cur]; c1 = colours[3 * (size_t)g_cur + 1]; c2 = colours[3 * (size_t)g_cur + 2];
+    }
     for (uint32_t b = start; b < end; b += BL_BATCH) {
         wave_sync();                            // everyone is done reading the previous batch
-        if (b + lane < end) {
-            uint32_t g = inst_g[b + lane];
-            s_p0[lane] = p0[g];
-            s_p1[lane] = p1[g];
-            float gm = __uint_as_float((uint32_t)(best_key[g] >> 32));
-            gm = fmaxf(gm, 1.17549435e-38f);                       // a zero contribution never updates anything
-            s_p2[lane] = make_float4(colours[3 * (size_t)g], colours[3 * (size_t)g + 1], colours[3 * (size_t)g + 2], gm);
-            s_g[lane] = g;
-        } else {                                // padding: opacity 0 -> alpha 0 -> no effect, never a candidate
-            s_p0[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-            s_p1[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-            s_p2[lane] = make_float4(0.f, 0.f, 0.f, 3.0e38f);
-            s_g[lane] = 0;
+        s_p0[lane] = r0;
+        s_p1[lane] = r1;
+        s_p2[lane] = make_float4(c0, c1, c2, fmaxf(__uint_as_float(gmb), 1.17549435e-38f));   // a 0 contribution never updates
+        s_g[lane] = g_cur;
+        // issue the loads of batch b+1 (parameters) and b+2 (ids); they complete under the blend of batch b
+        g_cur = g_nxt;
+        v_cur = v_nxt;
+        v_nxt = (b + 2 * BL_BATCH + lane) < end;
+        g_nxt = 0;
+        if (v_nxt) g_nxt = inst_g[b + 2 * BL_BATCH + lane];
+        r0 = zero4; r1 = zero4; c0 = c1 = c2 = 0.f; gmb = 0x7F000000u;
+        if (v_cur) {
+            r0 = p0[g_cur];
+            r1 = p1[g_cur];
+            gmb = key_hi[2 * (size_t)g_cur];
+            c0 = colours[3 * (size_t)g_cur]; c1 = colours[3 * (size_t)g_cur + 1]; c2 = colours[3 * (size_t)g_cur + 2];
         }
         wave_sync();
         const int cnt = (end - b) < (uint32_t)BL_BATCH ? (int)(end - b) : BL_BATCH;

@@ -44,6 +44,8 @@ size_t g2pc_scan_workspace(int64_t n);
 /* out[0..n] = exclusive prefix sums of in[0..n-1]; out[n] = total.  in may alias out. */
 int g2pc_scan_exclusive_u32(const uint32_t* in, uint32_t* out, int64_t n, void* ws, size_t ws_bytes, void* stream);
 size_t g2pc_sort_workspace(int64_t n);
+/* tuning: digit width (8 or 11 bits) for sorts of more than 8 bits; inputs up to small_input_keys use 4 keys/thread */
+int g2pc_set_sort_tuning(int wide_digit_bits, int64_t small_input_keys);
 /* stable LSD radix sort of (key,value) pairs on key bits [bit_lo, bit_hi) */
 int g2pc_sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
                         uint32_t* keys_tmp, uint32_t* vals_tmp, int64_t n, int bit_lo, int bit_hi, void* ws,
