@@ -194,7 +194,8 @@ __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __
                                                   const float4* __restrict__ p0, const float4* __restrict__ p1,
                                                   const float* __restrict__ colours,
                                                   unsigned long long* __restrict__ best_key, uint32_t order_base,
-                                                  float t_floor, float bg, float* __restrict__ tilebuf) {
+                                                  float t_floor, float bg, float* __restrict__ tilebuf,
+                                                  uint32_t* __restrict__ chunk_work) {
     // one wave64 per block: the LDS stage is wave-private, no s_barrier anywhere
     __shared__ float4 s_p0[BL_BATCH + 4];
     __shared__ float4 s_p1[BL_BATCH + 4];
@@ -241,7 +242,9 @@ __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __
         gmb = key_hi[2 * (size_t)g_cur];
         c0 = colours[3 * (size_t)g_cur]; c1 = colours[3 * (size_t)g_cur + 1]; c2 = colours[3 * (size_t)g_cur + 2];
     }
+    uint32_t processed = 0;
     for (uint32_t b = start; b < end; b += BL_BATCH) {
+        processed = b + BL_BATCH - start;
         wave_sync();                            // everyone is done reading the previous batch
         s_p0[lane] = r0;
         s_p1[lane] = r1;
@@ -317,6 +320,10 @@ __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __
             for (int j = 0; j < PPT; ++j) done = done && (T[j] < t_floor);
             if (__all(done ? 1 : 0)) break;
         }
+    }
+    if (chunk_work && lane == 0) {                 // diagnostics: list length and how far this wave walked it
+        chunk_work[2 * blockIdx.x] = end - start;
+        chunk_work[2 * blockIdx.x + 1] = processed;
     }
     float* out = tilebuf + 3 * (size_t)lay.tile_pix_off[tile];
 #pragma unroll
@@ -689,6 +696,8 @@ __global__ __launch_bounds__(RA_T) void k_fill_u32(uint32_t* __restrict__ p, lon
     if (i < n) p[i] = v;
 }
 
+static uint32_t* g_chunk_work = nullptr;      // diagnostics hook (g2pc_raster_debug_chunk_work)
+
 static Cam to_cam(const G2pcCamera* c) {
     Cam k;
     for (int i = 0; i < 16; ++i) { k.V[i] = c->view[i]; k.P[i] = c->proj[i]; }
@@ -798,7 +807,7 @@ int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, con
 #define G2PC_BLEND(PPT, U)                                                                                            \
     hipLaunchKernelGGL((k_blend_py<PPT, U>), dim3((unsigned)layout->num_chunks), dim3(BL_T), 0, s, lay, layout->chunk_tile, \
                        layout->chunk_pix0, tile_start, g_sorted, (const float4*)p0, (const float4*)p1, colours, best_key, \
-                       camera_slot << 24, t_floor, cam->bg[0], tilebuf)
+                       camera_slot << 24, t_floor, cam->bg[0], tilebuf, g_chunk_work)
     switch (layout->chunk_subblocks) {
         case 1: G2PC_BLEND(1, 4); break;
         case 2: G2PC_BLEND(2, 2); break;
@@ -814,6 +823,9 @@ int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, con
     }
     return check_launch("g2pc_raster_back_py");
 }
+
+/* diagnostics: when set, the PY blend writes (list length, entries walked) per chunk into u32[2*num_chunks] */
+int g2pc_raster_debug_chunk_work(uint32_t* buf) { g2pc::g_chunk_work = buf; return G2PC_OK; }
 
 int g2pc_raster_rebase_keys(unsigned long long* best_key, int64_t n, void* stream) {
     using namespace g2pc;

@@ -58,6 +58,7 @@ nv._RASTER_PROTOS.update({
     "g2pc_raster_back_py": (C.c_int, [C.POINTER(_Camera), C.POINTER(_Layout), C.c_void_p, C.c_int64, C.c_int64] +
                             [C.c_void_p] * 5 + [C.c_uint32, C.c_float] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "g2pc_raster_rebase_keys": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    "g2pc_raster_debug_chunk_work": (C.c_int, [C.c_void_p]),
     "g2pc_raster_keep_winner_colours": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "g2pc_raster_contributions": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
 })

@@ -197,6 +197,8 @@ int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, con
                         unsigned long long* best_key, float* colours_out, float* tilebuf, float* image, int phases,
                         void* ws, size_t ws_bytes, void* stream);
 int g2pc_raster_rebase_keys(unsigned long long* best_key, int64_t n, void* stream);
+/* diagnostics: when non-NULL, the PY blend records (tile list length, entries walked) per chunk in u32[2*num_chunks] */
+int g2pc_raster_debug_chunk_work(uint32_t* buf);
 /* --- native-rasteriser ("cuda") semantics: _C.rasterize_gaussians (rasterize_points.h:18-41) ----------------------
  * Deterministic spec of SURVEY.md §8(a.5): 16x16 tiles, near cull z_view <= 0.2, radius ceil(3 sqrt(lambda_max)),
  * stable (tile, depth) order, alpha rules (power > 0 skip, min(0.99, .), alpha < 1/255 skip, T(1-alpha) < 1e-4 stop),
