@@ -245,6 +245,9 @@ __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __
     uint32_t processed = 0;
     for (uint32_t b = start; b < end; b += BL_BATCH) {
         processed = b + BL_BATCH - start;
+        // waves still walking after many batches are the launch's critical path (most chunks saturate within
+        // ~700 entries): let them win issue arbitration over the short-lived waves sharing their SIMD
+        if (processed == 16 * BL_BATCH) __builtin_amdgcn_s_setprio(2);
         wave_sync();                            // everyone is done reading the previous batch
         s_p0[lane] = r0;
         s_p1[lane] = r1;

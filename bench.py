@@ -132,11 +132,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (run it through gpurun)"
+    if os.environ.get("G2PC_SHARE_GPU"):         # validation aid: several ranks on ONE GPU (gloo; RCCL refuses that)
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("G2PC_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     from g2pc import _native as nv
     from g2pc.synth import make_scene, make_cameras
     nv.lib()

@@ -336,3 +336,4 @@ static inline int __builtin_amdgcn_readlane(int v, int lane) {
     const uint64_t* t = hipemu::exchange((uint64_t)(uint32_t)v);
     return (int)(uint32_t)t[lane & 63];
 }
+static inline void __builtin_amdgcn_s_setprio(int) {}

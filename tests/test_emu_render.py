@@ -12,11 +12,6 @@ def test_render_matches_reference_python_renderer(emu, golden_dir):
     print(stats)
 
 
-def test_render_with_transmittance_floor_is_within_floor(emu, golden_dir):
-    g, R, images, contribs = run_render_case(golden_dir, t_floor=1e-6)
-    assert_render_matches(g, R, images, contribs)
-
-
 def test_render_1024_tiles_two_pass_tile_sort_vs_oracle(emu):
     """1280x720 = 1024 quad-tree leaves -> 10-bit tile ids -> two radix passes (ping-pong buffers)."""
     from render_checks import run_vs_oracle
