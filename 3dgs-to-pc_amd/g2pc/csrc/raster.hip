@@ -818,6 +818,8 @@ int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, con
         default: set_error("g2pc_raster_back_py", "chunk_subblocks must be 1, 2 or 4"); return G2PC_ERR_ARG;
     }
 #undef G2PC_BLEND
+    }
+    if (phases & 4) {
     hipLaunchKernelGGL(k_update_colours_py, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, lay, best_key, (long)n, camera_slot,
                        tilebuf, colours_out);
     if (image)

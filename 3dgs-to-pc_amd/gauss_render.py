@@ -90,6 +90,30 @@ class _DeviceLayout:
         self.total_pixels = lay["total_pixels"]
 
 
+class _Scratch:
+    """Per-stream scratch of one in-flight camera."""
+
+    def __init__(self, n, device, stream=None):
+        f32, i32 = dict(dtype=torch.float32, device=device), dict(dtype=torch.int32, device=device)
+        self.p0, self.p1 = torch.empty((n, 4), **f32), torch.empty((n, 4), **f32)
+        self.rect, self.sorted_idx = torch.empty((n,), **i32), torch.empty((n,), **i32)
+        self.offsets = torch.empty((n + 1,), **i32)
+        self.front_ws_bytes = nv.lib().g2pc_raster_front_workspace(n)
+        self.front_ws = nv.workspace(self.front_ws_bytes, device)
+        self.back_ws, self.back_ws_bytes = None, 0
+        self.tilebuf = None
+        self.stream = stream
+        self.count_host = torch.empty((1,), dtype=torch.int32).pin_memory() if stream is not None else None
+        self.front_done = torch.cuda.Event() if stream is not None else None
+
+
+# Cameras in flight when the caller does not need the image back (the pipeline of gauss_to_pc.py discards it).
+# The packed-key atomicMax makes the blends of different cameras commutative, so camera c+1's preprocess / sort /
+# binning (dozens of small launches that leave most CUs idle) and even its blend overlap camera c's blend on
+# another HIP stream, and the host never blocks on the per-camera instance-count read-back.
+PIPELINE_STREAMS = 3
+
+
 class GaussHipRenderer():
     """Stateful per-scene renderer: keeps, for every Gaussian, the largest blend contribution seen in any
     tile of any camera and the pixel colour rendered where it occurred (gauss_render.py:215-264)."""
@@ -100,7 +124,7 @@ class GaussHipRenderer():
     def __init__(self, means3D, opacity, colour, cov3d, white_bkgd=True, visible_gaussian_threshold=0.0,
                  semantics="python", t_floor=None):
         if semantics != "python":
-            raise NotImplementedError("native-rasteriser ('cuda') semantics are not built yet")
+            raise NotImplementedError("use gaussian_pointcloud_rasterization.GaussianRasterizer for 'cuda' semantics")
         nv.lib()
         self.white_bkgd = white_bkgd
         self.device = means3D.device
@@ -120,29 +144,31 @@ class GaussHipRenderer():
         self.gaussian_colours = torch.zeros((n, 3), dtype=torch.float32, device=self.device)
         self.camera_slot = 0
 
-        # per-camera scratch, allocated once
-        self.p0 = torch.empty((n, 4), dtype=torch.float32, device=self.device)
-        self.p1 = torch.empty((n, 4), dtype=torch.float32, device=self.device)
-        self.rect = torch.empty((n,), dtype=torch.int32, device=self.device)
-        self.sorted_idx = torch.empty((n,), dtype=torch.int32, device=self.device)
-        self.offsets = torch.empty((n + 1,), dtype=torch.int32, device=self.device)
-        self.front_ws_bytes = nv.lib().g2pc_raster_front_workspace(n)
-        self.front_ws = nv.workspace(self.front_ws_bytes, self.device)
-        self.back_ws = None
-        self.back_ws_bytes = 0
+        self.sync_scratch = _Scratch(n, self.device)
+        self.pipe = []                # lazily created per-stream scratch
+        self.pipe_next = 0
+        self.pending = []             # cameras whose front half is in flight: (scratch, cam struct, layout, slot)
+        self.last_update = None       # event after the latest colour update (updates are issued in camera order)
         self.layouts = {}
-        self.tilebuf = None
         self.last_stats = []          # (instances L, tile-sort passes, W*H) per rendered camera
+
+    def __del__(self):
+        try:
+            self.flush()
+        except Exception:
+            pass
 
     # ---- getters (gauss_render.py:237-264) -----------------------------------------------------------------
     @property
     def gaussian_max_contribution(self):
+        self.flush()
         out = torch.empty((self.n,), dtype=torch.float32, device=self.device)
         nv.check(nv.lib().g2pc_raster_contributions(nv.ptr(self.best_key), self.n, nv.ptr(out),
                                                     nv.stream_handle(self.device)), "contributions")
         return out
 
     def get_gaussian_colours(self):
+        self.flush()
         return self.gaussian_colours * 255
 
     def get_gaussians_above_contribution_threshold(self, contribution_threshold):
@@ -164,17 +190,14 @@ class GaussHipRenderer():
         key = (width, height)
         if key not in self.layouts:
             self.layouts[key] = _DeviceLayout(tiles.python_quadtree_layout(width, height, self.MAX_TILE_SIZE, BLEND_SUBBLOCKS), self.device)
-        lay = self.layouts[key]
-        need = lay.total_pixels * 3
-        if self.tilebuf is None or self.tilebuf.numel() < need:
-            self.tilebuf = torch.empty((need,), dtype=torch.float32, device=self.device)
-        return lay
+        return self.layouts[key]
 
     def all_reduce_visibility(self, group=None):
         """Multi-GPU (cameras sharded over ranks): combine the running state of all ranks.  all-reduce MAX of the
         packed (contribution, ~order) keys -- exact and order-free -- then every rank zeroes the colours it did
         not win and an all-reduce SUM delivers the winners' colours (one non-zero term per Gaussian)."""
         import torch.distributed as dist
+        self.flush()
         if not dist.is_initialized() or dist.get_world_size(group) == 1:
             return
         global_key = self.best_key.clone()
@@ -187,54 +210,114 @@ class GaussHipRenderer():
 
     def rebase_keys(self):
         """Forget the camera order of the current keys (they become "earliest"), freeing the 8-bit order field."""
+        self.flush()
         nv.check(nv.lib().g2pc_raster_rebase_keys(nv.ptr(self.best_key), self.n, nv.stream_handle(self.device)), "rebase")
         self.camera_slot = 0
 
-    def __call__(self, camera, return_image=True, slot=None, **kwargs):
-        L = nv.lib()
-        st = nv.stream_handle(self.device)
-        W, H = int(camera.image_width), int(camera.image_height)
-        lay = self._layout(W, H)
+    def _camera_struct(self, camera):
         cam = _Camera()
         cam.view[:] = camera.world_view_transform.reshape(-1).tolist()
         cam.proj[:] = camera.projection_matrix.reshape(-1).tolist()
         cam.tan_fovx, cam.tan_fovy = tan(camera.FoVx * 0.5), tan(camera.FoVy * 0.5)
         cam.focal_x, cam.focal_y = camera.focal_x, camera.focal_y
-        cam.width, cam.height = W, H
+        cam.width, cam.height = int(camera.image_width), int(camera.image_height)
         bgv = 1.0 if self.white_bkgd else 0.0
         cam.bg[:] = [bgv, bgv, bgv]
+        return cam
 
+    def _front(self, sc, cam, lay):
         with nv.region("raster_front", self.device):
-            nv.check(L.g2pc_raster_front_py(C.byref(cam), C.byref(lay.c), nv.ptr(self.means3D), nv.ptr(self.cov3d),
-                                            nv.ptr(self.opacity), self.n, nv.ptr(self.p0), nv.ptr(self.p1),
-                                            nv.ptr(self.rect), nv.ptr(self.sorted_idx), nv.ptr(self.offsets),
-                                            nv.ptr(self.front_ws), self.front_ws_bytes, st), "raster_front_py")
-        num_inst = int(self.offsets[self.n].item())                       # the one read-back per camera
+            nv.check(nv.lib().g2pc_raster_front_py(C.byref(cam), C.byref(lay.c), nv.ptr(self.means3D), nv.ptr(self.cov3d),
+                                                   nv.ptr(self.opacity), self.n, nv.ptr(sc.p0), nv.ptr(sc.p1),
+                                                   nv.ptr(sc.rect), nv.ptr(sc.sorted_idx), nv.ptr(sc.offsets),
+                                                   nv.ptr(sc.front_ws), sc.front_ws_bytes, nv.stream_handle(self.device)),
+                     "raster_front_py")
+
+    def _back(self, sc, cam, lay, slot, num_inst, image, phases, name):
+        L = nv.lib()
         need = L.g2pc_raster_back_workspace(num_inst, lay.num_tiles)
-        if need > self.back_ws_bytes:
-            self.back_ws_bytes = int(need * 1.25)
-            self.back_ws = nv.workspace(self.back_ws_bytes, self.device)
+        if need > sc.back_ws_bytes:
+            sc.back_ws_bytes = int(need * 1.25)
+            sc.back_ws = nv.workspace(sc.back_ws_bytes, self.device)
+        if sc.tilebuf is None or sc.tilebuf.numel() < lay.total_pixels * 3:
+            sc.tilebuf = torch.empty((lay.total_pixels * 3,), dtype=torch.float32, device=self.device)
+        with nv.region(name, self.device):
+            nv.check(L.g2pc_raster_back_py(C.byref(cam), C.byref(lay.c), nv.ptr(self.colour), self.n, num_inst,
+                                           nv.ptr(sc.p0), nv.ptr(sc.p1), nv.ptr(sc.rect), nv.ptr(sc.sorted_idx),
+                                           nv.ptr(sc.offsets), slot, self.t_floor, nv.ptr(self.best_key),
+                                           nv.ptr(self.gaussian_colours), nv.ptr(sc.tilebuf), nv.ptr(image), phases,
+                                           nv.ptr(sc.back_ws), sc.back_ws_bytes, nv.stream_handle(self.device)),
+                     "raster_back_py")
+
+    def _note(self, lay, num_inst, W, H):
+        bits = max(1, int(np.ceil(np.log2(max(lay.num_tiles, 2)))))
+        self.last_stats.append((num_inst, (bits + 7) // 8, W * H))
+        RENDER_STATS.append((num_inst, (bits + 7) // 8, W * H))
+
+    def _finish(self, entry):
+        """Back half of a pipelined camera: its instance count is (long) there; the colour updates are chained."""
+        sc, cam, lay, slot = entry
+        sc.front_done.synchronize()
+        num_inst = int(sc.count_host[0])
+        with torch.cuda.stream(sc.stream):
+            self._back(sc, cam, lay, slot, num_inst, None, 1, "raster_bin")
+            self._back(sc, cam, lay, slot, num_inst, None, 2, "raster_blend")
+            if self.last_update is not None:
+                sc.stream.wait_event(self.last_update)
+            self._back(sc, cam, lay, slot, num_inst, None, 4, "raster_update")
+            self.last_update = torch.cuda.Event()
+            self.last_update.record(sc.stream)
+        self._note(lay, num_inst, cam.width, cam.height)
+
+    def flush(self):
+        """Complete every camera in flight and make the running state visible to the current stream."""
+        if not self.pending and not self.pipe:
+            return
+        while self.pending:
+            self._finish(self.pending.pop(0))
+        cur = torch.cuda.current_stream(self.device)
+        for sc in self.pipe:
+            cur.wait_stream(sc.stream)
+
+    def __call__(self, camera, return_image=True, slot=None, **kwargs):
+        W, H = int(camera.image_width), int(camera.image_height)
+        lay = self._layout(W, H)
+        cam = self._camera_struct(camera)
         if slot is not None:                       # caller-assigned global camera order (multi-GPU camera sharding)
             if not (1 <= slot <= 255):
                 raise ValueError("camera slot must be in [1, 255]")
             self.camera_slot = int(slot)
         else:
             if self.camera_slot >= 255:
-                nv.check(L.g2pc_raster_rebase_keys(nv.ptr(self.best_key), self.n, st), "rebase")
-                self.camera_slot = 0
+                self.rebase_keys()
             self.camera_slot += 1
+        slot = self.camera_slot
+
+        pipelined = (not return_image) and PIPELINE_STREAMS > 1 and self.device.type == "cuda" and not nv.emulated()
+        if pipelined:
+            if not self.pipe:
+                self.pipe = [_Scratch(self.n, self.device, torch.cuda.Stream(self.device)) for _ in range(PIPELINE_STREAMS)]
+            while len(self.pending) >= PIPELINE_STREAMS:
+                self._finish(self.pending.pop(0))
+            sc = self.pipe[self.pipe_next]
+            self.pipe_next = (self.pipe_next + 1) % PIPELINE_STREAMS
+            sc.stream.wait_stream(torch.cuda.current_stream(self.device))      # scene tensors are ready
+            with torch.cuda.stream(sc.stream):
+                self._front(sc, cam, lay)
+                sc.count_host.copy_(sc.offsets[self.n:self.n + 1], non_blocking=True)
+                sc.front_done.record(sc.stream)
+            self.pending.append((sc, cam, lay, slot))
+            return None, None, None, None
+
+        self.flush()
+        sc = self.sync_scratch
+        self._front(sc, cam, lay)
+        num_inst = int(sc.offsets[self.n].item())                       # the one read-back per camera
         image = torch.empty((H, W, 3), dtype=torch.float32, device=self.device) if return_image else None
-        for phase, name in ((1, "raster_bin"), (2, "raster_blend")):
-            with nv.region(name, self.device):
-                nv.check(L.g2pc_raster_back_py(C.byref(cam), C.byref(lay.c), nv.ptr(self.colour), self.n, num_inst,
-                                               nv.ptr(self.p0), nv.ptr(self.p1), nv.ptr(self.rect),
-                                               nv.ptr(self.sorted_idx), nv.ptr(self.offsets), self.camera_slot,
-                                               self.t_floor, nv.ptr(self.best_key), nv.ptr(self.gaussian_colours),
-                                               nv.ptr(self.tilebuf), nv.ptr(image), phase, nv.ptr(self.back_ws),
-                                               self.back_ws_bytes, st), "raster_back_py")
-        bits = max(1, int(np.ceil(np.log2(max(lay.num_tiles, 2)))))
-        self.last_stats.append((num_inst, (bits + 7) // 8, W * H))
-        RENDER_STATS.append((num_inst, (bits + 7) // 8, W * H))
+        self._back(sc, cam, lay, slot, num_inst, image, 1, "raster_bin")
+        self._back(sc, cam, lay, slot, num_inst, image, 2, "raster_blend")
+        self._back(sc, cam, lay, slot, num_inst, image, 4, "raster_update")
+        self._note(lay, num_inst, W, H)
         return image, None, None, None
 
 

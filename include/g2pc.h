@@ -189,8 +189,9 @@ size_t g2pc_raster_back_workspace(int64_t num_instances, int32_t num_tiles);
  * [1,255] must increase from camera to camera (call g2pc_raster_rebase_keys before wrapping around).
  * t_floor: 0 = exact python semantics; > 0 stops a pixel chunk once every pixel's transmittance is below it
  * (all later contributions and colour terms are then < t_floor).
- * phases: bit 0 = binning (duplicate, tile sort, ranges), bit 1 = blend + colour update + image; 3 = both
- * (the two halves share `ws`; bench.py times them separately). */
+ * phases: bit 0 = binning (duplicate, tile sort, ranges), bit 1 = blend, bit 2 = colour update + image; 7 = all
+ * (the phases share `ws`).  The packed-key atomicMax is commutative, so the blends of different cameras may run
+ * concurrently on different streams; only the colour updates must be issued in camera order. */
 int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, const float* colours, int64_t n,
                         int64_t num_instances, const float* p0, const float* p1, const uint32_t* rect,
                         const uint32_t* sorted_idx, const uint32_t* offsets, uint32_t camera_slot, float t_floor,

@@ -74,3 +74,27 @@ def test_render_vs_oracle_other_sizes(n, w, h, f, res):
     assert r["image_frac_off"] < 1e-4 and r["contribution_frac_off"] < 1e-4 and r["colour_frac_off"] < 1e-4, r
     assert r["image"] < 2e-2 and r["contribution"] < 2e-2, r
     assert r["flips"] <= r["near_threshold"] + 1, r   # a mask may only flip where the oracle sits within 1e-5 of 0.05
+
+
+def test_pipelined_cameras_equal_synchronous(monkeypatch):
+    """Cameras overlapped on several HIP streams (commutative packed-key atomics) == one camera at a time."""
+    import gauss_render
+    import camera_handler
+    from gauss_handler import Gaussians
+    from g2pc.synth import make_scene, make_cameras
+    sc = make_scene(150_000, 1240, device=DEV)
+    G = Gaussians(sc.xyz, sc.scales, sc.rots, sc.colours, sc.opacities)
+    transforms, intr = make_cameras(7)
+    states = []
+    for streams in (1, 3, 3):
+        monkeypatch.setattr(gauss_render, "PIPELINE_STREAMS", streams)
+        R = gauss_render.get_renderer("python", G.xyz, G.opacities.unsqueeze(1), G.colours, G.covariances,
+                                      visible_gaussian_threshold=0.05)
+        for name in transforms:
+            cam = camera_handler.get_camera("python", torch.tensor(transforms[name]), intr[name], colour_resolution=1280)
+            R(cam, return_image=False)
+        states.append((R.gaussian_max_contribution.clone(), R.get_gaussian_colours().clone(), R.best_key.clone()))
+    for a, b in zip(states[0], states[1]):
+        assert torch.equal(a, b)
+    for a, b in zip(states[1], states[2]):
+        assert torch.equal(a, b)
