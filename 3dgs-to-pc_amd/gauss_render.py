@@ -111,7 +111,8 @@ class _Scratch:
 # The packed-key atomicMax makes the blends of different cameras commutative, so camera c+1's preprocess / sort /
 # binning (dozens of small launches that leave most CUs idle) and even its blend overlap camera c's blend on
 # another HIP stream, and the host never blocks on the per-camera instance-count read-back.
-PIPELINE_STREAMS = 3
+PIPELINE_STREAMS = 4
+_LAYOUT_CACHE = {}
 
 
 class GaussHipRenderer():
@@ -187,10 +188,11 @@ class GaussHipRenderer():
 
     # ---- rendering ---------------------------------------------------------------------------------------------
     def _layout(self, width, height):
-        key = (width, height)
-        if key not in self.layouts:
-            self.layouts[key] = _DeviceLayout(tiles.python_quadtree_layout(width, height, self.MAX_TILE_SIZE, BLEND_SUBBLOCKS), self.device)
-        return self.layouts[key]
+        # tile layouts depend only on the image size and tiling: built and uploaded once per process and device
+        key = (width, height, self.MAX_TILE_SIZE, BLEND_SUBBLOCKS, str(self.device))
+        if key not in _LAYOUT_CACHE:
+            _LAYOUT_CACHE[key] = _DeviceLayout(tiles.python_quadtree_layout(width, height, self.MAX_TILE_SIZE, BLEND_SUBBLOCKS), self.device)
+        return _LAYOUT_CACHE[key]
 
     def all_reduce_visibility(self, group=None):
         """Multi-GPU (cameras sharded over ranks): combine the running state of all ranks.  all-reduce MAX of the

@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--sort-bits", type=int, default=0, help="tuning aid: wide radix digit bits (8 or 11)")
     ap.add_argument("--sort-small", type=int, default=2 << 20, help="tuning aid: inputs up to this many keys use 4 keys/thread")
     ap.add_argument("--blend-subblocks", type=int, default=0, help="tuning aid: 8x8 sub-blocks per blend wave (1, 2, 4)")
+    ap.add_argument("--streams", type=int, default=0, help="tuning aid: cameras in flight (HIP streams) of the renderer")
     ap.add_argument("--camera-subset", type=int, default=0, help="profiling aid: render only the first k cameras of the rig")
     ap.add_argument("--t-floor", type=float, default=None, help="blend transmittance floor (default: gauss_render.DEFAULT_T_FLOOR)")
     return ap.parse_args()
@@ -154,6 +155,8 @@ def main():
         nv.lib().g2pc_set_sort_tuning(a.sort_bits, a.sort_small)
     if a.blend_subblocks:
         gauss_render.BLEND_SUBBLOCKS = a.blend_subblocks
+    if a.streams:
+        gauss_render.PIPELINE_STREAMS = a.streams
 
     # strong scaling: ONE scene (same seed on every rank, replicated read-only); cameras are split over the ranks,
     # the visibility state is all-reduced, sampling is sharded by Gaussian index, the points are gathered on rank 0

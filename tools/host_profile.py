@@ -1,0 +1,21 @@
+"""Diagnostics: where does the HOST spend its time in the camera loop? (run on the GPU box)"""
+import cProfile, pstats, sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "3dgs-to-pc_amd"), ROOT]
+import torch
+import bench
+from g2pc.synth import make_scene, make_cameras
+import gauss_render
+gauss_render.PIPELINE_STREAMS = 4
+dev = torch.device("cuda:0")
+scene = make_scene(1_000_000, 1237, device=dev)
+cams = make_cameras(50)
+bench.one_step(scene, cams, "render", 10_000_000, dev, 1)
+torch.cuda.synchronize()
+t = time.perf_counter()
+pr = cProfile.Profile(); pr.enable()
+bench.one_step(scene, cams, "render", 10_000_000, dev, 2)
+torch.cuda.synchronize()
+pr.disable()
+print("step wall ms", (time.perf_counter() - t) * 1e3)
+pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
