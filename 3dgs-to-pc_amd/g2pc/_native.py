@@ -132,17 +132,19 @@ PROFILE = None   # dict name -> list of (start_event, end_event) when enabled
 
 
 @contextlib.contextmanager
-def region(name: str, device=None):
+def region(name: str, device=None, stream=None):
+    """Brackets the kernels launched inside with HIP events on the stream they are launched on."""
     if PROFILE is None or _EMULATED:
         yield
         return
     a = torch.cuda.Event(enable_timing=True)
     b = torch.cuda.Event(enable_timing=True)
-    a.record(torch.cuda.current_stream(device))
+    st = stream if stream is not None else torch.cuda.current_stream(device)
+    a.record(st)
     try:
         yield
     finally:
-        b.record(torch.cuda.current_stream(device))
+        b.record(st)
         PROFILE.setdefault(name, []).append((a, b))
 
 

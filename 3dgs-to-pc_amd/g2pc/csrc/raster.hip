@@ -730,7 +730,7 @@ size_t g2pc_raster_front_workspace(int64_t n) {
 // offsets u32[n+1] (offsets[n] = L, the number of (tile, Gaussian) instances) for the back half.
 int g2pc_raster_front_py(const G2pcCamera* cam, const G2pcTileLayout* layout, const float* means3D, const float* cov9,
                          const float* opacity, int64_t n, float* p0, float* p1, uint32_t* rect, uint32_t* sorted_idx,
-                         uint32_t* offsets, void* ws, size_t ws_bytes, void* stream) {
+                         uint32_t* offsets, uint32_t* count_host, void* ws, size_t ws_bytes, void* stream) {
     using namespace g2pc;
     G2PC_REQUIRE(cam && layout && means3D && cov9 && opacity && p0 && p1 && rect && sorted_idx && offsets && ws && n > 0,
                  G2PC_ERR_ARG, "bad arguments");
@@ -755,6 +755,7 @@ int g2pc_raster_front_py(const G2pcCamera* cam, const G2pcTileLayout* layout, co
     hipLaunchKernelGGL(k_gather_u32, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, touched, sorted_idx, (long)n, ktmp);
     rc = scan_exclusive_u32(ktmp, offsets, n, scan_ws, scan_bytes, s);
     if (rc) return rc;
+    if (count_host) hipMemcpyAsync(count_host, offsets + n, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
     return check_launch("g2pc_raster_front_py");
 }
 

@@ -53,7 +53,7 @@ class _Layout(C.Structure):
 nv._RASTER_PROTOS.update({
     "g2pc_raster_front_workspace": (C.c_size_t, [C.c_int64]),
     "g2pc_raster_front_py": (C.c_int, [C.POINTER(_Camera), C.POINTER(_Layout)] + [C.c_void_p] * 3 + [C.c_int64] +
-                             [C.c_void_p] * 6 + [C.c_size_t, C.c_void_p]),
+                             [C.c_void_p] * 7 + [C.c_size_t, C.c_void_p]),
     "g2pc_raster_back_workspace": (C.c_size_t, [C.c_int64, C.c_int32]),
     "g2pc_raster_back_py": (C.c_int, [C.POINTER(_Camera), C.POINTER(_Layout), C.c_void_p, C.c_int64, C.c_int64] +
                             [C.c_void_p] * 5 + [C.c_uint32, C.c_float] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -105,6 +105,12 @@ class _Scratch:
         self.stream = stream
         self.count_host = torch.empty((1,), dtype=torch.int32).pin_memory() if stream is not None else None
         self.front_done = torch.cuda.Event() if stream is not None else None
+        self.update_done = torch.cuda.Event() if stream is not None else None
+        self.stream_ptr = C.c_void_p(stream.cuda_stream) if stream is not None else None
+        # raw pointers of the fixed scratch tensors (ctypes marshalling is a visible share of the host time per camera)
+        self.ptrs = tuple(nv.ptr(t) for t in (self.p0, self.p1, self.rect, self.sorted_idx, self.offsets))
+        self.front_ws_ptr = nv.ptr(self.front_ws)
+        self.count_ptr = C.c_void_p(self.count_host.data_ptr()) if stream is not None else None
 
 
 # Cameras in flight when the caller does not need the image back (the pipeline of gauss_to_pc.py discards it).
@@ -146,12 +152,17 @@ class GaussHipRenderer():
         self.camera_slot = 0
 
         self.sync_scratch = _Scratch(n, self.device)
+        self.scene_ptrs = (nv.ptr(self.means3D), nv.ptr(self.cov3d), nv.ptr(self.opacity))
+        self.colour_ptr = nv.ptr(self.colour)
         self.pipe = []                # lazily created per-stream scratch
         self.pipe_next = 0
         self.pending = []             # cameras whose front half is in flight: (scratch, cam struct, layout, slot)
         self.last_update = None       # event after the latest colour update (updates are issued in camera order)
         self.layouts = {}
         self.last_stats = []          # (instances L, tile-sort passes, W*H) per rendered camera
+
+    def state_ptrs(self):
+        return nv.ptr(self.best_key), nv.ptr(self.gaussian_colours)
 
     def __del__(self):
         try:
@@ -227,28 +238,33 @@ class GaussHipRenderer():
         cam.bg[:] = [bgv, bgv, bgv]
         return cam
 
+    def _stream_ptr(self, sc):
+        return sc.stream_ptr if sc.stream is not None else nv.stream_handle(self.device)
+
     def _front(self, sc, cam, lay):
-        with nv.region("raster_front", self.device):
-            nv.check(nv.lib().g2pc_raster_front_py(C.byref(cam), C.byref(lay.c), nv.ptr(self.means3D), nv.ptr(self.cov3d),
-                                                   nv.ptr(self.opacity), self.n, nv.ptr(sc.p0), nv.ptr(sc.p1),
-                                                   nv.ptr(sc.rect), nv.ptr(sc.sorted_idx), nv.ptr(sc.offsets),
-                                                   nv.ptr(sc.front_ws), sc.front_ws_bytes, nv.stream_handle(self.device)),
+        with nv.region("raster_front", self.device, sc.stream):
+            nv.check(nv.lib().g2pc_raster_front_py(C.byref(cam), C.byref(lay.c), *self.scene_ptrs, self.n, *sc.ptrs,
+                                                   sc.count_ptr, sc.front_ws_ptr, sc.front_ws_bytes, self._stream_ptr(sc)),
                      "raster_front_py")
 
     def _back(self, sc, cam, lay, slot, num_inst, image, phases, name):
         L = nv.lib()
         need = L.g2pc_raster_back_workspace(num_inst, lay.num_tiles)
-        if need > sc.back_ws_bytes:
-            sc.back_ws_bytes = int(need * 1.25)
-            sc.back_ws = nv.workspace(sc.back_ws_bytes, self.device)
-        if sc.tilebuf is None or sc.tilebuf.numel() < lay.total_pixels * 3:
-            sc.tilebuf = torch.empty((lay.total_pixels * 3,), dtype=torch.float32, device=self.device)
-        with nv.region(name, self.device):
-            nv.check(L.g2pc_raster_back_py(C.byref(cam), C.byref(lay.c), nv.ptr(self.colour), self.n, num_inst,
-                                           nv.ptr(sc.p0), nv.ptr(sc.p1), nv.ptr(sc.rect), nv.ptr(sc.sorted_idx),
-                                           nv.ptr(sc.offsets), slot, self.t_floor, nv.ptr(self.best_key),
-                                           nv.ptr(self.gaussian_colours), nv.ptr(sc.tilebuf), nv.ptr(image), phases,
-                                           nv.ptr(sc.back_ws), sc.back_ws_bytes, nv.stream_handle(self.device)),
+        if need > sc.back_ws_bytes or sc.tilebuf is None or sc.tilebuf.numel() < lay.total_pixels * 3:
+            # (re)allocate on the stream that uses the buffers
+            import contextlib
+            with (torch.cuda.stream(sc.stream) if sc.stream is not None else contextlib.nullcontext()):
+                if need > sc.back_ws_bytes:
+                    sc.back_ws_bytes = int(need * 1.25)
+                    sc.back_ws = nv.workspace(sc.back_ws_bytes, self.device)
+                    sc.back_ws_ptr = nv.ptr(sc.back_ws)
+                if sc.tilebuf is None or sc.tilebuf.numel() < lay.total_pixels * 3:
+                    sc.tilebuf = torch.empty((lay.total_pixels * 3,), dtype=torch.float32, device=self.device)
+                    sc.tilebuf_ptr = nv.ptr(sc.tilebuf)
+        with nv.region(name, self.device, sc.stream):
+            nv.check(L.g2pc_raster_back_py(C.byref(cam), C.byref(lay.c), self.colour_ptr, self.n, num_inst, *sc.ptrs,
+                                           slot, self.t_floor, self.state_ptrs()[0], self.state_ptrs()[1], sc.tilebuf_ptr,
+                                           nv.ptr(image), phases, sc.back_ws_ptr, sc.back_ws_bytes, self._stream_ptr(sc)),
                      "raster_back_py")
 
     def _note(self, lay, num_inst, W, H):
@@ -261,14 +277,16 @@ class GaussHipRenderer():
         sc, cam, lay, slot = entry
         sc.front_done.synchronize()
         num_inst = int(sc.count_host[0])
-        with torch.cuda.stream(sc.stream):
+        if nv.PROFILE is None:
+            self._back(sc, cam, lay, slot, num_inst, None, 3, "raster_bin+blend")
+        else:
             self._back(sc, cam, lay, slot, num_inst, None, 1, "raster_bin")
             self._back(sc, cam, lay, slot, num_inst, None, 2, "raster_blend")
-            if self.last_update is not None:
-                sc.stream.wait_event(self.last_update)
-            self._back(sc, cam, lay, slot, num_inst, None, 4, "raster_update")
-            self.last_update = torch.cuda.Event()
-            self.last_update.record(sc.stream)
+        if self.last_update is not None:
+            sc.stream.wait_event(self.last_update)
+        self._back(sc, cam, lay, slot, num_inst, None, 4, "raster_update")
+        sc.update_done.record(sc.stream)
+        self.last_update = sc.update_done
         self._note(lay, num_inst, cam.width, cam.height)
 
     def flush(self):
@@ -303,18 +321,18 @@ class GaussHipRenderer():
                 self._finish(self.pending.pop(0))
             sc = self.pipe[self.pipe_next]
             self.pipe_next = (self.pipe_next + 1) % PIPELINE_STREAMS
-            sc.stream.wait_stream(torch.cuda.current_stream(self.device))      # scene tensors are ready
-            with torch.cuda.stream(sc.stream):
-                self._front(sc, cam, lay)
-                sc.count_host.copy_(sc.offsets[self.n:self.n + 1], non_blocking=True)
-                sc.front_done.record(sc.stream)
+            if not self.pending:
+                for other in self.pipe:
+                    other.stream.wait_stream(torch.cuda.current_stream(self.device))      # scene tensors are ready
+            self._front(sc, cam, lay)              # also queues the async copy of the instance count to pinned memory
+            sc.front_done.record(sc.stream)
             self.pending.append((sc, cam, lay, slot))
             return None, None, None, None
 
         self.flush()
         sc = self.sync_scratch
         self._front(sc, cam, lay)
-        num_inst = int(sc.offsets[self.n].item())                       # the one read-back per camera
+        num_inst = int(sc.offsets[self.n].item())                       # the one read-back per camera (synchronous path)
         image = torch.empty((H, W, 3), dtype=torch.float32, device=self.device) if return_image else None
         self._back(sc, cam, lay, slot, num_inst, image, 1, "raster_bin")
         self._back(sc, cam, lay, slot, num_inst, image, 2, "raster_blend")

@@ -177,10 +177,11 @@ size_t g2pc_raster_front_workspace(int64_t n);
 /* PY semantics front half (gauss_render.py:101-193,404-437): projection, EWA covariance, conic, radius, rect ->
  * tile ranges; depth sort (nearest first, ties in descending index = torch.sort + flip); tiles-touched scan.
  * means3D f32[n,3], cov9 f32[n,3,3], opacity f32[n].  Out: p0/p1 f32[n,4] blend parameters, rect u32[n],
- * sorted_idx u32[n] (Gaussian indices in depth order), offsets u32[n+1]. */
+ * sorted_idx u32[n] (Gaussian indices in depth order), offsets u32[n+1].  count_host (optional, PINNED host
+ * memory): receives offsets[n] by an asynchronous copy queued on `stream` behind the kernels. */
 int g2pc_raster_front_py(const G2pcCamera* cam, const G2pcTileLayout* layout, const float* means3D, const float* cov9,
                          const float* opacity, int64_t n, float* p0, float* p1, uint32_t* rect, uint32_t* sorted_idx,
-                         uint32_t* offsets, void* ws, size_t ws_bytes, void* stream);
+                         uint32_t* offsets, uint32_t* count_host, void* ws, size_t ws_bytes, void* stream);
 size_t g2pc_raster_back_workspace(int64_t num_instances, int32_t num_tiles);
 /* PY semantics back half (gauss_render.py:290-402): duplicate, stable tile sort, ranges, blend with per-Gaussian
  * max-contribution / arg-max pixel, colour update, optional image (f32[H,W,3], already flipped as the reference
