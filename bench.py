@@ -90,6 +90,18 @@ def algorithmic_bytes(workload, n, n_kept, m, cams, stats):
     return b
 
 
+def pmc_traffic(region, a):
+    """HBM bytes per launch of the region's kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
+    in separate runs of THIS bench command, tools/pmc_traffic.py -> profiles/r01_c_pmc_traffic.json); only valid for
+    the default workload it was collected on.  Raw counter sum; FETCH_SIZE may under-report wide reads by up to 2x."""
+    kernel = {"raster_blend": "void g2pc::k_blend_py<1, 4>", "sampler_emit": "g2pc::k_emit_wave"}.get(region)
+    path = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")
+    if kernel is None or not os.path.isfile(path) or (a.gaussians, a.cameras) != (1_000_000, 50):
+        return None
+    rec = json.load(open(path)).get(kernel)
+    return rec["hbm_bytes_raw"] if rec else None
+
+
 def cpu_baseline(workload):
     """The oracle (CPU restatement of the reference, `kind: port`; pinned bit-exactly to the reference's own
     outputs by tests/test_oracle_*.py) on a bounded sample of the same workload, on this box's host cores."""
@@ -222,8 +234,10 @@ def main():
         if per_launch is not None and ms > 0:
             ach = per_launch / (ms / launches * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ms / launches,
-                    "algorithmic_bytes_per_launch": per_launch}
+                    "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(name, a), "avg_launch_ms": ms / launches,
+                    "algorithmic_bytes_per_launch": per_launch,
+                    "note": "k_blend_py is VALU/v_exp bound, not HBM bound (DESIGN.md §3); frac is its HBM share only"
+                    if name == "raster_blend" else None}
     out = {
         "metric": "coloured points/sec", "value": points_all / dt_all, "unit": "points/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt_all / a.steps * 1e3, "higher_is_better": True,
