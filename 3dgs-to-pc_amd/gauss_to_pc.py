@@ -159,12 +159,14 @@ def generate_pointcloud(gaussians, num_points, contributions=None, mahalanobis_d
 
 
 def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, pointcloud_settings, seed=None,
-                            group=None):
+                            group=None, render_shs=False):
     """The body of convert_3dgs_to_pc (gauss_to_pc.py:414-601) on already-loaded data:
     `gaussians` is a gauss_handler.Gaussians, transforms / intrinsics are name -> 4x4 c2w / [w, h, fx, fy].
     Under torch.distributed (one process per GPU) the cameras are split over the ranks, the per-Gaussian
     visibility state is all-reduced once, and every rank returns the points of its Gaussian-index shard
-    (g2pc.dist.gather_pointcloud assembles them); see g2pc/dist.py."""
+    (g2pc.dist.gather_pointcloud assembles them); see g2pc/dist.py.
+    render_shs=True hands gaussians.shs to the native rasteriser (SH evaluated per camera, forward.cu:22-73); the
+    reference's convert_3dgs_to_pc never does (gauss_to_pc.py:429-432) and renders the DC colours."""
     from g2pc.dist import rank_world
     s = pointcloud_settings
     device = gaussians.xyz.device
@@ -182,6 +184,7 @@ def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, poin
 
         gaussian_renderer = get_renderer(s.renderer_type, gaussians.xyz, torch.unsqueeze(torch.clone(gaussians.opacities), 1),
                                          gaussians.colours, gaussians.covariances,
+                                         shs=gaussians.shs if (render_shs and s.renderer_type != "python") else None,
                                          visible_gaussian_threshold=s.visibility_threshold,
                                          surface_distance_std=s.surface_distance_std,
                                          calculate_surface_distance=True if (s.surface_distance_std is not None or s.generate_mesh) else False)

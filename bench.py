@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default=None, choices=[None, "render", "sample"])
+    ap.add_argument("--workload", default=None, choices=[None, "render", "sample", "render_cuda"])
     ap.add_argument("--gaussians", type=int, default=1_000_000)
     ap.add_argument("--points", type=int, default=10_000_000)
     ap.add_argument("--cameras", type=int, default=50)
@@ -59,21 +59,24 @@ def have_renderer():
 
 def settings(workload, num_points, device):
     from gauss_to_pc import GaussPointCloudSettings
+    cu = workload == "render_cuda"        # configs[4]: native-rasteriser semantics + surface cull + exact points + SH
     return GaussPointCloudSettings(
-        renderer_type="python", num_points=num_points, prioritise_visible_gaussians=True,
-        mahalanobis_distance_std=2.0, camera_skip_rate=0, render_colours=(workload == "render"), min_opacity=0.0,
+        renderer_type="cuda" if cu else "python", num_points=num_points, prioritise_visible_gaussians=True,
+        mahalanobis_distance_std=2.0, camera_skip_rate=0, render_colours=(workload != "sample"), min_opacity=0.0,
         bounding_box_min=None, bounding_box_max=None, calculate_normals=True, cull_large_percentage=0.0,
-        remove_unrendered_gaussians=True, colour_resolution=1280, max_sh_degree=3, exact_num_points=False,
-        visibility_threshold=0.05, surface_distance_std=None, generate_mesh=False, quiet=True, device=str(device))
+        remove_unrendered_gaussians=True, colour_resolution=1280, max_sh_degree=3, exact_num_points=cu,
+        visibility_threshold=0.05, surface_distance_std=2.0 if cu else None, generate_mesh=False, quiet=True,
+        device=str(device))
 
 
 def one_step(scene, cams, workload, num_points, device, seed):
     """One pass of the hot path; returns the number of coloured points produced."""
     from gauss_handler import Gaussians
     from gauss_to_pc import convert_gaussians_to_pc
-    g = Gaussians(scene.xyz, scene.scales, scene.rots, scene.colours.clone(), scene.opacities)
+    g = Gaussians(scene.xyz, scene.scales, scene.rots, scene.colours.clone(), scene.opacities, shs=scene.shs)
     transforms, intr = cams if cams is not None else (None, None)
-    cloud, _ = convert_gaussians_to_pc(g, transforms, intr, None, settings(workload, num_points, device), seed=seed)
+    cloud, _ = convert_gaussians_to_pc(g, transforms, intr, None, settings(workload, num_points, device), seed=seed,
+                                       render_shs=(workload == "render_cuda"))
     from g2pc.dist import gather_pointcloud, rank_world
     n_local = cloud.points.shape[0]
     if rank_world()[1] > 1:
@@ -172,8 +175,8 @@ def main():
 
     # strong scaling: ONE scene (same seed on every rank, replicated read-only); cameras are split over the ranks,
     # the visibility state is all-reduced, sampling is sharded by Gaussian index, the points are gathered on rank 0
-    scene = make_scene(a.gaussians, 1234 + 3, device=device)
-    cams = make_cameras(a.cameras) if workload == "render" else None
+    scene = make_scene(a.gaussians, 1234 + 3, device=device, with_sh=(workload == "render_cuda"))
+    cams = make_cameras(a.cameras) if workload != "sample" else None
     if cams is not None and a.camera_subset:
         keep = sorted(cams[0])[:a.camera_subset]              # profiling aid: first k of the SAME 50-camera rig
         cams = ({k: cams[0][k] for k in keep}, {k: cams[1][k] for k in keep})
@@ -188,8 +191,7 @@ def main():
     for w in range(a.warmup):
         one_step(scene, cams, workload, a.points, device, seed=100 + w)
     nv.PROFILE = {}
-    if workload == "render":
-        import gauss_render
+    if workload != "sample":
         gauss_render.RENDER_STATS.clear()
     sync()
     t0 = time.perf_counter()
@@ -242,11 +244,12 @@ def main():
         "metric": "coloured points/sec", "value": points_all / dt_all, "unit": "points/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt_all / a.steps * 1e3, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": ("configs[2]: 1M Gaussians, 50 cameras 1280x720, 10M points, python-renderer semantics"
-                                if workload == "render" else
-                                "configs[1]: 1M Gaussians, no_render_colours, 10M points (sampling pipeline)"),
+        "config": {"workload": {"render": "configs[2]: 1M Gaussians, 50 cameras 1280x720, 10M points, python-renderer semantics",
+                                "render_cuda": "configs[4]: 1M Gaussians, 50 cameras, native-rasteriser semantics, SH degree 3, "
+                                               "surface_distance_std=2.0, exact_num_points, 10M points",
+                                "sample": "configs[1]: 1M Gaussians, no_render_colours, 10M points (sampling pipeline)"}[workload],
                    "gaussians": a.gaussians, "points": a.points,
-                   "cameras": a.cameras if workload == "render" else 0,
+                   "cameras": a.cameras if workload != "sample" else 0,
                    "blend_transmittance_floor": gauss_render.DEFAULT_T_FLOOR, "parallelism": "cameras and Gaussian-index shards over %d GPU(s), RCCL all-reduce of visibility + gather of points" % world},
         "roofline": roof,
         "instances_per_camera": (float(np.mean([x[0] for x in gauss_render.RENDER_STATS])) if gauss_render.RENDER_STATS else None),
