@@ -556,6 +556,7 @@ __global__ __launch_bounds__(BL_T) void k_blend_cu(int W, int H, int grid_x, con
     __shared__ float4 s_p2[BL_BATCH];
     __shared__ uint32_t s_g[256];
     __shared__ float s_depth[256];
+    __shared__ uint32_t s_surf[256];              // per-camera surface distance known when the batch was staged (filter only)
     const int tile = blockIdx.x;
     const int tx = tile % grid_x, ty = tile / grid_x;
     const unsigned lane = threadIdx.x;
@@ -592,6 +593,7 @@ __global__ __launch_bounds__(BL_T) void k_blend_cu(int W, int H, int grid_x, con
                 s_p2[lane] = make_float4(rgb[3 * (size_t)g], rgb[3 * (size_t)g + 1], rgb[3 * (size_t)g + 2], gm);
                 s_g[b - b256 + lane] = g;
                 s_depth[b - b256 + lane] = q.z;
+                if (calc_surf) s_surf[b - b256 + lane] = cam_surf[g];
             }
             wave_sync();
             const int cnt = (bend - b) < (uint32_t)BL_BATCH ? (int)(bend - b) : BL_BATCH;
@@ -644,8 +646,12 @@ __global__ __launch_bounds__(BL_T) void k_blend_cu(int W, int H, int grid_x, con
                     float d = fabsf(depth - E[j]);
                     dmin = (takes_part && d < dmin) ? d : dmin;
                 }
-                uint32_t m = wave_min_u32_dpp(__float_as_uint(dmin));
-                if (lane == 0) atomicMin(&cam_surf[s_g[k]], m);
+                // non-negative floats order like their bit patterns; reduce only if some lane can lower the minimum
+                const uint32_t bits = __float_as_uint(dmin);
+                if (__any(bits < s_surf[k])) {
+                    uint32_t m = wave_min_u32_dpp(bits);
+                    if (lane == 0) atomicMin(&cam_surf[s_g[k]], m);
+                }
             }
         }
     }
@@ -863,8 +869,8 @@ extern "C" {
 int g2pc_raster_front_cu(const G2pcCamera* cam, const float* means3D, const float* cov6, const float* opacity,
                          const float* colours_precomp, const float* shs, int32_t sh_degree, int32_t sh_coeffs,
                          const float* campos, int64_t n, float* p0, float* p1, uint32_t* rect, float* rgb,
-                         int32_t* radii, uint32_t* sorted_idx, uint32_t* offsets, void* ws, size_t ws_bytes,
-                         void* stream) {
+                         int32_t* radii, uint32_t* sorted_idx, uint32_t* offsets, uint32_t* count_host, void* ws,
+                         size_t ws_bytes, void* stream) {
     using namespace g2pc;
     G2PC_REQUIRE(cam && means3D && cov6 && opacity && campos && p0 && p1 && rect && rgb && radii && sorted_idx &&
                      offsets && ws && n > 0,
@@ -895,6 +901,7 @@ int g2pc_raster_front_cu(const G2pcCamera* cam, const float* means3D, const floa
     hipLaunchKernelGGL(k_gather_u32, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, touched, sorted_idx, (long)n, ktmp);
     rc = scan_exclusive_u32(ktmp, offsets, n, scan_ws, scan_bytes, s);
     if (rc) return rc;
+    if (count_host) hipMemcpyAsync(count_host, offsets + n, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
     return check_launch("g2pc_raster_front_cu");
 }
 
@@ -907,7 +914,7 @@ int g2pc_raster_back_cu(const G2pcCamera* cam, const int32_t* mask, int64_t n, i
                         uint32_t* cam_surf, float* out_color, float* out_depth, float* out_invdepth,
                         float* max_contrib, float* total_contrib, float* colours, float* min_surf,
                         int32_t* winner_cam, int32_t cam_index, float* cur_contrib, int32_t* cur_pixels, float* cur_surf,
-                        void* ws, size_t ws_bytes, void* stream) {
+                        int phases, void* ws, size_t ws_bytes, void* stream) {
     using namespace g2pc;
     G2PC_REQUIRE(cam && p0 && p1 && rect && rgb && sorted_idx && offsets && cam_key && cam_surf && out_color &&
                      out_depth && out_invdepth && max_contrib && total_contrib && colours && min_surf && ws && n > 0,
@@ -928,6 +935,7 @@ int g2pc_raster_back_cu(const G2pcCamera* cam, const int32_t* mask, int64_t n, i
     char* sort_ws = ar.get<char>(sort_bytes);
     char* scan_ws = ar.get<char>(scan_bytes);
     G2PC_REQUIRE(ar.ok(), G2PC_ERR_WORKSPACE, "workspace too small");
+    if (phases & 1) {
     hipMemsetAsync(tile_start, 0, (size_t)(T + 2) * 4, s);
     hipMemsetAsync(cam_key, 0, (size_t)n * 8, s);
     hipMemsetAsync(out_color, 0, (size_t)3 * W * H * 4, s);
@@ -945,9 +953,12 @@ int g2pc_raster_back_cu(const G2pcCamera* cam, const int32_t* mask, int64_t n, i
     }
     int rc = scan_exclusive_u32(tile_start, tile_start, T, scan_ws, scan_bytes, s);
     if (rc) return rc;
+    }
+    if (phases & 2)
     hipLaunchKernelGGL(k_blend_cu, dim3((unsigned)T), dim3(BL_T), 0, s, W, H, gx, tile_start, g_sorted, (const float4*)p0,
                        (const float4*)p1, rgb, mask, make_float3(cam->bg[0], cam->bg[1], cam->bg[2]),
                        calculate_surface_distance, cam_key, cam_surf, out_color, out_depth, out_invdepth);
+    if (phases & 4)
     hipLaunchKernelGGL(k_update_cu, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, cam_key, cam_surf, (long)n, W, H, out_color,
                        max_contrib, total_contrib, colours, min_surf, winner_cam, cam_index, cur_contrib, cur_pixels, cur_surf);
     return check_launch("g2pc_raster_back_cu");

@@ -47,12 +47,36 @@ nv._RASTER_PROTOS.update({
     "g2pc_raster_front_workspace": (C.c_size_t, [C.c_int64]),
     "g2pc_raster_back_workspace": (C.c_size_t, [C.c_int64, C.c_int32]),
     "g2pc_raster_front_cu": (C.c_int, [C.POINTER(_Camera)] + [_vp] * 5 + [C.c_int32, C.c_int32, _vp, C.c_int64] +
-                             [_vp] * 8 + [C.c_size_t, _vp]),
+                             [_vp] * 9 + [C.c_size_t, _vp]),
     "g2pc_raster_back_cu": (C.c_int, [C.POINTER(_Camera), _vp, C.c_int64, C.c_int64] + [_vp] * 6 + [C.c_int] + [_vp] * 10 +
-                            [C.c_int32] + [_vp] * 4 + [C.c_size_t, _vp]),
+                            [C.c_int32] + [_vp] * 3 + [C.c_int, _vp, C.c_size_t, _vp]),
 })
 if nv._LIB is not None:
     nv._bind(nv._LIB)
+
+
+PIPELINE_STREAMS = 4
+
+
+class _CuScratch:
+    """Per-stream scratch of one in-flight camera."""
+
+    def __init__(self, n, dev, stream=None):
+        f32, i32 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.int32, device=dev)
+        self.p0, self.p1 = torch.empty((n, 4), **f32), torch.empty((n, 4), **f32)
+        self.rect, self.sorted, self.offsets = torch.empty(n, **i32), torch.empty(n, **i32), torch.empty(n + 1, **i32)
+        self.rgb = torch.empty((n, 3), **f32)
+        self.radii = torch.empty(n, **i32)
+        self.cam_key = torch.empty(n, dtype=torch.int64, device=dev)
+        self.cam_surf = torch.empty(n, **i32)
+        self.front_bytes = nv.lib().g2pc_raster_front_workspace(n)
+        self.front_ws = nv.workspace(self.front_bytes, dev)
+        self.back_bytes, self.back_ws = 0, None
+        self.colour = self.depths = self.invdepths = None
+        self.stream = stream
+        self.count_host = torch.empty((1,), dtype=torch.int32).pin_memory() if stream is not None else None
+        self.front_done = torch.cuda.Event() if stream is not None else None
+        self.update_done = torch.cuda.Event() if stream is not None else None
 
 
 class GaussianRasterizer(nn.Module):
@@ -95,78 +119,130 @@ class GaussianRasterizer(nn.Module):
         self.surface_distance_std = surface_distance_std
         self.calculate_surface_distance = calculate_surface_distance
 
-        # per-camera scratch, allocated once
-        f32 = dict(dtype=torch.float32, device=dev)
-        i32 = dict(dtype=torch.int32, device=dev)
-        self._p0, self._p1 = torch.empty((n, 4), **f32), torch.empty((n, 4), **f32)
-        self._rect, self._sorted, self._offsets = torch.empty(n, **i32), torch.empty(n, **i32), torch.empty(n + 1, **i32)
-        self._rgb = torch.empty((n, 3), **f32)
-        self._cam_key = torch.empty(n, dtype=torch.int64, device=dev)
-        self._cam_surf = torch.empty(n, **i32)
-        self._winner_cam = torch.full((n,), 1 << 30, **i32)
+        self._sync = _CuScratch(n, dev)
+        self._pipe, self._pipe_next, self._pending, self._last_update = [], 0, [], None
+        self._winner_cam = torch.full((n,), 1 << 30, dtype=torch.int32, device=dev)
         self._camera_counter = 0
-        self._front_bytes = nv.lib().g2pc_raster_front_workspace(n)
-        self._front_ws = nv.workspace(self._front_bytes, dev)
-        self._back_bytes, self._back_ws = 0, None
         self.last = {}
 
-    def forward(self, raster_settings, return_per_camera=False, cam_index=None):
-        """__init__.py:90-140.  cam_index: global camera order (multi-GPU camera sharding); default = call order."""
-        if cam_index is None:
-            cam_index = self._camera_counter
-        self._camera_counter = int(cam_index) + 1
-        L = nv.lib()
-        rs = raster_settings
-        st = nv.stream_handle(self.device)
-        H, W = int(rs.image_height), int(rs.image_width)
+    # ---- one camera = front (async) / back (bin + blend) / ordered running-state update ------------------------------
+    def _camera(self, rs):
         cam = _Camera()
         cam.view[:] = rs.viewmatrix.reshape(-1).tolist()
         cam.proj[:] = rs.projmatrix.reshape(-1).tolist()
         cam.tan_fovx, cam.tan_fovy = rs.tanfovx, rs.tanfovy
-        cam.width, cam.height = W, H
+        cam.width, cam.height = int(rs.image_width), int(rs.image_height)
         cam.bg[:] = rs.bg.reshape(-1).tolist()
         campos = (C.c_float * 3)(*rs.campos.reshape(-1).tolist())
         mask = rs.mask.to(device=self.device, dtype=torch.int32).contiguous() if rs.mask is not None else None
-        n = self.n
-        radii = torch.empty(n, dtype=torch.int32, device=self.device)
+        return cam, campos, mask
+
+    def _stream_ptr(self, sc):
+        return C.c_void_p(sc.stream.cuda_stream) if sc.stream is not None else nv.stream_handle(self.device)
+
+    def _front(self, sc, cam, campos, sh_degree):
         shs = self.shs
         coeffs = int(shs.shape[1]) if shs is not None else 0
-        with nv.region("raster_front", self.device):
-            nv.check(L.g2pc_raster_front_cu(C.byref(cam), nv.ptr(self.means3D), nv.ptr(self.cov3D_precomp),
-                                            nv.ptr(self.opacities), nv.ptr(self.colors_precomp), nv.ptr(shs),
-                                            int(rs.sh_degree) if shs is not None else 0, coeffs,
-                                            C.cast(campos, C.c_void_p), n, nv.ptr(self._p0), nv.ptr(self._p1),
-                                            nv.ptr(self._rect), nv.ptr(self._rgb), nv.ptr(radii), nv.ptr(self._sorted),
-                                            nv.ptr(self._offsets), nv.ptr(self._front_ws), self._front_bytes, st),
-                     "raster_front_cu")
-        num_rendered = int(self._offsets[n].item())              # rasterizer_impl.cu:289 has the same read-back
+        with nv.region("raster_front", self.device, sc.stream):
+            nv.check(nv.lib().g2pc_raster_front_cu(
+                C.byref(cam), nv.ptr(self.means3D), nv.ptr(self.cov3D_precomp), nv.ptr(self.opacities),
+                nv.ptr(self.colors_precomp), nv.ptr(shs), int(sh_degree) if shs is not None else 0, coeffs,
+                C.cast(campos, C.c_void_p), self.n, nv.ptr(sc.p0), nv.ptr(sc.p1), nv.ptr(sc.rect), nv.ptr(sc.rgb),
+                nv.ptr(sc.radii), nv.ptr(sc.sorted), nv.ptr(sc.offsets),
+                C.c_void_p(sc.count_host.data_ptr()) if sc.count_host is not None else None, nv.ptr(sc.front_ws),
+                sc.front_bytes, self._stream_ptr(sc)), "raster_front_cu")
+
+    def _back(self, sc, cam, mask, num_rendered, cam_index, phases, name, cur=(None, None, None)):
+        import contextlib
+        L = nv.lib()
+        W, H = cam.width, cam.height
         tiles_n = ((W + 15) // 16) * ((H + 15) // 16)
         need = L.g2pc_raster_back_workspace(num_rendered, tiles_n)
-        if need > self._back_bytes:
-            self._back_bytes = int(need * 1.25)
-            self._back_ws = nv.workspace(self._back_bytes, self.device)
-        colour = torch.empty((3, H, W), dtype=torch.float32, device=self.device)
-        depths = torch.empty((1, H, W), dtype=torch.float32, device=self.device)
-        invdepths = torch.empty((1, H, W), dtype=torch.float32, device=self.device)
+        with (torch.cuda.stream(sc.stream) if sc.stream is not None else contextlib.nullcontext()):
+            if need > sc.back_bytes:
+                sc.back_bytes = int(need * 1.25)
+                sc.back_ws = nv.workspace(sc.back_bytes, self.device)
+            if sc.colour is None or sc.colour.shape[1:] != (H, W):
+                sc.colour = torch.empty((3, H, W), dtype=torch.float32, device=self.device)
+                sc.depths = torch.empty((1, H, W), dtype=torch.float32, device=self.device)
+                sc.invdepths = torch.empty((1, H, W), dtype=torch.float32, device=self.device)
+        with nv.region(name, self.device, sc.stream):
+            nv.check(L.g2pc_raster_back_cu(
+                C.byref(cam), nv.ptr(mask), self.n, num_rendered, nv.ptr(sc.p0), nv.ptr(sc.p1), nv.ptr(sc.rect),
+                nv.ptr(sc.rgb), nv.ptr(sc.sorted), nv.ptr(sc.offsets), 1 if self.calculate_surface_distance else 0,
+                nv.ptr(sc.cam_key), nv.ptr(sc.cam_surf), nv.ptr(sc.colour), nv.ptr(sc.depths), nv.ptr(sc.invdepths),
+                nv.ptr(self.gaussian_max_contribution), nv.ptr(self.gaussian_total_contribution),
+                nv.ptr(self.gaussian_colours), nv.ptr(self.gaussian_min_surface_distance), nv.ptr(self._winner_cam),
+                int(cam_index), nv.ptr(cur[0]), nv.ptr(cur[1]), nv.ptr(cur[2]), phases, nv.ptr(sc.back_ws), sc.back_bytes,
+                self._stream_ptr(sc)), "raster_back_cu")
+
+    def _finish(self, entry):
+        sc, cam, mask, cam_index = entry
+        sc.front_done.synchronize()
+        num_rendered = int(sc.count_host[0])
+        self._back(sc, cam, mask, num_rendered, cam_index, 3, "raster_bin+blend_cu")
+        if self._last_update is not None:
+            sc.stream.wait_event(self._last_update)
+        self._back(sc, cam, mask, num_rendered, cam_index, 4, "raster_update_cu")
+        sc.update_done.record(sc.stream)
+        self._last_update = sc.update_done
+
+    def flush(self):
+        """Complete every camera in flight (pipelined mode) and make the running state visible to the current stream."""
+        if not self._pending and not self._pipe:
+            return
+        while self._pending:
+            self._finish(self._pending.pop(0))
+        cur = torch.cuda.current_stream(self.device)
+        for sc in self._pipe:
+            cur.wait_stream(sc.stream)
+
+    def __del__(self):
+        try:
+            self.flush()
+        except Exception:
+            pass
+
+    def forward(self, raster_settings, return_per_camera=False, cam_index=None, discard_images=False):
+        """__init__.py:90-140.  cam_index: global camera order (multi-GPU camera sharding); default = call order.
+        discard_images=True (what the point-cloud pipeline wants): nothing is returned and up to PIPELINE_STREAMS
+        cameras are kept in flight on separate HIP streams; only the running-state updates are serialised."""
+        if cam_index is None:
+            cam_index = self._camera_counter
+        self._camera_counter = int(cam_index) + 1
+        rs = raster_settings
+        cam, campos, mask = self._camera(rs)
+        n = self.n
+        if discard_images and PIPELINE_STREAMS > 1 and self.device.type == "cuda" and not nv.emulated():
+            if not self._pipe:
+                self._pipe = [_CuScratch(n, self.device, torch.cuda.Stream(self.device)) for _ in range(PIPELINE_STREAMS)]
+            while len(self._pending) >= PIPELINE_STREAMS:
+                self._finish(self._pending.pop(0))
+            sc = self._pipe[self._pipe_next]
+            self._pipe_next = (self._pipe_next + 1) % PIPELINE_STREAMS
+            if not self._pending:
+                for other in self._pipe:
+                    other.stream.wait_stream(torch.cuda.current_stream(self.device))
+            self._front(sc, cam, campos, rs.sh_degree)
+            sc.front_done.record(sc.stream)
+            self._pending.append((sc, cam, mask, int(cam_index)))
+            return None, None, None, None
+
+        self.flush()
+        sc = self._sync
+        self._front(sc, cam, campos, rs.sh_degree)
+        num_rendered = int(sc.offsets[n].item())              # rasterizer_impl.cu:289 has the same read-back
         cur = (torch.empty(n, dtype=torch.float32, device=self.device), torch.empty(n, dtype=torch.int32, device=self.device),
                torch.empty(n, dtype=torch.float32, device=self.device)) if return_per_camera else (None, None, None)
-        with nv.region("raster_back_cu", self.device):
-            nv.check(L.g2pc_raster_back_cu(C.byref(cam), nv.ptr(mask), n, num_rendered, nv.ptr(self._p0), nv.ptr(self._p1),
-                                           nv.ptr(self._rect), nv.ptr(self._rgb), nv.ptr(self._sorted),
-                                           nv.ptr(self._offsets), 1 if self.calculate_surface_distance else 0,
-                                           nv.ptr(self._cam_key), nv.ptr(self._cam_surf), nv.ptr(colour), nv.ptr(depths),
-                                           nv.ptr(invdepths), nv.ptr(self.gaussian_max_contribution),
-                                           nv.ptr(self.gaussian_total_contribution), nv.ptr(self.gaussian_colours),
-                                           nv.ptr(self.gaussian_min_surface_distance), nv.ptr(self._winner_cam),
-                                           int(cam_index), nv.ptr(cur[0]), nv.ptr(cur[1]), nv.ptr(cur[2]),
-                                           nv.ptr(self._back_ws), self._back_bytes, st),
-                     "raster_back_cu")
+        sc.colour = None                                      # fresh output tensors: they are handed to the caller
+        self._back(sc, cam, mask, num_rendered, cam_index, 7, "raster_back_cu", cur)
         self.last = dict(num_rendered=num_rendered, contributions=cur[0], pixels=cur[1], surface_distances=cur[2])
-        return colour, radii, invdepths, depths
+        return sc.colour, sc.radii.clone(), sc.invdepths, sc.depths
 
     # the reference's renderer objects are called like functions by the pipeline (gauss_to_pc.py:454)
     def __call__(self, raster_settings, **kwargs):
-        kwargs.pop("return_image", None)
+        if kwargs.pop("return_image", True) is False:
+            kwargs["discard_images"] = True
         slot = kwargs.pop("slot", None)
         if slot is not None:
             kwargs["cam_index"] = slot - 1
@@ -174,12 +250,15 @@ class GaussianRasterizer(nn.Module):
 
     # ---- getters (__init__.py:160-219) ----------------------------------------------------------------------
     def get_gaussian_colours(self):
+        self.flush()
         return self.gaussian_colours * 255
 
     def get_max_gaussian_contributions(self):
+        self.flush()
         return self.gaussian_max_contribution
 
     def get_total_gaussian_contributions(self):
+        self.flush()
         return self.gaussian_total_contribution
 
     def get_gaussians_above_contribution_threshold(self, contribution_threshold):
@@ -191,6 +270,7 @@ class GaussianRasterizer(nn.Module):
     def get_surface_gaussians_below_distance_threshold(self, surface_distance_threshold):
         if not self.calculate_surface_distance:
             raise Exception("Cannot determine Gaussian surface distance as this feature was not set at the start of rendering")
+        self.flush()
         surface_indices = (self.gaussian_min_surface_distance < FLT_MAX)
         mean_and_std = torch.std_mean(self.gaussian_min_surface_distance[surface_indices])
         return self.gaussian_min_surface_distance < mean_and_std[1] * surface_distance_threshold
@@ -208,6 +288,7 @@ class GaussianRasterizer(nn.Module):
         """Multi-GPU, cameras sharded over ranks.  max / min / sum are exact up to the fp32 order of the SUM; the
         winner's colour is selected by (max contribution, then earliest global camera index)."""
         import torch.distributed as dist
+        self.flush()
         if not dist.is_initialized() or dist.get_world_size(group) == 1:
             return
         gmax = self.gaussian_max_contribution.clone()

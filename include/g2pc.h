@@ -212,20 +212,22 @@ int g2pc_raster_debug_chunk_work(uint32_t* buf);
 int g2pc_raster_front_cu(const G2pcCamera* cam, const float* means3D, const float* cov6, const float* opacity,
                          const float* colours_precomp, const float* shs, int32_t sh_degree, int32_t sh_coeffs,
                          const float* campos, int64_t n, float* p0, float* p1, uint32_t* rect, float* rgb,
-                         int32_t* radii, uint32_t* sorted_idx, uint32_t* offsets, void* ws, size_t ws_bytes,
-                         void* stream);
+                         int32_t* radii, uint32_t* sorted_idx, uint32_t* offsets, uint32_t* count_host, void* ws,
+                         size_t ws_bytes, void* stream);
 /* back: out_color f32[3,H,W], out_depth / out_invdepth f32[H,W] (zero-filled here, masked pixels stay 0);
  * running state max_contrib / total_contrib / min_surf f32[n], colours f32[n,3] updated as the reference's binding does
  * (gaussian_pointcloud_rasterization/__init__.py:128-158); winner_cam i32[n] (optional) records cam_index of the camera
  * that set the running maximum (multi-GPU tie-break); cur_* (optional) = this camera's gauss_contributions,
- * gauss_pixels, gauss_surface_distances.  Workspace size: g2pc_raster_back_workspace(num_instances, tiles). */
+ * gauss_pixels, gauss_surface_distances.  phases: bit 0 = binning + zero fills, bit 1 = blend, bit 2 = running-state
+ * update (must be issued in camera order; bits 0-1 of different cameras may overlap on different streams with
+ * per-stream scratch).  Workspace size: g2pc_raster_back_workspace(num_instances, tiles). */
 int g2pc_raster_back_cu(const G2pcCamera* cam, const int32_t* mask, int64_t n, int64_t num_instances, const float* p0,
                         const float* p1, const uint32_t* rect, const float* rgb, const uint32_t* sorted_idx,
                         const uint32_t* offsets, int calculate_surface_distance, unsigned long long* cam_key,
                         uint32_t* cam_surf, float* out_color, float* out_depth, float* out_invdepth,
                         float* max_contrib, float* total_contrib, float* colours, float* min_surf,
                         int32_t* winner_cam, int32_t cam_index, float* cur_contrib, int32_t* cur_pixels, float* cur_surf,
-                        void* ws, size_t ws_bytes, void* stream);
+                        int phases, void* ws, size_t ws_bytes, void* stream);
 
 /* multi-GPU (no counterpart in the reference): zero colours[i,:] unless local_key[i] == global_key[i] != 0, so that an
  * all-reduce(SUM) over ranks after an all-reduce(MAX) of the keys reproduces "earliest camera wins" exactly. */
