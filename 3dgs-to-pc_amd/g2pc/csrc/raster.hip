@@ -17,6 +17,7 @@
 namespace g2pc {
 
 constexpr int RA_T = 256;
+__global__ void k_tile_ranges(const uint32_t* __restrict__ tile_sorted, long L, int T, uint32_t* __restrict__ tile_start);
 constexpr float LOG2E = 1.4426950408889634f;
 
 struct Cam {            // device copy of G2pcCamera (passed by value as kernel argument)
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(RA_T) void k_duplicate(const uint32_t* __restrict__
 // lane 0 publishes  key = contribution_bits << 32 | ~(slot << 24 | tile_seq << 12 | pixel)  with one 64-bit
 // atomicMax -- but only when some lane can beat the value staged from the running maximum.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int BL_T = 64, BL_PPT = 4, BL_BATCH = 64;
+constexpr int BL_T = 64, BL_BATCH = 64;
 
 // Pixels of a tile are grouped in 8x8 sub-blocks (row-major inside the tile); a chunk = PPT consecutive sub-blocks,
 // lane l owns pixel (l % 8, l / 8) of each of them.  Compact blocks saturate together (early exit) and the PPT
@@ -541,131 +542,129 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_cu(Cam cam, int grid_x, int
     radii[i] = rad;
 }
 
-// forward.cu:303-497 (renderCUDA).  One wave64 per 16x16 tile, 4 pixels per lane (thread rank t = lane + 64 j,
-// pixel (t % 16, t / 16) of the tile).  The reference's 256-instance batches are kept as the unit of the
-// "everyone done" test and of the surface-distance pass; inside a batch the list is staged 64 at a time.
-__global__ __launch_bounds__(BL_T) void k_blend_cu(int W, int H, int grid_x, const uint32_t* __restrict__ tile_start,
+// forward.cu:303-497 (renderCUDA).  One 256-thread block per 16x16 tile, one pixel per lane (thread rank t -> pixel
+// (t % 16, t / 16), as in the reference); the tile's list is staged 256 instances at a time (= the reference's batches:
+// the unit of the "everyone done" test and of the surface-distance pass).  Inside a batch the four waves run
+// independently: 4 Gaussians per trip (independent exp chains), wave64 DPP reductions for the per-Gaussian maximum and
+// for the surface distance, each guarded by a cheap "can any lane improve the staged value" ballot.
+constexpr int CU_T = 256;
+
+__global__ __launch_bounds__(CU_T) void k_blend_cu(int W, int H, int grid_x, const uint32_t* __restrict__ tile_start,
                                                   const uint32_t* __restrict__ inst_g, const float4* __restrict__ p0,
                                                   const float4* __restrict__ p1, const float* __restrict__ rgb,
                                                   const int32_t* __restrict__ mask, float3 bg, int calc_surf,
                                                   unsigned long long* __restrict__ cam_key,
                                                   uint32_t* __restrict__ cam_surf, float* __restrict__ out_color,
                                                   float* __restrict__ out_depth, float* __restrict__ out_invdepth) {
-    __shared__ float4 s_p0[BL_BATCH];
-    __shared__ float4 s_p1[BL_BATCH];
-    __shared__ float4 s_p2[BL_BATCH];
-    __shared__ uint32_t s_g[256];
-    __shared__ float s_depth[256];
-    __shared__ uint32_t s_surf[256];              // per-camera surface distance known when the batch was staged (filter only)
+    __shared__ float4 s_p0[CU_T];
+    __shared__ float4 s_p1[CU_T];
+    __shared__ float4 s_p2[CU_T];
+    __shared__ uint32_t s_g[CU_T];
+    __shared__ uint32_t s_surf[CU_T];             // surface distance known when the batch was staged (filter only)
     const int tile = blockIdx.x;
     const int tx = tile % grid_x, ty = tile / grid_x;
-    const unsigned lane = threadIdx.x;
-    float px[BL_PPT], py[BL_PPT], T[BL_PPT], cr[BL_PPT], cg[BL_PPT], cb[BL_PPT], E[BL_PPT], Ei[BL_PPT];
-    uint32_t pixid[BL_PPT];
-    bool done[BL_PPT], part[BL_PPT], inside[BL_PPT];
-#pragma unroll
-    for (int j = 0; j < BL_PPT; ++j) {
-        int t = (int)lane + 64 * j;
-        int x = tx * 16 + (t & 15), y = ty * 16 + (t >> 4);
-        inside[j] = (x < W) && (y < H);
-        bool masked = inside[j] && mask && (mask[(size_t)W * y + x] == 0);
-        part[j] = inside[j] && !masked;              // takes part in blending
-        done[j] = !part[j];
-        px[j] = (float)x; py[j] = (float)y;
-        pixid[j] = (uint32_t)(W * y + x);
-        T[j] = 1.0f; cr[j] = cg[j] = cb[j] = 0.0f; E[j] = 0.0f; Ei[j] = 0.0f;
-    }
+    const unsigned t = threadIdx.x, lane = t & 63;
+    const int x = tx * 16 + (int)(t & 15), y = ty * 16 + (int)(t >> 4);
+    const bool inside = (x < W) && (y < H);
+    const bool masked = inside && mask && (mask[(size_t)W * y + x] == 0);
+    const bool part = inside && !masked;              // takes part in blending
+    const bool surf_part = !inside || part;           // out-of-image threads take part (E = 0), masked pixels do not
+    bool done = !part;
+    const float px = (float)x, py = (float)y;
+    const uint32_t pixid = (uint32_t)(W * y + x);
+    float T = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, E = 0.f, Ei = 0.f;
+    const uint32_t* key_hi = (const uint32_t*)cam_key + 1;
     const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
-    for (uint32_t b256 = start; b256 < end; b256 += 256) {
-        bool all_done = true;
+    for (uint32_t b = start; b < end; b += CU_T) {
+        if (__syncthreads_and(done ? 1 : 0)) break;                       // forward.cu:373-375 (also: LDS is free again)
+        if (b + t < end) {
+            uint32_t g = inst_g[b + t];
+            float4 q = p1[g];
+            s_p0[t] = p0[g];
+            s_p1[t] = q;
+            float gm = fmaxf(__uint_as_float(key_hi[2 * (size_t)g]), 1.17549435e-38f);
+            s_p2[t] = make_float4(rgb[3 * (size_t)g], rgb[3 * (size_t)g + 1], rgb[3 * (size_t)g + 2], gm);
+            s_g[t] = g;
+            if (calc_surf) s_surf[t] = cam_surf[g];
+        } else {                                   // padding: opacity 0 -> alpha 0 < 1/255 -> skipped
+            s_p0[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            s_p1[t] = make_float4(0.f, 0.f, 1.f, 0.f);
+            s_p2[t] = make_float4(0.f, 0.f, 0.f, 3.0e38f);
+            s_g[t] = 0;
+            s_surf[t] = 0;
+        }
+        __syncthreads();
+        const int cnt = (end - b) < (uint32_t)CU_T ? (int)(end - b) : CU_T;
+        // wave-uniform early out inside the batch: nothing left to blend for these 64 pixels
+        for (int k0 = 0; k0 < cnt && !__all(done ? 1 : 0); k0 += 4) {
+            float alpha[4], power[4];
 #pragma unroll
-        for (int j = 0; j < BL_PPT; ++j) all_done = all_done && done[j];
-        if (__all(all_done ? 1 : 0)) break;                               // forward.cu:373-375
-        const uint32_t bend = (end - b256) < 256u ? end : b256 + 256;
-        for (uint32_t b = b256; b < bend; b += BL_BATCH) {
-            wave_sync();
-            if (b + lane < bend) {
-                uint32_t g = inst_g[b + lane];
-                float4 q = p1[g];
-                s_p0[lane] = p0[g];
-                s_p1[lane] = q;
-                float gm = __uint_as_float((uint32_t)(cam_key[g] >> 32));
-                s_p2[lane] = make_float4(rgb[3 * (size_t)g], rgb[3 * (size_t)g + 1], rgb[3 * (size_t)g + 2], gm);
-                s_g[b - b256 + lane] = g;
-                s_depth[b - b256 + lane] = q.z;
-                if (calc_surf) s_surf[b - b256 + lane] = cam_surf[g];
+            for (int u = 0; u < 4; ++u) {
+                const float4 a = s_p0[k0 + u], q = s_p1[k0 + u];
+                float dx = a.x - px, dy = a.y - py;
+                power[u] = fmaf(a.z * dx, dx, fmaf(q.x * dy, dy, a.w * dx * dy));
+                alpha[u] = fminf(0.99f, q.y * __builtin_amdgcn_exp2f(power[u]));
             }
-            wave_sync();
-            const int cnt = (bend - b) < (uint32_t)BL_BATCH ? (int)(bend - b) : BL_BATCH;
-            for (int k = 0; k < cnt; ++k) {
-                const float4 a = s_p0[k], q = s_p1[k], c = s_p2[k];
-                const float depth = q.z, inv_depth = 1.0f / q.z;
-                float best = 0.0f;
-                uint32_t bestpix = 0xFFFFFFFFu;
 #pragma unroll
-                for (int j = 0; j < BL_PPT; ++j) {
-                    float dx = a.x - px[j], dy = a.y - py[j];
-                    float power = fmaf(a.z * dx, dx, fmaf(q.x * dy, dy, a.w * dx * dy));
-                    float alpha = fminf(0.99f, q.y * __builtin_amdgcn_exp2f(power));
-                    float test_T = T[j] * (1.0f - alpha);
-                    bool live = !done[j] && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-                    bool stop = live && (test_T < 0.0001f);
-                    done[j] = done[j] || stop;
-                    bool blend = live && !stop;
-                    float contrib = blend ? alpha * T[j] : 0.0f;
-                    cr[j] = fmaf(c.x, contrib, cr[j]);
-                    cg[j] = fmaf(c.y, contrib, cg[j]);
-                    cb[j] = fmaf(c.z, contrib, cb[j]);
-                    Ei[j] = fmaf(inv_depth, contrib, Ei[j]);
-                    E[j] = fmaf(depth, contrib, E[j]);
-                    T[j] = blend ? test_T : T[j];
-                    if (contrib > best) { best = contrib; bestpix = pixid[j]; }      // pixel ids ascend with j
-                }
-                const bool cand = (best > 0.0f) && (best >= c.w);
-                if (__any(cand)) {
-                    uint32_t bits = __float_as_uint(best);
+            for (int u = 0; u < 4; ++u) G2PC_PIN(alpha[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 c = s_p2[k0 + u];
+                const float depth = s_p1[k0 + u].z;
+                float test_T = T * (1.0f - alpha[u]);
+                bool live = !done && !(power[u] > 0.0f) && !(alpha[u] < 1.0f / 255.0f);
+                bool stop = live && (test_T < 0.0001f);
+                done = done || stop;
+                bool blend = live && !stop;
+                float contrib = blend ? alpha[u] * T : 0.0f;
+                cr = fmaf(c.x, contrib, cr);
+                cg = fmaf(c.y, contrib, cg);
+                cb = fmaf(c.z, contrib, cb);
+                Ei = fmaf(1.0f / depth, contrib, Ei);
+                E = fmaf(depth, contrib, E);
+                T = blend ? test_T : T;
+                if (__any(contrib >= c.w)) {
+                    uint32_t bits = __float_as_uint(contrib);
                     uint32_t m = wave_max_u32_dpp(bits);
-                    uint32_t pm = wave_min_u32_dpp(bits == m ? bestpix : 0xFFFFFFFFu);
+                    uint32_t pm = wave_min_u32_dpp(bits == m ? pixid : 0xFFFFFFFFu);
                     if (lane == 0) {
                         unsigned long long key = ((unsigned long long)m << 32) | (unsigned long long)(uint32_t)(~pm);
-                        atomicMax(&cam_key[s_g[b - b256 + k]], key);
+                        atomicMax(&cam_key[s_g[k0 + u]], key);
                     }
                 }
             }
         }
         if (calc_surf) {                                                   // forward.cu:460-477
-            wave_sync();
-            const int cnt256 = (int)(bend - b256);
-            for (int k = 0; k < cnt256; ++k) {
-                const float depth = s_depth[k];
-                float dmin = 3.402823466e+38f;
-#pragma unroll
-                for (int j = 0; j < BL_PPT; ++j) {
-                    // out-of-image threads take part with expected depth 0, masked pixels do not
-                    bool takes_part = !inside[j] || part[j];
-                    float d = fabsf(depth - E[j]);
-                    dmin = (takes_part && d < dmin) ? d : dmin;
-                }
-                // non-negative floats order like their bit patterns; reduce only if some lane can lower the minimum
-                const uint32_t bits = __float_as_uint(dmin);
-                if (__any(bits < s_surf[k])) {
+            __syncthreads();                                               // E of the whole batch is final for this wave
+            for (int k = 0; k < cnt; ++k) {
+                float d = fabsf(s_p1[k].z - E);
+                const uint32_t bits = surf_part ? __float_as_uint(d) : 0x7F7FFFFFu;
+                if (__any(bits < s_surf[k])) {                            // non-negative floats order like their bits
                     uint32_t m = wave_min_u32_dpp(bits);
                     if (lane == 0) atomicMin(&cam_surf[s_g[k]], m);
                 }
             }
         }
     }
-    const size_t plane = (size_t)W * H;
-#pragma unroll
-    for (int j = 0; j < BL_PPT; ++j) {
-        if (part[j]) {
-            out_color[pixid[j]] = fmaf(T[j], bg.x, cr[j]);
-            out_color[plane + pixid[j]] = fmaf(T[j], bg.y, cg[j]);
-            out_color[2 * plane + pixid[j]] = fmaf(T[j], bg.z, cb[j]);
-            out_invdepth[pixid[j]] = Ei[j];
-            out_depth[pixid[j]] = E[j];
-        }
+    if (part) {
+        const size_t plane = (size_t)W * H;
+        out_color[pixid] = fmaf(T, bg.x, cr);
+        out_color[plane + pixid] = fmaf(T, bg.y, cg);
+        out_color[2 * plane + pixid] = fmaf(T, bg.z, cb);
+        out_invdepth[pixid] = Ei;
+        out_depth[pixid] = E;
     }
+}
+
+// tile_start[t] = first sorted instance of tile t (exclusive offsets, tile_start[T] = L): boundary detection on the
+// sorted tile ids (rasterizer_impl.cu:115-137 identifyTileRanges), no histogram, no scan.
+__global__ __launch_bounds__(RA_T) void k_tile_ranges(const uint32_t* __restrict__ tile_sorted, long L, int T,
+                                                     uint32_t* __restrict__ tile_start) {
+    long l = (long)blockIdx.x * RA_T + threadIdx.x;
+    if (l > L) return;
+    int prev = l == 0 ? -1 : (int)tile_sorted[l - 1];
+    int cur = l == L ? T : (int)tile_sorted[l];
+    for (int t = prev + 1; t <= cur; ++t) tile_start[t] = (uint32_t)l;
 }
 
 // binding-side reductions (gaussian_pointcloud_rasterization/__init__.py:128-158): gather the colour of the arg-max
@@ -807,11 +806,9 @@ int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, con
         int rc = sort_pairs_u32(inst_tile, inst_g, tile_sorted, g_sorted, tile_tmp, g_tmp, L, 0, bits_for_tiles((unsigned)T),
                                 sort_ws, sort_bytes, s);
         if (rc) return rc;
-        rc = g2pc_bincount_i32((const int32_t*)tile_sorted, L, tile_start, T, stream);
-        if (rc) return rc;
     }
-    int rc = scan_exclusive_u32(tile_start, tile_start, T, scan_ws, scan_bytes, s);
-    if (rc) return rc;
+    (void)scan_ws; (void)scan_bytes;
+    hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T)), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start);
     }
     if (phases & 2) {
 #define G2PC_BLEND(PPT, U)                                                                                            \
@@ -938,24 +935,24 @@ int g2pc_raster_back_cu(const G2pcCamera* cam, const int32_t* mask, int64_t n, i
     if (phases & 1) {
     hipMemsetAsync(tile_start, 0, (size_t)(T + 2) * 4, s);
     hipMemsetAsync(cam_key, 0, (size_t)n * 8, s);
-    hipMemsetAsync(out_color, 0, (size_t)3 * W * H * 4, s);
-    hipMemsetAsync(out_depth, 0, (size_t)W * H * 4, s);
-    hipMemsetAsync(out_invdepth, 0, (size_t)W * H * 4, s);
-    hipLaunchKernelGGL(k_fill_u32, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, cam_surf, (long)n, 0x7F7FFFFFu);   // FLT_MAX
+    if (mask) {                                   // without a mask every pixel is written by the blend kernel
+        hipMemsetAsync(out_color, 0, (size_t)3 * W * H * 4, s);
+        hipMemsetAsync(out_depth, 0, (size_t)W * H * 4, s);
+        hipMemsetAsync(out_invdepth, 0, (size_t)W * H * 4, s);
+    }
+    hipLaunchKernelGGL(k_fill_u32, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, cam_surf, (long)n, 0x7F7FFFFFu);   // FLT_MAX (k_update_cu reads it)
     if (L > 0) {
         hipLaunchKernelGGL(k_duplicate, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, sorted_idx, offsets, rect, (long)n, gx,
                            inst_tile, inst_g);
         int rc = sort_pairs_u32(inst_tile, inst_g, tile_sorted, g_sorted, tile_tmp, g_tmp, L, 0, bits_for_tiles((unsigned)T),
                                 sort_ws, sort_bytes, s);
         if (rc) return rc;
-        rc = g2pc_bincount_i32((const int32_t*)tile_sorted, L, tile_start, T, stream);
-        if (rc) return rc;
     }
-    int rc = scan_exclusive_u32(tile_start, tile_start, T, scan_ws, scan_bytes, s);
-    if (rc) return rc;
+    (void)scan_ws; (void)scan_bytes;
+    hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T)), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start);
     }
     if (phases & 2)
-    hipLaunchKernelGGL(k_blend_cu, dim3((unsigned)T), dim3(BL_T), 0, s, W, H, gx, tile_start, g_sorted, (const float4*)p0,
+    hipLaunchKernelGGL(k_blend_cu, dim3((unsigned)T), dim3(CU_T), 0, s, W, H, gx, tile_start, g_sorted, (const float4*)p0,
                        (const float4*)p1, rgb, mask, make_float3(cam->bg[0], cam->bg[1], cam->bg[2]),
                        calculate_surface_distance, cam_key, cam_surf, out_color, out_depth, out_invdepth);
     if (phases & 4)
