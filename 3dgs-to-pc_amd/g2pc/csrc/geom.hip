@@ -233,6 +233,38 @@ __global__ __launch_bounds__(GEO_T) void k_gather_rows(const uint32_t* __restric
     dst[t] = src[(size_t)index[j] * row_words + w];
 }
 
+
+// save_xyz_to_ply (gauss_dataloader.py:172-202): pack one binary-little-endian PLY vertex record per point,
+// x y z [nx ny nz] r g b = 3 (or 6) float32 + 3 uchar (colours truncated like numpy's astype(np.uint8)).
+// Records are 15 / 27 bytes (unaligned): a block stages 256 records in LDS and streams them out as whole dwords.
+__global__ __launch_bounds__(GEO_T) void k_pack_ply(const float* __restrict__ pts, const float* __restrict__ nrm,
+                                                   const float* __restrict__ col, long m, int rec,
+                                                   uint32_t* __restrict__ out) {
+    __shared__ uint32_t stage[GEO_T * 27 / 4 + 1];
+    uint8_t* sb = (uint8_t*)stage;
+    const long base = (long)blockIdx.x * GEO_T;
+    const long i = base + threadIdx.x;
+    if (i < m) {
+        uint8_t* r = sb + (size_t)threadIdx.x * rec;
+        float v[6];
+        int nf = 3;
+        v[0] = pts[3 * i]; v[1] = pts[3 * i + 1]; v[2] = pts[3 * i + 2];
+        if (nrm) { v[3] = nrm[3 * i]; v[4] = nrm[3 * i + 1]; v[5] = nrm[3 * i + 2]; nf = 6; }
+        for (int k = 0; k < nf; ++k) {
+            uint32_t bits = __float_as_uint(v[k]);
+            r[4 * k + 0] = (uint8_t)bits; r[4 * k + 1] = (uint8_t)(bits >> 8);
+            r[4 * k + 2] = (uint8_t)(bits >> 16); r[4 * k + 3] = (uint8_t)(bits >> 24);
+        }
+        for (int k = 0; k < 3; ++k) r[4 * nf + k] = (uint8_t)(int)col[3 * i + k];
+    }
+    __syncthreads();
+    const long cnt = (m - base) < GEO_T ? (m - base) : GEO_T;
+    const long bytes = cnt * rec;
+    const long words = (bytes + 3) / 4;                 // the output buffer is padded to a multiple of 4 bytes
+    uint32_t* dst = out + (size_t)blockIdx.x * (GEO_T * rec / 4);
+    for (long w = threadIdx.x; w < words; w += GEO_T) dst[w] = stage[w];
+}
+
 }  // namespace g2pc
 
 extern "C" {
@@ -314,5 +346,18 @@ int g2pc_gather_rows(const void* src, const uint32_t* index, int64_t m, int32_t 
     hipLaunchKernelGGL(k_gather_rows, dim3(cdiv(total, GEO_T)), dim3(GEO_T), 0, (hipStream_t)stream,
                        (const uint32_t*)src, index, (long)m, (int)(row_bytes / 4), (uint32_t*)dst);
     return check_launch("g2pc_gather_rows");
+}
+}
+
+extern "C" {
+int g2pc_pack_ply_vertices(const float* points, const float* normals, const float* colours, int64_t m, void* out,
+                           void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(m >= 0, G2PC_ERR_ARG, "negative count");
+    if (m == 0) return G2PC_OK;
+    G2PC_REQUIRE(points && colours && out, G2PC_ERR_ARG, "null pointer");
+    hipLaunchKernelGGL(k_pack_ply, dim3(cdiv(m, GEO_T)), dim3(GEO_T), 0, (hipStream_t)stream, points, normals, colours,
+                       (long)m, normals ? 27 : 15, (uint32_t*)out);
+    return check_launch("g2pc_pack_ply_vertices");
 }
 }

@@ -309,16 +309,11 @@ def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, poin
 
 
 def convert_3dgs_to_pc(input_path, transform_path, mask_path, pointcloud_settings):
-    """gauss_to_pc.py:373-601.  File loading is the reference's own I/O layer (gauss_dataloader.py,
-    transform_dataloader.py, mask_dataloader.py -- outside the hot path): those modules are
-    imported from the python path if present; the compute body is convert_gaussians_to_pc."""
+    """gauss_to_pc.py:373-601.  File loading (gauss_dataloader.py, transform_dataloader.py, mask_dataloader.py) is the
+    I/O layer around the hot path; the compute body is convert_gaussians_to_pc."""
     s = pointcloud_settings
-    try:
-        from transform_dataloader import load_transform_data
-        from gauss_dataloader import load_gaussians
-    except ImportError as e:  # pragma: no cover - the I/O adapters are not part of this package yet
-        raise Exception("convert_3dgs_to_pc needs the reference's gauss_dataloader / transform_dataloader modules "
-                        "on the python path for file I/O (%s); use convert_gaussians_to_pc for in-memory data" % e)
+    from transform_dataloader import load_transform_data
+    from gauss_dataloader import load_gaussians
 
     transforms = intrinsics = mask_images = None
     if transform_path is not None:

@@ -83,6 +83,12 @@ int g2pc_compact_index(const uint8_t* mask, int64_t n, uint32_t* index, uint32_t
                        void* stream);
 int g2pc_gather_rows(const void* src, const uint32_t* index, int64_t m, int32_t row_bytes, void* dst, void* stream);
 
+/* save_xyz_to_ply (gauss_dataloader.py:118-202), "next" row f1: pack m binary-little-endian PLY vertex records
+ * (x y z [nx ny nz] red green blue; 27 bytes with normals, 15 without; colours f32 -> uchar by truncation) into `out`
+ * (device, 4-byte aligned, at least ceil(m*rec/4)*4 bytes). */
+int g2pc_pack_ply_vertices(const float* points, const float* normals, const float* colours, int64_t m, void* out,
+                           void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Point allocation (gauss_to_pc.py:73-138)
  * ------------------------------------------------------------------------------------------- */
