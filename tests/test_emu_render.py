@@ -6,8 +6,10 @@ from emu_util import emu  # noqa: F401
 from render_checks import run_render_case, assert_render_matches
 
 
-def test_render_matches_reference_python_renderer(emu, golden_dir):
-    g, R, images, contribs = run_render_case(golden_dir)
+def test_render_matches_reference_python_renderer(emu, golden_dir, monkeypatch):
+    import gauss_render
+    monkeypatch.setattr(gauss_render, "BLEND_SUBBLOCKS", 4)      # 4 pixels per lane: 4x fewer emulated waves (speed only;
+    g, R, images, contribs = run_render_case(golden_dir)          # the default 1 px/lane runs in the pipeline golden test)
     stats = assert_render_matches(g, R, images, contribs)
     print(stats)
 
