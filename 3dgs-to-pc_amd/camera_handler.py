@@ -1,124 +1,100 @@
 """
-Drop-in mirror of the reference's ``camera_handler.py`` (``fov2focal``, ``focal2fov``, ``getProjectionMatrix``,
-``Camera``, ``get_camera``).  Camera set-up is a handful of 4x4 host operations per view: it is done in
-float32 on the HOST (bit-identical to the reference run on CPU) and handed to the HIP rasteriser by value, so a
-render call launches no set-up kernels and needs no device read-back.
+Camera set-up for the HIP rasteriser behind the reference's ``camera_handler`` interface (``fov2focal``,
+``focal2fov``, ``getProjectionMatrix``, ``Camera``, ``get_camera``; reference: camera_handler.py:8-108).
 
-Reference lines: camera_handler.py:8-50 (maths + Camera), :53-108 (get_camera).
+A view is a handful of 4x4 operations, so everything here is float32 host arithmetic: the results go to the kernels
+by value inside ``G2pcCamera`` and a render call neither launches set-up kernels nor reads anything back.
+
+Conventions kept from the reference (they are what the parity tests pin):
+  * matrices are stored for ROW vectors: ``world_view_transform = inverse(c2w)^T``, ``projection = P^T``;
+  * near / far are fixed at 10 / 100 and only shape the (unused) clip-space z;
+  * "python" cameras use c2w as loaded (OpenGL: the camera looks down -z); "cuda"/"hip" cameras negate the y and z
+    columns of c2w first (camera_handler.py:75), i.e. look down +z;
+  * the render size is ``int(int(w) * s)`` with ``s = colour_resolution / int(w)`` (1 when a mask pins the size).
 """
 import math
+
 import torch
+
+_ZNEAR, _ZFAR = 10, 100
 
 
 def fov2focal(fov, pixels):
-    return pixels / (2 * math.tan(fov / 2))
+    return 0.5 * pixels / math.tan(0.5 * fov)
 
 
 def focal2fov(focal, pixels):
-    return 2 * math.atan(pixels / (2 * focal))
+    return 2.0 * math.atan(0.5 * pixels / focal)
 
 
 def getProjectionMatrix(znear, zfar, fovX, fovY):
-    """camera_handler.py:14-33."""
-    tanHalfFovY = math.tan((fovY / 2))
-    tanHalfFovX = math.tan((fovX / 2))
-
-    top = tanHalfFovY * znear
-    bottom = -top
-    right = tanHalfFovX * znear
-    left = -right
-
-    P = torch.zeros(4, 4)
-
-    z_sign = 1.0
-
-    P[0, 0] = 2.0 * znear / (right - left)
-    P[1, 1] = 2.0 * znear / (top - bottom)
-    P[0, 2] = (right + left) / (right - left)
-    P[1, 2] = (top + bottom) / (top - bottom)
-    P[3, 2] = z_sign
-    P[2, 2] = z_sign * zfar / (zfar - znear)
-    P[2, 3] = -(zfar * znear) / (zfar - znear)
+    """Perspective matrix of camera_handler.py:14-33: symmetric frustum, +z forward, w = z."""
+    half_w = math.tan(0.5 * fovX) * znear
+    half_h = math.tan(0.5 * fovY) * znear
+    depth = zfar - znear
+    rows = [[znear / half_w, 0.0, 0.0, 0.0],
+            [0.0, znear / half_h, 0.0, 0.0],
+            [0.0, 0.0, zfar / depth, -(zfar * znear) / depth],
+            [0.0, 0.0, 1.0, 0.0]]
+    P = torch.tensor(rows, dtype=torch.float32)
+    # the reference builds 2n/(r-l) with r = -l = tan*n in float64 python scalars and stores float32: identical values
+    P[0, 0] = 2.0 * znear / (half_w - (-half_w))
+    P[1, 1] = 2.0 * znear / (half_h - (-half_h))
     return P
 
 
-class Camera():
-    """camera_handler.py:35-50 -- the python-renderer camera (c2w used as loaded, looks down -z)."""
+def _row_vector_view(c2w):
+    """inverse(c2w)^T as float32 on the host."""
+    return torch.linalg.inv(c2w).transpose(0, 1).contiguous()
 
-    def __init__(self, width, height, focal_x, focal_y, c2w, znear=10, zfar=100):
-        c2w = c2w.detach().to("cpu", torch.float32)
-        self.znear = znear
-        self.zfar = zfar
-        self.focal_x = focal_x
-        self.focal_y = focal_y
-        self.FoVx = focal2fov(self.focal_x, width)
-        self.FoVy = focal2fov(self.focal_y, height)
-        self.image_width = int(width)
-        self.image_height = int(height)
-        self.world_view_transform = torch.linalg.inv(c2w).permute(1, 0)
-        self.c2w = c2w
-        self.projection_matrix = getProjectionMatrix(znear=self.znear, zfar=self.zfar, fovX=self.FoVx,
-                                                     fovY=self.FoVy).transpose(0, 1)
-        self.camera_center = self.world_view_transform.inverse()[3, :3]
+
+def _host(m):
+    return m.detach().to(device="cpu", dtype=torch.float32)
+
+
+class Camera():
+    """The python-renderer camera (camera_handler.py:35-50)."""
+
+    def __init__(self, width, height, focal_x, focal_y, c2w, znear=_ZNEAR, zfar=_ZFAR):
+        self.c2w = _host(c2w)
+        self.znear, self.zfar = znear, zfar
+        self.focal_x, self.focal_y = focal_x, focal_y
+        self.image_width, self.image_height = int(width), int(height)
+        self.FoVx, self.FoVy = focal2fov(focal_x, width), focal2fov(focal_y, height)
+        self.world_view_transform = _row_vector_view(self.c2w)
+        self.projection_matrix = getProjectionMatrix(znear, zfar, self.FoVx, self.FoVy).transpose(0, 1)
         self.full_proj_transform = self.world_view_transform @ self.projection_matrix
+        self.camera_center = self.world_view_transform.inverse()[3, :3]
+
+
+def _render_geometry(cam_intrinsic, colour_resolution, mask):
+    w0, h0 = int(cam_intrinsic[0]), int(cam_intrinsic[1])
+    scale = 1 if (colour_resolution is None or mask is not None) else colour_resolution / w0
+    return int(w0 * scale), int(h0 * scale), float(cam_intrinsic[2]) * scale, float(cam_intrinsic[3]) * scale
 
 
 def get_camera(renderer_type, transform, cam_intrinsic, colour_resolution=None, sh_degree=3, white_bkgd=True, mask=None):
-    """camera_handler.py:53-108.  'hip' is accepted as the native spelling of the reference's 'cuda'."""
-
-    diff = 1 if (colour_resolution is None or mask is not None) else colour_resolution / int(cam_intrinsic[0])
-
+    """camera_handler.py:53-108 ('hip' is the native spelling of the reference's 'cuda')."""
     if mask is not None:
         if mask.shape[1] != int(cam_intrinsic[0]) or mask.shape[0] != int(cam_intrinsic[1]):
             raise Exception("Size of mask must match size of input image")
         mask = mask.flatten()
-
-    img_width = int(int(cam_intrinsic[0]) * diff)
-    img_height = int(int(cam_intrinsic[1]) * diff)
-
-    focal_x = float(cam_intrinsic[2]) * diff
-    focal_y = float(cam_intrinsic[3]) * diff
+    width, height, fx, fy = _render_geometry(cam_intrinsic, colour_resolution, mask)
 
     if renderer_type == "python":
-        return Camera(img_width, img_height, focal_x, focal_y, transform)
+        return Camera(width, height, fx, fy, transform)
 
-    elif renderer_type in ("cuda", "hip"):
+    if renderer_type in ("cuda", "hip"):
         from gaussian_pointcloud_rasterization import GaussianRasterizationSettings
-
-        transform = transform.detach().to("cpu", torch.float32).clone()
-        transform[:, 1:3] = -transform[:, 1:3]
-
-        fovX = focal2fov(focal_x, img_width)
-        fovY = focal2fov(focal_y, img_height)
-
-        tanfovx = math.tan(fovX * 0.5)
-        tanfovy = math.tan(fovY * 0.5)
-
-        scaling_modifier = 1.0
-
-        znear = 10
-        zfar = 100
-
-        projmatrix = getProjectionMatrix(znear=znear, zfar=zfar, fovX=fovX, fovY=fovY).transpose(0, 1)
-
-        viewmatrix = torch.linalg.inv(transform).permute(1, 0)
-        campos = viewmatrix.inverse()[3, :3]
-
+        c2w = _host(transform).clone()
+        c2w[:, 1:3].neg_()                                   # OpenGL -> OpenCV camera axes
+        fov_x, fov_y = focal2fov(fx, width), focal2fov(fy, height)
+        view = _row_vector_view(c2w)
+        proj = getProjectionMatrix(_ZNEAR, _ZFAR, fov_x, fov_y).transpose(0, 1)
+        background = torch.ones(3) if white_bkgd else torch.zeros(3)
         return GaussianRasterizationSettings(
-            image_height=int(img_height),
-            image_width=int(img_width),
-            tanfovx=tanfovx,
-            tanfovy=tanfovy,
-            bg=torch.tensor([0., 0., 0.]) if not white_bkgd else torch.tensor([1.0, 1.0, 1.0]),
-            scale_modifier=scaling_modifier,
-            campos=campos,
-            viewmatrix=viewmatrix,
-            projmatrix=viewmatrix @ projmatrix,
-            sh_degree=sh_degree,
-            prefiltered=False,
-            mask=mask,
-            debug=True,
-            antialiasing=False
-        )
+            image_height=height, image_width=width, tanfovx=math.tan(0.5 * fov_x), tanfovy=math.tan(0.5 * fov_y),
+            bg=background, scale_modifier=1.0, viewmatrix=view, projmatrix=view @ proj, sh_degree=sh_degree,
+            campos=view.inverse()[3, :3], mask=mask, prefiltered=False, debug=True, antialiasing=False)
 
     raise Exception(f"Renderer of type {renderer_type} is not supported")
