@@ -82,8 +82,16 @@ __global__ __launch_bounds__(AL_T) void k_fill_zeros(double* __restrict__ ppg, i
         ppg_i32[i] = iv;
         local_max = iv > local_max ? iv : local_max;
     }
+    // one atomic per block (a per-wave atomic on a single address serialises: 98 us at 1 M Gaussians)
+    __shared__ unsigned wmax[AL_T / kWave];
     unsigned m = wave_max_u32((unsigned)local_max);
-    if ((threadIdx.x & 63) == 0) atomicMax((unsigned long long*)&stats[3], (unsigned long long)m);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned bm = 0;
+        for (int i = 0; i < AL_T / kWave; ++i) bm = wmax[i] > bm ? wmax[i] : bm;
+        if (bm > 0) atomicMax((unsigned long long*)&stats[3], (unsigned long long)bm);
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         stats[0] = (int64_t)sum;
         stats[1] = zeros;
