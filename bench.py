@@ -99,7 +99,9 @@ def pmc_traffic(region, a):
     the default workload it was collected on.  Raw counter sum; FETCH_SIZE may under-report wide reads by up to 2x."""
     kernel = {"raster_blend": "void g2pc::k_blend_py<1, 4>", "sampler_emit": "g2pc::k_emit_wave"}.get(region)
     path = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")
-    if kernel is None or not os.path.isfile(path) or (a.gaussians, a.cameras) != (1_000_000, 50):
+    import gauss_render
+    if (kernel is None or not os.path.isfile(path) or (a.gaussians, a.cameras) != (1_000_000, 50)
+            or (region == "raster_blend" and gauss_render.DEFAULT_T_FLOOR != 1e-6)):
         return None
     rec = json.load(open(path)).get(kernel)
     return rec["hbm_bytes_raw"] if rec else None
