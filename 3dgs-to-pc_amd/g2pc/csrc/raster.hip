@@ -318,10 +318,12 @@ __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __
                 }
             }
         }
-        if (t_floor > 0.0f) {
+        {   // chunk-level early exit.  t_floor = 0: only once every transmittance has underflowed to exactly 0.0f -- all
+            // later contributions and colour terms are then exactly 0 in fp32 (as in the reference's cumprod), so this
+            // is bit-exact; t_floor > 0: everything still to come is below t_floor.
             bool done = true;
 #pragma unroll
-            for (int j = 0; j < PPT; ++j) done = done && (T[j] < t_floor);
+            for (int j = 0; j < PPT; ++j) done = done && (T[j] <= t_floor);
             if (__all(done ? 1 : 0)) break;
         }
     }

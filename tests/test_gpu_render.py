@@ -98,3 +98,13 @@ def test_pipelined_cameras_equal_synchronous(monkeypatch):
         assert torch.equal(a, b)
     for a, b in zip(states[1], states[2]):
         assert torch.equal(a, b)
+
+
+def test_render_100k_gaussians_vs_oracle():
+    """One configs[2]-shaped camera at a tenth of the Gaussians (the CPU oracle needs ~15 s for it)."""
+    from render_checks import run_vs_oracle
+    r = run_vs_oracle(100_000, 1239, 1280, 720, 1100.0, 1, device=DEV, scale=(0.002, 0.02), t_floor=1e-6)
+    print(r)
+    assert r["image_frac_off"] < 1e-4 and r["contribution_frac_off"] < 1e-4 and r["colour_frac_off"] < 1e-4, r
+    assert r["image"] < 2e-2 and r["contribution"] < 2e-2, r
+    assert r["flips"] <= r["near_threshold"] + 1, r
