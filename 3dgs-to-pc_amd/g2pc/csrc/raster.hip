@@ -273,6 +273,9 @@ __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __
         // transmittance recurrence and the visibility bookkeeping then run in depth order.
         for (int k0 = 0; k0 < cnt; k0 += U) {
             float alpha[U][PPT];
+            float4 cc[U];                                               // colour + staged maximum, read with the rest so
+#pragma unroll                                                          // the serial part below never waits on the LDS
+            for (int u = 0; u < U; ++u) cc[u] = s_p2[k0 + u];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const float4 a = s_p0[k0 + u], q = s_p1[k0 + u];       // entries past cnt are zero-opacity padding
@@ -285,13 +288,15 @@ __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __
                 }
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u)
+            for (int u = 0; u < U; ++u) {
 #pragma unroll
                 for (int j = 0; j < PPT; ++j) G2PC_PIN(alpha[u][j]);
+                G2PC_PIN(cc[u].x); G2PC_PIN(cc[u].y); G2PC_PIN(cc[u].z); G2PC_PIN(cc[u].w);
+            }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 {
-                    const float4 c = s_p2[k0 + u];
+                    const float4 c = cc[u];
                     float best = 0.0f;
                     uint32_t bestpix = 0xFFFFFFFFu;
 #pragma unroll
