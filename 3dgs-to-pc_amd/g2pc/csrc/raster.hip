@@ -282,7 +282,8 @@ __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __
 #pragma unroll
                 for (int j = 0; j < PPT; ++j) {
                     float dx = px[j] - a.x, dy = py[j] - a.y;
-                    float power = fmaf(a.z * dx, dx, fmaf(q.x * dy, dy, a.w * dx * dy));
+                    // A dx^2 + B dx dy + C dy^2 = dx (A dx + B dy) + (C dy) dy : 5 VALU
+                    float power = fmaf(dx, fmaf(a.w, dy, a.z * dx), (q.x * dy) * dy);
                     float wgt = __builtin_amdgcn_exp2f(power);      // raw v_exp_f32 (results below 2^-126 flush to 0)
                     alpha[u][j] = fminf(wgt * q.y, 0.99f);
                 }
