@@ -605,20 +605,27 @@ __global__ __launch_bounds__(CU_T) void k_blend_cu(int W, int H, int grid_x, con
         const int cnt = (end - b) < (uint32_t)CU_T ? (int)(end - b) : CU_T;
         // wave-uniform early out inside the batch: nothing left to blend for these 64 pixels
         for (int k0 = 0; k0 < cnt && !__all(done ? 1 : 0); k0 += 4) {
-            float alpha[4], power[4];
+            float alpha[4], power[4], dep[4];
+            float4 cc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cc[u] = s_p2[k0 + u];       // read with the rest: the serial part never waits on LDS
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const float4 a = s_p0[k0 + u], q = s_p1[k0 + u];
                 float dx = a.x - px, dy = a.y - py;
-                power[u] = fmaf(a.z * dx, dx, fmaf(q.x * dy, dy, a.w * dx * dy));
+                power[u] = fmaf(dx, fmaf(a.w, dy, a.z * dx), (q.x * dy) * dy);
                 alpha[u] = fminf(0.99f, q.y * __builtin_amdgcn_exp2f(power[u]));
+                dep[u] = q.z;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) G2PC_PIN(alpha[u]);
+            for (int u = 0; u < 4; ++u) {
+                G2PC_PIN(alpha[u]); G2PC_PIN(dep[u]);
+                G2PC_PIN(cc[u].x); G2PC_PIN(cc[u].y); G2PC_PIN(cc[u].z); G2PC_PIN(cc[u].w);
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float4 c = s_p2[k0 + u];
-                const float depth = s_p1[k0 + u].z;
+                const float4 c = cc[u];
+                const float depth = dep[u];
                 float test_T = T * (1.0f - alpha[u]);
                 bool live = !done && !(power[u] > 0.0f) && !(alpha[u] < 1.0f / 255.0f);
                 bool stop = live && (test_T < 0.0001f);
