@@ -294,28 +294,38 @@ __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __
                 for (int j = 0; j < PPT; ++j) G2PC_PIN(alpha[u][j]);
                 G2PC_PIN(cc[u].x); G2PC_PIN(cc[u].y); G2PC_PIN(cc[u].z); G2PC_PIN(cc[u].w);
             }
+            // serial part: transmittance recurrence for the U Gaussians, branch-free; the (rare, after the first few
+            // cameras) visibility updates are handled behind ONE wave-uniform test per trip
+            float bestv[U];
+            uint32_t bestp[U];
+            bool any_cand = false;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                {
-                    const float4 c = cc[u];
-                    float best = 0.0f;
-                    uint32_t bestpix = 0xFFFFFFFFu;
+                const float4 c = cc[u];
+                float best = 0.0f;
+                uint32_t bestpix = 0xFFFFFFFFu;
 #pragma unroll
-                    for (int j = 0; j < PPT; ++j) {
-                        float contrib = T[j] * alpha[u][j];
-                        cr[j] = fmaf(contrib, c.x, cr[j]);
-                        cg[j] = fmaf(contrib, c.y, cg[j]);
-                        cb[j] = fmaf(contrib, c.z, cb[j]);
-                        T[j] -= contrib;
-                        if (PPT == 1) { best = contrib; bestpix = (uint32_t)pix[j]; }
-                        // sub-blocks of one lane are not ordered by pixel index: explicit tie-break to the lowest index
-                        else if (contrib > best || (contrib == best && contrib > 0.0f && (uint32_t)pix[j] < bestpix)) { best = contrib; bestpix = (uint32_t)pix[j]; }
-                    }
-                    const bool cand = best >= c.w;                   // c.w = max(running maximum, FLT_MIN)
-                    if (__any(cand)) {
-                        uint32_t bits = __float_as_uint(best);
+                for (int j = 0; j < PPT; ++j) {
+                    float contrib = T[j] * alpha[u][j];
+                    cr[j] = fmaf(contrib, c.x, cr[j]);
+                    cg[j] = fmaf(contrib, c.y, cg[j]);
+                    cb[j] = fmaf(contrib, c.z, cb[j]);
+                    T[j] -= contrib;
+                    if (PPT == 1) { best = contrib; bestpix = (uint32_t)pix[j]; }
+                    // sub-blocks of one lane are not ordered by pixel index: explicit tie-break to the lowest index
+                    else if (contrib > best || (contrib == best && contrib > 0.0f && (uint32_t)pix[j] < bestpix)) { best = contrib; bestpix = (uint32_t)pix[j]; }
+                }
+                bestv[u] = best;
+                bestp[u] = bestpix;
+                any_cand = any_cand || (best >= c.w);                  // c.w = max(running maximum, FLT_MIN)
+            }
+            if (__any(any_cand ? 1 : 0)) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (__any(bestv[u] >= cc[u].w)) {
+                        uint32_t bits = __float_as_uint(bestv[u]);
                         uint32_t m = wave_max_u32_dpp(bits);
-                        uint32_t pm = wave_min_u32_dpp(bits == m ? bestpix : 0xFFFFFFFFu);
+                        uint32_t pm = wave_min_u32_dpp(bits == m ? bestp[u] : 0xFFFFFFFFu);
                         if (lane == 0) {
                             unsigned long long key = ((unsigned long long)m << 32) | (unsigned long long)(uint32_t)(~(order_tile | pm));
                             atomicMax(&best_key[s_g[k0 + u]], key);
