@@ -692,6 +692,14 @@ __global__ __launch_bounds__(RA_T) void k_tile_ranges(const uint32_t* __restrict
     for (int t = prev + 1; t <= cur; ++t) tile_start[t] = (uint32_t)l;
 }
 
+// the reference's quad-tree keeps splitting a leaf that holds more than max_gaussians_per_tile Gaussians
+// (gauss_render.py:319); the fixed leaf layout used here cannot follow it there -> raise a flag the host checks
+__global__ __launch_bounds__(RA_T) void k_check_tile_load(const uint32_t* __restrict__ tile_start, int T, uint32_t limit,
+                                                         uint32_t* __restrict__ flag) {
+    int t = blockIdx.x * RA_T + threadIdx.x;
+    if (t < T && tile_start[t + 1] - tile_start[t] > limit) atomicMax(flag, tile_start[t + 1] - tile_start[t]);
+}
+
 // binding-side reductions (gaussian_pointcloud_rasterization/__init__.py:128-158): gather the colour of the arg-max
 // pixel from the final image, strict-> running max (earliest camera wins ties), running SUM of the per-camera
 // maxima, running min of the surface distance.
@@ -800,7 +808,7 @@ int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, con
                         int64_t num_instances, const float* p0, const float* p1, const uint32_t* rect,
                         const uint32_t* sorted_idx, const uint32_t* offsets, uint32_t camera_slot, float t_floor,
                         unsigned long long* best_key, float* colours_out, float* tilebuf, float* image, int phases,
-                        void* ws, size_t ws_bytes, void* stream) {
+                        uint32_t max_per_tile, uint32_t* overflow_flag, void* ws, size_t ws_bytes, void* stream) {
     using namespace g2pc;
     G2PC_REQUIRE(cam && layout && colours && p0 && p1 && rect && sorted_idx && offsets && best_key && colours_out &&
                      tilebuf && ws && n > 0,
@@ -834,6 +842,8 @@ int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, con
     }
     (void)scan_ws; (void)scan_bytes;
     hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T)), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start);
+    if (overflow_flag && max_per_tile)
+        hipLaunchKernelGGL(k_check_tile_load, dim3(cdiv(T, RA_T)), dim3(RA_T), 0, s, tile_start, T, max_per_tile, overflow_flag);
     }
     if (phases & 2) {
 #define G2PC_BLEND(PPT, U)                                                                                            \

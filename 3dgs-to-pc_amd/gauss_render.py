@@ -56,7 +56,7 @@ nv._RASTER_PROTOS.update({
                              [C.c_void_p] * 7 + [C.c_size_t, C.c_void_p]),
     "g2pc_raster_back_workspace": (C.c_size_t, [C.c_int64, C.c_int32]),
     "g2pc_raster_back_py": (C.c_int, [C.POINTER(_Camera), C.POINTER(_Layout), C.c_void_p, C.c_int64, C.c_int64] +
-                            [C.c_void_p] * 5 + [C.c_uint32, C.c_float] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+                            [C.c_void_p] * 5 + [C.c_uint32, C.c_float] + [C.c_void_p] * 4 + [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "g2pc_raster_rebase_keys": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "g2pc_raster_debug_chunk_work": (C.c_int, [C.c_void_p]),
     "g2pc_raster_keep_winner_colours": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
@@ -152,6 +152,8 @@ class GaussHipRenderer():
         self.camera_slot = 0
 
         self.sync_scratch = _Scratch(n, self.device)
+        self.overflow = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        self.overflow_ptr = nv.ptr(self.overflow)
         self.scene_ptrs = (nv.ptr(self.means3D), nv.ptr(self.cov3d), nv.ptr(self.opacity))
         self.colour_ptr = nv.ptr(self.colour)
         self.pipe = []                # lazily created per-stream scratch
@@ -181,6 +183,7 @@ class GaussHipRenderer():
 
     def get_gaussian_colours(self):
         self.flush()
+        self.check_tile_load()
         return self.gaussian_colours * 255
 
     def get_gaussians_above_contribution_threshold(self, contribution_threshold):
@@ -264,7 +267,8 @@ class GaussHipRenderer():
         with nv.region(name, self.device, sc.stream):
             nv.check(L.g2pc_raster_back_py(C.byref(cam), C.byref(lay.c), self.colour_ptr, self.n, num_inst, *sc.ptrs,
                                            slot, self.t_floor, self.state_ptrs()[0], self.state_ptrs()[1], sc.tilebuf_ptr,
-                                           nv.ptr(image), phases, sc.back_ws_ptr, sc.back_ws_bytes, self._stream_ptr(sc)),
+                                           nv.ptr(image), phases, self.MAX_GAUSSIANS_PER_TILE, self.overflow_ptr, sc.back_ws_ptr,
+                                           sc.back_ws_bytes, self._stream_ptr(sc)),
                      "raster_back_py")
 
     def _note(self, lay, num_inst, W, H):
@@ -298,6 +302,15 @@ class GaussHipRenderer():
         cur = torch.cuda.current_stream(self.device)
         for sc in self.pipe:
             cur.wait_stream(sc.stream)
+
+    def check_tile_load(self):
+        """Raises if some leaf tile held more Gaussians than the reference allows per tile (it would have split the
+        leaf further; results would then differ from the reference's)."""
+        worst = int(self.overflow.item())
+        if worst:
+            raise NotImplementedError("a %dx%d-limited leaf tile holds %d Gaussians (> max_gaussians_per_tile = %d): the "
+                                      "reference's quad-tree would subdivide it further; not supported"
+                                      % (self.MAX_TILE_SIZE, self.MAX_TILE_SIZE, worst, self.MAX_GAUSSIANS_PER_TILE))
 
     def __call__(self, camera, return_image=True, slot=None, **kwargs):
         W, H = int(camera.image_width), int(camera.image_height)

@@ -198,12 +198,14 @@ size_t g2pc_raster_back_workspace(int64_t num_instances, int32_t num_tiles);
  * (all later contributions and colour terms are then < t_floor).
  * phases: bit 0 = binning (duplicate, tile sort, ranges), bit 1 = blend, bit 2 = colour update + image; 7 = all
  * (the phases share `ws`).  The packed-key atomicMax is commutative, so the blends of different cameras may run
- * concurrently on different streams; only the colour updates must be issued in camera order. */
+ * concurrently on different streams; only the colour updates must be issued in camera order.
+ * overflow_flag (optional, device u32, zeroed by the caller): receives max(tile load) if any tile holds more than
+ * max_per_tile Gaussians -- the reference would subdivide such a leaf further (gauss_render.py:319), this layout cannot. */
 int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, const float* colours, int64_t n,
                         int64_t num_instances, const float* p0, const float* p1, const uint32_t* rect,
                         const uint32_t* sorted_idx, const uint32_t* offsets, uint32_t camera_slot, float t_floor,
                         unsigned long long* best_key, float* colours_out, float* tilebuf, float* image, int phases,
-                        void* ws, size_t ws_bytes, void* stream);
+                        uint32_t max_per_tile, uint32_t* overflow_flag, void* ws, size_t ws_bytes, void* stream);
 int g2pc_raster_rebase_keys(unsigned long long* best_key, int64_t n, void* stream);
 /* diagnostics: when non-NULL, the PY blend records (tile list length, entries walked) per chunk in u32[2*num_chunks] */
 int g2pc_raster_debug_chunk_work(uint32_t* buf);

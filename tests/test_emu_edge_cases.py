@@ -109,3 +109,18 @@ def test_wide_radix_digits_and_zero_budget(emu):
     sizes = torch.tensor([1.0, 2.0, 3.0], dtype=torch.float64)
     p, _, st = ops.distribute_points(sizes, 1)             # budget smaller than the number of Gaussians
     assert p.tolist() == RG.distribute_points(sizes, 1).tolist()
+
+
+def test_tile_overflow_is_reported(emu, monkeypatch):
+    """More Gaussians in one leaf than max_gaussians_per_tile: the reference would split the leaf; we must say so."""
+    import gauss_render, camera_handler
+    from gauss_handler import Gaussians
+    sc = make_scene(600, 12, scale_lo=0.05, scale_hi=0.1)
+    G = Gaussians(sc.xyz * 0.05, sc.scales, sc.rots, sc.colours, sc.opacities)          # everything in the centre
+    tr, intr = make_cameras(1, width=96, height=64, focal=80.0)
+    name = next(iter(tr))
+    monkeypatch.setattr(gauss_render.GaussHipRenderer, "MAX_GAUSSIANS_PER_TILE", 100)
+    R = gauss_render.get_renderer("python", G.xyz, G.opacities.unsqueeze(1), G.colours, G.covariances)
+    R(camera_handler.get_camera("python", torch.tensor(tr[name]), intr[name]))
+    with pytest.raises(NotImplementedError, match="max_gaussians_per_tile"):
+        R.get_gaussian_colours()
