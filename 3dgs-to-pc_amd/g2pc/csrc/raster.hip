@@ -389,11 +389,14 @@ __global__ __launch_bounds__(RA_T) void k_rebase_keys(unsigned long long* __rest
 // owns the winning key; the all-reduce(SUM) of the colours then has exactly one non-zero term per Gaussian.
 __global__ __launch_bounds__(RA_T) void k_keep_winner_colours(const unsigned long long* __restrict__ local_key,
                                                              const unsigned long long* __restrict__ global_key,
-                                                             long n, float* __restrict__ colours) {
+                                                             long n, int rank, float* __restrict__ colours) {
     long i = (long)blockIdx.x * RA_T + threadIdx.x;
     if (i >= n) return;
     unsigned long long g = global_key[i];
-    if ((g >> 32) == 0ull || local_key[i] != g) {
+    // keys rebased after an earlier exchange (order 0) are identical on every rank, and so are their colours:
+    // only rank 0 contributes them to the sum
+    const bool from_earlier_epoch = (uint32_t)g == 0xFFFFFFFFu;
+    if ((g >> 32) == 0ull || local_key[i] != g || (from_earlier_epoch && rank != 0)) {
         colours[3 * i + 0] = 0.0f; colours[3 * i + 1] = 0.0f; colours[3 * i + 2] = 0.0f;
     }
 }
@@ -879,12 +882,12 @@ int g2pc_raster_rebase_keys(unsigned long long* best_key, int64_t n, void* strea
 }
 
 int g2pc_raster_keep_winner_colours(const unsigned long long* local_key, const unsigned long long* global_key,
-                                    int64_t n, float* colours, void* stream) {
+                                    int64_t n, int32_t rank, float* colours, void* stream) {
     using namespace g2pc;
     if (n <= 0) return G2PC_OK;
     G2PC_REQUIRE(local_key && global_key && colours, G2PC_ERR_ARG, "null pointer");
     hipLaunchKernelGGL(k_keep_winner_colours, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, (hipStream_t)stream, local_key,
-                       global_key, (long)n, colours);
+                       global_key, (long)n, (int)rank, colours);
     return check_launch("g2pc_raster_keep_winner_colours");
 }
 

@@ -59,7 +59,7 @@ nv._RASTER_PROTOS.update({
                             [C.c_void_p] * 5 + [C.c_uint32, C.c_float] + [C.c_void_p] * 4 + [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "g2pc_raster_rebase_keys": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "g2pc_raster_debug_chunk_work": (C.c_int, [C.c_void_p]),
-    "g2pc_raster_keep_winner_colours": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "g2pc_raster_keep_winner_colours": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "g2pc_raster_contributions": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
 })
 if nv._LIB is not None:
@@ -125,6 +125,7 @@ class GaussHipRenderer():
     """Stateful per-scene renderer: keeps, for every Gaussian, the largest blend contribution seen in any
     tile of any camera and the pixel colour rendered where it occurred (gauss_render.py:215-264)."""
 
+    needs_camera_epochs = True         # 8-bit camera-order field in the packed keys (multi-GPU: exchange + rebase per epoch)
     MAX_GAUSSIANS_PER_TILE = 60000     # `render()` defaults the reference's __call__ is pinned to in parity runs
     MAX_TILE_SIZE = 60
 
@@ -219,7 +220,8 @@ class GaussHipRenderer():
         global_key = self.best_key.clone()
         dist.all_reduce(global_key, op=dist.ReduceOp.MAX, group=group)
         nv.check(nv.lib().g2pc_raster_keep_winner_colours(nv.ptr(self.best_key), nv.ptr(global_key), self.n,
-                                                          nv.ptr(self.gaussian_colours), nv.stream_handle(self.device)),
+                                                          dist.get_rank(group), nv.ptr(self.gaussian_colours),
+                                                          nv.stream_handle(self.device)),
                  "keep_winner_colours")
         dist.all_reduce(self.gaussian_colours, op=dist.ReduceOp.SUM, group=group)
         self.best_key = global_key

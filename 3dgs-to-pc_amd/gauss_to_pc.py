@@ -32,6 +32,7 @@ from camera_handler import get_camera
 COLOR_QUALITY_OPTIONS = {"tiny": 180, "low": 360, "medium": 720, "high": 1280, "ultra": 1920, "original": None}
 
 SAMPLER_SEED = 0
+CAMERA_EPOCH = 255          # cameras per epoch of the renderer's 8-bit camera-order field (multi-GPU camera sharding)
 REFERENCE_DTYPES = False
 
 
@@ -193,8 +194,9 @@ def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, poin
             raise Exception("Transforms are required to render colours")
 
         for cam_index, (img_name, transform) in enumerate(transforms.items()):
+            epochs = getattr(gaussian_renderer, "needs_camera_epochs", False)
             if world > 1:
-                if cam_index > 0 and cam_index % 255 == 0:           # camera-order field of the keys is 8 bits wide
+                if epochs and cam_index > 0 and cam_index % CAMERA_EPOCH == 0:   # 8-bit camera-order field of the keys
                     gaussian_renderer.all_reduce_visibility(group)
                     gaussian_renderer.rebase_keys()
                 if cam_index % world != rank:
@@ -207,7 +209,7 @@ def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, poin
                                 sh_degree=s.max_sh_degree, white_bkgd=True, mask=mask)
             # Render new image and Gaussian contributions (the image itself is not used by the pipeline)
             if world > 1:
-                gaussian_renderer(camera, return_image=False, slot=cam_index % 255 + 1)
+                gaussian_renderer(camera, return_image=False, slot=(cam_index % CAMERA_EPOCH if epochs else cam_index) + 1)
             else:
                 gaussian_renderer(camera, return_image=False)
         if world > 1:

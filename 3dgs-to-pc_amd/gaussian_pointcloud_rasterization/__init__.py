@@ -80,6 +80,8 @@ class _CuScratch:
 
 
 class GaussianRasterizer(nn.Module):
+    needs_camera_epochs = False        # the winner camera is a plain int32 index here
+
     def __init__(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                  cov3D_precomp=None, visible_gaussian_threshold=0.0, surface_distance_std=None,
                  calculate_surface_distance=False):

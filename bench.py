@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--points", type=int, default=10_000_000)
     ap.add_argument("--cameras", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = every GPU brings its own 50 cameras and 10M-point budget (50N cameras, 10M*N points "
+                         "on the shared scene); strong = the N = 1 job split N ways")
     ap.add_argument("--sort-bits", type=int, default=0, help="tuning aid: wide radix digit bits (8 or 11)")
     ap.add_argument("--sort-small", type=int, default=2 << 20, help="tuning aid: inputs up to this many keys use 4 keys/thread")
     ap.add_argument("--blend-subblocks", type=int, default=0, help="tuning aid: 8x8 sub-blocks per blend wave (1, 2, 4)")
@@ -175,10 +178,14 @@ def main():
     if a.streams:
         gauss_render.PIPELINE_STREAMS = a.streams
 
-    # strong scaling: ONE scene (same seed on every rank, replicated read-only); cameras are split over the ranks,
-    # the visibility state is all-reduced, sampling is sharded by Gaussian index, the points are gathered on rank 0
+    # ONE scene (same seed on every rank, replicated read-only); the cameras are split over the ranks (rank r renders
+    # cameras r, r+N, ...), the visibility state is all-reduced, sampling is sharded by Gaussian index and the points
+    # are gathered on rank 0.  Weak scaling (default): the camera rig and the point budget grow with N, so every GPU
+    # keeps the configs[2] load of 50 cameras / 10M points; strong: the N = 1 job is split N ways.
+    scale = world if a.scaling == "weak" else 1
+    total_cameras, total_points = a.cameras * scale, a.points * scale
     scene = make_scene(a.gaussians, 1234 + 3, device=device, with_sh=(workload == "render_cuda"))
-    cams = make_cameras(a.cameras) if workload != "sample" else None
+    cams = make_cameras(total_cameras) if workload != "sample" else None
     if cams is not None and a.camera_subset:
         keep = sorted(cams[0])[:a.camera_subset]              # profiling aid: first k of the SAME 50-camera rig
         cams = ({k: cams[0][k] for k in keep}, {k: cams[1][k] for k in keep})
@@ -191,7 +198,7 @@ def main():
         torch.cuda.synchronize()
 
     for w in range(a.warmup):
-        one_step(scene, cams, workload, a.points, device, seed=100 + w)
+        one_step(scene, cams, workload, total_points, device, seed=100 + w)
     nv.PROFILE = {}
     if workload != "sample":
         gauss_render.RENDER_STATS.clear()
@@ -199,7 +206,7 @@ def main():
     t0 = time.perf_counter()
     points = 0
     for k in range(a.steps):
-        points += one_step(scene, cams, workload, a.points, device, seed=200 + k)
+        points += one_step(scene, cams, workload, total_points, device, seed=200 + k)
     sync()
     dt = time.perf_counter() - t0
     prof = nv.profile_summary()
@@ -245,13 +252,13 @@ def main():
     out = {
         "metric": "coloured points/sec", "value": points_all / dt_all, "unit": "points/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt_all / a.steps * 1e3, "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": a.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": {"render": "configs[2]: 1M Gaussians, 50 cameras 1280x720, 10M points, python-renderer semantics",
                                 "render_cuda": "configs[4]: 1M Gaussians, 50 cameras, native-rasteriser semantics, SH degree 3, "
                                                "surface_distance_std=2.0, exact_num_points, 10M points",
                                 "sample": "configs[1]: 1M Gaussians, no_render_colours, 10M points (sampling pipeline)"}[workload],
-                   "gaussians": a.gaussians, "points": a.points,
-                   "cameras": a.cameras if workload != "sample" else 0,
+                   "gaussians": a.gaussians, "points": total_points, "points_per_gpu": total_points // world,
+                   "cameras": total_cameras if workload != "sample" else 0, "cameras_per_gpu": (total_cameras // world) if workload != "sample" else 0,
                    "blend_transmittance_floor": gauss_render.DEFAULT_T_FLOOR, "parallelism": "cameras and Gaussian-index shards over %d GPU(s), RCCL all-reduce of visibility + gather of points" % world},
         "roofline": roof,
         "instances_per_camera": (float(np.mean([x[0] for x in gauss_render.RENDER_STATS])) if gauss_render.RENDER_STATS else None),

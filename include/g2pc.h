@@ -238,9 +238,10 @@ int g2pc_raster_back_cu(const G2pcCamera* cam, const int32_t* mask, int64_t n, i
                         int phases, void* ws, size_t ws_bytes, void* stream);
 
 /* multi-GPU (no counterpart in the reference): zero colours[i,:] unless local_key[i] == global_key[i] != 0, so that an
- * all-reduce(SUM) over ranks after an all-reduce(MAX) of the keys reproduces "earliest camera wins" exactly. */
+ * all-reduce(SUM) over ranks after an all-reduce(MAX) of the keys reproduces "earliest camera wins" exactly.  Keys that
+ * were rebased after an earlier exchange are shared by all ranks: only `rank` 0 keeps their colour. */
 int g2pc_raster_keep_winner_colours(const unsigned long long* local_key, const unsigned long long* global_key,
-                                    int64_t n, float* colours, void* stream);
+                                    int64_t n, int32_t rank, float* colours, void* stream);
 /* gaussian_max_contribution f32[n] out of the packed keys (gauss_render.py:243-264 getters read this) */
 int g2pc_raster_contributions(const unsigned long long* best_key, int64_t n, float* out, void* stream);
 

@@ -23,7 +23,7 @@ def _settings(num_points, renderer="python"):
         surface_distance_std=2.0 if renderer == "cuda" else None, generate_mesh=False, quiet=True, device="cpu")
 
 
-def _run(rank, world, port, out_dir, renderer="python"):
+def _run(rank, world, port, out_dir, renderer="python", epoch=255, ncam=3):
     for p in (os.path.join(ROOT, "3dgs-to-pc_amd"), os.path.join(ROOT, "oracle"), HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -33,18 +33,20 @@ def _run(rank, world, port, out_dir, renderer="python"):
     from g2pc.synth import make_scene, make_cameras
     from g2pc.dist import gather_pointcloud
     from gauss_handler import Gaussians
+    import gauss_to_pc
     from gauss_to_pc import convert_gaussians_to_pc
+    gauss_to_pc.CAMERA_EPOCH = epoch
     if world > 1:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
         dist.init_process_group("gloo", rank=rank, world_size=world)
     sc = make_scene(1200, 91, scale_lo=0.01, scale_hi=0.06)
-    transforms, intr = make_cameras(3, width=180, height=101, focal=155.0)
+    transforms, intr = make_cameras(ncam, width=180, height=101, focal=155.0)
     G = Gaussians(sc.xyz, sc.scales, sc.rots, sc.colours, sc.opacities)
     cloud, _ = convert_gaussians_to_pc(G, transforms, intr, None, _settings(12000, renderer), seed=5)
     full = gather_pointcloud(cloud, dst=0)
     if rank == 0:
-        np.savez(os.path.join(out_dir, "%s_w%d.npz" % (renderer, world)), points=full.points.numpy(), colours=full.colours.numpy(),
+        np.savez(os.path.join(out_dir, "%s_w%d_e%d.npz" % (renderer, world, epoch)), points=full.points.numpy(), colours=full.colours.numpy(),
                  normals=full.normals.numpy())
     if world > 1:
         dist.barrier()
@@ -57,7 +59,7 @@ def test_two_rank_pipeline_equals_single_process(tmp_path):
     _run(0, 1, 0, str(tmp_path))
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_run, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    a, b = np.load(tmp_path / "python_w1.npz"), np.load(tmp_path / "python_w2.npz")
+    a, b = np.load(tmp_path / "python_w1_e255.npz"), np.load(tmp_path / "python_w2_e255.npz")
     assert a["points"].shape == b["points"].shape and a["points"].shape[0] > 10000
 
     def canon(d):
@@ -74,10 +76,25 @@ def test_two_rank_pipeline_cuda_semantics(tmp_path):
     _run(0, 1, 0, str(tmp_path), "cuda")
     port = 31500 + (os.getpid() % 2000)
     mp.spawn(_run, args=(2, port, str(tmp_path), "cuda"), nprocs=2, join=True)
-    a, b = np.load(tmp_path / "cuda_w1.npz"), np.load(tmp_path / "cuda_w2.npz")
+    a, b = np.load(tmp_path / "cuda_w1_e255.npz"), np.load(tmp_path / "cuda_w2_e255.npz")
     assert abs(a["points"].shape[0] - b["points"].shape[0]) <= 12
     if a["points"].shape == b["points"].shape:
         rows = lambda d: np.concatenate([d["points"], d["colours"], d["normals"]], axis=1)
         ca, cb = rows(a), rows(b)
         ca, cb = ca[np.lexsort(ca.T[::-1])], cb[np.lexsort(cb.T[::-1])]
         assert float((np.abs(ca - cb) > 1e-5).any(axis=1).mean()) < 0.01
+
+
+def test_two_rank_pipeline_across_camera_epochs(tmp_path):
+    """More cameras than the 8-bit camera-order field holds (epoch shrunk to 2 for the test): the ranks all-reduce and
+    rebase the keys at every epoch boundary; the result must still equal the single-process run."""
+    from emu_util import build_emu
+    build_emu()
+    _run(0, 1, 0, str(tmp_path), "python", 255, 5)
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_run, args=(2, port, str(tmp_path), "python", 2, 5), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "python_w1_e255.npz"), np.load(tmp_path / "python_w2_e2.npz")
+    rows = lambda d: np.concatenate([d["points"], d["colours"], d["normals"]], axis=1)
+    ca, cb = rows(a), rows(b)
+    assert ca.shape == cb.shape
+    assert np.array_equal(ca[np.lexsort(ca.T[::-1])], cb[np.lexsort(cb.T[::-1])])
