@@ -28,39 +28,55 @@ def rank_world(group=None) -> Tuple[int, int]:
     return 0, 1
 
 
-def gather_rows(t: Optional[torch.Tensor], dst: int = 0, group=None) -> Optional[torch.Tensor]:
-    """Concatenate the ranks' [m_r, k] tensors on `dst` in rank order (None elsewhere)."""
+def gather_rows_many(tensors, dst: int = 0, group=None):
+    """Concatenate, for each tensor of the list, the ranks' [m_r, ...] pieces on `dst` in rank order (None elsewhere).
+    All tensors of one rank share m_r: ONE count exchange, then ONE batch of point-to-point transfers (RCCL groups
+    them, so the seven incoming xGMI links of `dst` are driven concurrently)."""
     rank, world = rank_world(group)
-    if world == 1 or t is None:
-        return t
-    t = t.contiguous()
-    counts = torch.zeros((world,), dtype=torch.int64, device=t.device)
-    counts[rank] = t.shape[0]
+    present = [t for t in tensors if t is not None]
+    if world == 1 or not present:
+        return list(tensors)
+    tensors = [t.contiguous() if t is not None else None for t in tensors]
+    m = present[0].shape[0]
+    counts = torch.zeros((world,), dtype=torch.int64, device=present[0].device)
+    counts[rank] = m
     dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
     counts = counts.tolist()
-    if rank == dst:
-        out = torch.empty((int(sum(counts)),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        offs = [0]
-        for c in counts:
-            offs.append(offs[-1] + int(c))
-        out[offs[rank]:offs[rank + 1]] = t
-        ops_ = [dist.P2POp(dist.irecv, out[offs[r]:offs[r + 1]], r, group) for r in range(world)
-                if r != dst and counts[r] > 0]
-        if ops_:
-            for req in dist.batch_isend_irecv(ops_):
+    if rank != dst:
+        sends = [dist.P2POp(dist.isend, t, dst, group) for t in tensors if t is not None and m > 0]
+        if sends:
+            for req in dist.batch_isend_irecv(sends):
                 req.wait()
-        return out
-    if t.shape[0] > 0:
-        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, t, dst, group)]):
+        return [None] * len(tensors)
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + int(c))
+    outs, recvs = [], []
+    for t in tensors:
+        if t is None:
+            outs.append(None)
+            continue
+        out = torch.empty((offs[-1],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        out[offs[rank]:offs[rank + 1]] = t
+        outs.append(out)
+    for r in range(world):                      # rank-major so the order matches the senders' posting order
+        if r == dst or counts[r] == 0:
+            continue
+        recvs += [dist.P2POp(dist.irecv, out[offs[r]:offs[r + 1]], r, group) for out in outs if out is not None]
+    if recvs:
+        for req in dist.batch_isend_irecv(recvs):
             req.wait()
-    return None
+    return outs
+
+
+def gather_rows(t: Optional[torch.Tensor], dst: int = 0, group=None) -> Optional[torch.Tensor]:
+    """Concatenate the ranks' [m_r, k] tensors on `dst` in rank order (None elsewhere)."""
+    return gather_rows_many([t], dst, group)[0]
 
 
 def gather_pointcloud(cloud, dst: int = 0, group=None):
     """PointCloudData of every rank's shard -> the whole cloud on `dst` (None on the other ranks)."""
-    pts = gather_rows(cloud.points, dst, group)
-    cols = gather_rows(cloud.colours, dst, group)
-    nrm = gather_rows(cloud.normals, dst, group) if cloud.normals is not None else None
+    pts, cols, nrm = gather_rows_many([cloud.points, cloud.colours, cloud.normals], dst, group)
     if rank_world(group)[0] != dst:
         return None
     return type(cloud)(points=pts, colours=cols, normals=nrm)
