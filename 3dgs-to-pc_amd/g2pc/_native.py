@@ -153,5 +153,6 @@ def profile_summary():
     """name -> (launch count, total ms); call after torch.cuda.synchronize()."""
     out = {}
     for name, evs in (PROFILE or {}).items():
-        out[name] = (len(evs), sum(a.elapsed_time(b) for a, b in evs))
+        # entries: (begin, end) torch events, or milliseconds already read from HIP events recorded inside a graph
+        out[name] = (len(evs), sum(e if isinstance(e, float) else e[0].elapsed_time(e[1]) for e in evs))
     return out

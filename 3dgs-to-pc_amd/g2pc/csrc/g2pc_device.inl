@@ -47,6 +47,24 @@ __device__ __forceinline__ unsigned wave_min_u32_dpp(unsigned v) {
 }
 #undef G2PC_DPP_STEP
 
+// ---- packed f32 pairs: v_pk_add/mul/fma_f32 retire two IEEE f32 operations per lane per issue slot (the 157 TF
+// vector peak of the part is quoted on them); element-wise results are bit-identical to the scalar instructions.
+#if defined(__clang__)
+typedef float pk2 __attribute__((ext_vector_type(2)));
+#else
+typedef float pk2 __attribute__((vector_size(8)));      // tests/hipemu builds this file with g++
+#endif
+__device__ __forceinline__ pk2 pk_make(float a, float b) { pk2 v = {a, b}; return v; }
+__device__ __forceinline__ pk2 pk_splat(float a) { pk2 v = {a, a}; return v; }
+__device__ __forceinline__ pk2 pk_fma(pk2 a, pk2 b, pk2 c) {
+#if defined(__clang__)
+    return __builtin_elementwise_fma(a, b, c);
+#else
+    pk2 r = {fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])};
+    return r;
+#endif
+}
+
 // ---- Philox4x32-10 ------------------------------------------------------------------------------
 __device__ __forceinline__ void philox_round(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3,
                                              unsigned k0, unsigned k1) {

@@ -81,7 +81,7 @@ int scan_exclusive_u32(const uint32_t* in, uint32_t* out, long n, void* ws, size
 size_t sort_workspace(long n);
 int sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
                    uint32_t* keys_tmp, uint32_t* vals_tmp, long n, int bit_lo, int bit_hi, void* ws,
-                   size_t ws_bytes, hipStream_t s);
+                   size_t ws_bytes, hipStream_t s, const uint32_t* n_dev = nullptr);
 
 // Philox4x32-10 keyed standard normals (see oracle/np_philox.py for the definition)
 struct Normal3 { float x, y, z; };

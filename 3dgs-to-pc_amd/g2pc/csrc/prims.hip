@@ -134,9 +134,11 @@ constexpr int RS_T = 256, RS_W = RS_T / kWave;
 
 template <int BITS, int ITEMS>
 __global__ __launch_bounds__(RS_T) void k_radix_hist(const uint32_t* __restrict__ keys, long n, int shift,
-                                                    unsigned mask, uint32_t* __restrict__ ghist, unsigned nb) {
+                                                    unsigned mask, uint32_t* __restrict__ ghist, unsigned nb,
+                                                    const uint32_t* __restrict__ n_dev) {
     constexpr int BINS = 1 << BITS, TILE = RS_T * ITEMS;
     __shared__ uint32_t hist[BINS];
+    if (n_dev) { const long m = (long)*n_dev; n = m < n ? m : n; }      // device-side count (n = the launch capacity)
     for (int i = threadIdx.x; i < BINS; i += RS_T) hist[i] = 0;
     __syncthreads();
     const long base = (long)blockIdx.x * TILE;
@@ -155,10 +157,16 @@ __global__ __launch_bounds__(RS_T) void k_radix_scatter(const uint32_t* __restri
                                                        uint32_t* __restrict__ keys_out,
                                                        uint32_t* __restrict__ vals_out, long n, int shift,
                                                        unsigned mask, int nbits,
-                                                       const uint32_t* __restrict__ goffs, unsigned nb) {
+                                                       const uint32_t* __restrict__ goffs, unsigned nb,
+                                                       const uint32_t* __restrict__ n_dev) {
     constexpr int BINS = 1 << BITS, TILE = RS_T * ITEMS;
     __shared__ uint32_t whist[RS_W][BINS];      // per-wave running digit counts, then exclusive offsets
     __shared__ uint32_t gbase[BINS];
+    if (n_dev) {
+        const long m = (long)*n_dev;
+        n = m < n ? m : n;
+        if ((long)blockIdx.x * TILE >= n) return;                        // idle tail block of a capacity-sized launch
+    }
     const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < RS_W * BINS; i += RS_T) (&whist[0][0])[i] = 0;
     for (unsigned d = threadIdx.x; d <= mask; d += RS_T) gbase[d] = goffs[(size_t)d * nb + blockIdx.x];
@@ -224,18 +232,21 @@ size_t sort_workspace(long n) {
 
 template <int BITS, int ITEMS>
 static void radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, long n, int bit,
-                       int nbits, uint32_t* ghist, unsigned nb, char* scan_ws, size_t scan_bytes, hipStream_t s, int& rc) {
+                       int nbits, uint32_t* ghist, unsigned nb, char* scan_ws, size_t scan_bytes, hipStream_t s, int& rc,
+                       const uint32_t* n_dev) {
     unsigned mask = (1u << nbits) - 1u;
-    hipLaunchKernelGGL((k_radix_hist<BITS, ITEMS>), dim3(nb), dim3(RS_T), 0, s, kin, n, bit, mask, ghist, nb);
+    hipLaunchKernelGGL((k_radix_hist<BITS, ITEMS>), dim3(nb), dim3(RS_T), 0, s, kin, n, bit, mask, ghist, nb, n_dev);
     rc = scan_exclusive_u32(ghist, ghist, (long)(mask + 1) * nb, scan_ws, scan_bytes, s);
     if (rc) return;
     hipLaunchKernelGGL((k_radix_scatter<BITS, ITEMS>), dim3(nb), dim3(RS_T), 0, s, kin, vin, kout, vout, n, bit, mask, nbits,
-                       ghist, nb);
+                       ghist, nb, n_dev);
 }
 
 int sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
                    uint32_t* keys_tmp, uint32_t* vals_tmp, long n, int bit_lo, int bit_hi, void* ws,
-                   size_t ws_bytes, hipStream_t s) {
+                   size_t ws_bytes, hipStream_t s, const uint32_t* n_dev) {
+    // n_dev (optional, device): the number of keys actually present (<= n).  The launch geometry then depends on n
+    // (a capacity) only, so the same sequence of launches -- e.g. a captured hipGraph -- serves any count.
     if (n <= 0) return G2PC_OK;
     if (keys_tmp == keys_in || vals_tmp == vals_in || keys_tmp == keys_out || vals_tmp == vals_out ||
         keys_out == keys_in || vals_out == vals_in) {
@@ -268,11 +279,11 @@ int sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* k
         uint32_t* kout = to_out ? keys_out : keys_tmp;
         uint32_t* vout = to_out ? vals_out : vals_tmp;
         if (maxbits == 8) {
-            if (items == 4) radix_pass<8, 4>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc);
-            else radix_pass<8, 8>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc);
+            if (items == 4) radix_pass<8, 4>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc, n_dev);
+            else radix_pass<8, 8>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc, n_dev);
         } else {
-            if (items == 4) radix_pass<11, 4>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc);
-            else radix_pass<11, 8>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc);
+            if (items == 4) radix_pass<11, 4>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc, n_dev);
+            else radix_pass<11, 8>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc, n_dev);
         }
         if (rc) return rc;
         kin = kout; vin = vout;
@@ -299,6 +310,37 @@ int g2pc_set_sort_tuning(int wide_digit_bits, int64_t small_input_keys) {
     if (wide_digit_bits != 8 && wide_digit_bits != 11) return G2PC_ERR_ARG;
     g2pc::g_radix_wide_bits = wide_digit_bits;
     g2pc::g_radix_small_n = small_input_keys;
+    return G2PC_OK;
+}
+#define G2PC_HIP_CALL(expr, where)                                                  \
+    do {                                                                            \
+        hipError_t e_ = (expr);                                                     \
+        if (e_ != hipSuccess) { g2pc::set_error(where, hipGetErrorString(e_)); return G2PC_ERR_LAUNCH; } \
+    } while (0)
+
+int g2pc_graph_capture_begin(void* stream) {
+    G2PC_REQUIRE(stream, G2PC_ERR_ARG, "capture needs a non-default stream");
+    G2PC_HIP_CALL(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal), "g2pc_graph_capture_begin");
+    return G2PC_OK;
+}
+int g2pc_graph_capture_end(void* stream, void** graph_exec) {
+    G2PC_REQUIRE(stream && graph_exec, G2PC_ERR_ARG, "bad arguments");
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    G2PC_HIP_CALL(hipStreamEndCapture((hipStream_t)stream, &graph), "g2pc_graph_capture_end");
+    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    G2PC_HIP_CALL(e, "g2pc_graph_capture_end (instantiate)");
+    *graph_exec = (void*)exec;
+    return G2PC_OK;
+}
+int g2pc_graph_launch(void* graph_exec, void* stream) {
+    G2PC_REQUIRE(graph_exec, G2PC_ERR_ARG, "null graph");
+    G2PC_HIP_CALL(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream), "g2pc_graph_launch");
+    return G2PC_OK;
+}
+int g2pc_graph_destroy(void* graph_exec) {
+    if (graph_exec) G2PC_HIP_CALL(hipGraphExecDestroy((hipGraphExec_t)graph_exec), "g2pc_graph_destroy");
     return G2PC_OK;
 }
 int g2pc_selftest_wave_reduce(const uint32_t* in, uint32_t* out, int64_t waves, void* stream) {

@@ -17,7 +17,8 @@
 namespace g2pc {
 
 constexpr int RA_T = 256;
-__global__ void k_tile_ranges(const uint32_t* __restrict__ tile_sorted, long L, int T, uint32_t* __restrict__ tile_start);
+__global__ void k_tile_ranges(const uint32_t* __restrict__ tile_sorted, long L, int T, uint32_t* __restrict__ tile_start,
+                              const uint32_t* __restrict__ l_dev);
 constexpr float LOG2E = 1.4426950408889634f;
 
 struct Cam {            // device copy of G2pcCamera (passed by value as kernel argument)
@@ -50,7 +51,9 @@ __device__ __forceinline__ void interval_range(const int32_t* __restrict__ start
     }
 }
 
-__global__ __launch_bounds__(RA_T) void k_preprocess_py(Cam cam, Layout lay, const float* __restrict__ means3D,
+template <bool CAM_ON_DEVICE>
+__global__ __launch_bounds__(RA_T) void k_preprocess_py(Cam cam_val, const Cam* __restrict__ cam_dev, Layout lay,
+                                                       const float* __restrict__ means3D,
                                                        const float* __restrict__ cov9,
                                                        const float* __restrict__ opacity, long n,
                                                        uint32_t* __restrict__ depth_key_rev,
@@ -58,8 +61,16 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_py(Cam cam, Layout lay, con
                                                        uint32_t* __restrict__ tiles_touched,
                                                        float4* __restrict__ p0, float4* __restrict__ p1,
                                                        uint32_t* __restrict__ rect) {
+    // device-resident camera: lets ONE captured launch sequence serve every camera.  Staged through LDS once per block
+    // (per-thread loads of the 172-byte struct made this kernel 6x slower than the by-value variant).
+    __shared__ Cam s_cam;
+    if (CAM_ON_DEVICE) {
+        if (threadIdx.x < sizeof(Cam) / 4) ((uint32_t*)&s_cam)[threadIdx.x] = ((const uint32_t*)cam_dev)[threadIdx.x];
+        __syncthreads();
+    }
     long i = (long)blockIdx.x * RA_T + threadIdx.x;
     if (i >= n) return;
+    const Cam& cam = CAM_ON_DEVICE ? s_cam : cam_val;
     const float x = means3D[3 * i], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
     const float* V = cam.V;
     // p_view = [x,1] @ V  (gauss_render.py:163)
@@ -159,9 +170,11 @@ __global__ __launch_bounds__(RA_T) void k_gather_u32(const uint32_t* __restrict_
 __global__ __launch_bounds__(RA_T) void k_duplicate(const uint32_t* __restrict__ sorted_idx,
                                                    const uint32_t* __restrict__ offsets,
                                                    const uint32_t* __restrict__ rect, long n, int nx,
-                                                   uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ inst_g) {
+                                                   uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ inst_g,
+                                                   const uint32_t* __restrict__ l_eff) {
     long p = (long)blockIdx.x * RA_T + threadIdx.x;
     if (p >= n) return;
+    if (l_eff && *l_eff == 0u) return;          // capacity-sized launch: nothing to emit (or more than fits)
     uint32_t off = offsets[p], end = offsets[p + 1];
     if (end == off) return;
     uint32_t g = sorted_idx[p];
@@ -196,8 +209,10 @@ __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __
                                                   const float* __restrict__ colours,
                                                   unsigned long long* __restrict__ best_key, uint32_t order_base,
                                                   float t_floor, float bg, float* __restrict__ tilebuf,
-                                                  uint32_t* __restrict__ chunk_work) {
+                                                  uint32_t* __restrict__ chunk_work,
+                                                  const G2pcCameraJob* __restrict__ job) {
     // one wave64 per block: the LDS stage is wave-private, no s_barrier anywhere
+    if (job) { order_base = job->camera_slot << 24; t_floor = job->t_floor; bg = job->cam.bg[0]; }   // see k_preprocess_py
     __shared__ float4 s_p0[BL_BATCH + 4];
     __shared__ float4 s_p1[BL_BATCH + 4];
     __shared__ float4 s_p2[BL_BATCH];
@@ -350,6 +365,157 @@ __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __
     float* out = tilebuf + 3 * (size_t)lay.tile_pix_off[tile];
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
+        if (pix[j] >= 0) {
+            out[3 * (size_t)pix[j] + 0] = fmaf(T[j], bg, cr[j]);
+            out[3 * (size_t)pix[j] + 1] = fmaf(T[j], bg, cg[j]);
+            out[3 * (size_t)pix[j] + 2] = fmaf(T[j], bg, cb[j]);
+        }
+    }
+}
+
+// K6 (PY), packed variant: a chunk = 2 consecutive 8x8 sub-blocks, lane l owns pixel (l % 8, l / 8) of both, and the two
+// pixels travel as one packed f32 pair through v_pk_{add,mul,fma}_f32 -- per Gaussian and lane 7 issue slots for the
+// two quadratic forms instead of 14, 1+1 for the transmittance recurrence instead of 4, 3 for the colours instead
+// of 6 (v_exp_f32 / v_min_f32 have no packed form).  Arithmetic per element is the scalar kernel's, bit for bit.
+// Sub-blocks are numbered row-major inside the tile, so pixel 0 of a lane always has the lower in-tile index: ties
+// between the two go to pixel 0, as the reference's arg-max does.
+template <int U>
+__global__ __launch_bounds__(BL_T) void k_blend_py_pk(Layout lay, const int32_t* __restrict__ chunk_tile,
+                                                     const int32_t* __restrict__ chunk_pix0,
+                                                     const uint32_t* __restrict__ tile_start,
+                                                     const uint32_t* __restrict__ inst_g,
+                                                     const float4* __restrict__ p0, const float4* __restrict__ p1,
+                                                     const float* __restrict__ colours,
+                                                     unsigned long long* __restrict__ best_key, uint32_t order_base,
+                                                     float t_floor, float bg, float* __restrict__ tilebuf,
+                                                     uint32_t* __restrict__ chunk_work,
+                                                     const G2pcCameraJob* __restrict__ job) {
+    if (job) { order_base = job->camera_slot << 24; t_floor = job->t_floor; bg = job->cam.bg[0]; }
+    __shared__ float4 s_p0[BL_BATCH + 4];
+    __shared__ float4 s_p1[BL_BATCH + 4];
+    __shared__ float4 s_p2[BL_BATCH];
+    __shared__ uint32_t s_g[BL_BATCH];
+    const int tile = chunk_tile[blockIdx.x];
+    const int sb0 = chunk_pix0[blockIdx.x];
+    const int ix = tile % lay.nx, iy = tile / lay.nx;
+    const int x0 = lay.xs[ix], w = lay.ws[ix], y0 = lay.ys[iy], h = lay.hs[iy];
+    const int nsbx = (w + 7) >> 3;
+    const uint32_t order_tile = order_base | ((uint32_t)lay.tile_seq[tile] << 12);
+    const unsigned lane = threadIdx.x;
+    const int lx = lane & 7, ly = lane >> 3;
+
+    int pix[2];
+    float pxs[2], pys[2], Ts[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int sb = sb0 + j;
+        int x = (sb % nsbx) * 8 + lx, y = (sb / nsbx) * 8 + ly;
+        bool valid = (x < w) && (y < h);
+        pix[j] = valid ? y * w + x : -1;
+        pxs[j] = (float)(x0 + x);
+        pys[j] = (float)(y0 + y);
+        Ts[j] = valid ? 1.0f : 0.0f;
+    }
+    const pk2 px = pk_make(pxs[0], pxs[1]), py = pk_make(pys[0], pys[1]);
+    pk2 T = pk_make(Ts[0], Ts[1]);
+    pk2 cr = pk_splat(0.f), cg = pk_splat(0.f), cb = pk_splat(0.f);
+
+    const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t g_cur = 0, g_nxt = 0;
+    bool v_cur = (start + lane) < end, v_nxt = (start + BL_BATCH + lane) < end;
+    if (v_cur) g_cur = inst_g[start + lane];
+    if (v_nxt) g_nxt = inst_g[start + BL_BATCH + lane];
+    float4 r0 = zero4, r1 = zero4;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    uint32_t gmb = 0x7F000000u;
+    const uint32_t* key_hi = (const uint32_t*)best_key + 1;
+    if (v_cur) {
+        r0 = p0[g_cur];
+        r1 = p1[g_cur];
+        gmb = key_hi[2 * (size_t)g_cur];
+        c0 = colours[3 * (size_t)g_cur]; c1 = colours[3 * (size_t)g_cur + 1]; c2 = colours[3 * (size_t)g_cur + 2];
+    }
+    uint32_t processed = 0;
+    for (uint32_t b = start; b < end; b += BL_BATCH) {
+        processed = b + BL_BATCH - start;
+        if (processed == 16 * BL_BATCH) __builtin_amdgcn_s_setprio(2);
+        wave_sync();
+        s_p0[lane] = r0;
+        s_p1[lane] = r1;
+        s_p2[lane] = make_float4(c0, c1, c2, fmaxf(__uint_as_float(gmb), 1.17549435e-38f));
+        s_g[lane] = g_cur;
+        g_cur = g_nxt;
+        v_cur = v_nxt;
+        v_nxt = (b + 2 * BL_BATCH + lane) < end;
+        g_nxt = 0;
+        if (v_nxt) g_nxt = inst_g[b + 2 * BL_BATCH + lane];
+        r0 = zero4; r1 = zero4; c0 = c1 = c2 = 0.f; gmb = 0x7F000000u;
+        if (v_cur) {
+            r0 = p0[g_cur];
+            r1 = p1[g_cur];
+            gmb = key_hi[2 * (size_t)g_cur];
+            c0 = colours[3 * (size_t)g_cur]; c1 = colours[3 * (size_t)g_cur + 1]; c2 = colours[3 * (size_t)g_cur + 2];
+        }
+        wave_sync();
+        const int cnt = (end - b) < (uint32_t)BL_BATCH ? (int)(end - b) : BL_BATCH;
+        for (int k0 = 0; k0 < cnt; k0 += U) {
+            pk2 alpha[U];
+            float4 cc[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) cc[u] = s_p2[k0 + u];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float4 a = s_p0[k0 + u], q = s_p1[k0 + u];
+                const pk2 dx = px - a.x, dy = py - a.y;
+                const pk2 power = pk_fma(dx, pk_fma(pk_splat(a.w), dy, a.z * dx), (q.x * dy) * dy);
+                const pk2 wgt = pk_make(__builtin_amdgcn_exp2f(power[0]), __builtin_amdgcn_exp2f(power[1]));
+                const pk2 al = wgt * q.y;
+                alpha[u] = pk_make(fminf(al[0], 0.99f), fminf(al[1], 0.99f));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                G2PC_PIN(alpha[u]);
+                G2PC_PIN(cc[u].x); G2PC_PIN(cc[u].y); G2PC_PIN(cc[u].z); G2PC_PIN(cc[u].w);
+            }
+            pk2 contrib[U];
+            bool any_cand = false;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float4 c = cc[u];
+                contrib[u] = T * alpha[u];
+                cr = pk_fma(contrib[u], pk_splat(c.x), cr);
+                cg = pk_fma(contrib[u], pk_splat(c.y), cg);
+                cb = pk_fma(contrib[u], pk_splat(c.z), cb);
+                T = T - contrib[u];
+                any_cand = any_cand || (fmaxf(contrib[u][0], contrib[u][1]) >= c.w);
+            }
+            if (__any(any_cand ? 1 : 0)) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float best = fmaxf(contrib[u][0], contrib[u][1]);
+                    if (__any(best >= cc[u].w)) {
+                        const uint32_t bestp = (uint32_t)(contrib[u][1] > contrib[u][0] ? pix[1] : pix[0]);
+                        uint32_t bits = __float_as_uint(best);
+                        uint32_t m = wave_max_u32_dpp(bits);
+                        uint32_t pm = wave_min_u32_dpp(bits == m ? bestp : 0xFFFFFFFFu);
+                        if (lane == 0) {
+                            unsigned long long key = ((unsigned long long)m << 32) | (unsigned long long)(uint32_t)(~(order_tile | pm));
+                            atomicMax(&best_key[s_g[k0 + u]], key);
+                        }
+                    }
+                }
+            }
+        }
+        if (__all((T[0] <= t_floor && T[1] <= t_floor) ? 1 : 0)) break;      // see k_blend_py
+    }
+    if (chunk_work && lane == 0) {
+        chunk_work[2 * blockIdx.x] = end - start;
+        chunk_work[2 * blockIdx.x + 1] = processed;
+    }
+    float* out = tilebuf + 3 * (size_t)lay.tile_pix_off[tile];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
         if (pix[j] >= 0) {
             out[3 * (size_t)pix[j] + 0] = fmaf(T[j], bg, cr[j]);
             out[3 * (size_t)pix[j] + 1] = fmaf(T[j], bg, cg[j]);
@@ -687,7 +853,9 @@ __global__ __launch_bounds__(CU_T) void k_blend_cu(int W, int H, int grid_x, con
 // tile_start[t] = first sorted instance of tile t (exclusive offsets, tile_start[T] = L): boundary detection on the
 // sorted tile ids (rasterizer_impl.cu:115-137 identifyTileRanges), no histogram, no scan.
 __global__ __launch_bounds__(RA_T) void k_tile_ranges(const uint32_t* __restrict__ tile_sorted, long L, int T,
-                                                     uint32_t* __restrict__ tile_start) {
+                                                     uint32_t* __restrict__ tile_start,
+                                                     const uint32_t* __restrict__ l_dev) {
+    if (l_dev) L = (long)*l_dev;                 // capacity-sized launch, count on the device
     long l = (long)blockIdx.x * RA_T + threadIdx.x;
     if (l > L) return;
     int prev = l == 0 ? -1 : (int)tile_sorted[l - 1];
@@ -701,6 +869,12 @@ __global__ __launch_bounds__(RA_T) void k_check_tile_load(const uint32_t* __rest
                                                          uint32_t* __restrict__ flag) {
     int t = blockIdx.x * RA_T + threadIdx.x;
     if (t < T && tile_start[t + 1] - tile_start[t] > limit) atomicMax(flag, tile_start[t + 1] - tile_start[t]);
+}
+
+// capacity-sized launches: the instance count stays on the device.  l_eff = L if it fits the buffers, else 0 (the
+// camera is then skipped altogether and the host, which receives L asynchronously, renders it again with more room)
+__global__ void k_resolve_count(const uint32_t* __restrict__ total, uint32_t capacity, uint32_t* __restrict__ l_eff) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) l_eff[0] = total[0] <= capacity ? total[0] : 0u;
 }
 
 // binding-side reductions (gaussian_pointcloud_rasterization/__init__.py:128-158): gather the colour of the arg-max
@@ -758,14 +932,104 @@ static Layout to_layout(const G2pcTileLayout* l) {
 }
 static int bits_for_tiles(unsigned t) { int b = 1; while ((1u << b) < t && b < 31) ++b; return b; }
 
+// ---- host side of the PY path, shared by the two-call API (count read back by the host) and the single-call,
+// capture-safe API (count stays on the device, launch geometry fixed by a capacity) -------------------------------
+struct PyFrontBuffers { float4 *p0, *p1; uint32_t *rect, *sorted_idx, *offsets; };
+
+static size_t py_front_ws(long n) { return align_up((size_t)n * 4) * 6 + sort_workspace(n) + scan_workspace(n) + 4096; }
+static size_t py_back_ws(long L, int T) {
+    return align_up((size_t)(L + 1) * 4) * 6 + sort_workspace(L) + scan_workspace(T + 1) + align_up((size_t)(T + 2) * 4) + 4096;
+}
+
+static int py_front(const Cam& cam_val, const Cam* cam_dev, const G2pcTileLayout* layout, const float* means3D,
+                    const float* cov9, const float* opacity, long n, const PyFrontBuffers& fb, void* ws, size_t ws_bytes,
+                    hipStream_t s) {
+    Arena ar(ws, ws_bytes);
+    uint32_t* key_rev = ar.get<uint32_t>((size_t)n);
+    uint32_t* idx_rev = ar.get<uint32_t>((size_t)n);
+    uint32_t* key_sorted = ar.get<uint32_t>((size_t)n);
+    uint32_t* ktmp = ar.get<uint32_t>((size_t)n);
+    uint32_t* vtmp = ar.get<uint32_t>((size_t)n);
+    uint32_t* touched = ar.get<uint32_t>((size_t)n);
+    size_t sort_bytes = sort_workspace(n), scan_bytes = scan_workspace(n);
+    char* sort_ws = ar.get<char>(sort_bytes);
+    char* scan_ws = ar.get<char>(scan_bytes);
+    if (!ar.ok()) { set_error("raster_front_py", "workspace too small"); return G2PC_ERR_WORKSPACE; }
+    if (cam_dev)
+        hipLaunchKernelGGL(k_preprocess_py<true>, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, cam_val, cam_dev, to_layout(layout),
+                           means3D, cov9, opacity, n, key_rev, idx_rev, touched, fb.p0, fb.p1, fb.rect);
+    else
+        hipLaunchKernelGGL(k_preprocess_py<false>, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, cam_val, cam_dev, to_layout(layout),
+                           means3D, cov9, opacity, n, key_rev, idx_rev, touched, fb.p0, fb.p1, fb.rect);
+    int rc = sort_pairs_u32(key_rev, idx_rev, key_sorted, fb.sorted_idx, ktmp, vtmp, n, 0, 32, sort_ws, sort_bytes, s);
+    if (rc) return rc;
+    // tiles touched in depth order (ktmp reused as the gathered array)
+    hipLaunchKernelGGL(k_gather_u32, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, touched, fb.sorted_idx, n, ktmp);
+    return scan_exclusive_u32(ktmp, fb.offsets, n, scan_ws, scan_bytes, s);
+}
+
+struct PyBlendArgs {                  // by value ...                      ... or device resident (job != nullptr)
+    uint32_t camera_slot; float t_floor; float bg; const G2pcCameraJob* job;
+};
+
+// L: the instance count, or (l_eff != nullptr) the capacity of the buffers with the count in device memory
+static int py_back(const G2pcTileLayout* layout, const float* colours, long n, long L, const uint32_t* l_eff,
+                   const PyBlendArgs& ba, int W, int H, const PyFrontBuffers& fb, unsigned long long* best_key,
+                   float* colours_out, float* tilebuf, float* image, int phases, uint32_t max_per_tile,
+                   uint32_t* overflow_flag, void* ws, size_t ws_bytes, hipStream_t s) {
+    const int T = layout->nx * layout->ny;
+    Arena ar(ws, ws_bytes);
+    uint32_t* inst_tile = ar.get<uint32_t>((size_t)L + 1);
+    uint32_t* inst_g = ar.get<uint32_t>((size_t)L + 1);
+    uint32_t* tile_sorted = ar.get<uint32_t>((size_t)L + 1);
+    uint32_t* g_sorted = ar.get<uint32_t>((size_t)L + 1);
+    uint32_t* tile_tmp = ar.get<uint32_t>((size_t)L + 1);       // ping-pong scratch of the multi-pass sort: must NOT
+    uint32_t* g_tmp = ar.get<uint32_t>((size_t)L + 1);          // alias its input (pass 0 writes here when #passes is even)
+    uint32_t* tile_start = ar.get<uint32_t>((size_t)T + 2);
+    size_t sort_bytes = sort_workspace(L);
+    char* sort_ws = ar.get<char>(sort_bytes);
+    if (!ar.ok()) { set_error("raster_back_py", "workspace too small"); return G2PC_ERR_WORKSPACE; }
+    Layout lay = to_layout(layout);
+    if (phases & 1) {
+        hipMemsetAsync(tile_start, 0, (size_t)(T + 2) * 4, s);
+        if (L > 0) {
+            hipLaunchKernelGGL(k_duplicate, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, fb.sorted_idx, fb.offsets, fb.rect, n, lay.nx,
+                               inst_tile, inst_g, l_eff);
+            int rc = sort_pairs_u32(inst_tile, inst_g, tile_sorted, g_sorted, tile_tmp, g_tmp, L, 0, bits_for_tiles((unsigned)T),
+                                    sort_ws, sort_bytes, s, l_eff);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T)), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start, l_eff);
+        if (overflow_flag && max_per_tile)
+            hipLaunchKernelGGL(k_check_tile_load, dim3(cdiv(T, RA_T)), dim3(RA_T), 0, s, tile_start, T, max_per_tile, overflow_flag);
+    }
+    if (phases & 2) {
+#define G2PC_BLEND(...)                                                                                                 \
+    hipLaunchKernelGGL((__VA_ARGS__), dim3((unsigned)layout->num_chunks), dim3(BL_T), 0, s, lay, layout->chunk_tile,          \
+                       layout->chunk_pix0, tile_start, g_sorted, (const float4*)fb.p0, (const float4*)fb.p1, colours,   \
+                       best_key, ba.camera_slot << 24, ba.t_floor, ba.bg, tilebuf, g_chunk_work, ba.job)
+        switch (layout->chunk_subblocks) {
+            case 1: G2PC_BLEND(k_blend_py<1, 4>); break;
+            case 2: G2PC_BLEND(k_blend_py_pk<4>); break;
+            case 4: G2PC_BLEND(k_blend_py<4, 1>); break;
+            default: set_error("raster_back_py", "chunk_subblocks must be 1, 2 or 4"); return G2PC_ERR_ARG;
+        }
+#undef G2PC_BLEND
+    }
+    if (phases & 4) {
+        hipLaunchKernelGGL(k_update_colours_py, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, lay, best_key, n, ba.camera_slot,
+                           tilebuf, colours_out);
+        if (image)
+            hipLaunchKernelGGL(k_assemble_image_py, dim3(cdiv((long)W * H, RA_T)), dim3(RA_T), 0, s, lay, W, H, tilebuf, image);
+    }
+    return G2PC_OK;
+}
+
 }  // namespace g2pc
 
 extern "C" {
 
-size_t g2pc_raster_front_workspace(int64_t n) {
-    using namespace g2pc;
-    return align_up((size_t)n * 4) * 6 + sort_workspace(n) + scan_workspace(n) + 4096;
-}
+size_t g2pc_raster_front_workspace(int64_t n) { return g2pc::py_front_ws(n); }
 
 // Front half of one camera: preprocess -> depth sort -> tiles-touched scan.  Leaves sorted_idx u32[n] and
 // offsets u32[n+1] (offsets[n] = L, the number of (tile, Gaussian) instances) for the back half.
@@ -777,33 +1041,15 @@ int g2pc_raster_front_py(const G2pcCamera* cam, const G2pcTileLayout* layout, co
                  G2PC_ERR_ARG, "bad arguments");
     G2PC_REQUIRE(layout->nx <= 256 && layout->ny <= 256, G2PC_ERR_UNSUPPORTED, "more than 256 tile intervals per axis");
     hipStream_t s = (hipStream_t)stream;
-    Arena ar(ws, ws_bytes);
-    uint32_t* key_rev = ar.get<uint32_t>((size_t)n);
-    uint32_t* idx_rev = ar.get<uint32_t>((size_t)n);
-    uint32_t* key_sorted = ar.get<uint32_t>((size_t)n);
-    uint32_t* ktmp = ar.get<uint32_t>((size_t)n);
-    uint32_t* vtmp = ar.get<uint32_t>((size_t)n);
-    uint32_t* touched = ar.get<uint32_t>((size_t)n);
-    size_t sort_bytes = sort_workspace(n), scan_bytes = scan_workspace(n);
-    char* sort_ws = ar.get<char>(sort_bytes);
-    char* scan_ws = ar.get<char>(scan_bytes);
-    G2PC_REQUIRE(ar.ok(), G2PC_ERR_WORKSPACE, "workspace too small");
-    hipLaunchKernelGGL(k_preprocess_py, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, to_cam(cam), to_layout(layout), means3D,
-                       cov9, opacity, (long)n, key_rev, idx_rev, touched, (float4*)p0, (float4*)p1, rect);
-    int rc = sort_pairs_u32(key_rev, idx_rev, key_sorted, sorted_idx, ktmp, vtmp, n, 0, 32, sort_ws, sort_bytes, s);
-    if (rc) return rc;
-    // tiles touched in depth order (ktmp reused as the gathered array)
-    hipLaunchKernelGGL(k_gather_u32, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, touched, sorted_idx, (long)n, ktmp);
-    rc = scan_exclusive_u32(ktmp, offsets, n, scan_ws, scan_bytes, s);
+    PyFrontBuffers fb{(float4*)p0, (float4*)p1, rect, sorted_idx, offsets};
+    int rc = py_front(to_cam(cam), nullptr, layout, means3D, cov9, opacity, (long)n, fb, ws, ws_bytes, s);
     if (rc) return rc;
     if (count_host) hipMemcpyAsync(count_host, offsets + n, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
     return check_launch("g2pc_raster_front_py");
 }
 
 size_t g2pc_raster_back_workspace(int64_t num_instances, int32_t num_tiles) {
-    using namespace g2pc;
-    return align_up((size_t)(num_instances + 1) * 4) * 6 + sort_workspace(num_instances) + scan_workspace(num_tiles + 1) +
-           align_up((size_t)(num_tiles + 2) * 4) + 4096;
+    return g2pc::py_back_ws((long)num_instances, num_tiles);
 }
 
 // Back half: duplicate -> stable sort by tile id -> tile ranges -> blend + visibility -> colour update.
@@ -817,58 +1063,75 @@ int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, con
                      tilebuf && ws && n > 0,
                  G2PC_ERR_ARG, "bad arguments");
     G2PC_REQUIRE(camera_slot >= 1 && camera_slot <= 255, G2PC_ERR_ARG, "camera_slot must be in [1,255]");
-    const int T = layout->nx * layout->ny;
-    G2PC_REQUIRE(T <= 4096, G2PC_ERR_UNSUPPORTED, "more than 4096 tiles");
-    hipStream_t s = (hipStream_t)stream;
-    const long L = num_instances;
-    Arena ar(ws, ws_bytes);
-    uint32_t* inst_tile = ar.get<uint32_t>((size_t)L + 1);
-    uint32_t* inst_g = ar.get<uint32_t>((size_t)L + 1);
-    uint32_t* tile_sorted = ar.get<uint32_t>((size_t)L + 1);
-    uint32_t* g_sorted = ar.get<uint32_t>((size_t)L + 1);
-    uint32_t* tile_tmp = ar.get<uint32_t>((size_t)L + 1);       // ping-pong scratch of the multi-pass sort: must NOT
-    uint32_t* g_tmp = ar.get<uint32_t>((size_t)L + 1);          // alias its input (pass 0 writes here when #passes is even)
-    uint32_t* tile_start = ar.get<uint32_t>((size_t)T + 2);
-    size_t sort_bytes = sort_workspace(L), scan_bytes = scan_workspace(T + 1);
-    char* sort_ws = ar.get<char>(sort_bytes);
-    char* scan_ws = ar.get<char>(scan_bytes);
-    G2PC_REQUIRE(ar.ok(), G2PC_ERR_WORKSPACE, "workspace too small");
-    Layout lay = to_layout(layout);
-    if (phases & 1) {
-    hipMemsetAsync(tile_start, 0, (size_t)(T + 2) * 4, s);
-    if (L > 0) {
-        hipLaunchKernelGGL(k_duplicate, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, sorted_idx, offsets, rect, (long)n, lay.nx,
-                           inst_tile, inst_g);
-        int rc = sort_pairs_u32(inst_tile, inst_g, tile_sorted, g_sorted, tile_tmp, g_tmp, L, 0, bits_for_tiles((unsigned)T),
-                                sort_ws, sort_bytes, s);
-        if (rc) return rc;
-    }
-    (void)scan_ws; (void)scan_bytes;
-    hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T)), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start);
-    if (overflow_flag && max_per_tile)
-        hipLaunchKernelGGL(k_check_tile_load, dim3(cdiv(T, RA_T)), dim3(RA_T), 0, s, tile_start, T, max_per_tile, overflow_flag);
-    }
-    if (phases & 2) {
-#define G2PC_BLEND(PPT, U)                                                                                            \
-    hipLaunchKernelGGL((k_blend_py<PPT, U>), dim3((unsigned)layout->num_chunks), dim3(BL_T), 0, s, lay, layout->chunk_tile, \
-                       layout->chunk_pix0, tile_start, g_sorted, (const float4*)p0, (const float4*)p1, colours, best_key, \
-                       camera_slot << 24, t_floor, cam->bg[0], tilebuf, g_chunk_work)
-    switch (layout->chunk_subblocks) {
-        case 1: G2PC_BLEND(1, 4); break;
-        case 2: G2PC_BLEND(2, 2); break;
-        case 4: G2PC_BLEND(4, 1); break;
-        default: set_error("g2pc_raster_back_py", "chunk_subblocks must be 1, 2 or 4"); return G2PC_ERR_ARG;
-    }
-#undef G2PC_BLEND
-    }
-    if (phases & 4) {
-    hipLaunchKernelGGL(k_update_colours_py, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, lay, best_key, (long)n, camera_slot,
-                       tilebuf, colours_out);
-    if (image)
-        hipLaunchKernelGGL(k_assemble_image_py, dim3(cdiv((long)cam->width * cam->height, RA_T)), dim3(RA_T), 0, s, lay,
-                           cam->width, cam->height, tilebuf, image);
-    }
+    G2PC_REQUIRE(layout->nx * layout->ny <= 4096, G2PC_ERR_UNSUPPORTED, "more than 4096 tiles");
+    PyFrontBuffers fb{(float4*)p0, (float4*)p1, (uint32_t*)rect, (uint32_t*)sorted_idx, (uint32_t*)offsets};
+    PyBlendArgs ba{camera_slot, t_floor, cam->bg[0], nullptr};
+    int rc = py_back(layout, colours, (long)n, (long)num_instances, nullptr, ba, cam->width, cam->height, fb, best_key,
+                     colours_out, tilebuf, image, phases, max_per_tile, overflow_flag, ws, ws_bytes, (hipStream_t)stream);
+    if (rc) return rc;
     return check_launch("g2pc_raster_back_py");
+}
+
+size_t g2pc_raster_camera_workspace(int64_t n, int64_t capacity, int32_t num_tiles) {
+    using namespace g2pc;
+    return align_up((size_t)n * 16) * 2 + align_up((size_t)n * 4) * 2 + align_up((size_t)(n + 1) * 4) + 256 +
+           py_front_ws((long)n) + py_back_ws((long)capacity, num_tiles) + 4096;
+}
+
+// One camera up to and including the blend, without any host round trip: the camera, its slot and the transmittance
+// floor are read from device memory (job_dev) and the instance count never leaves the device, so the launch sequence
+// depends on (n, capacity, layout) only and can be captured once into a hipGraph and replayed for every camera.
+int g2pc_raster_camera_py(const G2pcCameraJob* job_dev, const G2pcCameraJob* job_host, const G2pcTileLayout* layout,
+                          const float* means3D, const float* cov9, const float* opacity, const float* colours, int64_t n,
+                          int64_t capacity, unsigned long long* best_key, float* tilebuf, uint32_t* count_host,
+                          uint32_t max_per_tile, uint32_t* overflow_flag, int phases, void* ws, size_t ws_bytes,
+                          void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(job_dev && layout && means3D && cov9 && opacity && colours && best_key && tilebuf && ws && n > 0 &&
+                     capacity > 0,
+                 G2PC_ERR_ARG, "bad arguments");
+    G2PC_REQUIRE(layout->nx <= 256 && layout->ny <= 256, G2PC_ERR_UNSUPPORTED, "more than 256 tile intervals per axis");
+    G2PC_REQUIRE(layout->nx * layout->ny <= 4096, G2PC_ERR_UNSUPPORTED, "more than 4096 tiles");
+    G2PC_REQUIRE(capacity < (1ll << 31), G2PC_ERR_ARG, "capacity must be below 2^31 instances");
+    static_assert(sizeof(Cam) == sizeof(G2pcCamera), "Cam mirrors G2pcCamera");
+    hipStream_t s = (hipStream_t)stream;
+    const int T = layout->nx * layout->ny;
+    Arena ar(ws, ws_bytes);
+    PyFrontBuffers fb;
+    fb.p0 = ar.get<float4>((size_t)n);
+    fb.p1 = ar.get<float4>((size_t)n);
+    fb.rect = ar.get<uint32_t>((size_t)n);
+    fb.sorted_idx = ar.get<uint32_t>((size_t)n);
+    fb.offsets = ar.get<uint32_t>((size_t)n + 1);
+    uint32_t* l_eff = ar.get<uint32_t>(1);
+    const size_t front_bytes = py_front_ws((long)n), back_bytes = py_back_ws((long)capacity, T);
+    char* front_ws = ar.get<char>(front_bytes);
+    char* back_ws = ar.get<char>(back_bytes);
+    G2PC_REQUIRE(ar.ok(), G2PC_ERR_WORKSPACE, "workspace too small");
+    int rc;
+    if (phases & 1) {
+        if (job_host) hipMemcpyAsync((void*)job_dev, job_host, sizeof(G2pcCameraJob), hipMemcpyHostToDevice, s);
+        rc = py_front(Cam{}, (const Cam*)&job_dev->cam, layout, means3D, cov9, opacity, (long)n, fb, front_ws, front_bytes, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_resolve_count, dim3(1), dim3(64), 0, s, fb.offsets + n, (uint32_t)capacity, l_eff);
+        if (count_host) hipMemcpyAsync(count_host, fb.offsets + n, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    }
+    PyBlendArgs ba{0u, 0.0f, 0.0f, job_dev};
+    rc = py_back(layout, colours, (long)n, (long)capacity, l_eff, ba, 0, 0, fb, best_key, nullptr, tilebuf, nullptr,
+                 phases & 3, max_per_tile, overflow_flag, back_ws, back_bytes, s);
+    if (rc) return rc;
+    return check_launch("g2pc_raster_camera_py");
+}
+
+/* colour update of a camera rendered with g2pc_raster_camera_py (to be issued in camera order, see g2pc_raster_back_py) */
+int g2pc_raster_camera_update_py(const G2pcTileLayout* layout, int64_t n, uint32_t camera_slot,
+                                 const unsigned long long* best_key, const float* tilebuf, float* colours_out, void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(layout && best_key && tilebuf && colours_out && n > 0, G2PC_ERR_ARG, "bad arguments");
+    G2PC_REQUIRE(camera_slot >= 1 && camera_slot <= 255, G2PC_ERR_ARG, "camera_slot must be in [1,255]");
+    hipLaunchKernelGGL(k_update_colours_py, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, (hipStream_t)stream, to_layout(layout),
+                       best_key, (long)n, camera_slot, tilebuf, colours_out);
+    return check_launch("g2pc_raster_camera_update_py");
 }
 
 /* diagnostics: when set, the PY blend writes (list length, entries walked) per chunk into u32[2*num_chunks] */
@@ -981,13 +1244,13 @@ int g2pc_raster_back_cu(const G2pcCamera* cam, const int32_t* mask, int64_t n, i
     hipLaunchKernelGGL(k_fill_u32, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, cam_surf, (long)n, 0x7F7FFFFFu);   // FLT_MAX (k_update_cu reads it)
     if (L > 0) {
         hipLaunchKernelGGL(k_duplicate, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, sorted_idx, offsets, rect, (long)n, gx,
-                           inst_tile, inst_g);
+                           inst_tile, inst_g, (const uint32_t*)nullptr);
         int rc = sort_pairs_u32(inst_tile, inst_g, tile_sorted, g_sorted, tile_tmp, g_tmp, L, 0, bits_for_tiles((unsigned)T),
                                 sort_ws, sort_bytes, s);
         if (rc) return rc;
     }
     (void)scan_ws; (void)scan_bytes;
-    hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T)), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start);
+    hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T)), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start, (const uint32_t*)nullptr);
     }
     if (phases & 2)
     hipLaunchKernelGGL(k_blend_cu, dim3((unsigned)T), dim3(CU_T), 0, s, W, H, gx, tile_start, g_sorted, (const float4*)p0,

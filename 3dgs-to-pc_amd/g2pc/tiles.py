@@ -19,7 +19,7 @@ from typing import Dict
 
 import numpy as np
 
-SUBBLOCKS_PER_CHUNK = 1      # 8x8-pixel sub-blocks per blend wave (1, 2 or 4 pixels per lane)
+SUBBLOCKS_PER_CHUNK = 2      # 8x8-pixel sub-blocks per blend wave (1, 2 or 4 pixels per lane; 2 = packed-f32 kernel)
 
 
 def _finish(xs, ws, ys, hs, seq_of, subblocks=None) -> Dict[str, np.ndarray]:

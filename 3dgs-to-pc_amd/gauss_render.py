@@ -43,6 +43,11 @@ class _Camera(C.Structure):
                 ("bg", C.c_float * 3)]
 
 
+class _Job(C.Structure):
+    """G2pcCameraJob: what a captured camera graph reads from device memory."""
+    _fields_ = [("cam", _Camera), ("camera_slot", C.c_uint32), ("t_floor", C.c_float), ("reserved", C.c_uint32 * 3)]
+
+
 class _Layout(C.Structure):
     _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("xs", C.c_void_p), ("ws", C.c_void_p), ("ys", C.c_void_p),
                 ("hs", C.c_void_p), ("tile_seq", C.c_void_p), ("seq_tile", C.c_void_p), ("tile_pix_off", C.c_void_p),
@@ -57,6 +62,14 @@ nv._RASTER_PROTOS.update({
     "g2pc_raster_back_workspace": (C.c_size_t, [C.c_int64, C.c_int32]),
     "g2pc_raster_back_py": (C.c_int, [C.POINTER(_Camera), C.POINTER(_Layout), C.c_void_p, C.c_int64, C.c_int64] +
                             [C.c_void_p] * 5 + [C.c_uint32, C.c_float] + [C.c_void_p] * 4 + [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "g2pc_raster_camera_workspace": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32]),
+    "g2pc_raster_camera_py": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(_Layout)] + [C.c_void_p] * 4 + [C.c_int64, C.c_int64] +
+                              [C.c_void_p] * 3 + [C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "g2pc_raster_camera_update_py": (C.c_int, [C.POINTER(_Layout), C.c_int64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "g2pc_graph_capture_begin": (C.c_int, [C.c_void_p]),
+    "g2pc_graph_capture_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "g2pc_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "g2pc_graph_destroy": (C.c_int, [C.c_void_p]),
     "g2pc_raster_rebase_keys": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "g2pc_raster_debug_chunk_work": (C.c_int, [C.c_void_p]),
     "g2pc_raster_keep_winner_colours": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
@@ -91,9 +104,9 @@ class _DeviceLayout:
 
 
 class _Scratch:
-    """Per-stream scratch of one in-flight camera."""
+    """Scratch of the synchronous two-call path (image requested, first camera, emulator)."""
 
-    def __init__(self, n, device, stream=None):
+    def __init__(self, n, device):
         f32, i32 = dict(dtype=torch.float32, device=device), dict(dtype=torch.int32, device=device)
         self.p0, self.p1 = torch.empty((n, 4), **f32), torch.empty((n, 4), **f32)
         self.rect, self.sorted_idx = torch.empty((n,), **i32), torch.empty((n,), **i32)
@@ -102,23 +115,47 @@ class _Scratch:
         self.front_ws = nv.workspace(self.front_ws_bytes, device)
         self.back_ws, self.back_ws_bytes = None, 0
         self.tilebuf = None
-        self.stream = stream
-        self.count_host = torch.empty((1,), dtype=torch.int32).pin_memory() if stream is not None else None
-        self.front_done = torch.cuda.Event() if stream is not None else None
-        self.update_done = torch.cuda.Event() if stream is not None else None
-        self.stream_ptr = C.c_void_p(stream.cuda_stream) if stream is not None else None
-        # raw pointers of the fixed scratch tensors (ctypes marshalling is a visible share of the host time per camera)
         self.ptrs = tuple(nv.ptr(t) for t in (self.p0, self.p1, self.rect, self.sorted_idx, self.offsets))
         self.front_ws_ptr = nv.ptr(self.front_ws)
-        self.count_ptr = C.c_void_p(self.count_host.data_ptr()) if stream is not None else None
 
 
 # Cameras in flight when the caller does not need the image back (the pipeline of gauss_to_pc.py discards it).
-# The packed-key atomicMax makes the blends of different cameras commutative, so camera c+1's preprocess / sort /
-# binning (dozens of small launches that leave most CUs idle) and even its blend overlap camera c's blend on
-# another HIP stream, and the host never blocks on the per-camera instance-count read-back.
+# Each in-flight camera owns a HIP stream, a device-resident G2pcCameraJob and ONE captured hipGraph holding its
+# ~35 launches (preprocess, depth sort, binning, blend): per camera the host rewrites a pinned 192-byte struct and
+# issues one graph launch plus the (camera-ordered) colour update -- no read-back, no per-kernel launch cost.
+# The packed-key atomicMax makes the blends of different cameras commutative, so camera c+1's small sort / scan
+# kernels (which leave most CUs idle) and even its blend overlap camera c's blend.
 PIPELINE_STREAMS = 4
+PIPELINE_IN_EMULATOR = False      # tests: drive the capture / replay path through the CPU emulator too
+CAPACITY_HEADROOM = 1.5           # instance capacity of the captured graphs relative to the first camera's count
+MIN_CAPACITY = 1 << 16
 _LAYOUT_CACHE = {}
+
+
+class _GraphSlot:
+    """One in-flight camera of the capture-and-replay pipeline."""
+
+    def __init__(self, device, on_gpu):
+        self.on_gpu = on_gpu
+        self.stream = torch.cuda.Stream(device) if on_gpu else None
+        self.stream_ptr = C.c_void_p(self.stream.cuda_stream) if on_gpu else C.c_void_p(1)   # the emulator ignores streams
+        nbytes = C.sizeof(_Job)
+        self.job_host = torch.zeros((nbytes,), dtype=torch.uint8)
+        self.count_host = torch.zeros((1,), dtype=torch.int32)
+        if on_gpu:
+            self.job_host, self.count_host = self.job_host.pin_memory(), self.count_host.pin_memory()
+        self.job = _Job.from_address(self.job_host.data_ptr())
+        self.job_dev = torch.zeros((nbytes,), dtype=torch.uint8, device=device)
+        self.update_done = torch.cuda.Event() if on_gpu else None
+        self.graph, self.graph_key = C.c_void_p(None), None
+        self.ws, self.ws_bytes, self.tilebuf = None, 0, None
+        self.inflight = None                   # (camera struct, layout, slot, capacity) of the replay in flight
+
+    def release(self):
+        L = nv.lib()
+        if self.graph:
+            L.g2pc_graph_destroy(self.graph)
+            self.graph, self.graph_key = C.c_void_p(None), None
 
 
 class GaussHipRenderer():
@@ -157,10 +194,12 @@ class GaussHipRenderer():
         self.overflow_ptr = nv.ptr(self.overflow)
         self.scene_ptrs = (nv.ptr(self.means3D), nv.ptr(self.cov3d), nv.ptr(self.opacity))
         self.colour_ptr = nv.ptr(self.colour)
-        self.pipe = []                # lazily created per-stream scratch
-        self.pipe_next = 0
-        self.pending = []             # cameras whose front half is in flight: (scratch, cam struct, layout, slot)
+        self.slots = []               # lazily created _GraphSlot per in-flight camera
+        self.slot_next = 0
+        self.capacity = None          # instance capacity of the captured graphs (learned from the first camera)
+        self.redo = []                # cameras that did not fit their graph's capacity: (camera struct, layout, slot)
         self.last_update = None       # event after the latest colour update (updates are issued in camera order)
+        self.rerendered = 0           # cameras that overflowed their graph's capacity and went through the two-call path
         self.layouts = {}
         self.last_stats = []          # (instances L, tile-sort passes, W*H) per rendered camera
 
@@ -170,6 +209,8 @@ class GaussHipRenderer():
     def __del__(self):
         try:
             self.flush()
+            for sl in self.slots:
+                sl.release()
         except Exception:
             pass
 
@@ -232,8 +273,8 @@ class GaussHipRenderer():
         nv.check(nv.lib().g2pc_raster_rebase_keys(nv.ptr(self.best_key), self.n, nv.stream_handle(self.device)), "rebase")
         self.camera_slot = 0
 
-    def _camera_struct(self, camera):
-        cam = _Camera()
+    def _camera_struct(self, camera, cam=None):
+        cam = _Camera() if cam is None else cam
         cam.view[:] = camera.world_view_transform.reshape(-1).tolist()
         cam.proj[:] = camera.projection_matrix.reshape(-1).tolist()
         cam.tan_fovx, cam.tan_fovy = tan(camera.FoVx * 0.5), tan(camera.FoVy * 0.5)
@@ -243,34 +284,27 @@ class GaussHipRenderer():
         cam.bg[:] = [bgv, bgv, bgv]
         return cam
 
-    def _stream_ptr(self, sc):
-        return sc.stream_ptr if sc.stream is not None else nv.stream_handle(self.device)
-
     def _front(self, sc, cam, lay):
-        with nv.region("raster_front", self.device, sc.stream):
+        with nv.region("raster_front", self.device):
             nv.check(nv.lib().g2pc_raster_front_py(C.byref(cam), C.byref(lay.c), *self.scene_ptrs, self.n, *sc.ptrs,
-                                                   sc.count_ptr, sc.front_ws_ptr, sc.front_ws_bytes, self._stream_ptr(sc)),
+                                                   None, sc.front_ws_ptr, sc.front_ws_bytes, nv.stream_handle(self.device)),
                      "raster_front_py")
 
     def _back(self, sc, cam, lay, slot, num_inst, image, phases, name):
         L = nv.lib()
         need = L.g2pc_raster_back_workspace(num_inst, lay.num_tiles)
-        if need > sc.back_ws_bytes or sc.tilebuf is None or sc.tilebuf.numel() < lay.total_pixels * 3:
-            # (re)allocate on the stream that uses the buffers
-            import contextlib
-            with (torch.cuda.stream(sc.stream) if sc.stream is not None else contextlib.nullcontext()):
-                if need > sc.back_ws_bytes:
-                    sc.back_ws_bytes = int(need * 1.25)
-                    sc.back_ws = nv.workspace(sc.back_ws_bytes, self.device)
-                    sc.back_ws_ptr = nv.ptr(sc.back_ws)
-                if sc.tilebuf is None or sc.tilebuf.numel() < lay.total_pixels * 3:
-                    sc.tilebuf = torch.empty((lay.total_pixels * 3,), dtype=torch.float32, device=self.device)
-                    sc.tilebuf_ptr = nv.ptr(sc.tilebuf)
-        with nv.region(name, self.device, sc.stream):
+        if need > sc.back_ws_bytes:
+            sc.back_ws_bytes = int(need * 1.25)
+            sc.back_ws = nv.workspace(sc.back_ws_bytes, self.device)
+            sc.back_ws_ptr = nv.ptr(sc.back_ws)
+        if sc.tilebuf is None or sc.tilebuf.numel() < lay.total_pixels * 3:
+            sc.tilebuf = torch.empty((lay.total_pixels * 3,), dtype=torch.float32, device=self.device)
+            sc.tilebuf_ptr = nv.ptr(sc.tilebuf)
+        with nv.region(name, self.device):
             nv.check(L.g2pc_raster_back_py(C.byref(cam), C.byref(lay.c), self.colour_ptr, self.n, num_inst, *sc.ptrs,
                                            slot, self.t_floor, self.state_ptrs()[0], self.state_ptrs()[1], sc.tilebuf_ptr,
                                            nv.ptr(image), phases, self.MAX_GAUSSIANS_PER_TILE, self.overflow_ptr, sc.back_ws_ptr,
-                                           sc.back_ws_bytes, self._stream_ptr(sc)),
+                                           sc.back_ws_bytes, nv.stream_handle(self.device)),
                      "raster_back_py")
 
     def _note(self, lay, num_inst, W, H):
@@ -278,32 +312,117 @@ class GaussHipRenderer():
         self.last_stats.append((num_inst, (bits + 7) // 8, W * H))
         RENDER_STATS.append((num_inst, (bits + 7) // 8, W * H))
 
-    def _finish(self, entry):
-        """Back half of a pipelined camera: its instance count is (long) there; the colour updates are chained."""
-        sc, cam, lay, slot = entry
-        sc.front_done.synchronize()
-        num_inst = int(sc.count_host[0])
-        if nv.PROFILE is None:
-            self._back(sc, cam, lay, slot, num_inst, None, 3, "raster_bin+blend")
-        else:
-            self._back(sc, cam, lay, slot, num_inst, None, 1, "raster_bin")
-            self._back(sc, cam, lay, slot, num_inst, None, 2, "raster_blend")
-        if self.last_update is not None:
-            sc.stream.wait_event(self.last_update)
-        self._back(sc, cam, lay, slot, num_inst, None, 4, "raster_update")
-        sc.update_done.record(sc.stream)
-        self.last_update = sc.update_done
+    def _render_sync(self, cam, lay, slot, return_image):
+        """Two-call path on the current stream: the host reads the instance count between the halves."""
+        sc = self.sync_scratch
+        self._front(sc, cam, lay)
+        num_inst = int(sc.offsets[self.n].item())                       # the one read-back per camera
+        image = torch.empty((cam.height, cam.width, 3), dtype=torch.float32, device=self.device) if return_image else None
+        self._back(sc, cam, lay, slot, num_inst, image, 1, "raster_bin")
+        self._back(sc, cam, lay, slot, num_inst, image, 2, "raster_blend")
+        self._back(sc, cam, lay, slot, num_inst, image, 4, "raster_update")
         self._note(lay, num_inst, cam.width, cam.height)
+        return image, num_inst
+
+    # ---- capture-and-replay pipeline ------------------------------------------------------------------------------
+    def _capture(self, sl, lay, key):
+        """(Re)build the slot's hipGraph for (layout, capacity): buffers first, then one recorded camera call."""
+        L = nv.lib()
+        sl.release()
+        capacity = key[1]
+        need = L.g2pc_raster_camera_workspace(self.n, capacity, lay.num_tiles)
+        import contextlib
+        with (torch.cuda.stream(sl.stream) if sl.on_gpu else contextlib.nullcontext()):   # allocate on the stream using them
+            if need > sl.ws_bytes:
+                sl.ws = None
+                sl.ws_bytes = int(need)
+                sl.ws = nv.workspace(sl.ws_bytes, self.device)
+            if sl.tilebuf is None or sl.tilebuf.numel() < lay.total_pixels * 3:
+                sl.tilebuf = torch.empty((lay.total_pixels * 3,), dtype=torch.float32, device=self.device)
+        nv.check(L.g2pc_graph_capture_begin(sl.stream_ptr), "graph_capture_begin")
+        rc = self._camera_call(sl, lay, capacity, key[2])
+        graph = C.c_void_p(None)
+        rc_end = L.g2pc_graph_capture_end(sl.stream_ptr, C.byref(graph))
+        nv.check(rc or rc_end, "raster_camera_py (capture)")
+        sl.graph, sl.graph_key = graph, key
+
+    def _camera_call(self, sl, lay, capacity, phases):
+        return nv.lib().g2pc_raster_camera_py(nv.ptr(sl.job_dev), C.c_void_p(sl.job_host.data_ptr()), C.byref(lay.c),
+                                              *self.scene_ptrs, self.colour_ptr, self.n, capacity, self.state_ptrs()[0],
+                                              nv.ptr(sl.tilebuf), C.c_void_p(sl.count_host.data_ptr()),
+                                              self.MAX_GAUSSIANS_PER_TILE, self.overflow_ptr, phases, nv.ptr(sl.ws),
+                                              sl.ws_bytes, sl.stream_ptr)
+
+    def _retire(self, sl):
+        """The slot's previous camera: wait for it (normally long done), collect its count / timing, queue a re-render
+        if it did not fit."""
+        if sl.inflight is None:
+            return
+        cam, lay, slot, capacity = sl.inflight
+        sl.inflight = None
+        if sl.on_gpu:
+            sl.update_done.synchronize()
+        num_inst = int(sl.count_host[0])
+        if num_inst > capacity:
+            self.capacity = max(self.capacity, int(num_inst * CAPACITY_HEADROOM))
+            self.redo.append((cam, lay, slot))
+            self.rerendered += 1
+            return
+        self._note(lay, num_inst, cam.width, cam.height)
+
+    def _render_pipelined(self, camera, lay, slot):
+        L = nv.lib()
+        on_gpu = self.device.type == "cuda" and not nv.emulated()
+        if self.redo:
+            self.flush()
+        if self.capacity is None:                  # the first camera tells how many instances to expect
+            self.flush()
+            _, num_inst = self._render_sync(self._camera_struct(camera), lay, slot, False)
+            self.capacity = max(int(num_inst * CAPACITY_HEADROOM), MIN_CAPACITY)
+            return
+        if not self.slots:
+            self.slots = [_GraphSlot(self.device, on_gpu) for _ in range(PIPELINE_STREAMS)]
+            self.slot_next = 0
+        sl = self.slots[self.slot_next]
+        self.slot_next = (self.slot_next + 1) % len(self.slots)
+        self._retire(sl)
+        if on_gpu and not any(o.inflight for o in self.slots):
+            for o in self.slots:
+                o.stream.wait_stream(torch.cuda.current_stream(self.device))      # scene tensors / state are ready
+        # profiling: HIP events around the blend alone -> the graph stops before it and the blend is issued directly
+        # (this runtime refuses event-record nodes inside a captured graph)
+        key = (id(lay), self.capacity, 1 if nv.PROFILE is not None else 3)
+        if sl.graph_key != key:
+            self._capture(sl, lay, key)
+        self._camera_struct(camera, sl.job.cam)                                    # rewrite the pinned job in place
+        sl.job.camera_slot, sl.job.t_floor = slot, self.t_floor
+        nv.check(L.g2pc_graph_launch(sl.graph, sl.stream_ptr), "graph_launch")
+        if key[2] == 1:
+            with nv.region("raster_blend", self.device, sl.stream):
+                nv.check(self._camera_call(sl, lay, key[1], 2), "raster_camera_py (blend)")
+        if on_gpu and self.last_update is not None:
+            sl.stream.wait_event(self.last_update)
+        nv.check(L.g2pc_raster_camera_update_py(C.byref(lay.c), self.n, slot, self.state_ptrs()[0], nv.ptr(sl.tilebuf),
+                                                self.state_ptrs()[1], sl.stream_ptr), "raster_camera_update_py")
+        if on_gpu:
+            sl.update_done.record(sl.stream)
+            self.last_update = sl.update_done
+        cam_copy = _Camera.from_buffer_copy(sl.job.cam)
+        sl.inflight = (cam_copy, lay, slot, key[1])
 
     def flush(self):
         """Complete every camera in flight and make the running state visible to the current stream."""
-        if not self.pending and not self.pipe:
+        if not self.slots:
             return
-        while self.pending:
-            self._finish(self.pending.pop(0))
-        cur = torch.cuda.current_stream(self.device)
-        for sc in self.pipe:
-            cur.wait_stream(sc.stream)
+        for sl in self.slots:
+            self._retire(sl)
+        if self.device.type == "cuda" and not nv.emulated():
+            cur = torch.cuda.current_stream(self.device)
+            for sl in self.slots:
+                cur.wait_stream(sl.stream)
+        while self.redo:                           # cameras that overflowed their graph: two-call path, original slot
+            cam, lay, slot = self.redo.pop(0)
+            self._render_sync(cam, lay, slot, False)
 
     def check_tile_load(self):
         """Raises if some leaf tile held more Gaussians than the reference allows per tile (it would have split the
@@ -317,7 +436,6 @@ class GaussHipRenderer():
     def __call__(self, camera, return_image=True, slot=None, **kwargs):
         W, H = int(camera.image_width), int(camera.image_height)
         lay = self._layout(W, H)
-        cam = self._camera_struct(camera)
         if slot is not None:                       # caller-assigned global camera order (multi-GPU camera sharding)
             if not (1 <= slot <= 255):
                 raise ValueError("camera slot must be in [1, 255]")
@@ -328,31 +446,13 @@ class GaussHipRenderer():
             self.camera_slot += 1
         slot = self.camera_slot
 
-        pipelined = (not return_image) and PIPELINE_STREAMS > 1 and self.device.type == "cuda" and not nv.emulated()
-        if pipelined:
-            if not self.pipe:
-                self.pipe = [_Scratch(self.n, self.device, torch.cuda.Stream(self.device)) for _ in range(PIPELINE_STREAMS)]
-            while len(self.pending) >= PIPELINE_STREAMS:
-                self._finish(self.pending.pop(0))
-            sc = self.pipe[self.pipe_next]
-            self.pipe_next = (self.pipe_next + 1) % PIPELINE_STREAMS
-            if not self.pending:
-                for other in self.pipe:
-                    other.stream.wait_stream(torch.cuda.current_stream(self.device))      # scene tensors are ready
-            self._front(sc, cam, lay)              # also queues the async copy of the instance count to pinned memory
-            sc.front_done.record(sc.stream)
-            self.pending.append((sc, cam, lay, slot))
+        on_gpu = self.device.type == "cuda" and not nv.emulated()
+        if (not return_image) and PIPELINE_STREAMS > 1 and (on_gpu or (nv.emulated() and PIPELINE_IN_EMULATOR)):
+            self._render_pipelined(camera, lay, slot)
             return None, None, None, None
 
         self.flush()
-        sc = self.sync_scratch
-        self._front(sc, cam, lay)
-        num_inst = int(sc.offsets[self.n].item())                       # the one read-back per camera (synchronous path)
-        image = torch.empty((H, W, 3), dtype=torch.float32, device=self.device) if return_image else None
-        self._back(sc, cam, lay, slot, num_inst, image, 1, "raster_bin")
-        self._back(sc, cam, lay, slot, num_inst, image, 2, "raster_blend")
-        self._back(sc, cam, lay, slot, num_inst, image, 4, "raster_update")
-        self._note(lay, num_inst, W, H)
+        image, _ = self._render_sync(self._camera_struct(camera), lay, slot, return_image)
         return image, None, None, None
 
 

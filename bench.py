@@ -197,9 +197,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    nv.PROFILE = {}               # before the warm-up: the camera graphs are captured with their timing events
     for w in range(a.warmup):
         one_step(scene, cams, workload, total_points, device, seed=100 + w)
-    nv.PROFILE = {}
+    nv.PROFILE.clear()
     if workload != "sample":
         gauss_render.RENDER_STATS.clear()
     sync()

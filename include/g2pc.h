@@ -46,6 +46,17 @@ int g2pc_scan_exclusive_u32(const uint32_t* in, uint32_t* out, int64_t n, void* 
 size_t g2pc_sort_workspace(int64_t n);
 /* tuning: digit width (8 or 11 bits) for sorts of more than 8 bits; inputs up to small_input_keys use 4 keys/thread */
 int g2pc_set_sort_tuning(int wide_digit_bits, int64_t small_input_keys);
+
+/* --- hipGraph capture of a sequence of g2pc_* calls --------------------------------------------------------------------
+ * Every g2pc_* entry point only queues work on `stream` (no allocation, no synchronisation), so whatever is called
+ * between g2pc_graph_capture_begin(stream) and g2pc_graph_capture_end(stream, &graph) -- on that stream, with fixed
+ * sizes -- is recorded instead of executed and can then be replayed with ONE launch per replay.  `stream` must be a
+ * non-default stream. */
+int g2pc_graph_capture_begin(void* stream);
+int g2pc_graph_capture_end(void* stream, void** graph_exec);
+int g2pc_graph_launch(void* graph_exec, void* stream);
+int g2pc_graph_destroy(void* graph_exec);
+
 /* stable LSD radix sort of (key,value) pairs on key bits [bit_lo, bit_hi) */
 int g2pc_sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
                         uint32_t* keys_tmp, uint32_t* vals_tmp, int64_t n, int bit_lo, int bit_hi, void* ws,
@@ -206,6 +217,38 @@ int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, con
                         const uint32_t* sorted_idx, const uint32_t* offsets, uint32_t camera_slot, float t_floor,
                         unsigned long long* best_key, float* colours_out, float* tilebuf, float* image, int phases,
                         uint32_t max_per_tile, uint32_t* overflow_flag, void* ws, size_t ws_bytes, void* stream);
+/* --- the same camera without a host round trip (capture-safe) -----------------------------------------------------
+ * The two-call API above makes the host read the instance count between the halves (as the reference does at
+ * rasterizer_impl.cu:289) and costs ~35 kernel launches per camera; with ~0.5 ms of GPU work per camera the host's
+ * launch rate becomes the bound.  g2pc_raster_camera_py runs preprocess .. blend with every per-camera value in
+ * DEVICE memory: the camera, its slot and the transmittance floor in a G2pcCameraJob, the instance count L in the
+ * workspace.  All launch geometry derives from (n, capacity, layout), so the call can be captured once
+ * (g2pc_graph_capture_begin / _end) and replayed for every camera with one g2pc_graph_launch.
+ *   job_host (optional, PINNED host memory): copied to job_dev by the first queued operation -- inside a graph the
+ *            copy node re-reads it at every replay, so the host only rewrites the pinned struct between replays.
+ *   capacity: instances the buffers hold.  A camera with L > capacity is skipped as a whole (nothing is blended);
+ *            count_host (optional, PINNED) always receives the true L, so the caller can detect this and render the
+ *            camera again with more room.
+ *   phases:  bit 0 = preprocess .. tile ranges, bit 1 = blend; 3 = the whole camera.  (A caller that wants HIP events
+ *            around the blend alone captures phase 1 and issues phase 2 directly: this runtime refuses event-record
+ *            nodes inside a captured graph.)
+ * The colour update is not part of the call: updates must be issued in camera order across streams
+ * (g2pc_raster_camera_update_py, after the caller's cross-stream wait).  ws: g2pc_raster_camera_workspace bytes, private
+ * to the stream (it holds p0/p1/rect/sorted_idx/offsets too). */
+typedef struct G2pcCameraJob {       /* DEVICE (and pinned host staging) struct */
+    G2pcCamera cam;
+    uint32_t camera_slot;            /* [1,255], see g2pc_raster_back_py */
+    float t_floor;
+    uint32_t reserved[3];
+} G2pcCameraJob;
+size_t g2pc_raster_camera_workspace(int64_t n, int64_t capacity, int32_t num_tiles);
+int g2pc_raster_camera_py(const G2pcCameraJob* job_dev, const G2pcCameraJob* job_host, const G2pcTileLayout* layout,
+                          const float* means3D, const float* cov9, const float* opacity, const float* colours, int64_t n,
+                          int64_t capacity, unsigned long long* best_key, float* tilebuf, uint32_t* count_host,
+                          uint32_t max_per_tile, uint32_t* overflow_flag, int phases, void* ws, size_t ws_bytes,
+                          void* stream);
+int g2pc_raster_camera_update_py(const G2pcTileLayout* layout, int64_t n, uint32_t camera_slot,
+                                 const unsigned long long* best_key, const float* tilebuf, float* colours_out, void* stream);
 int g2pc_raster_rebase_keys(unsigned long long* best_key, int64_t n, void* stream);
 /* diagnostics: when non-NULL, the PY blend records (tile list length, entries walked) per chunk in u32[2*num_chunks] */
 int g2pc_raster_debug_chunk_work(uint32_t* buf);

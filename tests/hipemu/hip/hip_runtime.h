@@ -59,9 +59,29 @@ typedef int hipError_t;
 static inline hipError_t hipGetLastError() { return 0; }
 static inline hipError_t hipPeekAtLastError() { return 0; }
 static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
-static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
-static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
+// ---- stream capture / graphs: while capturing, queued operations are recorded as closures instead of executed ----
+typedef void* hipEvent_t;
+namespace hipemu {
+struct Graph { std::vector<std::function<void()>> ops; };
+inline Graph*& capturing() { static Graph* g = nullptr; return g; }
+template <typename F> inline void submit(F f) { if (capturing()) capturing()->ops.push_back(f); else f(); }
+}  // namespace hipemu
+typedef hipemu::Graph* hipGraph_t;
+typedef hipemu::Graph* hipGraphExec_t;
+enum hipStreamCaptureStatus { hipStreamCaptureStatusNone = 0, hipStreamCaptureStatusActive = 1 };
+#define hipStreamCaptureModeThreadLocal 1
+#define hipEventRecordDefault 0u
+#define hipEventRecordExternal 1u
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { hipemu::submit([=]() { memset(p, v, n); }); return 0; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { hipemu::submit([=]() { memcpy(d, s, n); }); return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+static inline hipError_t hipStreamBeginCapture(hipStream_t, int) { hipemu::capturing() = new hipemu::Graph(); return 0; }
+static inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = hipemu::capturing(); hipemu::capturing() = nullptr; return 0; }
+static inline hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* st) { *st = hipemu::capturing() ? hipStreamCaptureStatusActive : hipStreamCaptureStatusNone; return 0; }
+static inline hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, void*, void*, size_t) { *e = new hipemu::Graph(*g); return 0; }
+static inline hipError_t hipGraphDestroy(hipGraph_t g) { delete g; return 0; }
+static inline hipError_t hipGraphExecDestroy(hipGraphExec_t g) { delete g; return 0; }
+static inline hipError_t hipGraphLaunch(hipGraphExec_t g, hipStream_t) { for (auto& op : g->ops) op(); return 0; }
 
 namespace hipemu {
 struct Fiber {
@@ -152,7 +172,13 @@ inline void run_block(unsigned bx, unsigned by, unsigned bz) {
     }
 }
 template <typename K, typename... A>
+inline void launch_now(K kernel, dim3 grid, dim3 block, A... args);
+template <typename K, typename... A>
 inline void launch(K kernel, dim3 grid, dim3 block, A... args) {
+    submit([=]() { launch_now(kernel, grid, block, args...); });
+}
+template <typename K, typename... A>
+inline void launch_now(K kernel, dim3 grid, dim3 block, A... args) {
     State& s = S();
     s.grid = grid; s.block = block;
     s.nthreads = block.x * block.y * block.z;
