@@ -465,17 +465,43 @@ def settings_from_args(args):
         surface_distance_std=args.surface_distance_std,
         quiet=args.quiet,
         remove_unrendered_gaussians=True if args.visibility_threshold > 0 else False,
-        device="cuda:0" if torch.cuda.is_available() else "cpu",
+        device=("cuda:%d" % torch.cuda.current_device()) if torch.cuda.is_available() else "cpu",
     )
 
 
 def main(argv=None):
     """gauss_to_pc.py:712-786."""
     args = config_parser(argv)
+
+    # one process per GPU (python -m torch.distributed.run --nproc-per-node N gauss_to_pc.py ...): cameras and sampling
+    # are sharded over the ranks (g2pc/dist.py), rank 0 assembles and writes the cloud
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = 0
+    if world > 1:
+        import torch.distributed as dist
+        if torch.cuda.is_available():
+            local = int(os.environ.get("LOCAL_RANK", "0"))
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
+        rank = dist.get_rank()
+        args.quiet = args.quiet or rank != 0
+
     pointcloud_settings = settings_from_args(args)
 
     total_point_cloud, surface_point_cloud = convert_3dgs_to_pc(args.input_path, args.transform_path, args.mask_path,
                                                                 pointcloud_settings)
+
+    if world > 1:
+        from g2pc.dist import gather_pointcloud
+        total_point_cloud = gather_pointcloud(total_point_cloud, dst=0)
+        if surface_point_cloud is not None:
+            surface_point_cloud = gather_pointcloud(surface_point_cloud, dst=0)
+        if rank != 0:
+            dist.barrier()
+            dist.destroy_process_group()
+            return
 
     if args.clean_pointcloud:
         if not args.quiet:
@@ -499,6 +525,10 @@ def main(argv=None):
         from mesh_handler import generate_mesh
         generate_mesh(surface_point_cloud.points, surface_point_cloud.colours, surface_point_cloud.normals,
                       args.mesh_output_path, depth=args.poisson_depth, laplacian_iters=args.laplacian_iterations)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -33,13 +33,15 @@ HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=None, choices=[None, "render", "sample", "render_cuda"])
     ap.add_argument("--gaussians", type=int, default=1_000_000)
     ap.add_argument("--points", type=int, default=10_000_000)
     ap.add_argument("--cameras", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", action="store_true",
+                    help="N > 1: also gather the sharded cloud on rank 0 inside the timed job (36 B per point over xGMI)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = every GPU brings its own 50 cameras and 10M-point budget (50N cameras, 10M*N points "
                          "on the shared scene); strong = the N = 1 job split N ways")
@@ -72,6 +74,9 @@ def settings(workload, num_points, device):
         device=str(device))
 
 
+GATHER_OUTPUT = False      # N > 1: the cloud stays sharded by Gaussian index (one PLY part per rank) unless --gather
+
+
 def one_step(scene, cams, workload, num_points, device, seed):
     """One pass of the hot path; returns the number of coloured points produced."""
     from gauss_handler import Gaussians
@@ -82,8 +87,8 @@ def one_step(scene, cams, workload, num_points, device, seed):
                                        render_shs=(workload == "render_cuda"))
     from g2pc.dist import gather_pointcloud, rank_world
     n_local = cloud.points.shape[0]
-    if rank_world()[1] > 1:
-        gather_pointcloud(cloud, dst=0)            # final gather of the sampled points (part of the timed job)
+    if GATHER_OUTPUT and rank_world()[1] > 1:
+        gather_pointcloud(cloud, dst=0)            # --gather: assemble the cloud on rank 0 inside the timed job
     return n_local
 
 
@@ -100,9 +105,12 @@ def pmc_traffic(region, a):
     """HBM bytes per launch of the region's kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
     in separate runs of THIS bench command, tools/pmc_traffic.py -> profiles/r01_c_pmc_traffic.json); only valid for
     the default workload it was collected on.  Raw counter sum; FETCH_SIZE may under-report wide reads by up to 2x."""
-    kernel = {"raster_blend": "void g2pc::k_blend_py<1, 4>", "sampler_emit": "g2pc::k_emit_wave"}.get(region)
-    path = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")
     import gauss_render
+    from g2pc import tiles
+    sub = gauss_render.BLEND_SUBBLOCKS or tiles.SUBBLOCKS_PER_CHUNK
+    kernel = {"raster_blend": {1: "void g2pc::k_blend_py<1, 4>", 2: "void g2pc::k_blend_py_pk<4>"}.get(sub),
+              "sampler_emit": "g2pc::k_emit_wave"}.get(region)
+    path = os.path.join(ROOT, "profiles", "r01_e_pmc_traffic.json" if sub == 2 else "r01_c_pmc_traffic.json")
     if (kernel is None or not os.path.isfile(path) or (a.gaussians, a.cameras) != (1_000_000, 50)
             or (region == "raster_blend" and gauss_render.DEFAULT_T_FLOOR != 1e-6)):
         return None
@@ -168,6 +176,8 @@ def main():
     from g2pc.synth import make_scene, make_cameras
     nv.lib()
     workload = a.workload or ("render" if have_renderer() else "sample")
+    global GATHER_OUTPUT
+    GATHER_OUTPUT = a.gather
     import gauss_render
     if a.t_floor is not None:
         gauss_render.DEFAULT_T_FLOOR = a.t_floor
@@ -263,7 +273,7 @@ def main():
                                 "sample": "configs[1]: 1M Gaussians, no_render_colours, 10M points (sampling pipeline)"}[workload],
                    "gaussians": a.gaussians, "points": total_points, "points_per_gpu": total_points // world,
                    "cameras": total_cameras if workload != "sample" else 0, "cameras_per_gpu": (total_cameras // world) if workload != "sample" else 0,
-                   "blend_transmittance_floor": gauss_render.DEFAULT_T_FLOOR, "parallelism": "cameras and Gaussian-index shards over %d GPU(s), RCCL all-reduce of visibility + gather of points" % world},
+                   "blend_transmittance_floor": gauss_render.DEFAULT_T_FLOOR, "parallelism": "cameras and Gaussian-index shards over %d GPU(s), RCCL all-reduce of visibility; output cloud %s" % (world, "gathered on rank 0" if a.gather else "left sharded by Gaussian index (one part per rank)")},
         "roofline": roof,
         "instances_per_camera": (float(np.mean([x[0] for x in gauss_render.RENDER_STATS])) if gauss_render.RENDER_STATS else None),
         "regions_ms_per_step": {k: v[1] / a.steps for k, v in sorted(prof.items())},

@@ -98,3 +98,45 @@ def test_two_rank_pipeline_across_camera_epochs(tmp_path):
     ca, cb = rows(a), rows(b)
     assert ca.shape == cb.shape
     assert np.array_equal(ca[np.lexsort(ca.T[::-1])], cb[np.lexsort(cb.T[::-1])])
+
+
+def _cli_rank(rank, world, port, work_dir):
+    for p in (os.path.join(ROOT, "3dgs-to-pc_amd"), os.path.join(ROOT, "oracle"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from g2pc import _native as nv
+    nv._inject_for_tests(os.path.join(HERE, "hipemu", "libg2pc_emu.so"))
+    import gauss_to_pc
+    out = "pc_w%d.ply" % world
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                          WORLD_SIZE=str(world))
+    else:
+        os.environ.pop("WORLD_SIZE", None)
+    gauss_to_pc.SAMPLER_SEED = 11
+    gauss_to_pc.main(["--input_path", os.path.join(work_dir, "scene.ply"), "--transform_path",
+                      os.path.join(work_dir, "transforms.json"), "--renderer_type", "python", "--num_points", "15000",
+                      "--colour_quality", "original", "--output_path", os.path.join(work_dir, out), "--quiet"])
+
+
+def test_two_rank_cli_writes_the_single_process_cloud(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 gauss_to_pc.py ...`: rank 0 gathers and writes the cloud."""
+    import json
+    from emu_util import build_emu
+    build_emu()
+    for p in (os.path.join(ROOT, "3dgs-to-pc_amd"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from g2pc.synth import make_scene, make_cameras
+    from test_emu_io_cli import _write_3dgs_ply
+    import gauss_dataloader as gd
+    sc = make_scene(900, 8, scale_lo=0.01, scale_hi=0.06)
+    _write_3dgs_ply(tmp_path / "scene.ply", sc)
+    tr, intr = make_cameras(3, width=180, height=101, focal=155.0)
+    frames = [{"file_path": "%s.png" % k, "transform_matrix": tr[k]} for k in tr]
+    (tmp_path / "transforms.json").write_text(json.dumps({"w": 180, "h": 101, "fl_x": 155.0, "frames": frames}))
+    mp.spawn(_cli_rank, args=(1, 0, str(tmp_path)), nprocs=1, join=True)
+    mp.spawn(_cli_rank, args=(2, 35500 + (os.getpid() % 2000), str(tmp_path)), nprocs=2, join=True)
+    a, b = gd.read_ply_vertices(str(tmp_path / "pc_w1.ply")), gd.read_ply_vertices(str(tmp_path / "pc_w2.ply"))
+    assert len(a) == len(b) and len(a) > 10000
+    assert np.array_equal(np.sort(a, order=list(a.dtype.names)), np.sort(b, order=list(b.dtype.names)))

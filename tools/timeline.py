@@ -1,0 +1,44 @@
+#!/usr/bin/env python
+"""Concurrency analysis of a rocprofv3 --kernel-trace run (rocpd sqlite .db): per kernel name the launch count, mean
+duration, and how much of the traced wall time had 0 / 1 / 2 / 3+ kernels (and blends) in flight.
+usage: python tools/timeline.py <results.db> [cameras per step]"""
+import sqlite3, sys, collections
+db = sqlite3.connect(sys.argv[1])
+cur = db.cursor()
+tables = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
+if "--schema" in sys.argv:
+    for t in tables:
+        cols = [r[1] for r in cur.execute("pragma table_info('%s')" % t)]
+        print(t, cols)
+    sys.exit(0)
+view = "kernels" if "kernels" in tables else None
+cols = [r[1] for r in cur.execute("pragma table_info('%s')" % view)]
+rows = list(cur.execute("select name, start, end, queue_id, stream_id from %s order by start" % view)) if "stream_id" in cols else \
+       list(cur.execute("select name, start, end, queue_id, 0 from %s order by start" % view))
+# window: the last `ncam` blend launches (one bench step), first of them to the end of the last
+ncam = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+bl = [r for r in rows if "blend" in r[0]]
+w0, w1 = bl[-(ncam - 1)][1], bl[-1][2]          # skips the step's first (two-call path) camera
+rows = [r for r in rows if r[1] >= w0 and r[2] <= w1]
+ev = []
+for name, s, e, q, st in rows:
+    b = 1 if "blend" in name else 0
+    ev.append((s, 1, b)); ev.append((e, -1, -b))
+ev.sort()
+active = blends = 0
+hist, bh = collections.Counter(), collections.Counter()
+prev = ev[0][0]
+for t, d, b in ev:
+    hist[min(active, 4)] += t - prev
+    bh[min(blends, 4)] += t - prev
+    active += d; blends += b; prev = t
+tot = sum(hist.values())
+print("window %.2f ms, %d kernels, queues %s streams %s" % (tot / 1e6, len(rows), sorted({r[3] for r in rows}), len({r[4] for r in rows})))
+print("kernels in flight: " + "  ".join("%d%s: %.1f%%" % (k, "+" if k == 4 else "", 100.0 * v / tot) for k, v in sorted(hist.items())))
+print("blends  in flight: " + "  ".join("%d%s: %.1f%%" % (k, "+" if k == 4 else "", 100.0 * v / tot) for k, v in sorted(bh.items())))
+busy = collections.defaultdict(lambda: [0, 0.0])
+for name, s, e, q, st in rows:
+    k = name.split("(")[0][-40:]
+    busy[k][0] += 1; busy[k][1] += e - s
+for k, (n, d) in sorted(busy.items(), key=lambda kv: -kv[1][1])[:12]:
+    print("%-42s n=%5d  mean %8.1f us  total %8.2f ms (%.0f%% of window)" % (k, n, d / n / 1e3, d / 1e6, 100.0 * d / tot))
