@@ -909,6 +909,16 @@ __global__ __launch_bounds__(RA_T) void k_update_cu(const unsigned long long* __
     if (cur_surf) cur_surf[i] = sd;
 }
 
+// _C.mark_visible (rasterize_points.cu:147-166 -> checkFrustum -> in_frustum, auxiliary.h:151-176): z_view > 0.2
+struct View16 { float m[16]; };
+__global__ __launch_bounds__(RA_T) void k_mark_visible(View16 V, const float* __restrict__ means3D, long n,
+                                                      uint8_t* __restrict__ present) {
+    long i = (long)blockIdx.x * RA_T + threadIdx.x;
+    if (i >= n) return;
+    const float x = means3D[3 * i], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
+    present[i] = (V.m[2] * x + V.m[6] * y + V.m[10] * z + V.m[14]) > 0.2f ? 1 : 0;
+}
+
 __global__ __launch_bounds__(RA_T) void k_fill_u32(uint32_t* __restrict__ p, long n, uint32_t v) {
     long i = (long)blockIdx.x * RA_T + threadIdx.x;
     if (i < n) p[i] = v;
@@ -1152,6 +1162,15 @@ int g2pc_raster_keep_winner_colours(const unsigned long long* local_key, const u
     hipLaunchKernelGGL(k_keep_winner_colours, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, (hipStream_t)stream, local_key,
                        global_key, (long)n, (int)rank, colours);
     return check_launch("g2pc_raster_keep_winner_colours");
+}
+
+int g2pc_mark_visible(const float* means3D, int64_t n, const float* viewmatrix, uint8_t* present, void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(means3D && viewmatrix && present && n > 0, G2PC_ERR_ARG, "bad arguments");
+    View16 V;
+    for (int i = 0; i < 16; ++i) V.m[i] = viewmatrix[i];
+    hipLaunchKernelGGL(k_mark_visible, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, (hipStream_t)stream, V, means3D, (long)n, present);
+    return check_launch("g2pc_mark_visible");
 }
 
 int g2pc_raster_contributions(const unsigned long long* best_key, int64_t n, float* out, void* stream) {

@@ -50,6 +50,7 @@ nv._RASTER_PROTOS.update({
                              [_vp] * 9 + [C.c_size_t, _vp]),
     "g2pc_raster_back_cu": (C.c_int, [C.POINTER(_Camera), _vp, C.c_int64, C.c_int64] + [_vp] * 6 + [C.c_int] + [_vp] * 10 +
                             [C.c_int32] + [_vp] * 3 + [C.c_int, _vp, C.c_size_t, _vp]),
+    "g2pc_mark_visible": (C.c_int, [_vp, C.c_int64, C.POINTER(C.c_float * 16), _vp, _vp]),
 })
 if nv._LIB is not None:
     nv._bind(nv._LIB)
@@ -285,6 +286,16 @@ class GaussianRasterizer(nn.Module):
 
     def get_predicted_surface_gaussians(self, predicted_surface_std=0.5):
         return self.get_surface_gaussians_below_distance_threshold(predicted_surface_std)
+
+    def markVisible(self, positions, raster_settings):
+        """Frustum test of the native rasteriser (commented out in the reference's binding, __init__.py:79-88; the
+        native entry `_C.mark_visible` is still exported there): bool[P], centre in front of the near plane."""
+        positions = positions.to(torch.float32).contiguous()
+        out = torch.empty((positions.shape[0],), dtype=torch.uint8, device=positions.device)
+        view = (C.c_float * 16)(*raster_settings.viewmatrix.reshape(-1).tolist())
+        nv.check(nv.lib().g2pc_mark_visible(nv.ptr(positions), positions.shape[0], C.byref(view), nv.ptr(out),
+                                            nv.stream_handle(positions.device)), "mark_visible")
+        return out.bool()
 
     def all_reduce_visibility(self, group=None):
         """Multi-GPU, cameras sharded over ranks.  max / min / sum are exact up to the fp32 order of the SUM; the

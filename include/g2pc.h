@@ -94,6 +94,31 @@ int g2pc_compact_index(const uint8_t* mask, int64_t n, uint32_t* index, uint32_t
                        void* stream);
 int g2pc_gather_rows(const void* src, const uint32_t* index, int64_t m, int32_t row_bytes, void* dst, void* stream);
 
+/* --- clean_point_cloud (mesh_handler.py:89-94), "next" row f4 -----------------------------------------------------
+ * The reference hands the cloud to Open3D (not vendored, version unpinned): PointCloud::RemoveStatisticalOutliers(
+ * nb_neighbors = 20, std_ratio): for every point the mean Euclidean distance to its nb_neighbors nearest points (the
+ * point itself included at distance 0; float64; distances summed in ascending order); kept when
+ * 0 < mean < mean(means) + std_ratio * std(means) (sample std, over the means > 0).
+ * Here the means come from an exact kNN on a uniform grid: _grid_build bins the points into cubic cells of edge `cell`
+ * (grid origin[3], dims[3], dims[0]*dims[1]*dims[2] < 2^31; points outside are clamped into the border cells -- pass the
+ * bounding box) -> sorted_pos f32[m,4] (x, y, z, original index bits) in cell order, cell_start u32[cells+1], and
+ * (optional) the number of non-empty cells in *occupied (device) so the caller can refine the resolution;
+ * _knn_mean_distance searches growing shells of cells until the k-th distance is provably final and writes the
+ * mean distance of point i (original order) to avg[i] (f64).  k <= 32.  slack: absolute safety margin subtracted from
+ * the shell bound (covers the float rounding of the cell assignment; 1e-5 * cell + 1e-6 * max|coordinate| is ample).
+ * Queries: all m points (query_idx NULL) or the num_queries original indices in query_idx (then `points`, the cloud in
+ * original order, supplies their coordinates).  A query still open after max_rings shells is not answered but appended
+ * to unresolved[*unresolved_count] (device u32[queries], device u32 zeroed by the call): the caller rebuilds the grid
+ * with a larger cell and asks again for those -- a cascade that ends when the shells cover the whole grid. */
+size_t g2pc_outlier_grid_workspace(int64_t m);
+int g2pc_outlier_grid_build(const float* points, int64_t m, const float* origin, float cell, const int32_t* dims,
+                            float* sorted_pos, uint32_t* cell_start, uint32_t* occupied, void* ws, size_t ws_bytes,
+                            void* stream);
+int g2pc_outlier_knn_mean_distance(const float* sorted_pos, const uint32_t* cell_start, int64_t m, const float* origin,
+                                   float cell, const int32_t* dims, int32_t k, double slack, const float* points,
+                                   const uint32_t* query_idx, int64_t num_queries, int32_t max_rings, uint32_t* unresolved,
+                                   uint32_t* unresolved_count, double* avg, void* stream);
+
 /* save_xyz_to_ply (gauss_dataloader.py:118-202), "next" row f1: pack m binary-little-endian PLY vertex records
  * (x y z [nx ny nz] red green blue; 27 bytes with normals, 15 without; colours f32 -> uchar by truncation) into `out`
  * (device, 4-byte aligned, at least ceil(m*rec/4)*4 bytes). */
@@ -285,6 +310,10 @@ int g2pc_raster_back_cu(const G2pcCamera* cam, const int32_t* mask, int64_t n, i
  * were rebased after an earlier exchange are shared by all ranks: only `rank` 0 keeps their colour. */
 int g2pc_raster_keep_winner_colours(const unsigned long long* local_key, const unsigned long long* global_key,
                                     int64_t n, int32_t rank, float* colours, void* stream);
+/* _C.mark_visible (rasterize_points.h:43-46, unused by the reference's own pipeline): present[i] = the Gaussian centre is
+ * in front of the near plane of the native rasteriser (z_view > 0.2, auxiliary.h:166).  viewmatrix: HOST float[16] as in
+ * G2pcCamera.view. */
+int g2pc_mark_visible(const float* means3D, int64_t n, const float* viewmatrix, uint8_t* present, void* stream);
 /* gaussian_max_contribution f32[n] out of the packed keys (gauss_render.py:243-264 getters read this) */
 int g2pc_raster_contributions(const unsigned long long* best_key, int64_t n, float* out, void* stream);
 
