@@ -263,6 +263,13 @@ def main():
                     "algorithmic_bytes_per_launch": per_launch,
                     "note": "k_blend_py is VALU/v_exp bound, not HBM bound (DESIGN.md §3); frac is its HBM share only"
                     if name == "raster_blend" else None}
+    stats = gauss_render.RENDER_STATS[-(len(gauss_render.RENDER_STATS) // max(a.steps, 1)):] if gauss_render.RENDER_STATS else []
+    b_total = algorithmic_bytes(workload, a.gaussians, a.gaussians, points / max(a.steps, 1), cams, stats)
+    job_hbm = {"algorithmic_bytes_per_step": b_total, "achieved": b_total / (dt / a.steps) / 1e9, "peak": HBM_PEAK_GBS,
+               "unit": "GB/s", "frac": b_total / (dt / a.steps) / 1e9 / HBM_PEAK_GBS,
+               "note": "rank 0's share; B_samp uses N_kept = N (upper bound)"}
+    if workload == "render_cuda":
+        job_hbm = None                 # per-camera instance counts are not collected on this path
     out = {
         "metric": "coloured points/sec", "value": points_all / dt_all, "unit": "points/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt_all / a.steps * 1e3, "higher_is_better": True,
@@ -275,6 +282,8 @@ def main():
                    "cameras": total_cameras if workload != "sample" else 0, "cameras_per_gpu": (total_cameras // world) if workload != "sample" else 0,
                    "blend_transmittance_floor": gauss_render.DEFAULT_T_FLOOR, "parallelism": "cameras and Gaussian-index shards over %d GPU(s), RCCL all-reduce of visibility; output cloud %s" % (world, "gathered on rank 0" if a.gather else "left sharded by Gaussian index (one part per rank)")},
         "roofline": roof,
+        # the whole job against the HBM roofline (B_total = B_geom + C * B_cam + B_samp, per rank)
+        "job_hbm": job_hbm,
         "instances_per_camera": (float(np.mean([x[0] for x in gauss_render.RENDER_STATS])) if gauss_render.RENDER_STATS else None),
         "regions_ms_per_step": {k: v[1] / a.steps for k, v in sorted(prof.items())},
     }

@@ -12,6 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--gaussians", type=int, default=1_000_000)
 ap.add_argument("--points", type=int, default=10_000_000)
 ap.add_argument("--subblocks", type=int, default=None)
+ap.add_argument("--workload", default="render", choices=["render", "render_cuda", "sample"])
 a = ap.parse_args()
 if a.subblocks:
     gauss_render.BLEND_SUBBLOCKS = a.subblocks
@@ -33,21 +34,27 @@ G.filter_gaussians = timed("filter_gaussians", G.filter_gaussians)
 G.validate_covariances = timed("validate_covariances", G.validate_covariances)
 gauss_to_pc.get_renderer = timed("get_renderer", gauss_to_pc.get_renderer)
 gauss_to_pc.get_camera = timed("get_camera (host, 50x)", gauss_to_pc.get_camera, sync=False)
-R = gauss_render.GaussHipRenderer
-R.__call__ = timed("renderer.__call__ issue (host, 50x)", R.__call__, sync=False)
-R._capture = timed("  of which graph capture", R._capture, sync=False)
-R._render_sync = timed("  of which first camera (two-call path)", R._render_sync, sync=False)
+if a.workload == "render_cuda":
+    import gaussian_pointcloud_rasterization as gpr
+    R = gpr.GaussianRasterizer
+    R.forward = timed("renderer.forward issue (host, 50x)", R.forward, sync=False)
+    R.get_gaussians_with_low_surface_distance = timed("get_gaussians_with_low_surface_distance", R.get_gaussians_with_low_surface_distance)
+else:
+    R = gauss_render.GaussHipRenderer
+    R.__call__ = timed("renderer.__call__ issue (host, 50x)", R.__call__, sync=False)
+    R._capture = timed("  of which graph capture", R._capture, sync=False)
+    R._render_sync = timed("  of which first camera (two-call path)", R._render_sync, sync=False)
 R.get_gaussian_colours = timed("drain + get_gaussian_colours", R.get_gaussian_colours)
 R.get_visible_gaussians = timed("get_visible_gaussians", R.get_visible_gaussians)
 R.get_total_gaussian_contributions = timed("get_total_contributions", R.get_total_gaussian_contributions)
 gauss_to_pc.generate_pointcloud = timed("generate_pointcloud", gauss_to_pc.generate_pointcloud)
-scene = make_scene(a.gaussians, 1237, device=dev)
+scene = make_scene(a.gaussians, 1237, device=dev, with_sh=(a.workload == "render_cuda"))
 cams = make_cameras(50)
 for rep in range(3):
     T.clear()
     torch.cuda.synchronize()
     t = time.perf_counter()
-    bench.one_step(scene, cams, "render", a.points, dev, rep)
+    bench.one_step(scene, cams if a.workload != "sample" else None, a.workload, a.points, dev, rep)
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t) * 1e3
 print("step wall ms (with stage syncs) %.2f" % wall)
