@@ -29,3 +29,4 @@ def test_render_other_pixels_per_lane_vs_oracle(emu, sub, monkeypatch):
     monkeypatch.setattr(gauss_render, "BLEND_SUBBLOCKS", sub)
     w = run_vs_oracle(500, 23, 320, 180, 275.0, 1, scale=(0.01, 0.08), t_floor=1e-6)
     assert w["image"] < 1e-4 and w["contribution"] < 1e-4 and w["colour"] < 1e-4 and w["flips"] == 0
+
