@@ -154,6 +154,8 @@ class _GraphSlot:
     def release(self):
         L = nv.lib()
         if self.graph:
+            if self.on_gpu:
+                self.stream.synchronize()          # never destroy an executable graph that may still be in flight
             L.g2pc_graph_destroy(self.graph)
             self.graph, self.graph_key = C.c_void_p(None), None
 
