@@ -59,8 +59,8 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_py(Cam cam_val, const Cam* 
                                                        uint32_t* __restrict__ depth_key_rev,
                                                        uint32_t* __restrict__ index_rev,
                                                        uint32_t* __restrict__ tiles_touched,
-                                                       float4* __restrict__ p0, float4* __restrict__ p1,
-                                                       uint32_t* __restrict__ rect) {
+                                                       const float* __restrict__ colours,
+                                                       float4* __restrict__ rec, uint32_t* __restrict__ rect) {
     // device-resident camera: lets ONE captured launch sequence serve every camera.  Staged through LDS once per block
     // (per-thread loads of the 172-byte struct made this kernel 6x slower than the by-value variant).
     __shared__ Cam s_cam;
@@ -150,8 +150,13 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_py(Cam cam_val, const Cam* 
             rc = (uint32_t)ix0 | ((uint32_t)ix1 << 8) | ((uint32_t)iy0 << 16) | ((uint32_t)iy1 << 24);
             key = __float_as_uint(-pv[2]);                          // ascending = nearest first
         }
-        p0[i] = make_float4(mx, my, sc * k00, sc * (k01 + k10));
-        p1[i] = make_float4(sc * k11, opacity[i], pv[2], radius);
+        // ONE 64-byte record per Gaussian holds what the blend stages from it: a lane gathers one cache line per list
+        // entry (plus the live running maximum from best_key) instead of touching three arrays.  The running maximum is
+        // deliberately NOT snapshotted here: with four cameras in flight a snapshot is several blends old, the "can
+        // this beat the maximum" filter lets many more candidates through and the job takes 48 ms instead of 26.
+        rec[4 * i + 0] = make_float4(mx, my, sc * k00, sc * (k01 + k10));
+        rec[4 * i + 1] = make_float4(sc * k11, opacity[i], pv[2], radius);
+        rec[4 * i + 2] = make_float4(colours[3 * i], colours[3 * i + 1], colours[3 * i + 2], 0.0f);
     }
     const long r = n - 1 - i;
     depth_key_rev[r] = key;
@@ -205,8 +210,7 @@ __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __
                                                   const int32_t* __restrict__ chunk_pix0,
                                                   const uint32_t* __restrict__ tile_start,
                                                   const uint32_t* __restrict__ inst_g,
-                                                  const float4* __restrict__ p0, const float4* __restrict__ p1,
-                                                  const float* __restrict__ colours,
+                                                  const float4* __restrict__ rec,
                                                   unsigned long long* __restrict__ best_key, uint32_t order_base,
                                                   float t_floor, float bg, float* __restrict__ tilebuf,
                                                   uint32_t* __restrict__ chunk_work,
@@ -251,12 +255,11 @@ __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __
     float4 r0 = zero4, r1 = zero4;                       // zero opacity = padding
     float c0 = 0.f, c1 = 0.f, c2 = 0.f;
     uint32_t gmb = 0x7F000000u;                          // huge running maximum: padding is never a candidate
-    const uint32_t* key_hi = (const uint32_t*)best_key + 1;     // high word = contribution bits (little endian)
     if (v_cur) {
-        r0 = p0[g_cur];
-        r1 = p1[g_cur];
-        gmb = key_hi[2 * (size_t)g_cur];
-        c0 = colours[3 * (size_t)g_cur]; c1 = colours[3 * (size_t)g_cur + 1]; c2 = colours[3 * (size_t)g_cur + 2];
+        r0 = rec[4 * (size_t)g_cur];
+        r1 = rec[4 * (size_t)g_cur + 1];
+        const float4 r2 = rec[4 * (size_t)g_cur + 2];
+        c0 = r2.x; c1 = r2.y; c2 = r2.z; gmb = ((const uint32_t*)best_key)[2 * (size_t)g_cur + 1];   // live running maximum
     }
     uint32_t processed = 0;
     for (uint32_t b = start; b < end; b += BL_BATCH) {
@@ -277,10 +280,10 @@ __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __
         if (v_nxt) g_nxt = inst_g[b + 2 * BL_BATCH + lane];
         r0 = zero4; r1 = zero4; c0 = c1 = c2 = 0.f; gmb = 0x7F000000u;
         if (v_cur) {
-            r0 = p0[g_cur];
-            r1 = p1[g_cur];
-            gmb = key_hi[2 * (size_t)g_cur];
-            c0 = colours[3 * (size_t)g_cur]; c1 = colours[3 * (size_t)g_cur + 1]; c2 = colours[3 * (size_t)g_cur + 2];
+            r0 = rec[4 * (size_t)g_cur];
+            r1 = rec[4 * (size_t)g_cur + 1];
+            const float4 r2 = rec[4 * (size_t)g_cur + 2];
+            c0 = r2.x; c1 = r2.y; c2 = r2.z; gmb = ((const uint32_t*)best_key)[2 * (size_t)g_cur + 1];   // live running maximum
         }
         wave_sync();
         const int cnt = (end - b) < (uint32_t)BL_BATCH ? (int)(end - b) : BL_BATCH;
@@ -340,7 +343,13 @@ __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __
                     if (__any(bestv[u] >= cc[u].w)) {
                         uint32_t bits = __float_as_uint(bestv[u]);
                         uint32_t m = wave_max_u32_dpp(bits);
-                        uint32_t pm = wave_min_u32_dpp(bits == m ? bestp[u] : 0xFFFFFFFFu);
+                        uint32_t pm;
+                        if (PPT == 1) {     // pixel index grows with the lane: the lowest lane among the maxima owns it
+                            const unsigned long long at_max = __ballot(bits == m);
+                            pm = (uint32_t)__builtin_amdgcn_readlane((int)bestp[u], __ffsll(at_max) - 1);
+                        } else {
+                            pm = wave_min_u32_dpp(bits == m ? bestp[u] : 0xFFFFFFFFu);
+                        }
                         if (lane == 0) {
                             unsigned long long key = ((unsigned long long)m << 32) | (unsigned long long)(uint32_t)(~(order_tile | pm));
                             atomicMax(&best_key[s_g[k0 + u]], key);
@@ -384,8 +393,7 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_pk(Layout lay, const int32_t*
                                                      const int32_t* __restrict__ chunk_pix0,
                                                      const uint32_t* __restrict__ tile_start,
                                                      const uint32_t* __restrict__ inst_g,
-                                                     const float4* __restrict__ p0, const float4* __restrict__ p1,
-                                                     const float* __restrict__ colours,
+                                                     const float4* __restrict__ rec,
                                                      unsigned long long* __restrict__ best_key, uint32_t order_base,
                                                      float t_floor, float bg, float* __restrict__ tilebuf,
                                                      uint32_t* __restrict__ chunk_work,
@@ -429,12 +437,11 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_pk(Layout lay, const int32_t*
     float4 r0 = zero4, r1 = zero4;
     float c0 = 0.f, c1 = 0.f, c2 = 0.f;
     uint32_t gmb = 0x7F000000u;
-    const uint32_t* key_hi = (const uint32_t*)best_key + 1;
     if (v_cur) {
-        r0 = p0[g_cur];
-        r1 = p1[g_cur];
-        gmb = key_hi[2 * (size_t)g_cur];
-        c0 = colours[3 * (size_t)g_cur]; c1 = colours[3 * (size_t)g_cur + 1]; c2 = colours[3 * (size_t)g_cur + 2];
+        r0 = rec[4 * (size_t)g_cur];
+        r1 = rec[4 * (size_t)g_cur + 1];
+        const float4 r2 = rec[4 * (size_t)g_cur + 2];
+        c0 = r2.x; c1 = r2.y; c2 = r2.z; gmb = ((const uint32_t*)best_key)[2 * (size_t)g_cur + 1];   // live running maximum
     }
     uint32_t processed = 0;
     for (uint32_t b = start; b < end; b += BL_BATCH) {
@@ -452,10 +459,10 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_pk(Layout lay, const int32_t*
         if (v_nxt) g_nxt = inst_g[b + 2 * BL_BATCH + lane];
         r0 = zero4; r1 = zero4; c0 = c1 = c2 = 0.f; gmb = 0x7F000000u;
         if (v_cur) {
-            r0 = p0[g_cur];
-            r1 = p1[g_cur];
-            gmb = key_hi[2 * (size_t)g_cur];
-            c0 = colours[3 * (size_t)g_cur]; c1 = colours[3 * (size_t)g_cur + 1]; c2 = colours[3 * (size_t)g_cur + 2];
+            r0 = rec[4 * (size_t)g_cur];
+            r1 = rec[4 * (size_t)g_cur + 1];
+            const float4 r2 = rec[4 * (size_t)g_cur + 2];
+            c0 = r2.x; c1 = r2.y; c2 = r2.z; gmb = ((const uint32_t*)best_key)[2 * (size_t)g_cur + 1];   // live running maximum
         }
         wave_sync();
         const int cnt = (end - b) < (uint32_t)BL_BATCH ? (int)(end - b) : BL_BATCH;
@@ -495,10 +502,15 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_pk(Layout lay, const int32_t*
                 for (int u = 0; u < U; ++u) {
                     const float best = fmaxf(contrib[u][0], contrib[u][1]);
                     if (__any(best >= cc[u].w)) {
-                        const uint32_t bestp = (uint32_t)(contrib[u][1] > contrib[u][0] ? pix[1] : pix[0]);
                         uint32_t bits = __float_as_uint(best);
                         uint32_t m = wave_max_u32_dpp(bits);
-                        uint32_t pm = wave_min_u32_dpp(bits == m ? bestp : 0xFFFFFFFFu);
+                        // lowest pixel among the maxima: inside each sub-block the pixel index grows with the lane, so
+                        // per sub-block it is the lowest lane at the maximum (two ballots instead of a second reduction)
+                        const unsigned long long at0 = __ballot(__float_as_uint(contrib[u][0]) == m);
+                        const unsigned long long at1 = __ballot(__float_as_uint(contrib[u][1]) == m);
+                        const uint32_t pa = at0 ? (uint32_t)__builtin_amdgcn_readlane(pix[0], __ffsll(at0) - 1) : 0xFFFFFFFFu;
+                        const uint32_t pb = at1 ? (uint32_t)__builtin_amdgcn_readlane(pix[1], __ffsll(at1) - 1) : 0xFFFFFFFFu;
+                        const uint32_t pm = pa < pb ? pa : pb;
                         if (lane == 0) {
                             unsigned long long key = ((unsigned long long)m << 32) | (unsigned long long)(uint32_t)(~(order_tile | pm));
                             atomicMax(&best_key[s_g[k0 + u]], key);
@@ -820,7 +832,8 @@ __global__ __launch_bounds__(CU_T) void k_blend_cu(int W, int H, int grid_x, con
                 if (__any(contrib >= c.w)) {
                     uint32_t bits = __float_as_uint(contrib);
                     uint32_t m = wave_max_u32_dpp(bits);
-                    uint32_t pm = wave_min_u32_dpp(bits == m ? pixid : 0xFFFFFFFFu);
+                    // pixel id grows with the lane inside a wave (4 rows of the 16x16 tile): lowest lane at the maximum
+                    const uint32_t pm = (uint32_t)__builtin_amdgcn_readlane((int)pixid, __ffsll(__ballot(bits == m)) - 1);
                     if (lane == 0) {
                         unsigned long long key = ((unsigned long long)m << 32) | (unsigned long long)(uint32_t)(~pm);
                         atomicMax(&cam_key[s_g[k0 + u]], key);
@@ -944,7 +957,7 @@ static int bits_for_tiles(unsigned t) { int b = 1; while ((1u << b) < t && b < 3
 
 // ---- host side of the PY path, shared by the two-call API (count read back by the host) and the single-call,
 // capture-safe API (count stays on the device, launch geometry fixed by a capacity) -------------------------------
-struct PyFrontBuffers { float4 *p0, *p1; uint32_t *rect, *sorted_idx, *offsets; };
+struct PyFrontBuffers { float4* rec; uint32_t *rect, *sorted_idx, *offsets; };      // rec: 4 x float4 per Gaussian
 
 static size_t py_front_ws(long n) { return align_up((size_t)n * 4) * 6 + sort_workspace(n) + scan_workspace(n) + 4096; }
 static size_t py_back_ws(long L, int T) {
@@ -952,8 +965,8 @@ static size_t py_back_ws(long L, int T) {
 }
 
 static int py_front(const Cam& cam_val, const Cam* cam_dev, const G2pcTileLayout* layout, const float* means3D,
-                    const float* cov9, const float* opacity, long n, const PyFrontBuffers& fb, void* ws, size_t ws_bytes,
-                    hipStream_t s) {
+                    const float* cov9, const float* opacity, const float* colours, long n, const PyFrontBuffers& fb,
+                    void* ws, size_t ws_bytes, hipStream_t s) {
     Arena ar(ws, ws_bytes);
     uint32_t* key_rev = ar.get<uint32_t>((size_t)n);
     uint32_t* idx_rev = ar.get<uint32_t>((size_t)n);
@@ -967,10 +980,10 @@ static int py_front(const Cam& cam_val, const Cam* cam_dev, const G2pcTileLayout
     if (!ar.ok()) { set_error("raster_front_py", "workspace too small"); return G2PC_ERR_WORKSPACE; }
     if (cam_dev)
         hipLaunchKernelGGL(k_preprocess_py<true>, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, cam_val, cam_dev, to_layout(layout),
-                           means3D, cov9, opacity, n, key_rev, idx_rev, touched, fb.p0, fb.p1, fb.rect);
+                           means3D, cov9, opacity, n, key_rev, idx_rev, touched, colours, fb.rec, fb.rect);
     else
         hipLaunchKernelGGL(k_preprocess_py<false>, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, cam_val, cam_dev, to_layout(layout),
-                           means3D, cov9, opacity, n, key_rev, idx_rev, touched, fb.p0, fb.p1, fb.rect);
+                           means3D, cov9, opacity, n, key_rev, idx_rev, touched, colours, fb.rec, fb.rect);
     int rc = sort_pairs_u32(key_rev, idx_rev, key_sorted, fb.sorted_idx, ktmp, vtmp, n, 0, 32, sort_ws, sort_bytes, s);
     if (rc) return rc;
     // tiles touched in depth order (ktmp reused as the gathered array)
@@ -983,7 +996,7 @@ struct PyBlendArgs {                  // by value ...                      ... o
 };
 
 // L: the instance count, or (l_eff != nullptr) the capacity of the buffers with the count in device memory
-static int py_back(const G2pcTileLayout* layout, const float* colours, long n, long L, const uint32_t* l_eff,
+static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t* l_eff,
                    const PyBlendArgs& ba, int W, int H, const PyFrontBuffers& fb, unsigned long long* best_key,
                    float* colours_out, float* tilebuf, float* image, int phases, uint32_t max_per_tile,
                    uint32_t* overflow_flag, void* ws, size_t ws_bytes, hipStream_t s) {
@@ -1016,8 +1029,8 @@ static int py_back(const G2pcTileLayout* layout, const float* colours, long n, l
     if (phases & 2) {
 #define G2PC_BLEND(...)                                                                                                 \
     hipLaunchKernelGGL((__VA_ARGS__), dim3((unsigned)layout->num_chunks), dim3(BL_T), 0, s, lay, layout->chunk_tile,          \
-                       layout->chunk_pix0, tile_start, g_sorted, (const float4*)fb.p0, (const float4*)fb.p1, colours,   \
-                       best_key, ba.camera_slot << 24, ba.t_floor, ba.bg, tilebuf, g_chunk_work, ba.job)
+                       layout->chunk_pix0, tile_start, g_sorted, (const float4*)fb.rec, best_key,                      \
+                       ba.camera_slot << 24, ba.t_floor, ba.bg, tilebuf, g_chunk_work, ba.job)
         switch (layout->chunk_subblocks) {
             case 1: G2PC_BLEND(k_blend_py<1, 4>); break;
             case 2: G2PC_BLEND(k_blend_py_pk<4>); break;
@@ -1044,15 +1057,16 @@ size_t g2pc_raster_front_workspace(int64_t n) { return g2pc::py_front_ws(n); }
 // Front half of one camera: preprocess -> depth sort -> tiles-touched scan.  Leaves sorted_idx u32[n] and
 // offsets u32[n+1] (offsets[n] = L, the number of (tile, Gaussian) instances) for the back half.
 int g2pc_raster_front_py(const G2pcCamera* cam, const G2pcTileLayout* layout, const float* means3D, const float* cov9,
-                         const float* opacity, int64_t n, float* p0, float* p1, uint32_t* rect, uint32_t* sorted_idx,
-                         uint32_t* offsets, uint32_t* count_host, void* ws, size_t ws_bytes, void* stream) {
+                         const float* opacity, const float* colours, int64_t n, float* rec, uint32_t* rect,
+                         uint32_t* sorted_idx, uint32_t* offsets, uint32_t* count_host, void* ws, size_t ws_bytes,
+                         void* stream) {
     using namespace g2pc;
-    G2PC_REQUIRE(cam && layout && means3D && cov9 && opacity && p0 && p1 && rect && sorted_idx && offsets && ws && n > 0,
+    G2PC_REQUIRE(cam && layout && means3D && cov9 && opacity && colours && rec && rect && sorted_idx && offsets && ws && n > 0,
                  G2PC_ERR_ARG, "bad arguments");
     G2PC_REQUIRE(layout->nx <= 256 && layout->ny <= 256, G2PC_ERR_UNSUPPORTED, "more than 256 tile intervals per axis");
     hipStream_t s = (hipStream_t)stream;
-    PyFrontBuffers fb{(float4*)p0, (float4*)p1, rect, sorted_idx, offsets};
-    int rc = py_front(to_cam(cam), nullptr, layout, means3D, cov9, opacity, (long)n, fb, ws, ws_bytes, s);
+    PyFrontBuffers fb{(float4*)rec, rect, sorted_idx, offsets};
+    int rc = py_front(to_cam(cam), nullptr, layout, means3D, cov9, opacity, colours, (long)n, fb, ws, ws_bytes, s);
     if (rc) return rc;
     if (count_host) hipMemcpyAsync(count_host, offsets + n, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
     return check_launch("g2pc_raster_front_py");
@@ -1063,20 +1077,19 @@ size_t g2pc_raster_back_workspace(int64_t num_instances, int32_t num_tiles) {
 }
 
 // Back half: duplicate -> stable sort by tile id -> tile ranges -> blend + visibility -> colour update.
-int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, const float* colours, int64_t n,
-                        int64_t num_instances, const float* p0, const float* p1, const uint32_t* rect,
-                        const uint32_t* sorted_idx, const uint32_t* offsets, uint32_t camera_slot, float t_floor,
+int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, int64_t n, int64_t num_instances,
+                        const float* rec, const uint32_t* rect, const uint32_t* sorted_idx, const uint32_t* offsets,
+                        uint32_t camera_slot, float t_floor,
                         unsigned long long* best_key, float* colours_out, float* tilebuf, float* image, int phases,
                         uint32_t max_per_tile, uint32_t* overflow_flag, void* ws, size_t ws_bytes, void* stream) {
     using namespace g2pc;
-    G2PC_REQUIRE(cam && layout && colours && p0 && p1 && rect && sorted_idx && offsets && best_key && colours_out &&
-                     tilebuf && ws && n > 0,
+    G2PC_REQUIRE(cam && layout && rec && rect && sorted_idx && offsets && best_key && colours_out && tilebuf && ws && n > 0,
                  G2PC_ERR_ARG, "bad arguments");
     G2PC_REQUIRE(camera_slot >= 1 && camera_slot <= 255, G2PC_ERR_ARG, "camera_slot must be in [1,255]");
     G2PC_REQUIRE(layout->nx * layout->ny <= 4096, G2PC_ERR_UNSUPPORTED, "more than 4096 tiles");
-    PyFrontBuffers fb{(float4*)p0, (float4*)p1, (uint32_t*)rect, (uint32_t*)sorted_idx, (uint32_t*)offsets};
+    PyFrontBuffers fb{(float4*)rec, (uint32_t*)rect, (uint32_t*)sorted_idx, (uint32_t*)offsets};
     PyBlendArgs ba{camera_slot, t_floor, cam->bg[0], nullptr};
-    int rc = py_back(layout, colours, (long)n, (long)num_instances, nullptr, ba, cam->width, cam->height, fb, best_key,
+    int rc = py_back(layout, (long)n, (long)num_instances, nullptr, ba, cam->width, cam->height, fb, best_key,
                      colours_out, tilebuf, image, phases, max_per_tile, overflow_flag, ws, ws_bytes, (hipStream_t)stream);
     if (rc) return rc;
     return check_launch("g2pc_raster_back_py");
@@ -1084,7 +1097,7 @@ int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, con
 
 size_t g2pc_raster_camera_workspace(int64_t n, int64_t capacity, int32_t num_tiles) {
     using namespace g2pc;
-    return align_up((size_t)n * 16) * 2 + align_up((size_t)n * 4) * 2 + align_up((size_t)(n + 1) * 4) + 256 +
+    return align_up((size_t)n * 64) + align_up((size_t)n * 4) * 2 + align_up((size_t)(n + 1) * 4) + 256 +
            py_front_ws((long)n) + py_back_ws((long)capacity, num_tiles) + 4096;
 }
 
@@ -1108,8 +1121,7 @@ int g2pc_raster_camera_py(const G2pcCameraJob* job_dev, const G2pcCameraJob* job
     const int T = layout->nx * layout->ny;
     Arena ar(ws, ws_bytes);
     PyFrontBuffers fb;
-    fb.p0 = ar.get<float4>((size_t)n);
-    fb.p1 = ar.get<float4>((size_t)n);
+    fb.rec = ar.get<float4>((size_t)n * 4);
     fb.rect = ar.get<uint32_t>((size_t)n);
     fb.sorted_idx = ar.get<uint32_t>((size_t)n);
     fb.offsets = ar.get<uint32_t>((size_t)n + 1);
@@ -1121,13 +1133,14 @@ int g2pc_raster_camera_py(const G2pcCameraJob* job_dev, const G2pcCameraJob* job
     int rc;
     if (phases & 1) {
         if (job_host) hipMemcpyAsync((void*)job_dev, job_host, sizeof(G2pcCameraJob), hipMemcpyHostToDevice, s);
-        rc = py_front(Cam{}, (const Cam*)&job_dev->cam, layout, means3D, cov9, opacity, (long)n, fb, front_ws, front_bytes, s);
+        rc = py_front(Cam{}, (const Cam*)&job_dev->cam, layout, means3D, cov9, opacity, colours, (long)n, fb, front_ws,
+                      front_bytes, s);
         if (rc) return rc;
         hipLaunchKernelGGL(k_resolve_count, dim3(1), dim3(64), 0, s, fb.offsets + n, (uint32_t)capacity, l_eff);
         if (count_host) hipMemcpyAsync(count_host, fb.offsets + n, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
     }
     PyBlendArgs ba{0u, 0.0f, 0.0f, job_dev};
-    rc = py_back(layout, colours, (long)n, (long)capacity, l_eff, ba, 0, 0, fb, best_key, nullptr, tilebuf, nullptr,
+    rc = py_back(layout, (long)n, (long)capacity, l_eff, ba, 0, 0, fb, best_key, nullptr, tilebuf, nullptr,
                  phases & 3, max_per_tile, overflow_flag, back_ws, back_bytes, s);
     if (rc) return rc;
     return check_launch("g2pc_raster_camera_py");

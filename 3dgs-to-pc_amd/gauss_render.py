@@ -57,11 +57,11 @@ class _Layout(C.Structure):
 
 nv._RASTER_PROTOS.update({
     "g2pc_raster_front_workspace": (C.c_size_t, [C.c_int64]),
-    "g2pc_raster_front_py": (C.c_int, [C.POINTER(_Camera), C.POINTER(_Layout)] + [C.c_void_p] * 3 + [C.c_int64] +
-                             [C.c_void_p] * 7 + [C.c_size_t, C.c_void_p]),
+    "g2pc_raster_front_py": (C.c_int, [C.POINTER(_Camera), C.POINTER(_Layout)] + [C.c_void_p] * 4 + [C.c_int64] +
+                             [C.c_void_p] * 6 + [C.c_size_t, C.c_void_p]),
     "g2pc_raster_back_workspace": (C.c_size_t, [C.c_int64, C.c_int32]),
-    "g2pc_raster_back_py": (C.c_int, [C.POINTER(_Camera), C.POINTER(_Layout), C.c_void_p, C.c_int64, C.c_int64] +
-                            [C.c_void_p] * 5 + [C.c_uint32, C.c_float] + [C.c_void_p] * 4 + [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "g2pc_raster_back_py": (C.c_int, [C.POINTER(_Camera), C.POINTER(_Layout), C.c_int64, C.c_int64] +
+                            [C.c_void_p] * 4 + [C.c_uint32, C.c_float] + [C.c_void_p] * 4 + [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "g2pc_raster_camera_workspace": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32]),
     "g2pc_raster_camera_py": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(_Layout)] + [C.c_void_p] * 4 + [C.c_int64, C.c_int64] +
                               [C.c_void_p] * 3 + [C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -108,14 +108,14 @@ class _Scratch:
 
     def __init__(self, n, device):
         f32, i32 = dict(dtype=torch.float32, device=device), dict(dtype=torch.int32, device=device)
-        self.p0, self.p1 = torch.empty((n, 4), **f32), torch.empty((n, 4), **f32)
+        self.rec = torch.empty((n, 16), **f32)                    # one 64-byte blend record per Gaussian
         self.rect, self.sorted_idx = torch.empty((n,), **i32), torch.empty((n,), **i32)
         self.offsets = torch.empty((n + 1,), **i32)
         self.front_ws_bytes = nv.lib().g2pc_raster_front_workspace(n)
         self.front_ws = nv.workspace(self.front_ws_bytes, device)
         self.back_ws, self.back_ws_bytes = None, 0
         self.tilebuf = None
-        self.ptrs = tuple(nv.ptr(t) for t in (self.p0, self.p1, self.rect, self.sorted_idx, self.offsets))
+        self.ptrs = tuple(nv.ptr(t) for t in (self.rec, self.rect, self.sorted_idx, self.offsets))
         self.front_ws_ptr = nv.ptr(self.front_ws)
 
 
@@ -288,8 +288,9 @@ class GaussHipRenderer():
 
     def _front(self, sc, cam, lay):
         with nv.region("raster_front", self.device):
-            nv.check(nv.lib().g2pc_raster_front_py(C.byref(cam), C.byref(lay.c), *self.scene_ptrs, self.n, *sc.ptrs,
-                                                   None, sc.front_ws_ptr, sc.front_ws_bytes, nv.stream_handle(self.device)),
+            nv.check(nv.lib().g2pc_raster_front_py(C.byref(cam), C.byref(lay.c), *self.scene_ptrs, self.colour_ptr,
+                                                   self.n, *sc.ptrs, None, sc.front_ws_ptr, sc.front_ws_bytes,
+                                                   nv.stream_handle(self.device)),
                      "raster_front_py")
 
     def _back(self, sc, cam, lay, slot, num_inst, image, phases, name):
@@ -303,7 +304,7 @@ class GaussHipRenderer():
             sc.tilebuf = torch.empty((lay.total_pixels * 3,), dtype=torch.float32, device=self.device)
             sc.tilebuf_ptr = nv.ptr(sc.tilebuf)
         with nv.region(name, self.device):
-            nv.check(L.g2pc_raster_back_py(C.byref(cam), C.byref(lay.c), self.colour_ptr, self.n, num_inst, *sc.ptrs,
+            nv.check(L.g2pc_raster_back_py(C.byref(cam), C.byref(lay.c), self.n, num_inst, *sc.ptrs,
                                            slot, self.t_floor, self.state_ptrs()[0], self.state_ptrs()[1], sc.tilebuf_ptr,
                                            nv.ptr(image), phases, self.MAX_GAUSSIANS_PER_TILE, self.overflow_ptr, sc.back_ws_ptr,
                                            sc.back_ws_bytes, nv.stream_handle(self.device)),

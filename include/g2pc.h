@@ -218,16 +218,18 @@ typedef struct G2pcTileLayout {      /* HOST struct of DEVICE pointers: tiles = 
 size_t g2pc_raster_front_workspace(int64_t n);
 /* PY semantics front half (gauss_render.py:101-193,404-437): projection, EWA covariance, conic, radius, rect ->
  * tile ranges; depth sort (nearest first, ties in descending index = torch.sort + flip); tiles-touched scan.
- * means3D f32[n,3], cov9 f32[n,3,3], opacity f32[n].  Out: p0/p1 f32[n,4] blend parameters, rect u32[n],
- * sorted_idx u32[n] (Gaussian indices in depth order), offsets u32[n+1].  count_host (optional, PINNED host
+ * means3D f32[n,3], cov9 f32[n,3,3], opacity f32[n], colours f32[n,3] (what the python renderer blends).
+ * Out: rec f32[n,16] -- ONE 64-byte record per Gaussian with what the blend stages from it ((mx, my, A, B), (C, opacity,
+ * z, radius), (r, g, b, -), pad): a blend lane gathers one cache line per list entry --, rect u32[n], sorted_idx u32[n] (Gaussian indices in depth order), offsets u32[n+1].  count_host (optional, PINNED host
  * memory): receives offsets[n] by an asynchronous copy queued on `stream` behind the kernels. */
 int g2pc_raster_front_py(const G2pcCamera* cam, const G2pcTileLayout* layout, const float* means3D, const float* cov9,
-                         const float* opacity, int64_t n, float* p0, float* p1, uint32_t* rect, uint32_t* sorted_idx,
-                         uint32_t* offsets, uint32_t* count_host, void* ws, size_t ws_bytes, void* stream);
+                         const float* opacity, const float* colours, int64_t n, float* rec, uint32_t* rect,
+                         uint32_t* sorted_idx, uint32_t* offsets, uint32_t* count_host, void* ws, size_t ws_bytes,
+                         void* stream);
 size_t g2pc_raster_back_workspace(int64_t num_instances, int32_t num_tiles);
 /* PY semantics back half (gauss_render.py:290-402): duplicate, stable tile sort, ranges, blend with per-Gaussian
  * max-contribution / arg-max pixel, colour update, optional image (f32[H,W,3], already flipped as the reference
- * returns it).  colours f32[n,3] input colours; best_key u64[n] and colours_out f32[n,3] are the renderer's
+ * returns it).  rec / rect / sorted_idx / offsets from the front half; best_key u64[n] and colours_out f32[n,3] are the renderer's
  * running state (zero-initialised by the caller); tilebuf f32[tile_pix_off[T],3] scratch.  camera_slot in
  * [1,255] must increase from camera to camera (call g2pc_raster_rebase_keys before wrapping around).
  * t_floor: 0 = exact python semantics; > 0 stops a pixel chunk once every pixel's transmittance is below it
@@ -237,9 +239,9 @@ size_t g2pc_raster_back_workspace(int64_t num_instances, int32_t num_tiles);
  * concurrently on different streams; only the colour updates must be issued in camera order.
  * overflow_flag (optional, device u32, zeroed by the caller): receives max(tile load) if any tile holds more than
  * max_per_tile Gaussians -- the reference would subdivide such a leaf further (gauss_render.py:319), this layout cannot. */
-int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, const float* colours, int64_t n,
-                        int64_t num_instances, const float* p0, const float* p1, const uint32_t* rect,
-                        const uint32_t* sorted_idx, const uint32_t* offsets, uint32_t camera_slot, float t_floor,
+int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, int64_t n, int64_t num_instances,
+                        const float* rec, const uint32_t* rect, const uint32_t* sorted_idx, const uint32_t* offsets,
+                        uint32_t camera_slot, float t_floor,
                         unsigned long long* best_key, float* colours_out, float* tilebuf, float* image, int phases,
                         uint32_t max_per_tile, uint32_t* overflow_flag, void* ws, size_t ws_bytes, void* stream);
 /* --- the same camera without a host round trip (capture-safe) -----------------------------------------------------
