@@ -122,5 +122,9 @@ def test_tile_overflow_is_reported(emu, monkeypatch):
     monkeypatch.setattr(gauss_render.GaussHipRenderer, "MAX_GAUSSIANS_PER_TILE", 100)
     R = gauss_render.get_renderer("python", G.xyz, G.opacities.unsqueeze(1), G.colours, G.covariances)
     R(camera_handler.get_camera("python", torch.tensor(tr[name]), intr[name]))
+    with pytest.warns(UserWarning, match="max_gaussians_per_tile"):
+        R.get_gaussian_colours()                              # default: warn and keep the unsplit result
+    R(camera_handler.get_camera("python", torch.tensor(tr[name]), intr[name]))
+    monkeypatch.setattr(gauss_render, "STRICT_TILE_LOAD", True)
     with pytest.raises(NotImplementedError, match="max_gaussians_per_tile"):
         R.get_gaussian_colours()
