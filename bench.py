@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--sort-bits", type=int, default=0, help="tuning aid: wide radix digit bits (8 or 11)")
     ap.add_argument("--sort-small", type=int, default=2 << 20, help="tuning aid: inputs up to this many keys use 4 keys/thread")
     ap.add_argument("--blend-subblocks", type=int, default=0, help="tuning aid: 8x8 sub-blocks per blend wave (1, 2, 4)")
+    ap.add_argument("--no-context-pool", action="store_true", help="tuning aid: every job captures its camera graphs anew")
     ap.add_argument("--streams", type=int, default=0, help="tuning aid: cameras in flight (HIP streams) of the renderer")
     ap.add_argument("--camera-subset", type=int, default=0, help="profiling aid: render only the first k cameras of the rig")
     ap.add_argument("--t-floor", type=float, default=None, help="blend transmittance floor (default: gauss_render.DEFAULT_T_FLOOR)")
@@ -187,6 +188,8 @@ def main():
         gauss_render.BLEND_SUBBLOCKS = a.blend_subblocks
     if a.streams:
         gauss_render.PIPELINE_STREAMS = a.streams
+    if a.no_context_pool:
+        gauss_render.CONTEXT_POOL_SIZE = 0
 
     # ONE scene (same seed on every rank, replicated read-only); the cameras are split over the ranks (rank r renders
     # cameras r, r+N, ...), the visibility state is all-reduced, sampling is sharded by Gaussian index and the points
@@ -217,7 +220,10 @@ def main():
     t0 = time.perf_counter()
     points = 0
     for k in range(a.steps):
+        t_step = time.perf_counter()
         points += one_step(scene, cams, workload, total_points, device, seed=200 + k)
+        if os.environ.get("G2PC_BENCH_DEBUG"):
+            print("step %d: %.2f ms of host time" % (k, (time.perf_counter() - t_step) * 1e3), file=sys.stderr)
     sync()
     dt = time.perf_counter() - t0
     prof = nv.profile_summary()
