@@ -111,7 +111,7 @@ def pmc_traffic(region, a):
     sub = gauss_render.BLEND_SUBBLOCKS or tiles.SUBBLOCKS_PER_CHUNK
     kernel = {"raster_blend": {1: "void g2pc::k_blend_py<1, 4>", 2: "void g2pc::k_blend_py_pk<4>"}.get(sub),
               "sampler_emit": "g2pc::k_emit_wave"}.get(region)
-    path = os.path.join(ROOT, "profiles", "r01_e_pmc_traffic.json" if sub == 2 else "r01_c_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_f_pmc_traffic.json" if sub == 2 else "r01_c_pmc_traffic.json")
     if (kernel is None or not os.path.isfile(path) or (a.gaussians, a.cameras) != (1_000_000, 50)
             or (region == "raster_blend" and gauss_render.DEFAULT_T_FLOOR != 1e-6)):
         return None
