@@ -10,7 +10,8 @@ gauss_render.PIPELINE_STREAMS = 4
 dev = torch.device("cuda:0")
 scene = make_scene(1_000_000, 1237, device=dev)
 cams = make_cameras(50)
-bench.one_step(scene, cams, "render", 10_000_000, dev, 1)
+for w in range(4):
+    bench.one_step(scene, cams, "render", 10_000_000, dev, w)
 torch.cuda.synchronize()
 t = time.perf_counter()
 pr = cProfile.Profile(); pr.enable()
@@ -18,4 +19,4 @@ bench.one_step(scene, cams, "render", 10_000_000, dev, 2)
 torch.cuda.synchronize()
 pr.disable()
 print("step wall ms", (time.perf_counter() - t) * 1e3)
-pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
