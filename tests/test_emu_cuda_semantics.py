@@ -15,3 +15,24 @@ def test_cuda_semantics_sh_and_mask(emu):
     rep = run_cuda_case(800, 6, 168, 100, 150.0, 1, with_sh=True, surf=False, scale=(0.01, 0.06), use_mask=True)
     print(rep)
     assert_cuda_matches(rep, 800)
+
+
+def test_mark_visible_is_the_near_plane_test(emu):
+    """_C.mark_visible (rasterize_points.cu:147-166 -> in_frustum, auxiliary.h:151-176): z_view > 0.2 and nothing else."""
+    import numpy as np
+    import torch
+    import camera_handler
+    from gaussian_pointcloud_rasterization import GaussianRasterizer
+    from g2pc.synth import make_scene, make_cameras
+    sc = make_scene(3000, 3, scale_lo=0.01, scale_hi=0.05)
+    tr, intr = make_cameras(1, width=160, height=90, focal=140.0, radius=0.6)      # camera inside the cloud
+    name = next(iter(tr))
+    rs = camera_handler.get_camera("cuda", torch.tensor(tr[name]), intr[name])
+    R = GaussianRasterizer(sc.xyz, torch.zeros_like(sc.xyz), sc.opacities.unsqueeze(1), colors_precomp=sc.colours,
+                           scales=torch.exp(sc.scales), rotations=sc.rots)
+    vis = R.markVisible(sc.xyz, rs).numpy()
+    V = rs.viewmatrix.numpy().astype(np.float32)
+    x = sc.xyz.numpy()
+    z = (V[0, 2] * x[:, 0] + V[1, 2] * x[:, 1] + V[2, 2] * x[:, 2] + V[3, 2]).astype(np.float32)
+    assert vis.dtype == np.bool_ and np.array_equal(vis, z > np.float32(0.2))
+    assert 0 < vis.sum() < vis.size                                               # both sides of the plane are present
