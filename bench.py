@@ -119,6 +119,22 @@ def pmc_traffic(region, a):
     return rec["hbm_bytes_raw"] if rec else None
 
 
+def pmc_valu(region, a):
+    """VALU wave-instructions per launch of the blend kernel from the committed SQ counter pass (tools/pmc_kernel.py ->
+    profiles/r01_f_pmc_sq.json); same validity conditions as pmc_traffic."""
+    import gauss_render
+    from g2pc import tiles
+    sub = gauss_render.BLEND_SUBBLOCKS or tiles.SUBBLOCKS_PER_CHUNK
+    path = os.path.join(ROOT, "profiles", "r01_f_pmc_sq.json")
+    if (region != "raster_blend" or sub != 2 or not os.path.isfile(path) or (a.gaussians, a.cameras) != (1_000_000, 50)
+            or gauss_render.DEFAULT_T_FLOOR != 1e-6):
+        return None
+    rec = json.load(open(path)).get("void g2pc::k_blend_py_pk<4>")
+    if not rec:
+        return None
+    return {"insts": rec["SQ_INSTS_VALU"], "cycles_per_inst": 4.0 * rec["SQ_ACTIVE_INST_VALU"] / rec["SQ_INSTS_VALU"]}
+
+
 def cpu_baseline(workload):
     """The oracle (CPU restatement of the reference, `kind: port`; pinned bit-exactly to the reference's own
     outputs by tests/test_oracle_*.py) on a bounded sample of the same workload, on this box's host cores."""
@@ -269,6 +285,15 @@ def main():
                     "algorithmic_bytes_per_launch": per_launch,
                     "note": "k_blend_py is VALU/v_exp bound, not HBM bound (DESIGN.md §3); frac is its HBM share only"
                     if name == "raster_blend" else None}
+            valu = pmc_valu(name, a)
+            if valu is not None:
+                # the bound that applies to this kernel: VALU issue.  wave64 instructions per launch from the committed SQ
+                # PMC pass, 4 SIMDs x 256 CUs issuing one wave-instruction per 4.3 cycles (measured: ACTIVE_INST_VALU /
+                # INSTS_VALU) at 2.4 GHz
+                peak = 1024 * 2.4e9 / valu["cycles_per_inst"]
+                roof["valu"] = {"wave_insts_per_launch": valu["insts"], "achieved": valu["insts"] / (ms / launches * 1e-3),
+                                "peak": peak, "unit": "wave-instructions/s",
+                                "frac": valu["insts"] / (ms / launches * 1e-3) / peak}
     stats = gauss_render.RENDER_STATS[-(len(gauss_render.RENDER_STATS) // max(a.steps, 1)):] if gauss_render.RENDER_STATS else []
     b_total = algorithmic_bytes(workload, a.gaussians, a.gaussians, points / max(a.steps, 1), cams, stats)
     job_hbm = {"algorithmic_bytes_per_step": b_total, "achieved": b_total / (dt / a.steps) / 1e9, "peak": HBM_PEAK_GBS,

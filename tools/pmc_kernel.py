@@ -10,6 +10,11 @@ for r in csv.DictReader(open(sys.argv[1])):
         continue
     tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
     disp[k].add(r["Dispatch_Id"])
+if "--json" in sys.argv:
+    import json
+    json.dump({k: dict(launches=len(disp[k]), **{c: v / len(disp[k]) for c, v in tot[k].items()}) for k in tot},
+              sys.stdout, indent=1, sort_keys=True)
+    sys.exit(0)
 for k in tot:
     n = len(disp[k])
     print(k, "launches", n)
