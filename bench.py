@@ -318,7 +318,7 @@ def main():
         "instances_per_camera": (float(np.mean([x[0] for x in gauss_render.RENDER_STATS])) if gauss_render.RENDER_STATS else None),
         "regions_ms_per_step": {k: v[1] / a.steps for k, v in sorted(prof.items())},
     }
-    if not a.no_cpu_baseline:
+    if not a.no_cpu_baseline and world == 1:          # the CPU baseline is a 1-GPU companion figure (rank 0, N = 1 only)
         out["cpu_baseline"] = cpu_baseline(workload)
     print(json.dumps(out))
 
