@@ -251,11 +251,12 @@ int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, int
  * DEVICE memory: the camera, its slot and the transmittance floor in a G2pcCameraJob, the instance count L in the
  * workspace.  All launch geometry derives from (n, capacity, layout), so the call can be captured once
  * (g2pc_graph_capture_begin / _end) and replayed for every camera with one g2pc_graph_launch.
- *   job_host (optional, PINNED host memory): copied to job_dev by the first queued operation -- inside a graph the
- *            copy node re-reads it at every replay, so the host only rewrites the pinned struct between replays.
+ *   job_host (optional, PINNED = device-mapped host memory, e.g. hipHostMalloc / torch pin_memory): the first queued
+ *            kernel fetches it into job_dev through the device mapping -- inside a graph it is re-read at every replay,
+ *            so the host only rewrites the pinned struct between replays.
  *   capacity: instances the buffers hold.  A camera with L > capacity is skipped as a whole (nothing is blended);
- *            count_host (optional, PINNED) always receives the true L, so the caller can detect this and render the
- *            camera again with more room.
+ *            count_host (optional, PINNED, written by a kernel through the device mapping) always receives the true L,
+ *            so the caller can detect this and render the camera again with more room.
  *   phases:  bit 0 = preprocess .. tile ranges, bit 1 = blend; 3 = the whole camera.  (A caller that wants HIP events
  *            around the blend alone captures phase 1 and issues phase 2 directly: this runtime refuses event-record
  *            nodes inside a captured graph.)
