@@ -843,12 +843,38 @@ __global__ __launch_bounds__(CU_T) void k_blend_cu(int W, int H, int grid_x, con
         }
         if (calc_surf) {                                                   // forward.cu:460-477
             __syncthreads();                                               // E of the whole batch is final for this wave
-            for (int k = 0; k < cnt; ++k) {
-                float d = fabsf(s_p1[k].z - E);
-                const uint32_t bits = surf_part ? __float_as_uint(d) : 0x7F7FFFFFu;
-                if (__any(bits < s_surf[k])) {                            // non-negative floats order like their bits
-                    uint32_t m = wave_min_u32_dpp(bits);
-                    if (lane == 0) atomicMin(&cam_surf[s_g[k]], m);
+            // min over this wave's pixels of |depth_k - E_p| for every Gaussian k of the batch.  E_p >= 0 and almost every
+            // depth_k lies above (or below) ALL 64 expected depths -- the minimum is then |depth_k - Emax| (or Emin), the
+            // very subtraction the pixel holding that extreme would do -- so the lanes first go through the batch 64
+            // Gaussians at a time, one k per lane, and only a depth strictly inside (Emin, Emax) needs the per-pixel pass.
+            const uint32_t ebits = __float_as_uint(E);                     // non-negative floats order like their bits
+            const uint32_t emax_b = wave_max_u32_dpp(surf_part ? ebits : 0u);
+            const uint32_t emin_b = wave_min_u32_dpp(surf_part ? ebits : 0xFFFFFFFFu);
+            if (emin_b != 0xFFFFFFFFu) {                                   // some pixel of this wave takes part
+                const float emax = __uint_as_float(emax_b), emin = __uint_as_float(emin_b);
+                for (int k0 = 0; k0 < cnt; k0 += 64) {
+                    const int k = k0 + (int)lane;
+                    bool inside = false;
+                    if (k < cnt) {
+                        const float z = s_p1[k].z;
+                        if (z >= emax || z <= emin) {
+                            const uint32_t bits = __float_as_uint(fabsf(z - (z >= emax ? emax : emin)));
+                            if (bits < s_surf[k]) atomicMin(&cam_surf[s_g[k]], bits);
+                        } else {
+                            inside = true;
+                        }
+                    }
+                    unsigned long long todo = __ballot(inside);
+                    while (todo) {
+                        const int kk = k0 + __ffsll(todo) - 1;
+                        todo &= todo - 1;
+                        float d = fabsf(s_p1[kk].z - E);
+                        const uint32_t bits = surf_part ? __float_as_uint(d) : 0x7F7FFFFFu;
+                        if (__any(bits < s_surf[kk])) {
+                            uint32_t m = wave_min_u32_dpp(bits);
+                            if (lane == 0) atomicMin(&cam_surf[s_g[kk]], m);
+                        }
+                    }
                 }
             }
         }
