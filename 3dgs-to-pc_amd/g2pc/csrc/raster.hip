@@ -631,8 +631,7 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_cu(Cam cam, int grid_x, int
                                                        const float* __restrict__ shs, int sh_degree, int sh_coeffs,
                                                        float3 campos, long n, uint32_t* __restrict__ depth_key,
                                                        uint32_t* __restrict__ index, uint32_t* __restrict__ tiles_touched,
-                                                       float4* __restrict__ p0, float4* __restrict__ p1,
-                                                       uint32_t* __restrict__ rect, float* __restrict__ rgb,
+                                                       float4* __restrict__ rec, uint32_t* __restrict__ rect,
                                                        int32_t* __restrict__ radii) {
     long i = (long)blockIdx.x * RA_T + threadIdx.x;
     if (i >= n) return;
@@ -694,8 +693,8 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_cu(Cam cam, int grid_x, int
                 key = __float_as_uint(tz0);
                 rad = r;
                 const float sc = LOG2E;
-                p0[i] = make_float4(px, py, -0.5f * sc * kx, -sc * ky);
-                p1[i] = make_float4(-0.5f * sc * kz, opacity[i], tz0, my_radius);
+                rec[4 * i + 0] = make_float4(px, py, -0.5f * sc * kx, -sc * ky);        // one 64-byte record per Gaussian,
+                rec[4 * i + 1] = make_float4(-0.5f * sc * kz, opacity[i], tz0, my_radius);   // as on the PY path
                 float cr, cg, cb;
                 if (colours_precomp) {
                     cr = colours_precomp[3 * i]; cg = colours_precomp[3 * i + 1]; cb = colours_precomp[3 * i + 2];
@@ -730,7 +729,7 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_cu(Cam cam, int grid_x, int
                     }
                     cr = res[0]; cg = res[1]; cb = res[2];
                 }
-                rgb[3 * i] = cr; rgb[3 * i + 1] = cg; rgb[3 * i + 2] = cb;
+                rec[4 * i + 2] = make_float4(cr, cg, cb, 0.0f);
             }
         }
     }
@@ -749,8 +748,7 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_cu(Cam cam, int grid_x, int
 constexpr int CU_T = 256;
 
 __global__ __launch_bounds__(CU_T) void k_blend_cu(int W, int H, int grid_x, const uint32_t* __restrict__ tile_start,
-                                                  const uint32_t* __restrict__ inst_g, const float4* __restrict__ p0,
-                                                  const float4* __restrict__ p1, const float* __restrict__ rgb,
+                                                  const uint32_t* __restrict__ inst_g, const float4* __restrict__ rec,
                                                   const int32_t* __restrict__ mask, float3 bg, int calc_surf,
                                                   unsigned long long* __restrict__ cam_key,
                                                   uint32_t* __restrict__ cam_surf, float* __restrict__ out_color,
@@ -778,11 +776,11 @@ __global__ __launch_bounds__(CU_T) void k_blend_cu(int W, int H, int grid_x, con
         if (__syncthreads_and(done ? 1 : 0)) break;                       // forward.cu:373-375 (also: LDS is free again)
         if (b + t < end) {
             uint32_t g = inst_g[b + t];
-            float4 q = p1[g];
-            s_p0[t] = p0[g];
-            s_p1[t] = q;
+            s_p0[t] = rec[4 * (size_t)g];
+            s_p1[t] = rec[4 * (size_t)g + 1];
+            const float4 c3 = rec[4 * (size_t)g + 2];
             float gm = fmaxf(__uint_as_float(key_hi[2 * (size_t)g]), 1.17549435e-38f);
-            s_p2[t] = make_float4(rgb[3 * (size_t)g], rgb[3 * (size_t)g + 1], rgb[3 * (size_t)g + 2], gm);
+            s_p2[t] = make_float4(c3.x, c3.y, c3.z, gm);
             s_g[t] = g;
             if (calc_surf) s_surf[t] = cam_surf[g];
         } else {                                   // padding: opacity 0 -> alpha 0 < 1/255 -> skipped
@@ -1235,12 +1233,11 @@ extern "C" {
 // CU semantics, front half: preprocess (+SH) -> depth sort (ascending index on ties) -> tiles-touched scan.
 int g2pc_raster_front_cu(const G2pcCamera* cam, const float* means3D, const float* cov6, const float* opacity,
                          const float* colours_precomp, const float* shs, int32_t sh_degree, int32_t sh_coeffs,
-                         const float* campos, int64_t n, float* p0, float* p1, uint32_t* rect, float* rgb,
-                         int32_t* radii, uint32_t* sorted_idx, uint32_t* offsets, uint32_t* count_host, void* ws,
-                         size_t ws_bytes, void* stream) {
+                         const float* campos, int64_t n, float* rec, uint32_t* rect, int32_t* radii,
+                         uint32_t* sorted_idx, uint32_t* offsets, uint32_t* count_host, void* ws, size_t ws_bytes,
+                         void* stream) {
     using namespace g2pc;
-    G2PC_REQUIRE(cam && means3D && cov6 && opacity && campos && p0 && p1 && rect && rgb && radii && sorted_idx &&
-                     offsets && ws && n > 0,
+    G2PC_REQUIRE(cam && means3D && cov6 && opacity && campos && rec && rect && radii && sorted_idx && offsets && ws && n > 0,
                  G2PC_ERR_ARG, "bad arguments");
     G2PC_REQUIRE((colours_precomp != nullptr) != (shs != nullptr), G2PC_ERR_ARG,
                  "provide exactly one of precomputed colours or SHs");       // __init__.py:42-43
@@ -1262,7 +1259,7 @@ int g2pc_raster_front_cu(const G2pcCamera* cam, const float* means3D, const floa
     G2PC_REQUIRE(ar.ok(), G2PC_ERR_WORKSPACE, "workspace too small");
     hipLaunchKernelGGL(k_preprocess_cu, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, to_cam(cam), gx, gy, means3D, cov6, opacity,
                        colours_precomp, shs, (int)sh_degree, (int)sh_coeffs, make_float3(campos[0], campos[1], campos[2]),
-                       (long)n, key, idx, touched, (float4*)p0, (float4*)p1, rect, rgb, radii);
+                       (long)n, key, idx, touched, (float4*)rec, rect, radii);
     int rc = sort_pairs_u32(key, idx, key_sorted, sorted_idx, ktmp, vtmp, n, 0, 32, sort_ws, sort_bytes, s);
     if (rc) return rc;
     hipLaunchKernelGGL(k_gather_u32, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, touched, sorted_idx, (long)n, ktmp);
@@ -1275,15 +1272,14 @@ int g2pc_raster_front_cu(const G2pcCamera* cam, const float* means3D, const floa
 // CU semantics, back half: duplicate -> tile sort -> ranges -> blend -> running-state update.
 // out_color f32[3,H,W], out_depth / out_invdepth f32[H,W] are zero-filled here.  cam_key u64[n], cam_surf u32[n] are
 // per-camera scratch.  cur_* (optional) receive this camera's gauss_contributions / gauss_pixels / surface distances.
-int g2pc_raster_back_cu(const G2pcCamera* cam, const int32_t* mask, int64_t n, int64_t num_instances, const float* p0,
-                        const float* p1, const uint32_t* rect, const float* rgb, const uint32_t* sorted_idx,
-                        const uint32_t* offsets, int calculate_surface_distance, unsigned long long* cam_key,
+int g2pc_raster_back_cu(const G2pcCamera* cam, const int32_t* mask, int64_t n, int64_t num_instances, const float* rec,
+                        const uint32_t* rect, const uint32_t* sorted_idx, const uint32_t* offsets, int calculate_surface_distance, unsigned long long* cam_key,
                         uint32_t* cam_surf, float* out_color, float* out_depth, float* out_invdepth,
                         float* max_contrib, float* total_contrib, float* colours, float* min_surf,
                         int32_t* winner_cam, int32_t cam_index, float* cur_contrib, int32_t* cur_pixels, float* cur_surf,
                         int phases, void* ws, size_t ws_bytes, void* stream) {
     using namespace g2pc;
-    G2PC_REQUIRE(cam && p0 && p1 && rect && rgb && sorted_idx && offsets && cam_key && cam_surf && out_color &&
+    G2PC_REQUIRE(cam && rec && rect && sorted_idx && offsets && cam_key && cam_surf && out_color &&
                      out_depth && out_invdepth && max_contrib && total_contrib && colours && min_surf && ws && n > 0,
                  G2PC_ERR_ARG, "bad arguments");
     const int W = cam->width, H = cam->height;
@@ -1322,8 +1318,8 @@ int g2pc_raster_back_cu(const G2pcCamera* cam, const int32_t* mask, int64_t n, i
     hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T)), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start, (const uint32_t*)nullptr);
     }
     if (phases & 2)
-    hipLaunchKernelGGL(k_blend_cu, dim3((unsigned)T), dim3(CU_T), 0, s, W, H, gx, tile_start, g_sorted, (const float4*)p0,
-                       (const float4*)p1, rgb, mask, make_float3(cam->bg[0], cam->bg[1], cam->bg[2]),
+    hipLaunchKernelGGL(k_blend_cu, dim3((unsigned)T), dim3(CU_T), 0, s, W, H, gx, tile_start, g_sorted, (const float4*)rec,
+                       mask, make_float3(cam->bg[0], cam->bg[1], cam->bg[2]),
                        calculate_surface_distance, cam_key, cam_surf, out_color, out_depth, out_invdepth);
     if (phases & 4)
     hipLaunchKernelGGL(k_update_cu, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, cam_key, cam_surf, (long)n, W, H, out_color,

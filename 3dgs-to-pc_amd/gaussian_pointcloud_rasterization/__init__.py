@@ -47,8 +47,8 @@ nv._RASTER_PROTOS.update({
     "g2pc_raster_front_workspace": (C.c_size_t, [C.c_int64]),
     "g2pc_raster_back_workspace": (C.c_size_t, [C.c_int64, C.c_int32]),
     "g2pc_raster_front_cu": (C.c_int, [C.POINTER(_Camera)] + [_vp] * 5 + [C.c_int32, C.c_int32, _vp, C.c_int64] +
-                             [_vp] * 9 + [C.c_size_t, _vp]),
-    "g2pc_raster_back_cu": (C.c_int, [C.POINTER(_Camera), _vp, C.c_int64, C.c_int64] + [_vp] * 6 + [C.c_int] + [_vp] * 10 +
+                             [_vp] * 7 + [C.c_size_t, _vp]),
+    "g2pc_raster_back_cu": (C.c_int, [C.POINTER(_Camera), _vp, C.c_int64, C.c_int64] + [_vp] * 4 + [C.c_int] + [_vp] * 10 +
                             [C.c_int32] + [_vp] * 3 + [C.c_int, _vp, C.c_size_t, _vp]),
     "g2pc_mark_visible": (C.c_int, [_vp, C.c_int64, C.POINTER(C.c_float * 16), _vp, _vp]),
 })
@@ -64,9 +64,8 @@ class _CuScratch:
 
     def __init__(self, n, dev, stream=None):
         f32, i32 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.int32, device=dev)
-        self.p0, self.p1 = torch.empty((n, 4), **f32), torch.empty((n, 4), **f32)
+        self.rec = torch.empty((n, 16), **f32)                    # one 64-byte blend record per Gaussian
         self.rect, self.sorted, self.offsets = torch.empty(n, **i32), torch.empty(n, **i32), torch.empty(n + 1, **i32)
-        self.rgb = torch.empty((n, 3), **f32)
         self.radii = torch.empty(n, **i32)
         self.cam_key = torch.empty(n, dtype=torch.int64, device=dev)
         self.cam_surf = torch.empty(n, **i32)
@@ -150,8 +149,8 @@ class GaussianRasterizer(nn.Module):
             nv.check(nv.lib().g2pc_raster_front_cu(
                 C.byref(cam), nv.ptr(self.means3D), nv.ptr(self.cov3D_precomp), nv.ptr(self.opacities),
                 nv.ptr(self.colors_precomp), nv.ptr(shs), int(sh_degree) if shs is not None else 0, coeffs,
-                C.cast(campos, C.c_void_p), self.n, nv.ptr(sc.p0), nv.ptr(sc.p1), nv.ptr(sc.rect), nv.ptr(sc.rgb),
-                nv.ptr(sc.radii), nv.ptr(sc.sorted), nv.ptr(sc.offsets),
+                C.cast(campos, C.c_void_p), self.n, nv.ptr(sc.rec), nv.ptr(sc.rect), nv.ptr(sc.radii), nv.ptr(sc.sorted),
+                nv.ptr(sc.offsets),
                 C.c_void_p(sc.count_host.data_ptr()) if sc.count_host is not None else None, nv.ptr(sc.front_ws),
                 sc.front_bytes, self._stream_ptr(sc)), "raster_front_cu")
 
@@ -171,8 +170,8 @@ class GaussianRasterizer(nn.Module):
                 sc.invdepths = torch.empty((1, H, W), dtype=torch.float32, device=self.device)
         with nv.region(name, self.device, sc.stream):
             nv.check(L.g2pc_raster_back_cu(
-                C.byref(cam), nv.ptr(mask), self.n, num_rendered, nv.ptr(sc.p0), nv.ptr(sc.p1), nv.ptr(sc.rect),
-                nv.ptr(sc.rgb), nv.ptr(sc.sorted), nv.ptr(sc.offsets), 1 if self.calculate_surface_distance else 0,
+                C.byref(cam), nv.ptr(mask), self.n, num_rendered, nv.ptr(sc.rec), nv.ptr(sc.rect), nv.ptr(sc.sorted),
+                nv.ptr(sc.offsets), 1 if self.calculate_surface_distance else 0,
                 nv.ptr(sc.cam_key), nv.ptr(sc.cam_surf), nv.ptr(sc.colour), nv.ptr(sc.depths), nv.ptr(sc.invdepths),
                 nv.ptr(self.gaussian_max_contribution), nv.ptr(self.gaussian_total_contribution),
                 nv.ptr(self.gaussian_colours), nv.ptr(self.gaussian_min_surface_distance), nv.ptr(self._winner_cam),

@@ -287,12 +287,13 @@ int g2pc_raster_debug_chunk_work(uint32_t* buf);
  * depth at the end of every 256-instance batch, optional mask (i32[H*W], 0 = skip the pixel) and SH colours
  * (sh f32[n, sh_coeffs, 3], degree <= 3, forward.cu:22-73).  cam->view = viewmatrix, cam->proj = FULL projmatrix
  * (view @ proj), cam->tan_fovx/y; focal = W / (2 tan_fovx) (rasterizer_impl.cu:229-230).
- * front: p0/p1 f32[n,4], rect u32[n], rgb f32[n,3], radii i32[n], sorted_idx u32[n], offsets u32[n+1] out. */
+ * front: rec f32[n,16] (one 64-byte record per Gaussian: (x, y, conic a, b), (conic c, opacity, depth, radius), (r, g, b, -),
+ * pad), rect u32[n], radii i32[n], sorted_idx u32[n], offsets u32[n+1] out. */
 int g2pc_raster_front_cu(const G2pcCamera* cam, const float* means3D, const float* cov6, const float* opacity,
                          const float* colours_precomp, const float* shs, int32_t sh_degree, int32_t sh_coeffs,
-                         const float* campos, int64_t n, float* p0, float* p1, uint32_t* rect, float* rgb,
-                         int32_t* radii, uint32_t* sorted_idx, uint32_t* offsets, uint32_t* count_host, void* ws,
-                         size_t ws_bytes, void* stream);
+                         const float* campos, int64_t n, float* rec, uint32_t* rect, int32_t* radii,
+                         uint32_t* sorted_idx, uint32_t* offsets, uint32_t* count_host, void* ws, size_t ws_bytes,
+                         void* stream);
 /* back: out_color f32[3,H,W], out_depth / out_invdepth f32[H,W] (zero-filled here, masked pixels stay 0);
  * running state max_contrib / total_contrib / min_surf f32[n], colours f32[n,3] updated as the reference's binding does
  * (gaussian_pointcloud_rasterization/__init__.py:128-158); winner_cam i32[n] (optional) records cam_index of the camera
@@ -300,9 +301,9 @@ int g2pc_raster_front_cu(const G2pcCamera* cam, const float* means3D, const floa
  * gauss_pixels, gauss_surface_distances.  phases: bit 0 = binning + zero fills, bit 1 = blend, bit 2 = running-state
  * update (must be issued in camera order; bits 0-1 of different cameras may overlap on different streams with
  * per-stream scratch).  Workspace size: g2pc_raster_back_workspace(num_instances, tiles). */
-int g2pc_raster_back_cu(const G2pcCamera* cam, const int32_t* mask, int64_t n, int64_t num_instances, const float* p0,
-                        const float* p1, const uint32_t* rect, const float* rgb, const uint32_t* sorted_idx,
-                        const uint32_t* offsets, int calculate_surface_distance, unsigned long long* cam_key,
+int g2pc_raster_back_cu(const G2pcCamera* cam, const int32_t* mask, int64_t n, int64_t num_instances, const float* rec,
+                        const uint32_t* rect, const uint32_t* sorted_idx, const uint32_t* offsets,
+                        int calculate_surface_distance, unsigned long long* cam_key,
                         uint32_t* cam_surf, float* out_color, float* out_depth, float* out_invdepth,
                         float* max_contrib, float* total_contrib, float* colours, float* min_surf,
                         int32_t* winner_cam, int32_t cam_index, float* cur_contrib, int32_t* cur_pixels, float* cur_surf,
