@@ -22,7 +22,7 @@ import numpy as np
 SUBBLOCKS_PER_CHUNK = 2      # 8x8-pixel sub-blocks per blend wave (1, 2 or 4 pixels per lane; 2 = packed-f32 kernel)
 
 
-def _finish(xs, ws, ys, hs, seq_of, subblocks=None) -> Dict[str, np.ndarray]:
+def _finish(xs, ws, ys, hs, seq_of, subblocks=None, tile_shard=None) -> Dict[str, np.ndarray]:
     subblocks = SUBBLOCKS_PER_CHUNK if subblocks is None else subblocks
     nx, ny = len(xs), len(ys)
     T = nx * ny
@@ -50,8 +50,14 @@ def _finish(xs, ws, ys, hs, seq_of, subblocks=None) -> Dict[str, np.ndarray]:
         cx, cy = xs[ix] + ws[ix] / 2.0, ys[iy] + hs[iy] / 2.0
         return ((cx - W / 2.0) / W) ** 2 + ((cy - H / 2.0) / H) ** 2
     order_t = sorted(range(T), key=dist)
+    if tile_shard is not None:
+        # multi-GPU with fewer cameras than ranks: every rank renders every camera but blends only its share of the
+        # tiles (dealt out in the centre-out order, so dense and sparse tiles are spread evenly); preprocess, sort and
+        # binning are replicated, the visibility exchange is the usual one (g2pc/dist.py)
+        r, w = tile_shard
+        order_t = order_t[r::w]
     chunk_tile, chunk_pix0 = [], []
-    for g0 in range(0, T, 8):
+    for g0 in range(0, len(order_t), 8):
         group = order_t[g0:g0 + 8]
         per_tile = [list(range(0, ((ws[t % nx] + 7) // 8) * ((hs[t // nx] + 7) // 8), subblocks)) for t in group]
         for c in range(max(len(p) for p in per_tile)):
@@ -65,7 +71,8 @@ def _finish(xs, ws, ys, hs, seq_of, subblocks=None) -> Dict[str, np.ndarray]:
                 chunk_pix0=np.asarray(chunk_pix0, np.int32), total_pixels=int(off[-1]), chunk_subblocks=int(subblocks))
 
 
-def python_quadtree_layout(width: int, height: int, max_tile_size: int = 60, subblocks=None) -> Dict[str, np.ndarray]:
+def python_quadtree_layout(width: int, height: int, max_tile_size: int = 60, subblocks=None,
+                           tile_shard=None) -> Dict[str, np.ndarray]:
     queue = [([0, 0], [width, height])]          # ([row, col], [w, h]) as in the reference
     leaves = []
     while queue:
@@ -96,7 +103,8 @@ def python_quadtree_layout(width: int, height: int, max_tile_size: int = 60, sub
         if wof[x0] != w or hof[y0] != h:
             raise NotImplementedError("non-uniform quad-tree leaves")
         seq_of[(x0, y0)] = s
-    return _finish([x for x, _ in xs], [w for _, w in xs], [y for y, _ in ys], [h for _, h in ys], seq_of, subblocks)
+    return _finish([x for x, _ in xs], [w for _, w in xs], [y for y, _ in ys], [h for _, h in ys], seq_of, subblocks,
+                   tile_shard)
 
 
 def grid_layout(width: int, height: int, block: int = 16) -> Dict[str, np.ndarray]:

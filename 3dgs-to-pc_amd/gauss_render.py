@@ -214,7 +214,7 @@ class GaussHipRenderer():
     MAX_TILE_SIZE = 60
 
     def __init__(self, means3D, opacity, colour, cov3d, white_bkgd=True, visible_gaussian_threshold=0.0,
-                 semantics="python", t_floor=None):
+                 semantics="python", t_floor=None, tile_shard=None):
         if semantics != "python":
             raise NotImplementedError("use gaussian_pointcloud_rasterization.GaussianRasterizer for 'cuda' semantics")
         nv.lib()
@@ -223,6 +223,9 @@ class GaussHipRenderer():
         self.semantics = semantics
         self.visible_gaussian_threshold = visible_gaussian_threshold
         self.t_floor = DEFAULT_T_FLOOR if t_floor is None else float(t_floor)
+        # (rank, world): blend only this rank's share of every camera's tiles (multi-GPU jobs with fewer cameras than
+        # ranks; the images returned then hold this rank's tiles only)
+        self.tile_shard = tuple(tile_shard) if tile_shard is not None and tile_shard[1] > 1 else None
         n = means3D.shape[0]
         self.n = n
 
@@ -314,9 +317,10 @@ class GaussHipRenderer():
     # ---- rendering ---------------------------------------------------------------------------------------------
     def _layout(self, width, height):
         # tile layouts depend only on the image size and tiling: built and uploaded once per process and device
-        key = (width, height, self.MAX_TILE_SIZE, BLEND_SUBBLOCKS, str(self.device))
+        key = (width, height, self.MAX_TILE_SIZE, BLEND_SUBBLOCKS, self.tile_shard, str(self.device))
         if key not in _LAYOUT_CACHE:
-            _LAYOUT_CACHE[key] = _DeviceLayout(tiles.python_quadtree_layout(width, height, self.MAX_TILE_SIZE, BLEND_SUBBLOCKS), self.device)
+            _LAYOUT_CACHE[key] = _DeviceLayout(tiles.python_quadtree_layout(width, height, self.MAX_TILE_SIZE, BLEND_SUBBLOCKS,
+                                                                             self.tile_shard), self.device)
         return _LAYOUT_CACHE[key]
 
     def all_reduce_visibility(self, group=None):
@@ -540,8 +544,8 @@ class GaussHipRenderer():
 
 
 def get_renderer(renderer_type: str, xyz, opacities, colours, covariances, shs=None, visible_gaussian_threshold=0.0,
-                 surface_distance_std=None, calculate_surface_distance=False):
-    """gauss_render.py:467-493."""
+                 surface_distance_std=None, calculate_surface_distance=False, tile_shard=None):
+    """gauss_render.py:467-493.  tile_shard (not in the reference): see GaussHipRenderer."""
     if renderer_type in ("cuda", "hip"):
         from gaussian_pointcloud_rasterization import GaussianRasterizer as GaussianPCRasterizer
 
@@ -560,6 +564,6 @@ def get_renderer(renderer_type: str, xyz, opacities, colours, covariances, shs=N
 
     elif renderer_type == "python":
         return GaussHipRenderer(xyz, opacities, colours, covariances, semantics="python",
-                                visible_gaussian_threshold=visible_gaussian_threshold)
+                                visible_gaussian_threshold=visible_gaussian_threshold, tile_shard=tile_shard)
 
     raise Exception(f"Renderer of type {renderer_type} is not supported")

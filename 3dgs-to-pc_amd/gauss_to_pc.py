@@ -183,12 +183,17 @@ def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, poin
         if not s.quiet:
             print("Rendering Gaussian Colours")
 
+        # fewer cameras than ranks: split every camera's TILES over the ranks instead of the cameras (python semantics;
+        # the native-rasteriser path keeps the camera split and leaves the surplus ranks idle)
+        split_tiles = (world > 1 and transforms is not None and len(transforms) < world and s.renderer_type == "python")
+        extra = dict(tile_shard=(rank, world)) if split_tiles else {}
         gaussian_renderer = get_renderer(s.renderer_type, gaussians.xyz, torch.unsqueeze(torch.clone(gaussians.opacities), 1),
                                          gaussians.colours, gaussians.covariances,
                                          shs=gaussians.shs if (render_shs and s.renderer_type != "python") else None,
                                          visible_gaussian_threshold=s.visibility_threshold,
                                          surface_distance_std=s.surface_distance_std,
-                                         calculate_surface_distance=True if (s.surface_distance_std is not None or s.generate_mesh) else False)
+                                         calculate_surface_distance=True if (s.surface_distance_std is not None or s.generate_mesh) else False,
+                                         **extra)
 
         if transforms is None:
             raise Exception("Transforms are required to render colours")
@@ -199,7 +204,7 @@ def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, poin
                 if epochs and cam_index > 0 and cam_index % CAMERA_EPOCH == 0:   # 8-bit camera-order field of the keys
                     gaussian_renderer.all_reduce_visibility(group)
                     gaussian_renderer.rebase_keys()
-                if cam_index % world != rank:
+                if not split_tiles and cam_index % world != rank:
                     continue
             transform = torch.tensor(list(transform))
             mask = None

@@ -140,3 +140,32 @@ def test_two_rank_cli_writes_the_single_process_cloud(tmp_path):
     a, b = gd.read_ply_vertices(str(tmp_path / "pc_w1.ply")), gd.read_ply_vertices(str(tmp_path / "pc_w2.ply"))
     assert len(a) == len(b) and len(a) > 10000
     assert np.array_equal(np.sort(a, order=list(a.dtype.names)), np.sort(b, order=list(b.dtype.names)))
+
+
+def test_two_ranks_one_camera_split_the_tiles(tmp_path):
+    """Fewer cameras than ranks: every rank renders the camera but blends only its share of the tiles; the
+    usual visibility exchange must reproduce the single-process result exactly."""
+    from emu_util import build_emu
+    build_emu()
+    _run(0, 1, 0, str(tmp_path), "python", 255, 1)
+    port = 37500 + (os.getpid() % 2000)
+    mp.spawn(_run, args=(2, port, str(tmp_path), "python", 255, 1), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "python_w1_e255.npz"), np.load(tmp_path / "python_w2_e255.npz")
+    rows = lambda d: np.concatenate([d["points"], d["colours"], d["normals"]], axis=1)
+    ca, cb = rows(a), rows(b)
+    assert ca.shape == cb.shape and ca.shape[0] > 5000
+    assert np.array_equal(ca[np.lexsort(ca.T[::-1])], cb[np.lexsort(cb.T[::-1])])
+
+
+def test_tile_shards_partition_the_chunk_list():
+    sys.path.insert(0, os.path.join(ROOT, "3dgs-to-pc_amd"))
+    from g2pc import tiles
+    full = tiles.python_quadtree_layout(1280, 720, 60, 2)
+    whole = sorted(zip(full["chunk_tile"].tolist(), full["chunk_pix0"].tolist()))
+    for world in (2, 3, 8):
+        parts = [tiles.python_quadtree_layout(1280, 720, 60, 2, (r, world)) for r in range(world)]
+        got = sorted(c for p in parts for c in zip(p["chunk_tile"].tolist(), p["chunk_pix0"].tolist()))
+        assert got == whole                                                   # disjoint and complete
+        sizes = [len(p["chunk_tile"]) for p in parts]
+        assert max(sizes) - min(sizes) <= 8                                   # one tile's worth of chunks at most
+        assert all(np.array_equal(p["tile_seq"], full["tile_seq"]) for p in parts)   # keys mean the same on every rank
