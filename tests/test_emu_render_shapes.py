@@ -1,0 +1,42 @@
+"""Odd shapes through the python-semantics renderer (emulator) against the oracle: image sizes that are not multiples of
+the 8x8 sub-blocks, a single Gaussian, nothing in front of the camera, splats larger than the image, every pixels-per-lane
+variant, with and without the transmittance floor."""
+import numpy as np
+import pytest
+import torch
+
+from emu_util import emu  # noqa: F401
+
+
+@pytest.mark.parametrize("n,w,h,scale,sub,floor", [
+    (1, 64, 48, (0.05, 0.06), 2, 0.0),            # one Gaussian
+    (7, 17, 9, (0.02, 0.2), 1, 0.0),              # tiny image, sub-blocks mostly padding
+    (120, 61, 61, (0.3, 0.6), 2, 1e-6),           # one pixel over the 60-pixel tile limit; splats larger than the image
+    (300, 123, 77, (0.005, 0.05), 4, 1e-6),       # odd sizes, 4 pixels per lane
+    (300, 200, 50, (0.005, 0.05), 2, 0.0),        # wide image, packed kernel, exact mode
+])
+def test_shapes_vs_oracle(emu, monkeypatch, n, w, h, scale, sub, floor):
+    import gauss_render
+    from render_checks import run_vs_oracle
+    monkeypatch.setattr(gauss_render, "BLEND_SUBBLOCKS", sub)
+    res = run_vs_oracle(n, 100 + n, w, h, 0.9 * w, 2, scale=scale, t_floor=floor)
+    assert res["image"] < 1e-4 and res["contribution"] < 1e-4 and res["colour"] < 1e-4 and res["flips"] == 0, res
+
+
+def test_nothing_in_front_of_the_camera(emu):
+    """Every Gaussian behind the camera: zero instances, background image, no contribution, no visible Gaussian."""
+    import gauss_render
+    import camera_handler
+    from gauss_handler import Gaussians
+    from g2pc.synth import make_scene, make_cameras
+    sc = make_scene(50, 3, scale_lo=0.01, scale_hi=0.05)
+    tr, intr = make_cameras(1, width=64, height=40, focal=60.0)
+    name = next(iter(tr))
+    c2w = torch.tensor(tr[name])
+    xyz = sc.xyz * 0.1 + c2w[:3, 3] + 2.0 * c2w[:3, 2]          # the camera looks down -z: +z is behind it
+    G = Gaussians(xyz, sc.scales, sc.rots, sc.colours, sc.opacities)
+    R = gauss_render.get_renderer("python", G.xyz, G.opacities.unsqueeze(1), G.colours, G.covariances, visible_gaussian_threshold=0.05)
+    img = R(camera_handler.get_camera("python", c2w, intr[name]))[0]
+    assert R.last_stats[-1][0] == 0
+    assert torch.equal(img, torch.ones_like(img))                # white background
+    assert float(R.gaussian_max_contribution.max()) == 0.0 and int(R.get_visible_gaussians().sum()) == 0
