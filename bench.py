@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--sort-bits", type=int, default=0, help="tuning aid: wide radix digit bits (8 or 11)")
     ap.add_argument("--sort-small", type=int, default=2 << 20, help="tuning aid: inputs up to this many keys use 4 keys/thread")
     ap.add_argument("--blend-subblocks", type=int, default=0, help="tuning aid: 8x8 sub-blocks per blend wave (1, 2, 4)")
+    ap.add_argument("--scene-scales", type=float, nargs=2, default=None, metavar=("LO", "HI"),
+                    help="diagnostic: Gaussian scale range of the synthetic scene (default 0.002 0.02 = SURVEY.md's)")
     ap.add_argument("--no-context-pool", action="store_true", help="tuning aid: every job captures its camera graphs anew")
     ap.add_argument("--streams", type=int, default=0, help="tuning aid: cameras in flight (HIP streams) of the renderer")
     ap.add_argument("--camera-subset", type=int, default=0, help="profiling aid: render only the first k cameras of the rig")
@@ -213,7 +215,8 @@ def main():
     # keeps the configs[2] load of 50 cameras / 10M points; strong: the N = 1 job is split N ways.
     scale = world if a.scaling == "weak" else 1
     total_cameras, total_points = a.cameras * scale, a.points * scale
-    scene = make_scene(a.gaussians, 1234 + 3, device=device, with_sh=(workload == "render_cuda"))
+    scene_kw = dict(scale_lo=a.scene_scales[0], scale_hi=a.scene_scales[1]) if a.scene_scales else {}
+    scene = make_scene(a.gaussians, 1234 + 3, device=device, with_sh=(workload == "render_cuda"), **scene_kw)
     cams = make_cameras(total_cameras) if workload != "sample" else None
     if cams is not None and a.camera_subset:
         keep = sorted(cams[0])[:a.camera_subset]              # profiling aid: first k of the SAME 50-camera rig

@@ -40,3 +40,33 @@ def test_nothing_in_front_of_the_camera(emu):
     assert R.last_stats[-1][0] == 0
     assert torch.equal(img, torch.ones_like(img))                # white background
     assert float(R.gaussian_max_contribution.max()) == 0.0 and int(R.get_visible_gaussians().sum()) == 0
+
+
+
+@pytest.mark.parametrize("sub", [1, 2])
+def test_floor_mode_keeps_contributions_bit_identical(emu, monkeypatch, sub):
+    """The documented guarantee of the transmittance floor: every contribution above it equals the exact mode's bit for
+    bit (the floor only stops walks whose remaining contributions are all below it), and so do the winners."""
+    import gauss_render
+    import camera_handler
+    from gauss_handler import Gaussians
+    from g2pc.synth import make_scene, make_cameras
+    monkeypatch.setattr(gauss_render, "BLEND_SUBBLOCKS", sub)
+    sc = make_scene(1500, 41, scale_lo=0.004, scale_hi=0.03)
+    tr, intr = make_cameras(2, width=160, height=90, focal=140.0)
+    G = Gaussians(sc.xyz, sc.scales, sc.rots, sc.colours, sc.opacities)
+    out = []
+    for floor in (0.0, 1e-6):
+        R = gauss_render.get_renderer("python", G.xyz, G.opacities.unsqueeze(1), G.colours, G.covariances,
+                                      visible_gaussian_threshold=0.05)
+        R.t_floor = floor
+        imgs = [R(camera_handler.get_camera("python", torch.tensor(tr[k]), intr[k]))[0].numpy() for k in tr]
+        out.append((R.gaussian_max_contribution.numpy().copy(), R.get_gaussian_colours().numpy().copy(), np.stack(imgs),
+                    R.best_key.numpy().copy()))
+    exact, floored = out
+    seen = exact[0] >= 1e-5
+    assert seen.sum() > 300
+    assert np.array_equal(exact[0][seen], floored[0][seen])                    # contributions, bit for bit
+    assert np.array_equal(exact[3][seen], floored[3][seen])                    # and the winning (camera, tile, pixel)
+    assert np.abs(exact[1][seen] - floored[1][seen]).max() < 1e-3              # winners' colours (0..255 scale)
+    assert np.abs(exact[2] - floored[2]).max() < 2e-6                          # images
