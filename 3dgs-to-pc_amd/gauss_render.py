@@ -128,7 +128,7 @@ class _Scratch:
 # kernels (which leave most CUs idle) and even its blend overlap camera c's blend.
 PIPELINE_STREAMS = 4
 PIPELINE_IN_EMULATOR = False      # tests: drive the capture / replay path through the CPU emulator too
-CAPACITY_HEADROOM = 1.5           # instance capacity of the captured graphs relative to the first camera's count
+CAPACITY_HEADROOM = 1.25          # instance capacity of the captured graphs relative to the largest count seen so far
 MIN_CAPACITY = 1 << 16
 _LAYOUT_CACHE = {}
 
