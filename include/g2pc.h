@@ -100,8 +100,10 @@ int g2pc_gather_rows(const void* src, const uint32_t* index, int64_t m, int32_t 
  * point itself included at distance 0; float64; distances summed in ascending order); kept when
  * 0 < mean < mean(means) + std_ratio * std(means) (sample std, over the means > 0).
  * Here the means come from an exact kNN on a uniform grid: _grid_build bins the points into cubic cells of edge `cell`
- * (grid origin[3], dims[3], dims[0]*dims[1]*dims[2] < 2^31; points outside are clamped into the border cells -- pass the
- * bounding box) -> sorted_pos f32[m,4] (x, y, z, original index bits) in cell order, cell_start u32[cells+1], and
+ * (grid origin[3], dims[3], dims[0]*dims[1]*dims[2] < 2^31; points outside the grid are clamped into its border cells,
+ * which stays exact -- the shell bounds only rely on the cell index growing with the coordinate -- so the grid may cover
+ * a robust quantile box instead of the bounding box when a few far-away points would otherwise dictate the cell size)
+ * -> sorted_pos f32[m,4] (x, y, z, original index bits) in cell order, cell_start u32[cells+1], and
  * (optional) the number of non-empty cells in *occupied (device) so the caller can refine the resolution;
  * _knn_mean_distance searches growing shells of cells until the k-th distance is provably final and writes the
  * mean distance of point i (original order) to avg[i] (f64).  k <= 32.  slack: absolute safety margin subtracted from
