@@ -56,3 +56,31 @@ def test_packed_two_pixel_blend_in_graph(emu, monkeypatch):
     k0, c0, _, _ = _render_all(False, monkeypatch, subblocks=2, ncam=3)
     k1, c1, _, _ = _render_all(True, monkeypatch, subblocks=2, ncam=3)
     assert np.array_equal(k0, k1) and np.array_equal(c0, c1)
+
+
+def test_replayed_graph_with_an_empty_camera(emu, monkeypatch):
+    """A camera that sees nothing (instance count 0) in the middle of the replayed sequence: the capacity-sized launches
+    must all fall through and leave the state of the other cameras untouched."""
+    import gauss_render
+    import camera_handler
+    from gauss_handler import Gaussians
+    monkeypatch.setattr(gauss_render, "BLEND_SUBBLOCKS", 4)
+    monkeypatch.setattr(gauss_render, "PIPELINE_STREAMS", 2)
+    sc = make_scene(500, 78, scale_lo=0.01, scale_hi=0.07)
+    transforms, intr = make_cameras(4, width=160, height=90, focal=140.0)
+    names = sorted(transforms)
+    away = torch.tensor(transforms[names[1]]).clone()
+    away[:3, 3] = away[:3, 3] * 10.0                      # ten times further out ...
+    away[:3, :3] = away[:3, :3] @ torch.diag(torch.tensor([1.0, -1.0, -1.0], dtype=away.dtype))   # ... and looking away
+    cams = [torch.tensor(transforms[names[0]]), away, torch.tensor(transforms[names[2]]), torch.tensor(transforms[names[3]])]
+    G = Gaussians(sc.xyz, sc.scales, sc.rots, sc.colours, sc.opacities)
+    res = []
+    for pipelined in (False, True):
+        monkeypatch.setattr(gauss_render, "PIPELINE_IN_EMULATOR", pipelined)
+        R = gauss_render.get_renderer("python", G.xyz, G.opacities.unsqueeze(1), G.colours, G.covariances,
+                                      visible_gaussian_threshold=0.05)
+        for c2w in cams:
+            R(camera_handler.get_camera("python", c2w, intr[names[0]]), return_image=not pipelined)
+        res.append((R.best_key.numpy().copy(), R.get_gaussian_colours().numpy().copy(), [s[0] for s in R.last_stats]))
+    assert 0 in res[0][2] and sorted(res[0][2]) == sorted(res[1][2])          # the empty camera really was empty
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
