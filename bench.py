@@ -107,7 +107,9 @@ def algorithmic_bytes(workload, n, n_kept, m, cams, stats):
 def pmc_traffic(region, a):
     """HBM bytes per launch of the region's kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
     in separate runs of THIS bench command, tools/pmc_traffic.py -> profiles/r01_c_pmc_traffic.json); only valid for
-    the default workload it was collected on.  Raw counter sum; FETCH_SIZE may under-report wide reads by up to 2x."""
+    the default workload it was collected on.  Corrected as MI355X_MICROARCH.md §HBM prescribes for gfx950: FETCH_SIZE
+    counts 16-byte-per-lane loads (what the blend's record gathers are) at half their bytes, so it is doubled;
+    WRITE_SIZE is taken as is; both are KB."""
     import gauss_render
     from g2pc import tiles
     sub = gauss_render.BLEND_SUBBLOCKS or tiles.SUBBLOCKS_PER_CHUNK
@@ -118,7 +120,7 @@ def pmc_traffic(region, a):
             or (region == "raster_blend" and gauss_render.DEFAULT_T_FLOOR != 1e-6)):
         return None
     rec = json.load(open(path)).get(kernel)
-    return rec["hbm_bytes_raw"] if rec else None
+    return rec["hbm_bytes_fetch_x2"] if rec else None
 
 
 def pmc_valu(region, a):
