@@ -201,6 +201,13 @@ __global__ __launch_bounds__(SM_T) void k_emit_means(const float* __restrict__ m
     if (out_gauss) out_gauss[o] = (int32_t)g;
 }
 
+// Lane-per-Gaussian emission (quotas below a wave's worth of draws).  The draws of a lane go to a run of consecutive output
+// rows and the runs of consecutive lanes follow one another (prefix sums of d), so a wave's output for one attempt is
+// one contiguous range -- but written lane by lane it would be 64 scattered 12-byte rows per store.  The wave therefore
+// generates its points into a wave-private LDS window in output order and then writes the window row-per-lane:
+// fully coalesced 12-byte stores for the points, and for the colours / normals / ids of each row's owner (found by a
+// 6-step search of the lanes' run offsets).
+constexpr int EM_WIN = 512;                       // output rows staged per wave and pass
 __global__ __launch_bounds__(SM_T) void k_emit_thread(
     const float* __restrict__ means, const float* __restrict__ cov9, const float* __restrict__ colours,
     const float* __restrict__ normals, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ pbin,
@@ -208,33 +215,75 @@ __global__ __launch_bounds__(SM_T) void k_emit_thread(
     unsigned seed_lo, unsigned seed_hi, uint64_t gid_base, const uint32_t* __restrict__ dcount,
     const uint32_t* __restrict__ dscan, const int64_t* __restrict__ sec_base, float* __restrict__ out_points,
     float* __restrict__ out_colours, float* __restrict__ out_normals, int32_t* __restrict__ out_gauss) {
-    long p = (long)blockIdx.x * SM_T + threadIdx.x;
-    if (p >= p_end) return;
-    unsigned total = 0;
-    for (int a = 0; a < num_attempts; ++a) total += dcount[(size_t)a * gv + p];
-    if (total == 0) return;
-    const unsigned g = perm[p];
-    const unsigned b = pbin[p];
-    const unsigned bs = bin_start[b];
-    GaussSample s;
-    load_gauss(means, cov9, g, s);
-    const float cr = colours[3 * (size_t)g], cg = colours[3 * (size_t)g + 1], cb = colours[3 * (size_t)g + 2];
-    float nx = 0.f, ny = 0.f, nz = 0.f;
-    if (out_normals) { nx = normals[3 * (size_t)g]; ny = normals[3 * (size_t)g + 1]; nz = normals[3 * (size_t)g + 2]; }
-    const uint64_t gid = gid_base + g;
-    const unsigned gid_lo = (unsigned)gid, gid_hi = (unsigned)(gid >> 32);
+    constexpr int NW = SM_T / kWave;
+    __shared__ float s_xyz[NW][EM_WIN][3];
+    __shared__ uint32_t s_run[NW][kWave + 1];      // exclusive prefix of d over the lanes (+ total): where each run starts
+    __shared__ unsigned long long s_o0[NW][kWave]; // first output row of each lane's run
+    __shared__ float s_cn[NW][kWave][6];           // colour, normal of each lane's Gaussian
+    __shared__ int32_t s_id[NW][kWave];
+    const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long p = (long)blockIdx.x * SM_T + threadIdx.x;
+    const bool valid = p < p_end;
+    unsigned any_draws = 0;
+    if (valid)
+        for (int a = 0; a < num_attempts; ++a) any_draws += dcount[(size_t)a * gv + p];
+    if (!__any(any_draws != 0)) return;            // whole wave has nothing to emit
+    unsigned g = 0, b = 0, bs = 0;
+    GaussSample s = {};
+    unsigned gid_lo = 0, gid_hi = 0;
+    if (any_draws) {
+        g = perm[p];
+        b = pbin[p];
+        bs = bin_start[b];
+        load_gauss(means, cov9, g, s);
+        const uint64_t gid = gid_base + g;
+        gid_lo = (unsigned)gid; gid_hi = (unsigned)(gid >> 32);
+        s_cn[w][lane][0] = colours[3 * (size_t)g]; s_cn[w][lane][1] = colours[3 * (size_t)g + 1]; s_cn[w][lane][2] = colours[3 * (size_t)g + 2];
+        if (out_normals) { s_cn[w][lane][3] = normals[3 * (size_t)g]; s_cn[w][lane][4] = normals[3 * (size_t)g + 1]; s_cn[w][lane][5] = normals[3 * (size_t)g + 2]; }
+        s_id[w][lane] = (int32_t)g;
+    }
     for (int a = 0; a < num_attempts; ++a) {
-        const unsigned d = dcount[(size_t)a * gv + p];
-        if (d == 0) continue;
-        const uint32_t* sc = dscan + (size_t)a * (gv + 1);
-        size_t o = (size_t)sec_base[(size_t)b * sec_stride + 1 + attempt0 + a] + (size_t)(sc[p] - sc[bs]);
-        for (unsigned k = 0; k < d; ++k, ++o) {
-            float x, y, z;
-            draw(s, seed_lo, seed_hi, gid_lo, gid_hi, (unsigned)(attempt0 + a), k, 0.f, x, y, z);
-            put3(out_points, o, x, y, z);
-            put3(out_colours, o, cr, cg, cb);
-            if (out_normals) put3(out_normals, o, nx, ny, nz);
-            if (out_gauss) out_gauss[o] = (int32_t)g;
+        const unsigned d = any_draws ? dcount[(size_t)a * gv + p] : 0u;
+        const unsigned incl = wave_incl_scan_u32(d);
+        const unsigned total = __shfl(incl, 63);
+        if (total == 0) continue;                  // uniform
+        const unsigned run = incl - d;
+        wave_sync();                               // the previous attempt's readers are done
+        s_run[w][lane] = run;
+        if (lane == 63) s_run[w][kWave] = total;
+        if (d) {
+            const uint32_t* sc = dscan + (size_t)a * (gv + 1);
+            s_o0[w][lane] = (unsigned long long)sec_base[(size_t)b * sec_stride + 1 + attempt0 + a] + (unsigned long long)(sc[p] - sc[bs]);
+        }
+        for (unsigned w0 = 0; w0 < total; w0 += EM_WIN) {
+            // this lane's draws whose rows fall into [w0, w0 + EM_WIN)
+            const unsigned klo = w0 > run ? w0 - run : 0u;
+            const unsigned khi = (run + d > w0 + EM_WIN) ? (w0 + EM_WIN - run) : d;      // run <= w0 + EM_WIN whenever klo < d matters
+            if (run < w0 + EM_WIN)
+                for (unsigned k = klo; k < khi; ++k) {
+                    float x, y, z;
+                    draw(s, seed_lo, seed_hi, gid_lo, gid_hi, (unsigned)(attempt0 + a), k, 0.f, x, y, z);
+                    float* dst = s_xyz[w][run + k - w0];
+                    dst[0] = x; dst[1] = y; dst[2] = z;
+                }
+            wave_sync();
+            const unsigned wend = total < w0 + EM_WIN ? total : w0 + EM_WIN;
+            for (unsigned t = w0 + lane; t < wend; t += 64) {
+                // owner = the last lane whose run starts at or before row t (runs of d = 0 share their successor's start)
+                unsigned lo = 0, hi = kWave;                                  // invariant: s_run[lo] <= t < s_run[hi]
+#pragma unroll
+                for (int it = 0; it < 6; ++it) {
+                    const unsigned mid = (lo + hi) >> 1;
+                    if (s_run[w][mid] <= t) lo = mid; else hi = mid;
+                }
+                const size_t o = (size_t)s_o0[w][lo] + (size_t)(t - s_run[w][lo]);
+                const float* src = s_xyz[w][t - w0];
+                put3(out_points, o, src[0], src[1], src[2]);
+                put3(out_colours, o, s_cn[w][lo][0], s_cn[w][lo][1], s_cn[w][lo][2]);
+                if (out_normals) put3(out_normals, o, s_cn[w][lo][3], s_cn[w][lo][4], s_cn[w][lo][5]);
+                if (out_gauss) out_gauss[o] = s_id[w][lo];
+            }
+            wave_sync();                           // window drained before it is refilled
         }
     }
 }
