@@ -51,6 +51,11 @@ _PROTOS = {
     "g2pc_sampler_emit": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32,
                                     _u64, _u64, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
 }
+_PROTOS["g2pc_eval_sh"] = (C.c_int, [_i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp])
+_PROTOS["g2pc_build_covariance_2d"] = (C.c_int, [_vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _vp, _vp])
+_PROTOS["g2pc_projection_ndc"] = (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp])
+_PROTOS["g2pc_get_radius"] = (C.c_int, [_vp, _i64, _vp, _vp])
+_PROTOS["g2pc_get_rect"] = (C.c_int, [_vp, _vp, _i64, _f32, _f32, _vp, _vp, _vp])
 _PROTOS["g2pc_mahalanobis"] = (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp])
 _PROTOS["g2pc_sample_mvn"] = (C.c_int, [_vp, _vp, _i64, _i32, _u64, _u64, _i32, _vp, _vp])
 # rasteriser prototypes are appended by g2pc/_native_raster.py style additions below

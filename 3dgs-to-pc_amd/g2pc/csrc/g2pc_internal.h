@@ -75,7 +75,9 @@ __device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned v) {
 // ---- device-side primitives implemented in prims.hip -------------------------------------------
 // exclusive scan of n u32 values; out has n+1 entries (out[n] = total).  in may alias out.
 size_t scan_workspace(long n);
-int scan_exclusive_u32(const uint32_t* in, uint32_t* out, long n, void* ws, size_t ws_bytes, hipStream_t s);
+// gather != nullptr: scans in[gather[i]] (in and out must then be distinct)
+int scan_exclusive_u32(const uint32_t* in, uint32_t* out, long n, void* ws, size_t ws_bytes, hipStream_t s,
+                       const uint32_t* gather = nullptr);
 // stable LSD radix sort of (key,value) u32 pairs on bits [bit_lo, bit_hi).  Result ends in
 // keys_out/vals_out (ping-pong buffers keys_tmp/vals_tmp are scratch of n entries each).
 size_t sort_workspace(long n);

@@ -22,15 +22,17 @@ int check_launch(const char* where) {
 // ------------------------------------------------------------------------------------------------
 constexpr int SCAN_T = 256, SCAN_I = 4, SCAN_TILE = SCAN_T * SCAN_I;
 
+// gather (optional): scan in[gather[i]] instead of in[i] (the rasteriser's tiles-touched counts in depth order)
 __global__ __launch_bounds__(SCAN_T) void k_scan_tile(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                     long n, uint32_t* __restrict__ block_sums) {
+                                                     long n, uint32_t* __restrict__ block_sums,
+                                                     const uint32_t* __restrict__ gather) {
     __shared__ uint32_t wsum[SCAN_T / kWave];
     const long base = (long)blockIdx.x * SCAN_TILE + (long)threadIdx.x * SCAN_I;
     uint32_t v[SCAN_I];
     uint32_t tsum = 0;
 #pragma unroll
     for (int i = 0; i < SCAN_I; ++i) {
-        v[i] = (base + i < n) ? in[base + i] : 0u;
+        v[i] = (base + i < n) ? (gather ? in[gather[base + i]] : in[base + i]) : 0u;
         tsum += v[i];
     }
     const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -99,12 +101,13 @@ size_t scan_workspace(long n) {
     return bytes + 256;
 }
 
-static int scan_rec(const uint32_t* in, uint32_t* out, long n, Arena& ar, hipStream_t s) {
+static int scan_rec(const uint32_t* in, uint32_t* out, long n, Arena& ar, hipStream_t s,
+                    const uint32_t* gather = nullptr) {
     long nb = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (nb < 1) nb = 1;
     uint32_t* sums = ar.get<uint32_t>((size_t)nb + 1);
     if (!ar.ok()) { set_error("scan", "workspace too small"); return G2PC_ERR_WORKSPACE; }
-    hipLaunchKernelGGL(k_scan_tile, dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, out, n, sums);
+    hipLaunchKernelGGL(k_scan_tile, dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, out, n, sums, gather);
     if (nb == 1) return check_launch("scan");
     if (nb <= 2048) {
         hipLaunchKernelGGL(k_scan_add_self, dim3((unsigned)nb), dim3(SCAN_T), 0, s, out, n, sums);
@@ -116,13 +119,14 @@ static int scan_rec(const uint32_t* in, uint32_t* out, long n, Arena& ar, hipStr
     return check_launch("scan");
 }
 
-int scan_exclusive_u32(const uint32_t* in, uint32_t* out, long n, void* ws, size_t ws_bytes, hipStream_t s) {
+int scan_exclusive_u32(const uint32_t* in, uint32_t* out, long n, void* ws, size_t ws_bytes, hipStream_t s,
+                       const uint32_t* gather) {
     if (n <= 0) {
-        hipMemsetAsync(out, 0, sizeof(uint32_t), s);
+        if (hipMemsetAsync(out, 0, sizeof(uint32_t), s) != hipSuccess) { set_error("scan", "memset failed"); return G2PC_ERR_LAUNCH; }
         return G2PC_OK;
     }
     Arena ar(ws, ws_bytes);
-    return scan_rec(in, out, n, ar, s);
+    return scan_rec(in, out, n, ar, s, gather);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -349,7 +353,7 @@ int g2pc_selftest_wave_reduce(const uint32_t* in, uint32_t* out, int64_t waves, 
 }
 size_t g2pc_scan_workspace(int64_t n) { return g2pc::scan_workspace(n); }
 int g2pc_scan_exclusive_u32(const uint32_t* in, uint32_t* out, int64_t n, void* ws, size_t ws_bytes, void* stream) {
-    return g2pc::scan_exclusive_u32(in, out, n, ws, ws_bytes, (hipStream_t)stream);
+    return g2pc::scan_exclusive_u32(in, out, n, ws, ws_bytes, (hipStream_t)stream, nullptr);
 }
 size_t g2pc_sort_workspace(int64_t n) { return g2pc::sort_workspace(n); }
 int g2pc_sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,

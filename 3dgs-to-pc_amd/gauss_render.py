@@ -73,11 +73,89 @@ nv._RASTER_PROTOS.update({
     "g2pc_graph_destroy": (C.c_int, [C.c_void_p]),
     "g2pc_raster_rebase_keys": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "g2pc_raster_debug_chunk_work": (C.c_int, [C.c_void_p]),
+    "g2pc_set_blend_variant": (C.c_int, [C.c_int]),
     "g2pc_raster_keep_winner_colours": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "g2pc_raster_contributions": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
 })
 if nv._LIB is not None:
     nv._bind(nv._LIB)
+
+
+homogeneous = lambda points: torch.cat([points, torch.ones_like(points[..., :1])], dim=-1)     # gauss_render.py:41
+
+
+def _host16(m):
+    """A 4x4 torch / numpy matrix as 16 host floats (row-major), the way the C ABI takes camera matrices."""
+    v = m.detach().to("cpu", torch.float32).reshape(-1).tolist() if isinstance(m, torch.Tensor) else np.asarray(m, np.float32).reshape(-1).tolist()
+    if len(v) != 16:
+        raise ValueError("expected a 4x4 matrix")
+    return (C.c_float * 16)(*v)
+
+
+def eval_sh(deg, sh, dirs=None):
+    """gauss_render.py:43-99: evaluate spherical harmonics of degree `deg` (0..4) at unit directions.
+    sh [..., C, K >= (deg+1)^2], dirs [..., 3] -> [..., C].  Runs in libg2pc.so (g2pc_eval_sh)."""
+    assert deg <= 4 and deg >= 0
+    coeff = (deg + 1) ** 2
+    assert sh.shape[-1] >= coeff
+    if deg > 0:
+        assert dirs is not None
+    batch = tuple(sh.shape[:-2])
+    channels, k = int(sh.shape[-2]), int(sh.shape[-1])
+    s = ops._f32c(sh).reshape(-1, channels, k)
+    n = s.shape[0]
+    d = None
+    if dirs is not None:
+        d = ops._f32c(dirs.expand(*batch, 3) if tuple(dirs.shape[:-1]) != batch else dirs).reshape(-1, 3)
+    out = torch.empty((n, channels), dtype=torch.float32, device=s.device)
+    nv.check(nv.lib().g2pc_eval_sh(int(deg), nv.ptr(s), nv.ptr(d), n, channels, k, nv.ptr(out), nv.stream_handle(s.device)),
+             "eval_sh")
+    return out.reshape(*batch, channels)
+
+
+def build_covariance_2d(mean3d, cov3d, viewmatrix, fov_x, fov_y, focal_x, focal_y):
+    """gauss_render.py:101-148: EWA-splatting 2-D covariances [n,2,2] (low-pass filter 0.3 included)."""
+    m, c = ops._f32c(mean3d).reshape(-1, 3), ops._f32c(cov3d).reshape(-1, 3, 3)
+    n = m.shape[0]
+    out = torch.empty((n, 2, 2), dtype=torch.float32, device=m.device)
+    nv.check(nv.lib().g2pc_build_covariance_2d(nv.ptr(m), nv.ptr(c), n, C.cast(_host16(viewmatrix), C.c_void_p),
+                                               tan(fov_x * 0.5), tan(fov_y * 0.5), float(focal_x), float(focal_y),
+                                               nv.ptr(out), nv.stream_handle(m.device)), "build_covariance_2d")
+    return out
+
+
+def projection_ndc(points, viewmatrix, projmatrix):
+    """gauss_render.py:151-168 -> (p_proj [n,4], p_view [n,4], in_mask bool[n])."""
+    p = ops._f32c(points).reshape(-1, 3)
+    n = p.shape[0]
+    p_proj = torch.empty((n, 4), dtype=torch.float32, device=p.device)
+    p_view = torch.empty((n, 4), dtype=torch.float32, device=p.device)
+    mask = torch.empty((n,), dtype=torch.uint8, device=p.device)
+    nv.check(nv.lib().g2pc_projection_ndc(nv.ptr(p), n, C.cast(_host16(viewmatrix), C.c_void_p),
+                                          C.cast(_host16(projmatrix), C.c_void_p), nv.ptr(p_proj), nv.ptr(p_view),
+                                          nv.ptr(mask), nv.stream_handle(p.device)), "projection_ndc")
+    return p_proj, p_view, mask.to(torch.bool)
+
+
+@torch.no_grad()
+def get_radius(cov2d):
+    """gauss_render.py:171-180: 2-D radii of the Gaussians."""
+    c = ops._f32c(cov2d).reshape(-1, 2, 2)
+    out = torch.empty((c.shape[0],), dtype=torch.float32, device=c.device)
+    nv.check(nv.lib().g2pc_get_radius(nv.ptr(c), c.shape[0], nv.ptr(out), nv.stream_handle(c.device)), "get_radius")
+    return out
+
+
+@torch.no_grad()
+def get_rect(pix_coord, radii, width, height):
+    """gauss_render.py:183-193: pixel rectangles (rect_min, rect_max), each [n,2], clipped to the image."""
+    p, r = ops._f32c(pix_coord).reshape(-1, 2), ops._f32c(radii).reshape(-1)
+    n = p.shape[0]
+    rect_min = torch.empty((n, 2), dtype=torch.float32, device=p.device)
+    rect_max = torch.empty((n, 2), dtype=torch.float32, device=p.device)
+    nv.check(nv.lib().g2pc_get_rect(nv.ptr(p), nv.ptr(r), n, float(width), float(height), nv.ptr(rect_min),
+                                    nv.ptr(rect_max), nv.stream_handle(p.device)), "get_rect")
+    return rect_min, rect_max
 
 
 def strip_lowerdiag(L):
@@ -541,6 +619,10 @@ class GaussHipRenderer():
         self.flush()
         image, _ = self._render_sync(self._camera_struct(camera), lay, slot, return_image)
         return image, None, None, None
+
+
+# the reference's class name (gauss_render.py:210): same constructor signature, same getters, rendering in HIP
+GaussPythonRenderer = GaussHipRenderer
 
 
 def get_renderer(renderer_type: str, xyz, opacities, colours, covariances, shs=None, visible_gaussian_threshold=0.0,

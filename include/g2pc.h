@@ -178,6 +178,25 @@ int g2pc_sampler_emit(const float* means, const float* cov9, const float* colour
                       const uint32_t* dscan, const int64_t* sec_base, int emit_means, float* out_points,
                       float* out_colours, float* out_normals, int32_t* out_gauss, void* stream);
 
+/* --- stand-alone helpers of the python renderer (the reference's public gauss_render functions) ------------------
+ * eval_sh (gauss_render.py:43-99): sh f32[n, channels, coeffs] (coefficient index on the LAST axis, as the
+ * reference indexes it), dirs f32[n,3] (may be NULL for degree 0), out f32[n, channels]; degree 0..4. */
+int g2pc_eval_sh(int32_t deg, const float* sh, const float* dirs, int64_t n, int32_t channels, int32_t coeffs, float* out,
+                 void* stream);
+/* build_covariance_2d (gauss_render.py:101-148): cov2d f32[n,2,2] = (J W S W^T J^T)[:2,:2] + 0.3 I; viewmatrix is
+ * the HOST 4x4 world_view_transform (row-vector convention, 16 floats); tan_fov = tan(fov / 2). */
+int g2pc_build_covariance_2d(const float* means3D, const float* cov9, int64_t n, const float* viewmatrix, float tan_fovx,
+                             float tan_fovy, float focal_x, float focal_y, float* cov2d, void* stream);
+/* projection_ndc (gauss_render.py:151-168): p_proj f32[n,4], p_view f32[n,4], in_mask u8[n] (p_view.z <= -1e-6);
+ * viewmatrix / projmatrix are HOST 4x4 matrices (16 floats each). */
+int g2pc_projection_ndc(const float* points, int64_t n, const float* viewmatrix, const float* projmatrix, float* p_proj,
+                        float* p_view, uint8_t* in_mask, void* stream);
+/* get_radius (gauss_render.py:171-180): radius f32[n] = 3 ceil(sqrt(max eigenvalue)), discriminant clipped at 0.1 */
+int g2pc_get_radius(const float* cov2d, int64_t n, float* radius, void* stream);
+/* get_rect (gauss_render.py:183-193): rect_min / rect_max f32[n,2] = pix -+ radius clipped to [0, width-1] x [0, height-1] */
+int g2pc_get_rect(const float* pix_coord, const float* radii, int64_t n, float width, float height, float* rect_min,
+                  float* rect_max, void* stream);
+
 /* mahalanobis() (gauss_to_pc.py:92-103): out[i] = sqrt(d^T inv(cov_i) d), d = means_i - samples_i; NaN when the
  * quadratic form is negative (the caller's `<=` then rejects, as in the reference). */
 int g2pc_mahalanobis(const float* means, const float* samples, const float* cov9, int64_t n, float* out,
@@ -282,6 +301,10 @@ int g2pc_raster_camera_update_py(const G2pcTileLayout* layout, int64_t n, uint32
 int g2pc_raster_rebase_keys(unsigned long long* best_key, int64_t n, void* stream);
 /* diagnostics: when non-NULL, the PY blend records (tile list length, entries walked) per chunk in u32[2*num_chunks] */
 int g2pc_raster_debug_chunk_work(uint32_t* buf);
+/* tuning / A-B aid: which python-semantics blend kernel 2-sub-block layouts use.  0 = first generation
+ * (k_blend_py_pk), 1 = k_blend_py_v2 (default: LDS reads one trip ahead, 10-dword staged records, packed -> scalar
+ * width once one 8x8 sub-block is below the floor).  Same results above the transmittance floor, bit for bit. */
+int g2pc_set_blend_variant(int variant);
 /* --- native-rasteriser ("cuda") semantics: _C.rasterize_gaussians (rasterize_points.h:18-41) ----------------------
  * Deterministic spec of SURVEY.md §8(a.5): 16x16 tiles, near cull z_view <= 0.2, radius ceil(3 sqrt(lambda_max)),
  * stable (tile, depth) order, alpha rules (power > 0 skip, min(0.99, .), alpha < 1/255 skip, T(1-alpha) < 1e-4 stop),

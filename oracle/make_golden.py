@@ -202,8 +202,134 @@ def gen_pipeline(ref):
     print("pipeline: kept", int(culled.sum()), "points", pts.shape[0])
 
 
+def gen_render_big(ref, tag="1m", n=1_000_000, num_points=10_000_000, width=1280, height=720, focal=1100.0):
+    """BASELINE configs[2] at FULL size: the bench scene (1 M Gaussians, seed 1234+3), cameras 0 and 17 of the
+    50-camera rig at 1280x720, untouched reference python renderer on CPU (~minutes per camera), then the
+    reference's cull -> validate -> magnitudes -> distribute_points(10 M).  Stored compactly: the final
+    running-max contribution of every Gaussian (f32; after camera 0: every 8th), bit-packed visible mask, colours of every 16th Gaussian,
+    every 4th pixel (x and y) of both images, points-per-Gaussian of the kept set (u16)."""
+    import time
+    gh, gr, ch, g2p = (ref[k] for k in ("gauss_handler", "gauss_render", "camera_handler", "gauss_to_pc"))
+    seed = 1234 + 3
+    cam_ids = [0, 17]
+    sc = make_scene(n, seed)
+    transforms, intr = make_cameras(50, width=width, height=height, focal=focal)
+    names = sorted(transforms)
+    with CudaToCpu():
+        G = gh.Gaussians(sc.xyz.clone(), sc.scales.clone(), sc.rots.clone(), sc.colours.double(),
+                         sc.opacities.clone())
+        R = gr.get_renderer("python", G.xyz, torch.unsqueeze(torch.clone(G.opacities), 1),
+                            G.colours, G.covariances, visible_gaussian_threshold=0.05)
+        imgs, contribs, secs = [], [], []
+        for ci in cam_ids:
+            name = names[ci]
+            cam = ch.get_camera("python", torch.tensor(transforms[name]), intr[name], colour_resolution=width)
+            t0 = time.perf_counter()
+            img, _, _, _ = R(cam)
+            secs.append(time.perf_counter() - t0)
+            print("render_big: camera %d in %.1f s" % (ci, secs[-1]), flush=True)
+            imgs.append(_np(img).astype(np.float32)[::4, ::4].copy())
+            contribs.append(_np(R.gaussian_max_contribution).copy())
+        colours = _np(R.get_gaussian_colours())
+        visible = _np(R.get_visible_gaussians())
+        G.colours = R.get_gaussian_colours()
+        G.add_gaussians_to_cull(R.get_visible_gaussians())
+        G.apply_min_opacity(0.0)
+        G.apply_bounding_box(None, None)
+        culled = G.filter_gaussians()
+        contrib = R.get_total_gaussian_contributions()[culled]
+        keep = G.validate_covariances()
+        contrib = contrib[keep]
+        mags = G.get_gaussian_magnitudes(contrib)
+        ppg = g2p.distribute_points(mags, num_points)
+        # ... and the reference's sampler on the kept set, with keyed noise (the full 10 M-point cloud; every 64th row kept)
+        noise_seed = 4242
+        t0 = time.perf_counter()
+        with KeyedNoise(g2p, G.xyz, noise_seed):
+            pts, cols, nrms = g2p.generate_pointcloud(
+                G, num_points, exact_num_points=False, mahalanobis_distance_std=2.0,
+                calculate_normals=False, num_sample_attempts=5, contributions=contrib,
+                device="cpu", quiet=True)
+        sample_seconds = time.perf_counter() - t0
+        print("render_big: sampler %d points in %.1f s" % (pts.shape[0], sample_seconds), flush=True)
+    assert float(ppg.max()) < 65535
+    np.savez_compressed(os.path.join(GOLD, "sample_cfg2_%s.npz" % tag), n=n, seed=seed, noise_seed=noise_seed,
+                        num_points=num_points, m=pts.shape[0], sample_seconds=sample_seconds,
+                        kept_colours=_np(G.colours).astype(np.float32), kept_contrib=_np(contrib).astype(np.float32),
+                        kept_cov=_np(G.covariances).astype(np.float32),
+                        points_s64=_np(pts)[::64].copy(), colours_s64=_np(cols)[::64].astype(np.float32))
+    np.savez_compressed(os.path.join(GOLD, "render_py_cfg2_%s.npz" % tag), n=n, seed=seed, cam_ids=np.array(cam_ids),
+                        width=width, height=height, focal=focal,
+                        num_points=num_points, threads=torch.get_num_threads(), seconds_per_camera=np.array(secs),
+                        images_s4=np.stack(imgs), contrib_cam0_s8=contribs[0][::8].copy(), contrib_final=contribs[1],
+                        visible_bits=np.packbits(visible), colours_s16=colours[::16].astype(np.float32),
+                        culled_bits=np.packbits(_np(culled)), keep_bits=np.packbits(_np(keep)),
+                        ppg_u16=_np(ppg).astype(np.uint16), ppg_sum=float(ppg.sum()))
+    print("render_big: visible", int(visible.sum()), "kept", int(_np(keep).sum()), "ppg sum", float(ppg.sum()),
+          "s/camera", secs)
+
+
+def gen_helpers(ref):
+    """The reference's public helper functions on seeded inputs: eval_sh (degrees 0..4), build_covariance_2d,
+    projection_ndc, get_radius, get_rect (gauss_render.py:43-193); mahalanobis (gauss_to_pc.py:92-103); and a
+    geometry case whose validate_covariances really culls rows (gauss_handler.py:142-166)."""
+    gh, gr, ch, g2p = (ref[k] for k in ("gauss_handler", "gauss_render", "camera_handler", "gauss_to_pc"))
+    n, seed = 4096, 1234 + 21
+    sc = make_scene(n, seed, scale_lo=0.004, scale_hi=0.04)
+    transforms, intr = make_cameras(3, width=640, height=360, focal=550.0)
+    name = sorted(transforms)[1]
+    out = dict(n=n, seed=seed, cam=1)
+    g = torch.Generator().manual_seed(seed)
+    with CudaToCpu():
+        G = gh.Gaussians(sc.xyz.clone(), sc.scales.clone(), sc.rots.clone(), sc.colours.double(), sc.opacities.clone())
+        cam = ch.get_camera("python", torch.tensor(transforms[name]), intr[name], colour_resolution=None)
+        cov2d = gr.build_covariance_2d(G.xyz, G.covariances, cam.world_view_transform, cam.FoVx, cam.FoVy,
+                                       cam.focal_x, cam.focal_y)
+        p_proj, p_view, in_mask = gr.projection_ndc(G.xyz, cam.world_view_transform, cam.projection_matrix)
+        radii = gr.get_radius(cov2d)
+        pix = torch.stack([((p_proj[:, 0] + 1.0) * cam.image_width - 1.0) * 0.5,
+                           ((p_proj[:, 1] + 1.0) * cam.image_height - 1.0) * 0.5], dim=-1)
+        rmin, rmax = gr.get_rect(pix, radii, cam.image_width, cam.image_height)
+        out.update(cov2d=_np(cov2d), p_proj=_np(p_proj), p_view=_np(p_view), in_mask=_np(in_mask), radii=_np(radii),
+                   pix=_np(pix), rect_min=_np(rmin), rect_max=_np(rmax))
+        # eval_sh: [n, 3, 25] coefficients, unit directions
+        sh = torch.randn((n, 3, 25), generator=g, dtype=torch.float32) * 0.5
+        d = torch.randn((n, 3), generator=g, dtype=torch.float32)
+        d = d / d.norm(dim=1, keepdim=True)
+        out.update(sh=_np(sh), dirs=_np(d))
+        for deg in range(5):
+            out["sh_deg%d" % deg] = _np(gr.eval_sh(deg, sh, d))
+        # mahalanobis on draws around the means
+        eps = torch.randn((n, 3), generator=g, dtype=torch.float32)
+        L = torch.linalg.cholesky(G.covariances)
+        samples = G.xyz + torch.bmm(L, eps.unsqueeze(-1)).squeeze(-1) * 1.5
+        out.update(maha_samples=_np(samples), maha=_np(g2p.mahalanobis(G.xyz, samples, G.covariances)))
+        # validate_covariances that really culls (gauss_handler.py:142-166).  A row is only ever culled when, after three
+        # clamp-and-rebuild rounds in fp32, LAPACK still finds an eigenvalue <= 1e-8: that needs a dynamic range of the
+        # spectrum beyond fp32 (lambda_max * 6e-8 > 1e-7) and is then decided by rounding noise.  300 rows with
+        # lambda = (10^(-2..6), 1e-3, {0,-1e-3,-2e-3}) in random frames: the reference's own keep flags are the pin.
+        bad = G.covariances.clone()
+        gen = torch.Generator().manual_seed(5)
+        rows = list(range(300))
+        for i, r in enumerate(rows):
+            q, _ = torch.linalg.qr(torch.randn((3, 3), generator=gen))
+            lam = torch.tensor([10.0 ** (-2 + 8 * i / 300), 1e-3, -1e-3 * (i % 3)])
+            m = q @ torch.diag(lam) @ q.T
+            bad[r] = (m + m.T) * 0.5
+        G.covariances = bad.clone()
+        keep = G.validate_covariances().clone()
+        out.update(cull_rows=np.array(rows), cull_bad_cov=_np(bad[rows]), cull_keep=_np(keep),
+                   cull_cov_valid=_np(G.covariances))
+        print("helpers: validate_covariances culled", int((~keep).sum()))
+    np.savez_compressed(os.path.join(GOLD, "helpers_n4096.npz"), **out)
+    print("helpers: in_mask", int(out["in_mask"].sum()), "of", n)
+
+
 if __name__ == "__main__":
     ref = load_reference()
     which = sys.argv[1:] or ["geom", "sampler", "render", "pipeline"]
     for w in which:
-        {"geom": gen_geom, "sampler": gen_sampler, "render": gen_render, "pipeline": gen_pipeline}[w](ref)
+        {"geom": gen_geom, "sampler": gen_sampler, "render": gen_render, "pipeline": gen_pipeline,
+         "render_big": gen_render_big, "helpers": gen_helpers,
+         # the same job at a size the CPU emulator can follow: checks the checker (tools/parity_cfg2.py) without a GPU
+         "render_mini": lambda r: gen_render_big(r, "mini", 4000, 40_000, 320, 180, 275.0)}[w](ref)

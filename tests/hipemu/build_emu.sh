@@ -7,7 +7,7 @@ ROOT="$(cd "$HERE/../.." && pwd)"
 SRC="$ROOT/3dgs-to-pc_amd/g2pc/csrc"
 OUT="$HERE/libg2pc_emu.so"
 OBJS=""
-for f in prims geom alloc sampler raster clean; do
+for f in prims geom alloc sampler raster clean project; do
   [ -f "$SRC/$f.hip" ] || continue
   if [ ! -f "$HERE/$f.emu.o" ] || [ "$SRC/$f.hip" -nt "$HERE/$f.emu.o" ] || [ "$SRC/g2pc_internal.h" -nt "$HERE/$f.emu.o" ] \
      || [ "$SRC/g2pc_device.inl" -nt "$HERE/$f.emu.o" ] || [ "$HERE/hip/hip_runtime.h" -nt "$HERE/$f.emu.o" ] \

@@ -1,0 +1,161 @@
+"""
+CHECKER (test infrastructure): parity of the HIP hot path with the UNTOUCHED REFERENCE at the benchmark's own scale.
+
+tests/golden/render_py_cfg2_1m.npz and sample_cfg2_1m.npz are outputs of /root/reference (python renderer + sampler,
+run on CPU by oracle/make_golden.py::gen_render_big) on BASELINE configs[2]'s scene -- 1 M Gaussians (seed 1234+3),
+cameras 0 and 17 of the 50-camera rig at 1280x720, cull -> validate -> magnitudes -> distribute_points(10 M) ->
+generate_pointcloud with keyed noise.  `run(device)` repeats that job through the product path and returns the gates
+SURVEY.md §8(d) asks to be reported with every number:
+
+  mask_flips / mask_flip_margins    visible-mask (contribution > 0.05) differences and how far the reference's value
+                                    sits from the threshold at each of them
+  contrib_max / contrib_frac_gt_1e-4   per-Gaussian running-max contribution, all 1 M Gaussians
+  colour_max / colour_frac_gt_1e-4     per-Gaussian colour (0..1 scale) on every 16th Gaussian the reference coloured
+  image_max / image_frac_gt_1e-4       every 4th pixel (x and y) of both 1280x720 images
+  ppg_mismatch_given_ref_contrib       points-per-Gaussian differences when OUR magnitudes / distribute_points are fed
+                                       the reference's contributions (isolates the allocation: expected 0)
+  ppg_mismatch_end_to_end              the same from our own render (contributions differ by ~1e-6 -> a few +-1)
+  sample_*                             the 10 M-point cloud sampled from the reference's kept set with the same keyed
+                                       noise: point count, rows compared (every 64th), max |xyz| and |rgb| difference
+
+Used by tests/test_gpu_parity_scale.py (-m gpu) and by bench.py's `parity` block (outside the timed region).
+Never imported by the product package.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "3dgs-to-pc_amd"),):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def available(tag="1m"):
+    return all(os.path.isfile(os.path.join(GOLDEN, f % tag)) for f in ("render_py_cfg2_%s.npz", "sample_cfg2_%s.npz"))
+
+
+def _bits(a, n):
+    return np.unpackbits(a)[:n].astype(bool)
+
+
+def run(device="cuda:0", t_floor=None, sampler=True, tag="1m"):
+    import camera_handler
+    import gauss_render
+    import gauss_to_pc as g2p
+    from gauss_handler import Gaussians
+    from g2pc import ops
+    from g2pc.synth import make_scene, make_cameras
+
+    t_start = time.perf_counter()
+    g = np.load(os.path.join(GOLDEN, "render_py_cfg2_%s.npz" % tag))
+    n, seed = int(g["n"]), int(g["seed"])
+    width, height, focal = (int(g["width"]), int(g["height"]), float(g["focal"])) if "width" in g.files else (1280, 720, 1100.0)
+    dev = torch.device(device)
+    sc = make_scene(n, seed)
+    transforms, intr = make_cameras(50, width=width, height=height, focal=focal)
+    names = sorted(transforms)
+    G = Gaussians(sc.xyz.to(dev), sc.scales.to(dev), sc.rots.to(dev), sc.colours.to(dev), sc.opacities.to(dev))
+    R = gauss_render.get_renderer("python", G.xyz, torch.unsqueeze(torch.clone(G.opacities), 1), G.colours,
+                                  G.covariances, visible_gaussian_threshold=0.05)
+    if t_floor is not None:
+        R.t_floor = float(t_floor)
+    out = {"gaussians": n, "cameras": [int(c) for c in g["cam_ids"]], "resolution": "%dx%d" % (width, height),
+           "t_floor": float(R.t_floor), "oracle": "untouched reference on CPU (oracle/make_golden.py render_big)"}
+    img_max, img_frac = 0.0, 0.0
+    for k, ci in enumerate(g["cam_ids"]):
+        name = names[int(ci)]
+        cam = camera_handler.get_camera("python", torch.tensor(transforms[name]), intr[name], colour_resolution=width)
+        img = R(cam)[0]
+        d = (img[::4, ::4].cpu().numpy() - g["images_s4"][k])
+        img_max = max(img_max, float(np.abs(d).max()))
+        img_frac = max(img_frac, float((np.abs(d) > 1e-4).mean()))
+        if k == 0:
+            c0 = R.gaussian_max_contribution.cpu().numpy()[::8]
+            out["contrib_cam0_max"] = float(np.abs(c0 - g["contrib_cam0_s8"]).max())
+    out["image_max"], out["image_frac_gt_1e-4"] = img_max, img_frac
+    c = R.gaussian_max_contribution.cpu().numpy()
+    ref_c = g["contrib_final"]
+    dc = np.abs(c - ref_c)
+    out["contrib_max"], out["contrib_frac_gt_1e-4"] = float(dc.max()), float((dc > 1e-4).mean())
+    vis = R.get_visible_gaussians().cpu().numpy()
+    ref_vis = _bits(g["visible_bits"], n)
+    flips = np.nonzero(vis != ref_vis)[0]
+    out["mask_flips"] = int(flips.size)
+    out["mask_flip_margins"] = [float(x) for x in np.abs(ref_c[flips] - 0.05)[:16]]
+    out["near_threshold_1e-5"] = int((np.abs(ref_c - 0.05) < 1e-5).sum())
+    out["visible"] = int(ref_vis.sum())
+    cols = (R.get_gaussian_colours().cpu().numpy() / 255.0)[::16]
+    ref_cols = g["colours_s16"] / 255.0
+    seen = ref_c[::16] > max(R.t_floor, 0.0)            # below the floor a Gaussian may stay colourless
+    dcol = np.abs(cols - ref_cols)[seen]
+    out["colour_max"], out["colour_frac_gt_1e-4"] = float(dcol.max()), float((dcol.max(axis=1) > 1e-4).mean())
+
+    # allocation: cull -> validate -> magnitudes -> distribute, from our own render
+    ref_ppg = g["ppg_u16"].astype(np.int64)
+    G.colours = R.get_gaussian_colours()
+    G.add_gaussians_to_cull(R.get_visible_gaussians())
+    G.apply_min_opacity(0.0)
+    G.apply_bounding_box(None, None)
+    culled = G.filter_gaussians()
+    contrib = R.get_total_gaussian_contributions()[culled]
+    keep = G.validate_covariances()
+    out["culled_equal"] = bool(np.array_equal(culled.cpu().numpy(), _bits(g["culled_bits"], n)))
+    if out["culled_equal"]:
+        contrib = contrib[keep]
+        mags = G.get_gaussian_magnitudes(contributions=contrib)
+        ppg = ops.distribute_points(mags, int(g["num_points"]))[1].cpu().numpy().astype(np.int64)
+        out["ppg_mismatch_end_to_end"] = int((ppg != ref_ppg).sum()) if ppg.shape == ref_ppg.shape else -1
+        out["ppg_max_abs_diff_end_to_end"] = int(np.abs(ppg - ref_ppg).max()) if ppg.shape == ref_ppg.shape else -1
+    del R
+
+    # allocation + sampler from the REFERENCE's kept set (isolates distribute_points and the sampler)
+    s = np.load(os.path.join(GOLDEN, "sample_cfg2_%s.npz" % tag))
+    ref_culled = torch.from_numpy(_bits(g["culled_bits"], n))
+    G2 = Gaussians(sc.xyz[ref_culled].to(dev), sc.scales[ref_culled].to(dev), sc.rots[ref_culled].to(dev),
+                   torch.from_numpy(s["kept_colours"]).to(dev), sc.opacities[ref_culled].to(dev))
+    keep2 = G2.validate_covariances()
+    out["keep_equal"] = bool(keep2.all()) and int(keep2.numel()) == int(_bits(g["keep_bits"], keep2.numel()).sum())
+    dcov = np.abs(G2.covariances.cpu().numpy() - s["kept_cov"])
+    out["cov_rel_max"] = float((dcov / np.abs(s["kept_cov"]).max(axis=(1, 2), keepdims=True)).max())
+    kc = torch.from_numpy(s["kept_contrib"]).to(dev)
+    mags2 = G2.get_gaussian_magnitudes(contributions=kc)
+    ppg2 = ops.distribute_points(mags2, int(g["num_points"]))[1].cpu().numpy().astype(np.int64)
+    out["ppg_mismatch_given_ref_contrib"] = int((ppg2 != ref_ppg).sum())
+    if sampler:
+        pts, cols2, _ = g2p.generate_pointcloud(G2, int(g["num_points"]), exact_num_points=False,
+                                                mahalanobis_distance_std=2.0, calculate_normals=False,
+                                                num_sample_attempts=5, contributions=kc, device=str(dev), quiet=True,
+                                                seed=int(s["noise_seed"]))
+        out["sample_points"], out["sample_points_ref"] = int(pts.shape[0]), int(s["m"])
+        if pts.shape[0] == int(s["m"]):
+            p = pts[::64].cpu().numpy()
+            dx = np.abs(p - s["points_s64"]).max(axis=1)
+            out["sample_rows_compared"] = int(p.shape[0])
+            out["sample_xyz_max"] = float(dx.max())
+            out["sample_xyz_rows_gt_1e-4"] = int((dx > 1e-4).sum())
+            out["sample_rgb_max"] = float(np.abs(cols2[::64].cpu().numpy() - s["colours_s64"]).max() / 255.0)
+        else:
+            # a Gaussian whose quota differs by one shifts every later row: match the reference rows to their nearest
+            # neighbour in our cloud instead (bounded: 20 000 reference rows)
+            from scipy.spatial import cKDTree
+            tree = cKDTree(pts.cpu().numpy())
+            q = s["points_s64"][:20000]
+            dist, _ = tree.query(q, k=1)
+            out["sample_rows_compared"] = int(q.shape[0])
+            out["sample_xyz_max"] = float(dist.max())
+            out["sample_xyz_rows_gt_1e-4"] = int((dist > 1e-4).sum())
+    out["reference_cpu_seconds_per_camera"] = [float(x) for x in g["seconds_per_camera"]]
+    out["reference_cpu_threads"] = int(g["threads"])
+    out["check_seconds"] = time.perf_counter() - t_start
+    return out
+
+
+if __name__ == "__main__":
+    import json
+    print(json.dumps(run(sys.argv[1] if len(sys.argv) > 1 else "cuda:0")))
