@@ -69,8 +69,11 @@ __device__ __forceinline__ pk2 pk_fma(pk2 a, pk2 b, pk2 c) {
 __device__ __forceinline__ void philox_round(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3,
                                              unsigned k0, unsigned k1) {
     const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-    unsigned hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
-    unsigned hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    // 32x32 -> 64 products: one v_mad_u64_u32 each instead of a v_mul_hi_u32 + v_mul_lo_u32 pair (both quarter rate)
+    const unsigned long long p0 = (unsigned long long)M0 * (unsigned long long)c0;
+    const unsigned long long p1 = (unsigned long long)M1 * (unsigned long long)c2;
+    unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0;
+    unsigned hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
     unsigned n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
 }

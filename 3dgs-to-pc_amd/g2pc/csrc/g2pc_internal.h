@@ -78,6 +78,9 @@ size_t scan_workspace(long n);
 // gather != nullptr: scans in[gather[i]] (in and out must then be distinct)
 int scan_exclusive_u32(const uint32_t* in, uint32_t* out, long n, void* ws, size_t ws_bytes, hipStream_t s,
                        const uint32_t* gather = nullptr);
+// `rows` independent scans of n values each (row r: in + r*n -> out + r*(n+1)) in two launches; n <= 2M per row
+size_t scan_rows_workspace(long n, int rows);
+int scan_exclusive_rows_u32(const uint32_t* in, uint32_t* out, long n, int rows, void* ws, size_t ws_bytes, hipStream_t s);
 // stable LSD radix sort of (key,value) u32 pairs on bits [bit_lo, bit_hi).  Result ends in
 // keys_out/vals_out (ping-pong buffers keys_tmp/vals_tmp are scratch of n entries each).
 size_t sort_workspace(long n);

@@ -88,12 +88,16 @@ __device__ __forceinline__ void sym3_eigvec(const double A[6], double lam, doubl
     }
 }
 
-// clamp_covariances (gauss_handler.py:114-127): A <- V max(w, eps) V^T, robust to repeated eigenvalues.
-__device__ __forceinline__ void sym3_clamp(double A[6], const double e[3], double eps) {
-    // eigenvector of the best separated eigenvalue first, then deflate in its orthogonal complement
+// Eigen-decomposition of a symmetric 3x3 by deflation: the eigenvector of the best separated eigenvalue of the
+// closed-form estimate e[] first, then the exact 2x2 problem in its orthogonal complement.  The trigonometric closed
+// form loses half its digits on the two eigenvalues that are close RELATIVE TO THE SPREAD (acos near +-1): with a
+// spectrum (1e6, 1e-3, 1e-7) it is off by ~1e-2 on the small pair, while the isolated eigenvalue stays accurate to
+// fp64 rounding; the deflated pair then carries an absolute error of ~1e-16 * lambda_max.  lam[0] = the isolated
+// eigenvalue (v0), lam[1] >= lam[2] the pair (v1, v2).  Robust to repeated eigenvalues.
+__device__ __forceinline__ void sym3_decompose(const double A[6], const double e[3], double lam[3], double v0[3],
+                                               double v1[3], double v2[3]) {
     double gap_lo = e[1] - e[0], gap_hi = e[2] - e[1];
     int first = gap_hi >= gap_lo ? 2 : 0;
-    double v0[3];
     sym3_eigvec(A, e[first], v0);
     // orthonormal basis (u, w) of the complement
     double u[3];
@@ -123,11 +127,34 @@ __device__ __forceinline__ void sym3_clamp(double A[6], const double e[3], doubl
         double nn = sqrt(a * a + b * b);
         if (nn > 0.0) { cs = a / nn; sn = b / nn; }
     }
-    double v1[3] = {cs * u[0] + sn * w[0], cs * u[1] + sn * w[1], cs * u[2] + sn * w[2]};
-    double v2[3] = {-sn * u[0] + cs * w[0], -sn * u[1] + cs * w[1], -sn * u[2] + cs * w[2]};
-    double w0 = e[first] < eps ? eps : e[first];
-    double w1 = l1 < eps ? eps : l1;
-    double w2 = l2 < eps ? eps : l2;
+    v1[0] = cs * u[0] + sn * w[0]; v1[1] = cs * u[1] + sn * w[1]; v1[2] = cs * u[2] + sn * w[2];
+    v2[0] = -sn * u[0] + cs * w[0]; v2[1] = -sn * u[1] + cs * w[1]; v2[2] = -sn * u[2] + cs * w[2];
+    // the isolated eigenvalue as the Rayleigh quotient of its eigenvector (second-order accurate in the vector's error)
+    double Av[3] = {A[0] * v0[0] + A[1] * v0[1] + A[2] * v0[2], A[1] * v0[0] + A[3] * v0[1] + A[4] * v0[2],
+                    A[2] * v0[0] + A[4] * v0[1] + A[5] * v0[2]};
+    lam[0] = v0[0] * Av[0] + v0[1] * Av[1] + v0[2] * Av[2];
+    lam[1] = l1;
+    lam[2] = l2;
+}
+
+// smallest eigenvalue of symmetric A: the closed form where it is trustworthy (its error on a close pair is
+// ~1.5e-8 * spread: decided with a 100x margin), the deflated decomposition otherwise.  Well-conditioned matrices --
+// every Gaussian of a sane scene -- take the first branch.
+__device__ __forceinline__ double sym3_min_eig(const double A[6], const double e[3], double thr) {
+    const double spread = fmax(fabs(e[0]), fabs(e[2]));
+    if (fabs(e[0] - thr) > 1.5e-6 * spread || !(spread == spread)) return e[0];
+    double lam[3], v0[3], v1[3], v2[3];
+    sym3_decompose(A, e, lam, v0, v1, v2);
+    return fmin(lam[0], lam[2]);
+}
+
+// clamp_covariances (gauss_handler.py:114-127): A <- V max(w, eps) V^T.
+__device__ __forceinline__ void sym3_clamp(double A[6], const double e[3], double eps) {
+    double lam[3], v0[3], v1[3], v2[3];
+    sym3_decompose(A, e, lam, v0, v1, v2);
+    double w0 = lam[0] < eps ? eps : lam[0];
+    double w1 = lam[1] < eps ? eps : lam[1];
+    double w2 = lam[2] < eps ? eps : lam[2];
     A[0] = w0 * v0[0] * v0[0] + w1 * v1[0] * v1[0] + w2 * v2[0] * v2[0];
     A[1] = w0 * v0[0] * v0[1] + w1 * v1[0] * v1[1] + w2 * v2[0] * v2[1];
     A[2] = w0 * v0[0] * v0[2] + w1 * v1[0] * v1[2] + w2 * v2[0] * v2[2];
@@ -155,16 +182,17 @@ __global__ __launch_bounds__(GEO_T) void k_validate_cov(float* __restrict__ cov9
         double A[6] = {(double)m[0], 0.5 * ((double)m[1] + (double)m[3]), 0.5 * ((double)m[2] + (double)m[6]),
                        (double)m[4], 0.5 * ((double)m[5] + (double)m[7]), (double)m[8]};
         sym3_eigvals(A[0], A[1], A[2], A[3], A[4], A[5], e);
-        if (!(e[0] <= (double)eps)) break;
+        if (!(sym3_min_eig(A, e, (double)eps) <= (double)eps)) break;
         sym3_clamp(A, e, (double)eps);
         m[0] = (float)A[0]; m[1] = (float)A[1]; m[2] = (float)A[2];
         m[3] = (float)A[1]; m[4] = (float)A[3]; m[5] = (float)A[4];
         m[6] = (float)A[2]; m[7] = (float)A[4]; m[8] = (float)A[5];
         dirty = true;
     }
-    sym3_eigvals((double)m[0], 0.5 * ((double)m[1] + (double)m[3]), 0.5 * ((double)m[2] + (double)m[6]),
-                 (double)m[4], 0.5 * ((double)m[5] + (double)m[7]), (double)m[8], e);
-    keep[i] = (e[0] <= (double)min_eps) ? 0 : 1;   // NaN compares false -> kept, as in the reference
+    const double Af[6] = {(double)m[0], 0.5 * ((double)m[1] + (double)m[3]), 0.5 * ((double)m[2] + (double)m[6]),
+                          (double)m[4], 0.5 * ((double)m[5] + (double)m[7]), (double)m[8]};
+    sym3_eigvals(Af[0], Af[1], Af[2], Af[3], Af[4], Af[5], e);
+    keep[i] = (sym3_min_eig(Af, e, (double)min_eps) <= (double)min_eps) ? 0 : 1;   // NaN compares false -> kept, as in the reference
     if (dirty) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) c[k] = m[k];

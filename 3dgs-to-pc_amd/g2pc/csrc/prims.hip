@@ -88,6 +88,84 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_add(uint32_t* __restrict__ out,
     if (total_slot && blockIdx.x == 0 && threadIdx.x == 0) *total_slot = block_offs[gridDim.x];
 }
 
+// Batched form: blockIdx.y selects one of `rows` independent scans of n values each (in + row * n -> out + row * (n+1)),
+// two launches for all of them (the sampler's per-attempt count scans).  nb <= 2048 tiles per row.
+__global__ __launch_bounds__(SCAN_T) void k_scan_tile_rows(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                          long n, uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t wsum[SCAN_T / kWave];
+    const long row = blockIdx.y;
+    in += row * n; out += row * (n + 1); block_sums += row * gridDim.x;
+    const long base = (long)blockIdx.x * SCAN_TILE + (long)threadIdx.x * SCAN_I;
+    uint32_t v[SCAN_I];
+    uint32_t tsum = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_I; ++i) {
+        v[i] = (base + i < n) ? in[base + i] : 0u;
+        tsum += v[i];
+    }
+    const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t incl = wave_incl_scan_u32(tsum);
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    uint32_t woff = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_T / kWave; ++i) {
+        uint32_t s = wsum[i];
+        if (i < (int)w) woff += s;
+        total += s;
+    }
+    uint32_t run = woff + incl - tsum;
+#pragma unroll
+    for (int i = 0; i < SCAN_I; ++i) {
+        if (base + i < n) out[base + i] = run;
+        run += v[i];
+    }
+    if (threadIdx.x == 0) {
+        block_sums[blockIdx.x] = total;
+        if (gridDim.x == 1) out[n] = total;
+    }
+}
+__global__ __launch_bounds__(SCAN_T) void k_scan_add_self_rows(uint32_t* __restrict__ out, long n,
+                                                              const uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t wsum[SCAN_T / kWave];
+    const long row = blockIdx.y;
+    out += row * (n + 1); block_sums += row * gridDim.x;
+    uint32_t acc = 0;
+    for (unsigned i = threadIdx.x; i < blockIdx.x; i += SCAN_T) acc += block_sums[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    uint32_t off = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_T / kWave; ++i) off += wsum[i];
+    const long base = (long)blockIdx.x * SCAN_TILE + (long)threadIdx.x * SCAN_I;
+#pragma unroll
+    for (int i = 0; i < SCAN_I; ++i)
+        if (base + i < n) out[base + i] += off;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = off + block_sums[blockIdx.x];
+}
+
+size_t scan_rows_workspace(long n, int rows) {
+    long nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (nb < 1) nb = 1;
+    return align_up((size_t)nb * rows * sizeof(uint32_t)) + 256;
+}
+
+// rows independent exclusive scans; returns G2PC_ERR_UNSUPPORTED when a row needs more than 2048 tiles (the caller then
+// falls back to one scan_exclusive_u32 per row)
+int scan_exclusive_rows_u32(const uint32_t* in, uint32_t* out, long n, int rows, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (n <= 0 || rows <= 0) return G2PC_OK;
+    long nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (nb > 2048) return G2PC_ERR_UNSUPPORTED;
+    Arena ar(ws, ws_bytes);
+    uint32_t* sums = ar.get<uint32_t>((size_t)nb * rows);
+    if (!ar.ok()) { set_error("scan_rows", "workspace too small"); return G2PC_ERR_WORKSPACE; }
+    hipLaunchKernelGGL(k_scan_tile_rows, dim3((unsigned)nb, (unsigned)rows), dim3(SCAN_T), 0, s, in, out, n, sums);
+    if (nb > 1)
+        hipLaunchKernelGGL(k_scan_add_self_rows, dim3((unsigned)nb, (unsigned)rows), dim3(SCAN_T), 0, s, out, n, sums);
+    return check_launch("scan_rows");
+}
+
 size_t scan_workspace(long n) {
     size_t bytes = 0;
     long m = n;

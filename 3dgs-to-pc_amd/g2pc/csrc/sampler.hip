@@ -6,11 +6,11 @@
 //
 // The reference walks bins on the host and re-concatenates the whole cloud per bin (torch.cat).  Here every
 // bin is processed at once: Gaussians are stably partitioned by bin (radix sort on the bin id), a counting
-// pass produces d[attempt][position], per-attempt scans + a tiny host-side section table give every
-// (bin, attempt, Gaussian) its output offset, and an emission pass regenerates the keyed Philox draws and
-// writes them straight to their final place.  Small quotas run one Gaussian per lane (quota is uniform
-// inside a bin, so lanes of a wave run in lock-step); large quotas run one Gaussian per wave with the 64
-// lanes striding over the draws (ballot/popcount for the accept count, coalesced emission).
+// pass produces d[attempt][position] (small quotas: one Gaussian per lane -- the quota is uniform inside a bin, so
+// the lanes of a wave run in lock-step; large quotas: one Gaussian per wave, 64 lanes striding over the draws,
+// ballot/popcount for the accept count), a batched scan + a one-block section table turn d into output offsets
+// ON THE DEVICE, and a row-balanced emission kernel (one output row per lane) regenerates the keyed Philox draws
+// and writes every point straight to its final place in the reference's order.
 #include "g2pc_internal.h"
 
 namespace g2pc {
@@ -155,14 +155,15 @@ __global__ __launch_bounds__(SM_T) void k_count_wave(const float* __restrict__ m
         unsigned d = 0;
         if (have < (unsigned)n) {
             unsigned acc = 0;
-            for (int k0 = 0; k0 < n; k0 += 64) {
+            const unsigned room = (unsigned)n - have;
+            // d = min(accepted, room): once `room` draws are accepted the rest of the attempt cannot change d
+            for (int k0 = 0; k0 < n && acc < room; k0 += 64) {
                 int k = k0 + (int)lane;
                 float x, y, z;
                 bool ok = false;
                 if (k < n) ok = draw(s, seed_lo, seed_hi, gid_lo, gid_hi, (unsigned)(attempt0 + a), (unsigned)k, std_limit, x, y, z);
                 acc += (unsigned)__popcll(__ballot(ok));
             }
-            unsigned room = (unsigned)n - have;
             d = acc < room ? acc : room;
             have += d;
         }
@@ -174,152 +175,165 @@ __global__ __launch_bounds__(SM_T) void k_count_wave(const float* __restrict__ m
     }
 }
 
-// ---- emission pass --------------------------------------------------------------------------------------
-__device__ __forceinline__ void put3(float* __restrict__ dst, size_t idx, float a, float b, float c) {
-    dst[3 * idx + 0] = a; dst[3 * idx + 1] = b; dst[3 * idx + 2] = c;
+// ---- device-side section table ------------------------------------------------------------------------------------
+// The output is a sequence of sections in the reference's order: bin-major, and inside a bin the means (one row per
+// member) followed by the rows attempt 0, 1, ... emitted for the bin's members.  sec_base[b * (1 + A) + s] = first output
+// row of section s of bin b (exclusive scan of the section sizes); sec_base[B * (1 + A)] = M, the number of points.
+// One block: the table has B * (1 + A) entries (a few thousand at most).
+constexpr int SEC_T = 1024;
+__global__ __launch_bounds__(SEC_T) void k_sections(const uint32_t* __restrict__ bin_start,
+                                                    const int32_t* __restrict__ quota, int B, int A,
+                                                    const uint32_t* __restrict__ dscan, long gv, int emit_means,
+                                                    int64_t* __restrict__ sec_base, int64_t* __restrict__ info_host,
+                                                    const uint32_t* __restrict__ remaining) {
+    __shared__ uint32_t wsum[SEC_T / kWave];
+    __shared__ unsigned long long carry;
+    const int S = B * (1 + A);
+    if (threadIdx.x == 0) carry = 0ull;
+    __syncthreads();
+    for (int base = 0; base < S; base += SEC_T) {
+        const int i = base + (int)threadIdx.x;
+        uint32_t v = 0;
+        if (i < S) {
+            const int b = i / (1 + A), sct = i % (1 + A);
+            const uint32_t p0 = bin_start[b], p1 = bin_start[b + 1];
+            if (sct == 0) v = (quota[b] > 0 && emit_means) ? (p1 - p0) : 0u;
+            else { const uint32_t* sc = dscan + (size_t)(sct - 1) * (size_t)(gv + 1); v = sc[p1] - sc[p0]; }
+        }
+        const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const uint32_t incl = wave_incl_scan_u32(v);
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        uint32_t woff = 0, total = 0;
+        for (int k = 0; k < SEC_T / kWave; ++k) { const uint32_t t = wsum[k]; if (k < (int)w) woff += t; total += t; }
+        const unsigned long long c = carry;
+        if (i < S) sec_base[i] = (int64_t)(c + woff + incl - v);
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        sec_base[S] = (int64_t)carry;
+        if (info_host) {                               // pinned host memory through its device mapping
+            info_host[0] = (int64_t)carry;
+            info_host[1] = remaining ? (int64_t)*remaining : 0;
+        }
+    }
 }
 
-__global__ __launch_bounds__(SM_T) void k_emit_means(const float* __restrict__ means,
-                                                    const float* __restrict__ colours,
-                                                    const float* __restrict__ normals,
-                                                    const uint32_t* __restrict__ perm,
-                                                    const uint32_t* __restrict__ pbin,
-                                                    const uint32_t* __restrict__ bin_start,
-                                                    const int32_t* __restrict__ quota, long gv, int sec_stride,
-                                                    const int64_t* __restrict__ sec_base,
-                                                    float* __restrict__ out_points, float* __restrict__ out_colours,
-                                                    float* __restrict__ out_normals, int32_t* __restrict__ out_gauss) {
-    long p = (long)blockIdx.x * SM_T + threadIdx.x;
-    if (p >= gv) return;
-    const unsigned b = pbin[p];
-    if (quota[b] <= 0) return;
-    const unsigned g = perm[p];
-    const size_t o = (size_t)sec_base[(size_t)b * sec_stride] + (size_t)(p - bin_start[b]);
-    put3(out_points, o, means[3 * (size_t)g], means[3 * (size_t)g + 1], means[3 * (size_t)g + 2]);
-    put3(out_colours, o, colours[3 * (size_t)g], colours[3 * (size_t)g + 1], colours[3 * (size_t)g + 2]);
-    if (out_normals) put3(out_normals, o, normals[3 * (size_t)g], normals[3 * (size_t)g + 1], normals[3 * (size_t)g + 2]);
-    if (out_gauss) out_gauss[o] = (int32_t)g;
+// ---- row-balanced emission ------------------------------------------------------------------------------------------
+// One output row per lane: a block owns ER_ROWS consecutive output rows, finds the section(s) they fall into and, inside
+// an attempt section, the Gaussian and draw index of every row (rows of a Gaussian are consecutive, the per-attempt scan
+// of d gives their start) -- a window of the scan is staged in LDS for the searches.  Every lane then evaluates exactly
+// one keyed draw and writes one 12-byte row next to its neighbours': all lanes busy whatever the quotas are (32-draw
+// bins and 2000-draw bins alike), stores fully coalesced, no second pass over d for offsets.  The per-Gaussian inputs
+// are gathered straight from global memory: neighbouring rows share their Gaussian, so a wave touches a handful of lines.
+constexpr int ER_T = 256, ER_ROWS = 1024, ER_WIN = 1024;
+
+struct GaussChol { float mx, my, mz, l00, l10, l11, l20, l21, l22; };
+__device__ __forceinline__ void load_chol(const float* __restrict__ means, const float* __restrict__ cov9, unsigned g,
+                                          GaussChol& s) {
+    s.mx = means[3 * (size_t)g + 0]; s.my = means[3 * (size_t)g + 1]; s.mz = means[3 * (size_t)g + 2];
+    const float* c = cov9 + 9 * (size_t)g;
+    const float a00 = c[0], a10 = c[3], a11 = c[4], a20 = c[6], a21 = c[7], a22 = c[8];   // the lower triangle, as load_gauss
+    s.l00 = sqrtf(a00);
+    s.l10 = a10 / s.l00;
+    s.l20 = a20 / s.l00;
+    s.l11 = sqrtf(a11 - s.l10 * s.l10);
+    s.l21 = (a21 - s.l20 * s.l10) / s.l11;
+    s.l22 = sqrtf(a22 - s.l20 * s.l20 - s.l21 * s.l21);
 }
 
-// Lane-per-Gaussian emission (quotas below a wave's worth of draws).  The draws of a lane go to a run of consecutive output
-// rows and the runs of consecutive lanes follow one another (prefix sums of d), so a wave's output for one attempt is
-// one contiguous range -- but written lane by lane it would be 64 scattered 12-byte rows per store.  The wave therefore
-// generates its points into a wave-private LDS window in output order and then writes the window row-per-lane:
-// fully coalesced 12-byte stores for the points, and for the colours / normals / ids of each row's owner (found by a
-// 6-step search of the lanes' run offsets).
-constexpr int EM_WIN = 512;                       // output rows staged per wave and pass
-__global__ __launch_bounds__(SM_T) void k_emit_thread(
+// largest p in [lo, hi) with sc[p] <= t, for a non-decreasing sc with sc[lo] <= t (all threads of the block, same
+// arguments, same result): 256-way narrowing, one probe per thread and step
+__device__ __forceinline__ uint32_t block_search_le(const uint32_t* __restrict__ sc, uint32_t lo, uint32_t hi, uint32_t t) {
+    while (hi - lo > 1) {
+        const uint32_t span = hi - lo;
+        const uint32_t step = (span + ER_T - 1) / ER_T;
+        const uint32_t probe = lo + (threadIdx.x + 1) * step;               // probes lo+step, lo+2 step, ...
+        const int ok = (probe < hi) && (sc[probe] <= t);
+        const int cnt = __syncthreads_count(ok);                            // monotone: the first cnt probes hold
+        const uint32_t nlo = lo + (uint32_t)cnt * step;
+        const uint32_t nhi = nlo + step < hi ? nlo + step : hi;
+        lo = nlo; hi = nhi;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(ER_T) void k_emit_rows(
     const float* __restrict__ means, const float* __restrict__ cov9, const float* __restrict__ colours,
-    const float* __restrict__ normals, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ pbin,
-    const uint32_t* __restrict__ bin_start, long p_end, long gv, int attempt0, int num_attempts, int sec_stride,
-    unsigned seed_lo, unsigned seed_hi, uint64_t gid_base, const uint32_t* __restrict__ dcount,
+    const float* __restrict__ normals, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ bin_start, int B,
+    int A, long gv, int attempt0, unsigned seed_lo, unsigned seed_hi, uint64_t gid_base,
     const uint32_t* __restrict__ dscan, const int64_t* __restrict__ sec_base, float* __restrict__ out_points,
     float* __restrict__ out_colours, float* __restrict__ out_normals, int32_t* __restrict__ out_gauss) {
-    constexpr int NW = SM_T / kWave;
-    __shared__ float s_xyz[NW][EM_WIN][3];
-    __shared__ uint32_t s_run[NW][kWave + 1];      // exclusive prefix of d over the lanes (+ total): where each run starts
-    __shared__ unsigned long long s_o0[NW][kWave]; // first output row of each lane's run
-    __shared__ float s_cn[NW][kWave][6];           // colour, normal of each lane's Gaussian
-    __shared__ int32_t s_id[NW][kWave];
-    const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const long p = (long)blockIdx.x * SM_T + threadIdx.x;
-    const bool valid = p < p_end;
-    unsigned any_draws = 0;
-    if (valid)
-        for (int a = 0; a < num_attempts; ++a) any_draws += dcount[(size_t)a * gv + p];
-    if (!__any(any_draws != 0)) return;            // whole wave has nothing to emit
-    unsigned g = 0, b = 0, bs = 0;
-    GaussSample s = {};
-    unsigned gid_lo = 0, gid_hi = 0;
-    if (any_draws) {
-        g = perm[p];
-        b = pbin[p];
-        bs = bin_start[b];
-        load_gauss(means, cov9, g, s);
-        const uint64_t gid = gid_base + g;
-        gid_lo = (unsigned)gid; gid_hi = (unsigned)(gid >> 32);
-        s_cn[w][lane][0] = colours[3 * (size_t)g]; s_cn[w][lane][1] = colours[3 * (size_t)g + 1]; s_cn[w][lane][2] = colours[3 * (size_t)g + 2];
-        if (out_normals) { s_cn[w][lane][3] = normals[3 * (size_t)g]; s_cn[w][lane][4] = normals[3 * (size_t)g + 1]; s_cn[w][lane][5] = normals[3 * (size_t)g + 2]; }
-        s_id[w][lane] = (int32_t)g;
-    }
-    for (int a = 0; a < num_attempts; ++a) {
-        const unsigned d = any_draws ? dcount[(size_t)a * gv + p] : 0u;
-        const unsigned incl = wave_incl_scan_u32(d);
-        const unsigned total = __shfl(incl, 63);
-        if (total == 0) continue;                  // uniform
-        const unsigned run = incl - d;
-        wave_sync();                               // the previous attempt's readers are done
-        s_run[w][lane] = run;
-        if (lane == 63) s_run[w][kWave] = total;
-        if (d) {
-            const uint32_t* sc = dscan + (size_t)a * (gv + 1);
-            s_o0[w][lane] = (unsigned long long)sec_base[(size_t)b * sec_stride + 1 + attempt0 + a] + (unsigned long long)(sc[p] - sc[bs]);
-        }
-        for (unsigned w0 = 0; w0 < total; w0 += EM_WIN) {
-            // this lane's draws whose rows fall into [w0, w0 + EM_WIN)
-            const unsigned klo = w0 > run ? w0 - run : 0u;
-            const unsigned khi = (run + d > w0 + EM_WIN) ? (w0 + EM_WIN - run) : d;      // run <= w0 + EM_WIN whenever klo < d matters
-            if (run < w0 + EM_WIN)
-                for (unsigned k = klo; k < khi; ++k) {
-                    float x, y, z;
-                    draw(s, seed_lo, seed_hi, gid_lo, gid_hi, (unsigned)(attempt0 + a), k, 0.f, x, y, z);
-                    float* dst = s_xyz[w][run + k - w0];
-                    dst[0] = x; dst[1] = y; dst[2] = z;
-                }
-            wave_sync();
-            const unsigned wend = total < w0 + EM_WIN ? total : w0 + EM_WIN;
-            for (unsigned t = w0 + lane; t < wend; t += 64) {
-                // owner = the last lane whose run starts at or before row t (runs of d = 0 share their successor's start)
-                unsigned lo = 0, hi = kWave;                                  // invariant: s_run[lo] <= t < s_run[hi]
-#pragma unroll
-                for (int it = 0; it < 6; ++it) {
-                    const unsigned mid = (lo + hi) >> 1;
-                    if (s_run[w][mid] <= t) lo = mid; else hi = mid;
-                }
-                const size_t o = (size_t)s_o0[w][lo] + (size_t)(t - s_run[w][lo]);
-                const float* src = s_xyz[w][t - w0];
-                put3(out_points, o, src[0], src[1], src[2]);
-                put3(out_colours, o, s_cn[w][lo][0], s_cn[w][lo][1], s_cn[w][lo][2]);
-                if (out_normals) put3(out_normals, o, s_cn[w][lo][3], s_cn[w][lo][4], s_cn[w][lo][5]);
-                if (out_gauss) out_gauss[o] = s_id[w][lo];
+    __shared__ uint32_t s_win[ER_WIN + 1];
+    const int S = B * (1 + A);
+    const long M = (long)sec_base[S];
+    const long row0 = (long)blockIdx.x * ER_ROWS;
+    if (row0 >= M) return;
+    const long row1 = row0 + ER_ROWS < M ? row0 + ER_ROWS : M;
+    // first section that ends after row0 (the sections ending at or before row0 form a prefix of the table)
+    int before = 0;
+    for (int i = threadIdx.x; i < S; i += ER_T) before += (sec_base[i + 1] <= (int64_t)row0) ? 1 : 0;
+    __shared__ int s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    if (before) atomicAdd(&s_cnt, before);
+    __syncthreads();
+    int si = s_cnt;
+    for (; si < S; ++si) {
+        const long sb = (long)sec_base[si], se = (long)sec_base[si + 1];
+        if (sb >= row1) break;
+        if (se <= sb) continue;
+        const long r_lo = sb > row0 ? sb : row0, r_hi = se < row1 ? se : row1;
+        const int b = si / (1 + A), sct = si % (1 + A);
+        const uint32_t bs0 = bin_start[b], bs1 = bin_start[b + 1];
+        if (sct == 0) {                             // the means of the bin's members, in member order
+            for (long r = r_lo + threadIdx.x; r < r_hi; r += ER_T) {
+                const unsigned g = perm[bs0 + (uint32_t)(r - sb)];
+                const size_t o = (size_t)r;
+                out_points[3 * o + 0] = means[3 * (size_t)g]; out_points[3 * o + 1] = means[3 * (size_t)g + 1]; out_points[3 * o + 2] = means[3 * (size_t)g + 2];
+                out_colours[3 * o + 0] = colours[3 * (size_t)g]; out_colours[3 * o + 1] = colours[3 * (size_t)g + 1]; out_colours[3 * o + 2] = colours[3 * (size_t)g + 2];
+                if (out_normals) { out_normals[3 * o + 0] = normals[3 * (size_t)g]; out_normals[3 * o + 1] = normals[3 * (size_t)g + 1]; out_normals[3 * o + 2] = normals[3 * (size_t)g + 2]; }
+                if (out_gauss) out_gauss[o] = (int32_t)g;
             }
-            wave_sync();                           // window drained before it is refilled
+            continue;
         }
-    }
-}
-
-__global__ __launch_bounds__(SM_T) void k_emit_wave(
-    const float* __restrict__ means, const float* __restrict__ cov9, const float* __restrict__ colours,
-    const float* __restrict__ normals, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ pbin,
-    const uint32_t* __restrict__ bin_start, long p_begin, long gv, int attempt0, int num_attempts, int sec_stride,
-    unsigned seed_lo, unsigned seed_hi, uint64_t gid_base, const uint32_t* __restrict__ dcount,
-    const uint32_t* __restrict__ dscan, const int64_t* __restrict__ sec_base, float* __restrict__ out_points,
-    float* __restrict__ out_colours, float* __restrict__ out_normals, int32_t* __restrict__ out_gauss) {
-    const unsigned lane = threadIdx.x & 63;
-    long p = p_begin + (long)blockIdx.x * (SM_T / kWave) + (threadIdx.x >> 6);
-    if (p >= gv) return;
-    const unsigned g = perm[p];
-    const unsigned b = pbin[p];
-    const unsigned bs = bin_start[b];
-    GaussSample s;
-    load_gauss(means, cov9, g, s);
-    const float cr = colours[3 * (size_t)g], cg = colours[3 * (size_t)g + 1], cb = colours[3 * (size_t)g + 2];
-    float nx = 0.f, ny = 0.f, nz = 0.f;
-    if (out_normals) { nx = normals[3 * (size_t)g]; ny = normals[3 * (size_t)g + 1]; nz = normals[3 * (size_t)g + 2]; }
-    const uint64_t gid = gid_base + g;
-    const unsigned gid_lo = (unsigned)gid, gid_hi = (unsigned)(gid >> 32);
-    for (int a = 0; a < num_attempts; ++a) {
-        const unsigned d = dcount[(size_t)a * gv + p];
-        if (d == 0) continue;
-        const uint32_t* sc = dscan + (size_t)a * (gv + 1);
-        const size_t o0 = (size_t)sec_base[(size_t)b * sec_stride + 1 + attempt0 + a] + (size_t)(sc[p] - sc[bs]);
-        for (unsigned k = lane; k < d; k += 64) {
-            float x, y, z;
-            draw(s, seed_lo, seed_hi, gid_lo, gid_hi, (unsigned)(attempt0 + a), k, 0.f, x, y, z);
-            const size_t o = o0 + k;
-            put3(out_points, o, x, y, z);
-            put3(out_colours, o, cr, cg, cb);
-            if (out_normals) put3(out_normals, o, nx, ny, nz);
+        const int a = sct - 1;
+        const uint32_t* sc = dscan + (size_t)a * (size_t)(gv + 1);
+        const uint32_t sc0 = sc[bs0];
+        // owner of the first row, then a window of the scan from there (relative to the section)
+        const uint32_t t_first = sc0 + (uint32_t)(r_lo - sb);
+        const uint32_t p_first = block_search_le(sc, bs0, bs1, t_first);
+        const uint32_t wlen = (bs1 - p_first) < (uint32_t)ER_WIN ? (bs1 - p_first) : (uint32_t)ER_WIN;
+        __syncthreads();                            // previous section's readers are done with the window
+        for (uint32_t j = threadIdx.x; j <= wlen; j += ER_T) s_win[j] = sc[p_first + j];
+        __syncthreads();
+        const uint32_t win_end = s_win[wlen];       // first scan value NOT covered by the window's owners
+        for (long r = r_lo + threadIdx.x; r < r_hi; r += ER_T) {
+            const uint32_t t = sc0 + (uint32_t)(r - sb);
+            uint32_t p, start;
+            if (t < win_end) {                      // largest j in [0, wlen) with s_win[j] <= t
+                uint32_t lo = 0, hi = wlen;
+                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_win[mid] <= t) lo = mid; else hi = mid; }
+                p = p_first + lo; start = s_win[lo];
+            } else {                                // long runs of finished Gaussians (d = 0): search the global scan
+                uint32_t lo = p_first + wlen, hi = bs1;
+                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sc[mid] <= t) lo = mid; else hi = mid; }
+                p = lo; start = sc[lo];
+            }
+            const unsigned k = t - start;
+            const unsigned g = perm[p];
+            GaussChol s;
+            load_chol(means, cov9, g, s);
+            const uint64_t gid = gid_base + g;
+            const Normal3 e = keyed_normal3(seed_lo, seed_hi, (unsigned)gid, (unsigned)(gid >> 32), (unsigned)(attempt0 + a), k);
+            const size_t o = (size_t)r;
+            out_points[3 * o + 0] = s.mx + s.l00 * e.x;
+            out_points[3 * o + 1] = s.my + (s.l10 * e.x + s.l11 * e.y);
+            out_points[3 * o + 2] = s.mz + (s.l20 * e.x + s.l21 * e.y + s.l22 * e.z);
+            out_colours[3 * o + 0] = colours[3 * (size_t)g]; out_colours[3 * o + 1] = colours[3 * (size_t)g + 1]; out_colours[3 * o + 2] = colours[3 * (size_t)g + 2];
+            if (out_normals) { out_normals[3 * o + 0] = normals[3 * (size_t)g]; out_normals[3 * o + 1] = normals[3 * (size_t)g + 1]; out_normals[3 * o + 2] = normals[3 * (size_t)g + 2]; }
             if (out_gauss) out_gauss[o] = (int32_t)g;
         }
     }
@@ -354,7 +368,8 @@ __global__ __launch_bounds__(SM_T) void k_sample_mvn(const float* __restrict__ m
     for (int k = 0; k < n; ++k) {
         float x, y, z;
         draw(s, seed_lo, seed_hi, (unsigned)gid, (unsigned)(gid >> 32), attempt, (unsigned)k, 0.f, x, y, z);
-        put3(out, (size_t)k * g_count + g, x, y, z);
+        float* dst = out + 3 * ((size_t)k * g_count + g);
+        dst[0] = x; dst[1] = y; dst[2] = z;
     }
 }
 
@@ -398,6 +413,29 @@ int g2pc_sampler_plan(const int32_t* ppg, int64_t g, const int32_t* bin_of_ppg, 
     return check_launch("g2pc_sampler_plan");
 }
 
+/* The partition alone (bin keys + stable radix sort): perm / pbin as g2pc_sampler_plan, for callers that know the bin
+ * sizes already (the host derives them from the same histogram it builds the bin table from) and upload bin_start. */
+int g2pc_sampler_partition(const int32_t* ppg, int64_t g, const int32_t* bin_of_ppg, int64_t lut_len, int32_t num_bins,
+                           uint32_t* perm, uint32_t* pbin, void* ws, size_t ws_bytes, void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(g > 0 && ppg && bin_of_ppg && perm && pbin && ws, G2PC_ERR_ARG, "bad arguments");
+    G2PC_REQUIRE(num_bins >= 0 && num_bins < (1 << 16), G2PC_ERR_UNSUPPORTED, "more than 65535 bins");
+    hipStream_t s = (hipStream_t)stream;
+    Arena ar(ws, ws_bytes);
+    uint32_t* keys = ar.get<uint32_t>((size_t)g);
+    uint32_t* vals = ar.get<uint32_t>((size_t)g);
+    uint32_t* ktmp = ar.get<uint32_t>((size_t)g);
+    uint32_t* vtmp = ar.get<uint32_t>((size_t)g);
+    size_t sort_bytes = sort_workspace(g);
+    char* sort_ws = ar.get<char>(sort_bytes);
+    G2PC_REQUIRE(ar.ok(), G2PC_ERR_WORKSPACE, "workspace too small");
+    hipLaunchKernelGGL(k_bin_keys, dim3(cdiv(g, SM_T)), dim3(SM_T), 0, s, ppg, (long)g, bin_of_ppg, (long)lut_len,
+                       (int)num_bins, keys, vals);
+    int rc = sort_pairs_u32(keys, vals, pbin, perm, ktmp, vtmp, g, 0, bits_for((unsigned)num_bins), sort_ws, sort_bytes, s);
+    if (rc) return rc;
+    return check_launch("g2pc_sampler_partition");
+}
+
 int g2pc_sampler_count(const float* means, const float* cov9, const uint32_t* perm, const uint32_t* pbin,
                        const int32_t* quota, int64_t gv, int64_t p_wave_begin, float std_limit, int32_t attempt0,
                        int32_t num_attempts, uint64_t seed, uint64_t gid_base, uint32_t* added, uint32_t* dcount,
@@ -419,45 +457,62 @@ int g2pc_sampler_count(const float* means, const float* cov9, const uint32_t* pe
                            (int)num_attempts, slo, shi, gid_base, added, dcount, remaining);
     return check_launch("g2pc_sampler_count");
 }
-
-int g2pc_sampler_emit(const float* means, const float* cov9, const float* colours, const float* normals,
-                      const uint32_t* perm, const uint32_t* pbin, const uint32_t* bin_start, const int32_t* quota,
-                      int64_t gv, int64_t p_wave_begin, int32_t num_bins, int32_t attempt0, int32_t num_attempts,
-                      int32_t sec_stride, uint64_t seed, uint64_t gid_base, const uint32_t* dcount,
-                      const uint32_t* dscan, const int64_t* sec_base, int emit_means, float* out_points,
-                      float* out_colours, float* out_normals, int32_t* out_gauss, void* stream) {
-    using namespace g2pc;
-    G2PC_REQUIRE(gv >= 0 && means && cov9 && colours && perm && pbin && bin_start && quota && sec_base &&
-                     out_points && out_colours,
-                 G2PC_ERR_ARG, "bad arguments");
-    G2PC_REQUIRE(!out_normals || normals, G2PC_ERR_ARG, "normals requested but not given");
-    (void)num_bins;
-    if (gv == 0) return G2PC_OK;
-    if (p_wave_begin < 0 || p_wave_begin > gv) p_wave_begin = gv;
-    hipStream_t s = (hipStream_t)stream;
-    unsigned slo = (unsigned)seed, shi = (unsigned)(seed >> 32);
-    if (emit_means)
-        hipLaunchKernelGGL(k_emit_means, dim3(cdiv(gv, SM_T)), dim3(SM_T), 0, s, means, colours, normals, perm, pbin,
-                           bin_start, quota, (long)gv, (int)sec_stride, sec_base, out_points, out_colours,
-                           out_normals, out_gauss);
-    if (num_attempts > 0) {
-        G2PC_REQUIRE(dcount && dscan, G2PC_ERR_ARG, "missing counts");
-        if (p_wave_begin > 0)
-            hipLaunchKernelGGL(k_emit_thread, dim3(cdiv(p_wave_begin, SM_T)), dim3(SM_T), 0, s, means, cov9, colours,
-                               normals, perm, pbin, bin_start, (long)p_wave_begin, (long)gv, (int)attempt0,
-                               (int)num_attempts, (int)sec_stride, slo, shi, gid_base, dcount, dscan, sec_base,
-                               out_points, out_colours, out_normals, out_gauss);
-        if (p_wave_begin < gv)
-            hipLaunchKernelGGL(k_emit_wave, dim3(cdiv(gv - p_wave_begin, SM_T / kWave)), dim3(SM_T), 0, s, means, cov9,
-                               colours, normals, perm, pbin, bin_start, (long)p_wave_begin, (long)gv, (int)attempt0,
-                               (int)num_attempts, (int)sec_stride, slo, shi, gid_base, dcount, dscan, sec_base,
-                               out_points, out_colours, out_normals, out_gauss);
-    }
-    return check_launch("g2pc_sampler_emit");
-}
 }
 
 extern "C" {
+size_t g2pc_sampler_scan_workspace(int64_t gv, int32_t attempts) { return g2pc::scan_rows_workspace((long)gv, (int)attempts) + g2pc::scan_workspace((long)gv); }
+
+/* dscan[a] = exclusive scan of dcount[a] for a = 0 .. attempts-1 (rows of gv resp. gv+1 entries): two launches for all
+ * attempts when gv <= 2M, one scan per attempt beyond that */
+int g2pc_sampler_scan_counts(const uint32_t* dcount, uint32_t* dscan, int64_t gv, int32_t attempts, void* ws, size_t ws_bytes,
+                             void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(gv >= 0 && attempts >= 0, G2PC_ERR_ARG, "negative size");
+    if (gv == 0 || attempts == 0) return G2PC_OK;
+    G2PC_REQUIRE(dcount && dscan && ws, G2PC_ERR_ARG, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = scan_exclusive_rows_u32(dcount, dscan, (long)gv, (int)attempts, ws, ws_bytes, s);
+    if (rc != G2PC_ERR_UNSUPPORTED) return rc;
+    for (int a = 0; a < attempts; ++a) {
+        rc = scan_exclusive_u32(dcount + (size_t)a * gv, dscan + (size_t)a * (gv + 1), (long)gv, ws, ws_bytes, s);
+        if (rc) return rc;
+    }
+    return G2PC_OK;
+}
+
+/* Section table on the device (see k_sections): sec_base i64[num_bins * (1 + attempts) + 1]; info_host (optional,
+ * PINNED host memory, i64[2]) receives {total rows M, *remaining} when the kernel runs -- the one value the host needs
+ * before it can hand the cloud out, read after a single stream synchronisation at the very end of the job. */
+int g2pc_sampler_sections(const uint32_t* bin_start, const int32_t* quota, int32_t num_bins, int32_t attempts,
+                          const uint32_t* dscan, int64_t gv, int emit_means, int64_t* sec_base, int64_t* info_host,
+                          const uint32_t* remaining, void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(bin_start && quota && sec_base && num_bins >= 0 && attempts >= 0, G2PC_ERR_ARG, "bad arguments");
+    G2PC_REQUIRE(attempts == 0 || dscan, G2PC_ERR_ARG, "missing scans");
+    hipLaunchKernelGGL(k_sections, dim3(1), dim3(SEC_T), 0, (hipStream_t)stream, bin_start, quota, (int)num_bins, (int)attempts,
+                       dscan, (long)gv, emit_means, sec_base, info_host, remaining);
+    return check_launch("g2pc_sampler_sections");
+}
+
+/* Row-balanced emission of the whole cloud (means and every attempt's rows) in one launch: `rows_capacity` >= M is the
+ * size the output arrays were allocated for (the launch covers it; blocks beyond the real M, read from sec_base, exit). */
+int g2pc_sampler_emit_rows(const float* means, const float* cov9, const float* colours, const float* normals,
+                           const uint32_t* perm, const uint32_t* bin_start, int32_t num_bins, int32_t attempt0,
+                           int32_t attempts, int64_t gv, uint64_t seed, uint64_t gid_base, const uint32_t* dscan,
+                           const int64_t* sec_base, int64_t rows_capacity, float* out_points, float* out_colours,
+                           float* out_normals, int32_t* out_gauss, void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(means && cov9 && colours && perm && bin_start && sec_base && out_points && out_colours, G2PC_ERR_ARG,
+                 "bad arguments");
+    G2PC_REQUIRE(!out_normals || normals, G2PC_ERR_ARG, "normals requested but not given");
+    G2PC_REQUIRE(attempts == 0 || dscan, G2PC_ERR_ARG, "missing scans");
+    if (rows_capacity <= 0 || num_bins <= 0) return G2PC_OK;
+    hipLaunchKernelGGL(k_emit_rows, dim3(cdiv(rows_capacity, ER_ROWS)), dim3(ER_T), 0, (hipStream_t)stream, means, cov9, colours,
+                       normals, perm, bin_start, (int)num_bins, (int)attempts, (long)gv, (int)attempt0, (unsigned)seed,
+                       (unsigned)(seed >> 32), gid_base, dscan, sec_base, out_points, out_colours, out_normals, out_gauss);
+    return check_launch("g2pc_sampler_emit_rows");
+}
+
 int g2pc_mahalanobis(const float* means, const float* samples, const float* cov9, int64_t n, float* out,
                      void* stream) {
     using namespace g2pc;

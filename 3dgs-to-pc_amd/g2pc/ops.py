@@ -206,6 +206,20 @@ def sample_mvn(means: torch.Tensor, covs: torch.Tensor, n: int, seed: int, gid_b
     return out
 
 
+_PINNED = {}
+
+
+def _pinned_i64(device, n=2):
+    """A small pinned host buffer per device that kernels write through its device mapping (read after one sync)."""
+    key = (str(device), n)
+    if key not in _PINNED:
+        t = torch.zeros((n,), dtype=torch.int64)
+        if torch.device(device).type == "cuda" and not nv.emulated():
+            t = t.pin_memory()
+        _PINNED[key] = t
+    return _PINNED[key]
+
+
 def sample_pointcloud(xyz: torch.Tensor, cov: torch.Tensor, colours: torch.Tensor,
                       normals: Optional[torch.Tensor], ppg_i32: torch.Tensor, max_ppg: int, *, exact: bool,
                       std: float, attempts: int, seed: int, gid_base: int = 0, want_index: bool = False,
@@ -213,7 +227,12 @@ def sample_pointcloud(xyz: torch.Tensor, cov: torch.Tensor, colours: torch.Tenso
     """The bin loop of generate_pointcloud (gauss_to_pc.py:308-371) + create_new_gaussian_points
     (gauss_to_pc.py:157-275) for all bins at once, in the reference's output order.
     `bins` overrides the bin table ((start, end, quota) triples); emit_means=False drops the centre points
-    (create_new_gaussian_points on its own)."""
+    (create_new_gaussian_points on its own).
+
+    Host round trips: ONE to build the bin table from the points-per-Gaussian histogram (a few hundred numbers), and
+    one at the very end for the number of points produced.  Everything between -- partition by bin, count pass, scans,
+    section table, emission -- is queued without waiting (attempts <= ATTEMPT_CHUNK, i.e. the default binned mode);
+    `exact_num_points` (100 attempts) reads the number of unfinished Gaussians back after every chunk of attempts."""
     L = nv.lib()
     dev = xyz.device
     st = nv.stream_handle(dev)
@@ -221,7 +240,7 @@ def sample_pointcloud(xyz: torch.Tensor, cov: torch.Tensor, colours: torch.Tenso
     normals = _f32c(normals) if normals is not None else None
     G = xyz.shape[0]
 
-    hist = bincount(ppg_i32, int(max_ppg) + 1).cpu().numpy().astype(np.int64)          # sync #1
+    hist = bincount(ppg_i32, int(max_ppg) + 1).cpu().numpy().astype(np.int64)          # round trip #1
     if bins is None:
         bins = bin_table_from_hist(hist, exact)
     B = len(bins)
@@ -235,81 +254,111 @@ def sample_pointcloud(xyz: torch.Tensor, cov: torch.Tensor, colours: torch.Tenso
         if n > 0 and hi > lo:
             lut[lo:hi] = b
             members[b] = hist[lo:hi].sum()
-    lut_d = torch.from_numpy(lut).to(dev)
-    quota_d = torch.from_numpy(quota).to(dev)
+    # bin sizes are known on the host from the histogram: bin_start is uploaded with the other small tables (one copy)
+    bs_host = np.zeros((B + 2,), dtype=np.int64)
+    bs_host[1:B + 1] = np.cumsum(members[:B])
+    bs_host[B + 1] = bs_host[B]
+    gv = int(bs_host[B])
+    packed = torch.from_numpy(np.concatenate([lut, quota, bs_host.astype(np.int32)])).to(dev)
+    lut_d, quota_d = packed[:lut.shape[0]], packed[lut.shape[0]:lut.shape[0] + quota.shape[0]]
+    bin_start = packed[lut.shape[0] + quota.shape[0]:]
 
     perm = torch.empty((G,), dtype=torch.int32, device=dev)
     pbin = torch.empty((G,), dtype=torch.int32, device=dev)
-    bin_start = torch.empty((B + 2,), dtype=torch.int32, device=dev)
     ws_bytes = L.g2pc_sampler_plan_workspace(G)
     ws = nv.workspace(ws_bytes, dev)
-    nv.check(L.g2pc_sampler_plan(nv.ptr(ppg_i32), G, nv.ptr(lut_d), lut.shape[0], B, nv.ptr(perm), nv.ptr(pbin),
-                                 nv.ptr(bin_start), nv.ptr(ws), ws_bytes, st), "sampler_plan")
-    # bin sizes are known on the host from the histogram: no read-back needed
-    bs_host = np.zeros((B + 2,), dtype=np.int64)
-    bs_host[1:B + 1] = np.cumsum(members[:B])
-    gv = int(bs_host[B])
+    nv.check(L.g2pc_sampler_partition(nv.ptr(ppg_i32), G, nv.ptr(lut_d), lut.shape[0], B, nv.ptr(perm), nv.ptr(pbin),
+                                      nv.ptr(ws), ws_bytes, st), "sampler_partition")
     wave_bins = [b for b in range(B) if quota[b] - 1 >= WAVE_MODE_MIN_DRAWS and members[b] > 0]
     p_wave = int(bs_host[wave_bins[0]]) if wave_bins else gv
 
-    added = torch.zeros((max(gv, 1),), dtype=torch.int32, device=dev)
-    remaining = torch.zeros((1,), dtype=torch.int32, device=dev)
-    chunks = []            # (attempt0, count, dcount, dscan)
-    sec_cols = []          # per attempt: int64 [B] section sizes
-    a0 = 0
-    scan_bytes = L.g2pc_scan_workspace(gv)
-    scan_ws = nv.workspace(scan_bytes, dev)
     any_sampling = bool(np.any((quota[:B] > 1) & (members[:B] > 0))) if B else False
-    bs_idx = torch.from_numpy(bs_host[:B + 1]).to(dev)
+    means_rows = int(sum(members[b] for b in range(B) if quota[b] > 0)) if emit_means else 0
+    rows_ub = means_rows + int(sum(members[b] * max(int(quota[b]) - 1, 0) for b in range(B)))
+    added = torch.zeros((max(gv, 1) + 1,), dtype=torch.int32, device=dev)        # [gv] = unfinished Gaussians ("remaining")
+    remaining = added[max(gv, 1):]
+    info = _pinned_i64(dev)
+
+    def outputs(rows):
+        pts = torch.empty((rows, 3), dtype=torch.float32, device=dev)
+        cols = torch.empty((rows, 3), dtype=torch.float32, device=dev)
+        nrm = torch.empty((rows, 3), dtype=torch.float32, device=dev) if normals is not None else None
+        gidx = torch.empty((rows,), dtype=torch.int32, device=dev) if want_index else None
+        return pts, cols, nrm, gidx
+
+    def sync():
+        if dev.type == "cuda" and not nv.emulated():
+            torch.cuda.current_stream(dev).synchronize()
+
+    # ---- count pass: d[attempt][position]; exact mode loops over chunks of attempts until nothing is left unfinished ----
+    counts = []            # dcount chunks, each [na, gv]
+    a0 = 0
     while any_sampling and a0 < attempts:
         na = min(ATTEMPT_CHUNK, attempts - a0)
         dcount = torch.empty((na, gv), dtype=torch.int32, device=dev)
-        dscan = torch.empty((na, gv + 1), dtype=torch.int32, device=dev)
-        remaining.zero_()
+        if a0 > 0:
+            remaining.zero_()
         with nv.region("sampler_count", dev):
             nv.check(L.g2pc_sampler_count(nv.ptr(xyz), nv.ptr(cov), nv.ptr(perm), nv.ptr(pbin), nv.ptr(quota_d), gv,
                                           p_wave, float(std), a0, na, int(seed), int(gid_base), nv.ptr(added),
                                           nv.ptr(dcount), nv.ptr(remaining), st), "sampler_count")
-        for a in range(na):
-            nv.check(L.g2pc_scan_exclusive_u32(nv.ptr(dcount[a]), nv.ptr(dscan[a]), gv, nv.ptr(scan_ws), scan_bytes,
-                                               st), "scan")
-        edge = dscan[:, bs_idx].to(torch.int64)                     # [na, B+1] scan values at bin boundaries
-        host = torch.cat([edge.reshape(-1), remaining.to(torch.int64)]).cpu().numpy()     # sync
-        edge_h = host[:-1].reshape(na, B + 1)
-        for a in range(na):
-            sec_cols.append(edge_h[a, 1:] - edge_h[a, :-1])
-        chunks.append((a0, na, dcount, dscan))
+        counts.append(dcount)
         a0 += na
-        if int(host[-1]) == 0:
-            break
-    # trailing attempts that emitted nothing are dropped (the reference's loop would have stopped)
-    A_used = len(sec_cols)
-    sec_sizes = np.zeros((max(B, 1), 1 + A_used), dtype=np.int64)
-    for b in range(B):
-        sec_sizes[b, 0] = members[b] if (quota[b] > 0 and emit_means) else 0
-    for a in range(A_used):
-        sec_sizes[:B, 1 + a] = sec_cols[a]
-    flat = sec_sizes[:B].reshape(-1)
-    base = np.zeros_like(flat)
-    if flat.size:
-        base[1:] = np.cumsum(flat)[:-1]
-    M = int(flat.sum())
-    sec_base = torch.from_numpy(base.reshape(max(B, 0), 1 + A_used).copy() if B else np.zeros((1, 1), np.int64)).to(dev)
+        if a0 < attempts:                                        # only exact mode gets here: is anybody still short?
+            if int(remaining.cpu()[0]) == 0:
+                break
+    A = a0 if counts else 0
+    dcount = counts[0] if len(counts) == 1 else (torch.cat(counts, 0) if counts else None)
+    dscan = torch.empty((A, gv + 1), dtype=torch.int32, device=dev) if A else None
+    if A:
+        sb = L.g2pc_sampler_scan_workspace(gv, A)
+        sws = nv.workspace(sb, dev)
+        nv.check(L.g2pc_sampler_scan_counts(nv.ptr(dcount), nv.ptr(dscan), gv, A, nv.ptr(sws), sb, st), "sampler_scan_counts")
+    sec_base = torch.empty((max(B, 1) * (1 + A) + 1,), dtype=torch.int64, device=dev)
+    nv.check(L.g2pc_sampler_sections(nv.ptr(bin_start), nv.ptr(quota_d), B, A, nv.ptr(dscan), gv, 1 if emit_means else 0,
+                                     nv.ptr(sec_base), C_void(info), nv.ptr(remaining), st), "sampler_sections")
+    pts, cols, nrm, gidx = outputs(rows_ub)
+    if rows_ub > 0 and gv > 0 and B > 0:
+        with nv.region("sampler_emit", dev):
+            nv.check(L.g2pc_sampler_emit_rows(nv.ptr(xyz), nv.ptr(cov), nv.ptr(colours), nv.ptr(normals), nv.ptr(perm),
+                                              nv.ptr(bin_start), B, 0, A, gv, int(seed), int(gid_base), nv.ptr(dscan),
+                                              nv.ptr(sec_base), rows_ub, nv.ptr(pts), nv.ptr(cols), nv.ptr(nrm),
+                                              nv.ptr(gidx), st), "sampler_emit_rows")
+    sync()                                                        # round trip #2: how many points came out
+    M = int(info[0]) if B > 0 else 0
+    assert 0 <= M <= rows_ub, (M, rows_ub)
+    pts, cols = pts[:M], cols[:M]
+    nrm = nrm[:M] if nrm is not None else None
+    gidx = gidx[:M] if gidx is not None else None
+    return SampledCloud(pts, cols, nrm, gidx, bins, _LazyPerAttempt(sec_base, B, A))
 
-    pts = torch.empty((M, 3), dtype=torch.float32, device=dev)
-    cols = torch.empty((M, 3), dtype=torch.float32, device=dev)
-    nrm = torch.empty((M, 3), dtype=torch.float32, device=dev) if normals is not None else None
-    gidx = torch.empty((M,), dtype=torch.int32, device=dev) if want_index else None
-    if M > 0 and gv > 0:
-        common = (nv.ptr(xyz), nv.ptr(cov), nv.ptr(colours), nv.ptr(normals), nv.ptr(perm), nv.ptr(pbin),
-                  nv.ptr(bin_start), nv.ptr(quota_d), gv, p_wave, B)
-        if not chunks:
-            nv.check(L.g2pc_sampler_emit(*common, 0, 0, 1 + A_used, int(seed), int(gid_base), None, None,
-                                         nv.ptr(sec_base), 1 if emit_means else 0, nv.ptr(pts), nv.ptr(cols),
-                                         nv.ptr(nrm), nv.ptr(gidx), st), "sampler_emit")
-        for ci, (c0, na, dcount, dscan) in enumerate(chunks):
-            with nv.region("sampler_emit", dev):
-                nv.check(L.g2pc_sampler_emit(*common, c0, na, 1 + A_used, int(seed), int(gid_base), nv.ptr(dcount),
-                                             nv.ptr(dscan), nv.ptr(sec_base), 1 if (ci == 0 and emit_means) else 0,
-                                             nv.ptr(pts), nv.ptr(cols), nv.ptr(nrm), nv.ptr(gidx), st), "sampler_emit")
-    return SampledCloud(pts, cols, nrm, gidx, bins, [int(c.sum()) for c in sec_cols])
+
+def C_void(t: torch.Tensor):
+    import ctypes as C
+    return C.c_void_p(t.data_ptr())
+
+
+class _LazyPerAttempt:
+    """emitted rows per attempt (diagnostics): read from the device section table on first use."""
+
+    def __init__(self, sec_base, B, A):
+        self._t, self._B, self._A, self._v = sec_base, B, A, None
+
+    def _get(self):
+        if self._v is None:
+            sb = self._t.cpu().numpy()
+            size = (sb[1:] - sb[:-1]).reshape(max(self._B, 1), 1 + self._A) if self._B else np.zeros((1, 1 + self._A), np.int64)
+            per = [int(size[:, 1 + a].sum()) for a in range(self._A)]
+            while per and per[-1] == 0:          # trailing attempts that emitted nothing (the reference's loop would have stopped)
+                per.pop()
+            self._v = per
+        return self._v
+
+    def __getitem__(self, i):
+        return self._get()[i]
+
+    def __len__(self):
+        return len(self._get())
+
+    def __iter__(self):
+        return iter(self._get())

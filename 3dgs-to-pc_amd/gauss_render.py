@@ -264,7 +264,8 @@ class _RenderContext:
 
 
 CONTEXT_POOL_SIZE = 2
-POOL_SKIP_FIRST_JOBS = 1       # contexts of the first job(s) of a process are not kept, see GaussHipRenderer.close
+import os as _os
+POOL_SKIP_FIRST_JOBS = int(_os.environ.get("G2PC_POOL_SKIP_FIRST_JOBS", "1"))   # contexts of the first job(s) of a process are not kept, see GaussHipRenderer.close
 _JOBS_CLOSED = 0
 _CONTEXT_POOL = []            # free contexts, most recently used last
 
@@ -274,7 +275,16 @@ def _acquire_context(n, device):
         c = _CONTEXT_POOL[i]
         if c.n == n and c.device == device:
             return _CONTEXT_POOL.pop(i)
-    return _RenderContext(n, device)
+    clear_context_pool()          # a scene of another size: the pooled contexts (GBs of scene copies, workspaces and
+    return _RenderContext(n, device)   # captured graphs) are dead weight -- free them before allocating the new one
+
+
+def clear_context_pool():
+    """Release every pooled device context (scene copies, per-stream workspaces, captured graphs).  The pool only pays
+    off for a process that converts scene after scene of the same size; a one-shot conversion calls this after its
+    camera loop so that the sampler and the clean-up stages get the memory back."""
+    while _CONTEXT_POOL:
+        _CONTEXT_POOL.pop().release()
 
 
 def _return_context(ctx):

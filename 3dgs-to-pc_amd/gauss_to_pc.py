@@ -160,14 +160,16 @@ def generate_pointcloud(gaussians, num_points, contributions=None, mahalanobis_d
 
 
 def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, pointcloud_settings, seed=None,
-                            group=None, render_shs=False):
+                            group=None, render_shs=False, keep_render_context=True):
     """The body of convert_3dgs_to_pc (gauss_to_pc.py:414-601) on already-loaded data:
     `gaussians` is a gauss_handler.Gaussians, transforms / intrinsics are name -> 4x4 c2w / [w, h, fx, fy].
     Under torch.distributed (one process per GPU) the cameras are split over the ranks, the per-Gaussian
     visibility state is all-reduced once, and every rank returns the points of its Gaussian-index shard
     (g2pc.dist.gather_pointcloud assembles them); see g2pc/dist.py.
     render_shs=True hands gaussians.shs to the native rasteriser (SH evaluated per camera, forward.cu:22-73); the
-    reference's convert_3dgs_to_pc never does (gauss_to_pc.py:429-432) and renders the DC colours."""
+    reference's convert_3dgs_to_pc never does (gauss_to_pc.py:429-432) and renders the DC colours.
+    keep_render_context=False releases the renderer's pooled device context (scene copies, workspaces, captured camera
+    graphs) before sampling -- what a one-shot conversion wants; a process converting scene after scene keeps it."""
     from g2pc.dist import rank_world
     s = pointcloud_settings
     device = gaussians.xyz.device
@@ -256,6 +258,9 @@ def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, poin
             total_gaussian_contributions = gaussian_renderer.get_total_gaussian_contributions()[culled_indices]
 
         del gaussian_renderer
+        if not keep_render_context:
+            import gauss_render
+            gauss_render.clear_context_pool()
 
     else:
         # Convert colours from (0-1) to (0-255)
@@ -346,7 +351,7 @@ def convert_3dgs_to_pc(input_path, transform_path, mask_path, pointcloud_setting
     xyz, scales, rots, colours, opacities, shs = load_gaussians(input_path, max_sh_degree=s.max_sh_degree)
     gaussians = Gaussians(xyz, scales, rots, colours, opacities, shs=shs)
 
-    out = convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, s)
+    out = convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, s, keep_render_context=False)
 
     if torch.cuda.is_available():
         torch.cuda.empty_cache()

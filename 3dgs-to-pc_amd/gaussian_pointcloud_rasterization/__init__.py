@@ -59,6 +59,19 @@ if nv._LIB is not None:
 PIPELINE_STREAMS = 4
 
 
+def mark_visible(means3D, viewmatrix, projmatrix=None):
+    """_C.mark_visible(means3D, viewmatrix, projmatrix) -> bool[P] (rasterize_points.cu:147-166 -> checkFrustum ->
+    in_frustum, auxiliary.h:151-176): the centre lies in front of the near plane, z_view > 0.2.  projmatrix is accepted
+    for signature compatibility; the reference computes p_proj from it and never uses the result (auxiliary.h:160-166)."""
+    positions = means3D.to(torch.float32).contiguous()
+    out = torch.empty((positions.shape[0],), dtype=torch.uint8, device=positions.device)
+    view = (C.c_float * 16)(*viewmatrix.reshape(-1).tolist())
+    nv.check(nv.lib().g2pc_mark_visible(nv.ptr(positions), positions.shape[0], C.byref(view), nv.ptr(out),
+                                        nv.stream_handle(positions.device)), "mark_visible")
+    return out.bool()
+
+
+
 class _CuScratch:
     """Per-stream scratch of one in-flight camera."""
 

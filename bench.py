@@ -42,12 +42,15 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", action="store_true",
                     help="N > 1: also gather the sharded cloud on rank 0 inside the timed job (36 B per point over xGMI)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N > 1: weak = every GPU brings its own 50 cameras and 10M-point budget (50N cameras, 10M*N points "
-                         "on the shared scene); strong = the N = 1 job split N ways")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="N > 1: strong (default) = the job the metric is quoted on (50 cameras, 10M points) split N ways; "
+                         "weak = every GPU brings its own 50 cameras and 10M-point budget (50N cameras, 10M*N points)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity block (reference fixtures at the benchmark's scale)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra_workloads lines (configs[1] sampling job)")
     ap.add_argument("--sort-bits", type=int, default=0, help="tuning aid: wide radix digit bits (8 or 11)")
     ap.add_argument("--sort-small", type=int, default=2 << 20, help="tuning aid: inputs up to this many keys use 4 keys/thread")
     ap.add_argument("--blend-subblocks", type=int, default=0, help="tuning aid: 8x8 sub-blocks per blend wave (1, 2, 4)")
+    ap.add_argument("--blend-variant", type=int, default=1, help="tuning aid: 0 = first-generation blend kernel, 1 = k_blend_py_v2, 2 = v2 without adaptive width")
     ap.add_argument("--scene-scales", type=float, nargs=2, default=None, metavar=("LO", "HI"),
                     help="diagnostic: Gaussian scale range of the synthetic scene (default 0.002 0.02 = SURVEY.md's)")
     ap.add_argument("--no-context-pool", action="store_true", help="tuning aid: every job captures its camera graphs anew")
@@ -104,76 +107,127 @@ def algorithmic_bytes(workload, n, n_kept, m, cams, stats):
     return b
 
 
-def pmc_traffic(region, a):
-    """HBM bytes per launch of the region's kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
-    in separate runs of THIS bench command, tools/pmc_traffic.py -> profiles/r01_c_pmc_traffic.json); only valid for
-    the default workload it was collected on.  Corrected as MI355X_MICROARCH.md §HBM prescribes for gfx950: FETCH_SIZE
-    counts 16-byte-per-lane loads (what the blend's record gathers are) at half their bytes, so it is doubled;
-    WRITE_SIZE is taken as is; both are KB."""
+PMC_TRAFFIC_FILE = "profiles/r02_pmc_traffic.json"      # tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE passes of THIS command
+PMC_SQ_FILE = "profiles/r02_pmc_sq.json"                # tools/pmc_kernel.py: SQ counter pass of THIS command
+BLEND_KERNELS = {0: "void g2pc::k_blend_py_pk<4>", 1: "void g2pc::k_blend_py_v2<4, true>", 2: "void g2pc::k_blend_py_v2<4, false>"}
+
+
+def _default_config(a):
     import gauss_render
     from g2pc import tiles
     sub = gauss_render.BLEND_SUBBLOCKS or tiles.SUBBLOCKS_PER_CHUNK
-    kernel = {"raster_blend": {1: "void g2pc::k_blend_py<1, 4>", 2: "void g2pc::k_blend_py_pk<4>"}.get(sub),
-              "sampler_emit": "g2pc::k_emit_wave"}.get(region)
-    path = os.path.join(ROOT, "profiles", "r01_f_pmc_traffic.json" if sub == 2 else "r01_c_pmc_traffic.json")
-    if (kernel is None or not os.path.isfile(path) or (a.gaussians, a.cameras) != (1_000_000, 50)
-            or (region == "raster_blend" and gauss_render.DEFAULT_T_FLOOR != 1e-6)):
-        return None
+    return (a.gaussians, a.cameras) == (1_000_000, 50) and sub == 2 and gauss_render.DEFAULT_T_FLOOR == 1e-6
+
+
+def pmc_traffic(region, a):
+    """HBM bytes per launch of the region's kernel from a COMMITTED rocprofv3 PMC collection of this bench command (PMC
+    counters cannot be read from inside the run; FETCH_SIZE and WRITE_SIZE need separate passes).  Returned with its
+    source file so that the figure is never mistaken for a live measurement; None when the configuration differs from
+    the one profiled or the profiled kernel is not the one this build launches.  Corrected as MI355X_MICROARCH.md §HBM
+    prescribes for gfx950: FETCH_SIZE counts 16-byte-per-lane loads at half their bytes (doubled), WRITE_SIZE as is."""
+    path = os.path.join(ROOT, PMC_TRAFFIC_FILE)
+    kernel = {"raster_blend": BLEND_KERNELS.get(a.blend_variant), "sampler_emit": "g2pc::k_emit_rows"}.get(region)
+    if kernel is None or not os.path.isfile(path) or not _default_config(a):
+        return None, None
     rec = json.load(open(path)).get(kernel)
-    return rec["hbm_bytes_fetch_x2"] if rec else None
+    return (rec["hbm_bytes_fetch_x2"], PMC_TRAFFIC_FILE) if rec else (None, None)
 
 
 def pmc_valu(region, a):
-    """VALU wave-instructions per launch of the blend kernel from the committed SQ counter pass (tools/pmc_kernel.py ->
-    profiles/r01_f_pmc_sq.json); same validity conditions as pmc_traffic."""
-    import gauss_render
-    from g2pc import tiles
-    sub = gauss_render.BLEND_SUBBLOCKS or tiles.SUBBLOCKS_PER_CHUNK
-    path = os.path.join(ROOT, "profiles", "r01_f_pmc_sq.json")
-    if (region != "raster_blend" or sub != 2 or not os.path.isfile(path) or (a.gaussians, a.cameras) != (1_000_000, 50)
-            or gauss_render.DEFAULT_T_FLOOR != 1e-6):
+    """VALU wave-instructions per launch of the blend kernel from the committed SQ counter pass; same conditions."""
+    path = os.path.join(ROOT, PMC_SQ_FILE)
+    if region != "raster_blend" or not os.path.isfile(path) or not _default_config(a):
         return None
-    rec = json.load(open(path)).get("void g2pc::k_blend_py_pk<4>")
+    rec = json.load(open(path)).get(BLEND_KERNELS.get(a.blend_variant, ""))
     if not rec:
         return None
-    return {"insts": rec["SQ_INSTS_VALU"], "cycles_per_inst": 4.0 * rec["SQ_ACTIVE_INST_VALU"] / rec["SQ_INSTS_VALU"]}
+    return {"insts": rec["SQ_INSTS_VALU"], "cycles_per_inst": 4.0 * rec["SQ_ACTIVE_INST_VALU"] / rec["SQ_INSTS_VALU"],
+            "source": PMC_SQ_FILE}
 
 
-def cpu_baseline(workload):
-    """The oracle (CPU restatement of the reference, `kind: port`; pinned bit-exactly to the reference's own
-    outputs by tests/test_oracle_*.py) on a bounded sample of the same workload, on this box's host cores."""
+def cpu_baseline(workload, full_n, full_cams, full_points, n=200_000, pts=1_000_000):
+    """CPU baseline on THIS box's host cores, rank 0, N = 1, a bounded sample (~10-30 s) of the same workload.
+
+    kind "port": the untouched reference is Python and cannot travel to the GPU box (no /root/reference there), so
+    what is timed is oracle/ref_render.py + ref_gauss.py -- a restatement of the reference's python renderer and
+    sampler that is pinned BIT-EXACTLY to the reference's own outputs (tests/test_oracle_*.py) and issues the same
+    torch CPU ops.  Sample: the renderer on ONE 1280x720 camera at N = 200 k Gaussians (a fifth of the workload's) and
+    the sampler on 1 M points; the figure is the workload's point count over the extrapolated job time
+    C * t_camera * (N_full / N_sample) + t_sampler * (M_full / M_sample) -- linear in N is generous to the CPU
+    (SURVEY.md §6 measures 2 s -> 12.5 s -> ~2 min per camera for 10 k -> 100 k -> 1 M).  The untouched reference itself,
+    timed in the authoring container on the full-size scene (8 threads), is quoted from the parity fixture."""
     import ref_gauss as RG
     import ref_render as RR
     from np_philox import keyed_normals
     from g2pc.synth import make_scene, make_cameras
-    n, pts, ncam = 10_000, 100_000, 2
-    torch.set_num_threads(min(16, max(1, os.cpu_count() or 1)))     # torch CPU ops on 3x3 batches do not scale past this
-    sc = make_scene(n, 1234 + 2)
+    threads = max(1, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    sc = make_scene(n, 1234 + 3)
     t0 = time.perf_counter()
     cov = RG.covariances(sc.scales, sc.rots)
     nrm = RG.normals(sc.scales, sc.rots)
+    t_geom = time.perf_counter() - t0
     xyz, colours, weights = sc.xyz, sc.colours * 255, sc.opacities
-    t_render = 0.0
-    if workload == "render":
-        tr, intr = make_cameras(ncam)
+    t_cam = 0.0
+    if workload != "sample":
+        tr, intr = make_cameras(50)
+        name = sorted(tr)[17]
         R = RR.PythonRendererOracle(sc.xyz, sc.opacities.unsqueeze(1), sc.colours.double(), cov, threshold=0.05)
-        for name in tr:
-            R(RR.get_camera(torch.tensor(tr[name]), intr[name], colour_resolution=1280))
+        t1 = time.perf_counter()
+        R(RR.get_camera(torch.tensor(tr[name]), intr[name], colour_resolution=1280))
+        t_cam = time.perf_counter() - t1
         vis = R.get_visible_gaussians()
         xyz, cov, nrm = xyz[vis], cov[vis], nrm[vis]
         colours, weights = R.get_gaussian_colours()[vis].float(), R.max_contribution[vis]
-        t_render = time.perf_counter() - t0
+    t2 = time.perf_counter()
     cov, keep = RG.validate_covariances(cov)
     out = RG.generate_pointcloud(xyz[keep], cov[keep], colours[keep], nrm[keep], weights[keep], pts, std=2.0,
                                  exact=False, attempts=5,
                                  eps_fn=lambda gids, a, k: keyed_normals(7, gids[:, None], a, np.arange(k)[None, :]))
-    dt = time.perf_counter() - t0
-    what = ("%d cameras 1280x720 (%.1f s) + " % (ncam, t_render)) if workload == "render" else ""
-    return {"value": out["points"].shape[0] / dt, "unit": "points/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": "oracle (ref_render.py + ref_gauss.py): %d Gaussians, %scov/validate/magnitudes/distribute/sample "
-                      "-> %d points, %.1f s wall; the full workload has 100x the Gaussians, %sx the cameras and 100x "
-                      "the points" % (n, what, out["points"].shape[0], dt, "25" if workload == "render" else "0")}
+    t_samp = time.perf_counter() - t2
+    m = int(out["points"].shape[0])
+    est = full_cams * t_cam * (full_n / n) + (t_geom + t_samp) * (full_points / max(m, 1))
+    res = {"value": full_points / est, "unit": "points/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": "oracle port of the reference (ref_render.py + ref_gauss.py, bit-pinned to it): N = %d Gaussians, "
+                     "%s sampler %d points in %.1f s (geometry %.2f s); value = %d points / (%d cameras x t_camera x %.0f "
+                     "+ t_sampler x %.0f) = extrapolated job time %.0f s"
+                     % (n, ("1 camera 1280x720 in %.1f s," % t_cam) if workload != "sample" else "no cameras,", m, t_samp,
+                        t_geom, full_points, full_cams, full_n / n, full_points / max(m, 1), est),
+           "measured_seconds": {"camera": t_cam, "sampler": t_samp, "geometry": t_geom}}
+    fx = os.path.join(ROOT, "tests", "golden", "render_py_cfg2_1m.npz")
+    fs = os.path.join(ROOT, "tests", "golden", "sample_cfg2_1m.npz")
+    if os.path.isfile(fx) and os.path.isfile(fs):
+        g, gs = np.load(fx), np.load(fs)
+        spc = float(np.min(g["seconds_per_camera"]))
+        res["untouched_reference_authoring_container"] = {
+            "seconds_per_camera_1M_gaussians_1280x720": spc, "sampler_seconds_10M_points": float(gs["sample_seconds"]),
+            "threads": int(g["threads"]),
+            "points_per_s_configs2_extrapolated": full_points / (full_cams * spc + float(gs["sample_seconds"])) if workload != "sample"
+            else full_points / float(gs["sample_seconds"]),
+            "note": "the reference itself (renderer_type=python under oracle/ref_shim.py) on the full-size scene, timed by "
+                    "oracle/make_golden.py in the authoring container -- a different host than this GPU box"}
+    return res
+
+
+def extra_sample_line(a, device):
+    """BASELINE configs[1] (sampling pipeline only) timed the same way as the main workload, as an extra line."""
+    from g2pc.synth import make_scene
+    scene = make_scene(a.gaussians, 1234 + 2, device=device)
+    for w in range(2):
+        one_step(scene, None, "sample", a.points, device, seed=300 + w)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pts, k = 0, 5
+    for i in range(k):
+        pts += one_step(scene, None, "sample", a.points, device, seed=400 + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / k
+    b = algorithmic_bytes("sample", a.gaussians, a.gaussians, pts / k, None, [])
+    return {"config": "configs[1]: %d Gaussians, no_render_colours, %d points (cov build -> validate -> magnitudes -> "
+                      "distribute -> sample)" % (a.gaussians, a.points),
+            "value": pts / k / dt, "unit": "points/s", "ms_per_step": dt * 1e3, "steps": k,
+            "job_hbm": {"algorithmic_bytes_per_step": b, "achieved": b / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": b / dt / 1e9 / HBM_PEAK_GBS}}
 
 
 def main():
@@ -181,11 +235,22 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (run it through gpurun)"
-    if os.environ.get("G2PC_SHARE_GPU"):         # validation aid: several ranks on ONE GPU (gloo; RCCL refuses that)
-        local = 0
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    emulate = bool(os.environ.get("G2PC_BENCH_EMULATE")) and not torch.cuda.is_available()
+    assert torch.cuda.is_available() or emulate, "bench.py needs an MI355X (run it through gpurun)"
+    if emulate:
+        # authoring-container dry run of THIS script's code paths (argument handling, JSON assembly, parity / baseline
+        # plumbing) on the CPU emulator of the kernels at toy sizes; the numbers it prints mean nothing
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from emu_util import build_emu
+        from g2pc import _native as _nv
+        _nv._inject_for_tests(build_emu())
+        torch.cuda.synchronize = lambda *a, **k: None
+        device = torch.device("cpu")
+    else:
+        if os.environ.get("G2PC_SHARE_GPU"):         # validation aid: several ranks on ONE GPU (gloo; RCCL refuses that)
+            local = 0
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         backend = os.environ.get("G2PC_DIST_BACKEND", "nccl")
@@ -196,6 +261,7 @@ def main():
     from g2pc import _native as nv
     from g2pc.synth import make_scene, make_cameras
     nv.lib()
+    import gauss_render  # noqa: F401  (registers the rasteriser prototypes)
     workload = a.workload or ("render" if have_renderer() else "sample")
     global GATHER_OUTPUT
     GATHER_OUTPUT = a.gather
@@ -206,6 +272,7 @@ def main():
         nv.lib().g2pc_set_sort_tuning(a.sort_bits, a.sort_small)
     if a.blend_subblocks:
         gauss_render.BLEND_SUBBLOCKS = a.blend_subblocks
+    nv.check(nv.lib().g2pc_set_blend_variant(a.blend_variant), "set_blend_variant")
     if a.streams:
         gauss_render.PIPELINE_STREAMS = a.streams
     if a.no_context_pool:
@@ -232,8 +299,14 @@ def main():
         torch.cuda.synchronize()
 
     nv.PROFILE = {}               # before the warm-up: the camera graphs are captured with their timing events
+    first_job_ms = None
     for w in range(a.warmup):
+        t_w = time.perf_counter()
         one_step(scene, cams, workload, total_points, device, seed=100 + w)
+        if w == 0:
+            torch.cuda.synchronize()
+            first_job_ms = (time.perf_counter() - t_w) * 1e3      # what a one-shot `python gauss_to_pc.py ...` pays (graph capture,
+                                                                  # first-use allocations, no pooled context), library load excluded
     nv.PROFILE.clear()
     if workload != "sample":
         gauss_render.RENDER_STATS.clear()
@@ -286,7 +359,8 @@ def main():
         if per_launch is not None and ms > 0:
             ach = per_launch / (ms / launches * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(name, a), "avg_launch_ms": ms / launches,
+                    "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(name, a)[0], "traffic_source": pmc_traffic(name, a)[1],
+                    "avg_launch_ms": ms / launches,
                     "algorithmic_bytes_per_launch": per_launch,
                     "note": "k_blend_py is VALU/v_exp bound, not HBM bound (DESIGN.md §3); frac is its HBM share only"
                     if name == "raster_blend" else None}
@@ -297,7 +371,7 @@ def main():
                 # INSTS_VALU) at 2.4 GHz
                 peak = 1024 * 2.4e9 / valu["cycles_per_inst"]
                 roof["valu"] = {"wave_insts_per_launch": valu["insts"], "achieved": valu["insts"] / (ms / launches * 1e-3),
-                                "peak": peak, "unit": "wave-instructions/s",
+                                "peak": peak, "unit": "wave-instructions/s", "source": valu["source"],
                                 "frac": valu["insts"] / (ms / launches * 1e-3) / peak}
     stats = gauss_render.RENDER_STATS[-(len(gauss_render.RENDER_STATS) // max(a.steps, 1)):] if gauss_render.RENDER_STATS else []
     b_total = algorithmic_bytes(workload, a.gaussians, a.gaussians, points / max(a.steps, 1), cams, stats)
@@ -306,19 +380,10 @@ def main():
                "note": "rank 0's share; B_samp uses N_kept = N (upper bound)"}
     if workload == "render_cuda":
         job_hbm = None                 # per-camera instance counts are not collected on this path
-    # the same job priced with the bytes of the REFERENCE's algorithm (SURVEY.md §8d worked numbers: L = 8.5 N instances
-    # under 16x16 tiling, six 8-bit radix passes over 64-bit keys) -- the figure BASELINE.json's "% HBM roofline" target
-    # (>= 40 %) is stated against; this design moves fewer bytes (job_hbm above)
-    n_, m_ = float(a.gaussians), points / max(a.steps, 1)
-    ncam = len(cams[0]) / world if cams is not None else 0            # cameras this rank rendered per step
-    b_ref = 116.0 * n_ + 56.0 * n_ + 36.0 * m_ + ncam * (156.0 * n_ + (76.0 + 24.0 * 6) * 8.5 * n_ + 32.0 * 1280 * 720)
-    job_hbm_ref = {"algorithmic_bytes_per_step": b_ref, "achieved": b_ref / (dt / a.steps) / 1e9, "peak": HBM_PEAK_GBS,
-                   "unit": "GB/s", "frac": b_ref / (dt / a.steps) / 1e9 / HBM_PEAK_GBS,
-                   "note": "rank 0's share, SURVEY.md §8(d) B_total of the reference's algorithm"}
     out = {
         "metric": "coloured points/sec", "value": points_all / dt_all, "unit": "points/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt_all / a.steps * 1e3, "higher_is_better": True,
-        "scaling": a.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": a.scaling if world > 1 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": {"render": "configs[2]: 1M Gaussians, 50 cameras 1280x720, 10M points, python-renderer semantics",
                                 "render_cuda": "configs[4]: 1M Gaussians, 50 cameras, native-rasteriser semantics, SH degree 3, "
                                                "surface_distance_std=2.0, exact_num_points, 10M points",
@@ -329,12 +394,30 @@ def main():
         "roofline": roof,
         # the whole job against the HBM roofline (B_total = B_geom + C * B_cam + B_samp, per rank)
         "job_hbm": job_hbm,
-        "job_hbm_reference_algorithm": job_hbm_ref,
         "instances_per_camera": (float(np.mean([x[0] for x in gauss_render.RENDER_STATS])) if gauss_render.RENDER_STATS else None),
         "regions_ms_per_step": {k: v[1] / a.steps for k, v in sorted(prof.items())},
+        "first_job_ms": first_job_ms,
     }
+    if world == 1 and workload == "render" and not a.no_extra and not a.camera_subset:
+        out["extra_workloads"] = {"sample": extra_sample_line(a, device)}
+    if world == 1 and workload == "render" and not a.no_parity:
+        # parity gates, outside the timed region: the same scene, cameras 0 and 17 of the same rig, against
+        # outputs of the untouched reference (tests/golden/*_cfg2_1m.npz); tools/parity_cfg2.py documents every key
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import parity_cfg2
+        tag = "mini" if emulate else "1m"
+        if parity_cfg2.available(tag) and (a.gaussians == 1_000_000 or emulate):
+            gauss_render.clear_context_pool()
+            full = parity_cfg2.run(str(device), tag=tag)
+            out["parity"] = {k: full.get(k) for k in (
+                "mask_flips", "near_threshold_1e-5", "contrib_max", "contrib_frac_gt_1e-4", "colour_max", "colour_frac_gt_1e-4",
+                "image_max", "image_frac_gt_1e-4", "culled_equal", "ppg_mismatch_given_ref_contrib", "ppg_mismatch_end_to_end",
+                "sample_points", "sample_points_ref", "sample_xyz_max", "sample_rgb_max", "sample_rows_compared", "cameras",
+                "gaussians", "resolution", "t_floor", "oracle", "check_seconds")}
+            out["parity"]["ppg_equal"] = full.get("ppg_mismatch_given_ref_contrib") == 0
     if not a.no_cpu_baseline and world == 1:          # the CPU baseline is a 1-GPU companion figure (rank 0, N = 1 only)
-        out["cpu_baseline"] = cpu_baseline(workload)
+        out["cpu_baseline"] = cpu_baseline(workload, a.gaussians, a.cameras if workload != "sample" else 0, a.points,
+                                           **(dict(n=3000, pts=20_000) if emulate else {}))
     print(json.dumps(out))
 
 

@@ -165,18 +165,28 @@ int g2pc_sampler_count(const float* means, const float* cov9, const uint32_t* pe
                        int32_t num_attempts, uint64_t seed, uint64_t gid_base, uint32_t* added, uint32_t* dcount,
                        uint32_t* remaining, void* stream);
 
-/* Stage 3: emission in the reference's order (bins ascending; per bin: all means, then attempt 0, 1, ...;
- * inside a section Gaussians in index order, each with its FIRST d draws -- gauss_to_pc.py:247-258).
- * dscan u32[num_attempts, gv+1] = per-attempt exclusive scans of dcount; sec_base i64[num_bins, 1+num_attempts_total]
- * = output offset of every section (column 0 = means); colours f32[*,3], normals f32[*,3] or NULL by Gaussian.
- * Writes out_points/out_colours/out_normals f32[m,3] and (optional) out_gauss i32[m].
- * emit_means != 0 also writes the means sections (do it on the first attempt chunk only). */
-int g2pc_sampler_emit(const float* means, const float* cov9, const float* colours, const float* normals,
-                      const uint32_t* perm, const uint32_t* pbin, const uint32_t* bin_start, const int32_t* quota,
-                      int64_t gv, int64_t p_wave_begin, int32_t num_bins, int32_t attempt0, int32_t num_attempts,
-                      int32_t sec_stride, uint64_t seed, uint64_t gid_base, const uint32_t* dcount,
-                      const uint32_t* dscan, const int64_t* sec_base, int emit_means, float* out_points,
-                      float* out_colours, float* out_normals, int32_t* out_gauss, void* stream);
+/* Stage 3 (emission in the reference's order) is g2pc_sampler_scan_counts / _sections / _emit_rows below. */
+
+/* --- sampler, device-resident bookkeeping (no host round trip between the count and the emission) ---------------
+ * g2pc_sampler_scan_counts: dscan[a] (u32[gv+1] per attempt) = exclusive scan of dcount[a] (u32[gv] per attempt).
+ * g2pc_sampler_sections:    sec_base i64[num_bins * (1 + attempts) + 1] = first output row of every (bin, means |
+ *                           attempt a) section in the reference's order (gauss_to_pc.py:341-371), last entry = M;
+ *                           info_host (optional, pinned, i64[2]) <- {M, *remaining}.
+ * g2pc_sampler_emit_rows:   the whole cloud in one row-per-lane launch (create_new_gaussian_points' emission,
+ *                           gauss_to_pc.py:247-258, for all bins and attempts); outputs sized rows_capacity >= M. */
+int g2pc_sampler_partition(const int32_t* ppg, int64_t g, const int32_t* bin_of_ppg, int64_t lut_len, int32_t num_bins,
+                           uint32_t* perm, uint32_t* pbin, void* ws, size_t ws_bytes, void* stream);   /* g2pc_sampler_plan without bin_start */
+size_t g2pc_sampler_scan_workspace(int64_t gv, int32_t attempts);
+int g2pc_sampler_scan_counts(const uint32_t* dcount, uint32_t* dscan, int64_t gv, int32_t attempts, void* ws, size_t ws_bytes,
+                             void* stream);
+int g2pc_sampler_sections(const uint32_t* bin_start, const int32_t* quota, int32_t num_bins, int32_t attempts,
+                          const uint32_t* dscan, int64_t gv, int emit_means, int64_t* sec_base, int64_t* info_host,
+                          const uint32_t* remaining, void* stream);
+int g2pc_sampler_emit_rows(const float* means, const float* cov9, const float* colours, const float* normals,
+                           const uint32_t* perm, const uint32_t* bin_start, int32_t num_bins, int32_t attempt0,
+                           int32_t attempts, int64_t gv, uint64_t seed, uint64_t gid_base, const uint32_t* dscan,
+                           const int64_t* sec_base, int64_t rows_capacity, float* out_points, float* out_colours,
+                           float* out_normals, int32_t* out_gauss, void* stream);
 
 /* --- stand-alone helpers of the python renderer (the reference's public gauss_render functions) ------------------
  * eval_sh (gauss_render.py:43-99): sh f32[n, channels, coeffs] (coefficient index on the LAST axis, as the

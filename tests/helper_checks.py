@@ -1,0 +1,160 @@
+"""Shared assertions for the reference's public helper functions (gauss_render.py:43-193, gauss_to_pc.py:92-275,
+rasterize_points.cu:147-166) against tests/golden/helpers_n4096.npz (written by the untouched reference)."""
+import os
+
+import numpy as np
+import torch
+
+from g2pc.synth import make_scene, make_cameras
+
+
+def _case(golden_dir, device):
+    import camera_handler
+    from gauss_handler import Gaussians
+    g = np.load(os.path.join(golden_dir, "helpers_n4096.npz"))
+    dev = torch.device(device)
+    sc = make_scene(int(g["n"]), int(g["seed"]), scale_lo=0.004, scale_hi=0.04)
+    transforms, intr = make_cameras(3, width=640, height=360, focal=550.0)
+    name = sorted(transforms)[int(g["cam"])]
+    G = Gaussians(sc.xyz.to(dev), sc.scales.to(dev), sc.rots.to(dev), sc.colours.to(dev), sc.opacities.to(dev))
+    cam = camera_handler.get_camera("python", torch.tensor(transforms[name]), intr[name], colour_resolution=None)
+    return g, G, cam, dev
+
+
+def check_projection_helpers(golden_dir, device="cpu"):
+    import gauss_render as gr
+    g, G, cam, dev = _case(golden_dir, device)
+    cov2d = gr.build_covariance_2d(G.xyz, G.covariances, cam.world_view_transform, cam.FoVx, cam.FoVy, cam.focal_x, cam.focal_y)
+    assert cov2d.shape == (G.xyz.shape[0], 2, 2)
+    np.testing.assert_allclose(cov2d.cpu().numpy(), g["cov2d"], rtol=2e-5, atol=1e-5)
+    p_proj, p_view, in_mask = gr.projection_ndc(G.xyz, cam.world_view_transform, cam.projection_matrix)
+    np.testing.assert_allclose(p_proj.cpu().numpy(), g["p_proj"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(p_view.cpu().numpy(), g["p_view"], rtol=1e-5, atol=1e-6)
+    assert in_mask.dtype == torch.bool and np.array_equal(in_mask.cpu().numpy(), g["in_mask"])
+    # radius / rect from the REFERENCE's inputs: exact (integer-valued radii, clipped floats)
+    radii = gr.get_radius(torch.from_numpy(g["cov2d"]).to(dev))
+    assert np.array_equal(radii.cpu().numpy(), g["radii"])
+    rmin, rmax = gr.get_rect(torch.from_numpy(g["pix"]).to(dev), torch.from_numpy(g["radii"]).to(dev), cam.image_width, cam.image_height)
+    assert np.array_equal(rmin.cpu().numpy(), g["rect_min"]) and np.array_equal(rmax.cpu().numpy(), g["rect_max"])
+    # and from our own cov2d: radii are multiples of 3, a last-bit difference may move a ceil() by one step
+    r2 = gr.get_radius(cov2d).cpu().numpy()
+    assert float((r2 != g["radii"]).mean()) < 2e-3 and float(np.abs(r2 - g["radii"]).max()) <= 3.0
+    assert gr.GaussPythonRenderer is gr.GaussHipRenderer
+    h = gr.homogeneous(G.xyz[:4])
+    assert h.shape == (4, 4) and bool((h[:, 3] == 1).all())
+
+
+def check_eval_sh(golden_dir, device="cpu"):
+    import gauss_render as gr
+    g = np.load(os.path.join(golden_dir, "helpers_n4096.npz"))
+    dev = torch.device(device)
+    sh, d = torch.from_numpy(g["sh"]).to(dev), torch.from_numpy(g["dirs"]).to(dev)
+    for deg in range(5):
+        out = gr.eval_sh(deg, sh, d if deg else None)
+        assert out.shape == (sh.shape[0], 3)
+        np.testing.assert_allclose(out.cpu().numpy(), g["sh_deg%d" % deg], rtol=1e-5, atol=2e-6)
+    # batch dimensions [..., C, K] and exactly (deg+1)^2 coefficients
+    out = gr.eval_sh(2, sh[:64, :, :9].reshape(8, 8, 3, 9).contiguous(), d[:64].reshape(8, 8, 3))
+    np.testing.assert_allclose(out.reshape(64, 3).cpu().numpy(), g["sh_deg2"][:64], rtol=1e-5, atol=2e-6)
+    try:
+        gr.eval_sh(3, sh[:, :, :9], d)
+        raise RuntimeError("too few coefficients must be rejected")
+    except AssertionError:
+        pass
+
+
+def check_mahalanobis_and_mvn(golden_dir, device="cpu"):
+    """mahalanobis (gauss_to_pc.py:92-103), sample_from_multivariate_normal (:140-155, retry / None contract),
+    create_new_gaussian_points (:157-275)."""
+    import gauss_to_pc as g2p
+    import ref_gauss as RG
+    from np_philox import keyed_normals
+    g, G, cam, dev = _case(golden_dir, device)
+    m = g2p.mahalanobis(G.xyz, torch.from_numpy(g["maha_samples"]).to(dev), G.covariances)
+    np.testing.assert_allclose(m.cpu().numpy(), g["maha"], rtol=2e-4, atol=2e-5)
+
+    # sample_from_multivariate_normal: [n, G, 3], = mean + chol(cov) eps with the keyed noise
+    n_draw, seed = 5, 321
+    xyz, cov = G.xyz[:500].contiguous(), G.covariances[:500].contiguous()
+    s = g2p.sample_from_multivariate_normal(xyz, cov, n_draw, seed=seed)
+    assert s.shape == (n_draw, 500, 3)
+    eps = keyed_normals(seed, np.arange(500)[None, :], 0, np.arange(n_draw)[:, None])            # [n, G, 3]
+    Lc = torch.linalg.cholesky(cov.cpu().double())
+    ref = xyz.cpu().double()[None] + torch.einsum("gij,ngj->ngi", Lc, torch.from_numpy(eps).double())
+    assert float((s.cpu().double() - ref).abs().max()) < 1e-5
+    # non positive-definite covariance: NaN draw -> regularise in place (+epsilon I) and retry -> None when hopeless
+    bad = cov.clone()
+    bad[7] = torch.diag(torch.tensor([1e-4, 1e-4, -5e-7], device=dev))
+    before = bad[7].clone()
+    s2 = g2p.sample_from_multivariate_normal(xyz, bad, n_draw, max_num_gen_attempts=3, epsilon=1e-6, seed=seed)
+    assert s2 is not None and not bool(torch.isnan(s2).any())
+    assert float((bad[7] - before).diagonal().min()) >= 0.99e-6                                   # regularised in place
+    worse = cov.clone()
+    worse[3] = torch.diag(torch.tensor([1e-4, 1e-4, -1.0], device=dev))
+    assert g2p.sample_from_multivariate_normal(xyz, worse, n_draw, max_num_gen_attempts=2, epsilon=1e-6, seed=seed) is None
+
+    # create_new_gaussian_points: quota n per Gaussian, first-k emission, Gaussian-major inside every attempt
+    npts = 6
+    cols = torch.rand((500, 3), device=dev)
+    pts, pc, pn = g2p.create_new_gaussian_points(npts, xyz, cov, cols, mahalanobis_distance_std=2, num_attempts=5,
+                                                 normals=None, device=str(dev), seed=seed)
+    ref_pts, owner, _ = RG.sample_bin(torch.arange(500), xyz.cpu(), cov.cpu(), npts, 2.0, 5,
+                                      lambda gids, a, k: keyed_normals(seed, gids[:, None], a, np.arange(k)[None, :]))
+    assert pts.shape == tuple(ref_pts.shape), (pts.shape, ref_pts.shape)
+    assert float((pts.cpu() - ref_pts).abs().max()) < 1e-5
+    assert float((pc.cpu() - cols.cpu()[owner]).abs().max()) < 1e-6
+    assert pn is None
+
+
+def check_mark_visible(device="cpu"):
+    """_C.mark_visible (rasterize_points.cu:147-166): in_frustum = z_view > 0.2."""
+    import camera_handler
+    from gaussian_pointcloud_rasterization import mark_visible
+    dev = torch.device(device)
+    sc = make_scene(5000, 77)
+    transforms, intr = make_cameras(2, radius=1.2)           # camera inside the cloud: both sides of the near plane
+    for name in transforms:
+        cam = camera_handler.get_camera("cuda", torch.tensor(transforms[name]), intr[name])
+        vis = mark_visible(sc.xyz.to(dev), cam.viewmatrix.to(dev), cam.projmatrix.to(dev))
+        V = cam.viewmatrix.cpu().float()
+        z = sc.xyz @ V[:3, 2] + V[3, 2]
+        ref = z > 0.2
+        assert vis.dtype == torch.bool and 0 < int(ref.sum()) < 5000
+        flips = (vis.cpu() != ref)
+        assert int(flips.sum()) == 0 or float((z[flips] - 0.2).abs().max()) < 1e-6
+
+
+def check_validate_covariances_cull_branch(golden_dir, device="cpu"):
+    """validate_covariances with rows that really are culled (gauss_handler.py:142-166).  A row can only be culled when
+    three clamp-and-rebuild rounds in fp32 still leave an eigenvalue <= 1e-8, i.e. when lambda_max * 6e-8 exceeds the
+    1e-7 clamp: the verdict is then decided by the rounding of LAPACK's eigh / eigvals, which no other implementation
+    reproduces bit for bit.  Pinned here: (1) spectra within fp32's range agree EXACTLY with the reference (nothing is
+    culled), (2) beyond it the verdicts agree for most rows and ours never keeps a matrix whose smallest eigenvalue is
+    below the threshold, (3) the cull mechanics (keep mask -> filter -> every per-Gaussian array compacted)."""
+    from g2pc import ops
+    g, G, cam, dev = _case(golden_dir, device)
+    rows = g["cull_rows"]
+    cov = G.covariances.clone()
+    cov[torch.from_numpy(rows).to(dev)] = torch.from_numpy(g["cull_bad_cov"]).to(dev)
+    G.covariances = cov.clone()
+    n0 = G.xyz.shape[0]
+    keep = G.validate_covariances()
+    ref_keep = g["cull_keep"]
+    k = keep.cpu().numpy()
+    lam_max = 10.0 ** (-2 + 8 * np.arange(len(rows)) / 300.0)
+    inside = np.zeros(n0, dtype=bool)
+    inside[rows[lam_max < 1.0]] = True
+    rest = np.ones(n0, dtype=bool)
+    rest[rows] = False
+    assert np.array_equal(k[inside], ref_keep[inside]) and bool(k[inside].all())        # (1)
+    assert np.array_equal(k[rest], ref_keep[rest]) and bool(k[rest].all())
+    agree = float((k[rows] == ref_keep[rows]).mean())
+    assert agree > 0.7, agree                                                          # (2) noise regime
+    assert int((~k).sum()) > 0 and int((~ref_keep).sum()) > 0                           # both really cull
+    # (3) mechanics
+    m = int(k.sum())
+    assert G.xyz.shape[0] == m and G.covariances.shape[0] == m and G.opacities.shape[0] == m and G.colours.shape[0] == m
+    # every kept matrix is positive definite by an independent fp64 check
+    ev = np.linalg.eigvalsh(G.covariances.cpu().double().numpy())
+    assert float(ev.min()) > 0.0
+    return dict(ours_culled=int((~k).sum()), reference_culled=int((~ref_keep).sum()), agreement_on_ill_conditioned_rows=agree)
