@@ -792,20 +792,24 @@ __global__ __launch_bounds__(RA_T) void k_rebase_keys(unsigned long long* __rest
     if ((key >> 32) != 0ull) best_key[i] = key | 0xFFFFFFFFull;
 }
 
-// multi-GPU winner selection: after the all-reduce(MAX) of the packed keys, a rank keeps its colour only where it
-// owns the winning key; the all-reduce(SUM) of the colours then has exactly one non-zero term per Gaussian.
-__global__ __launch_bounds__(RA_T) void k_keep_winner_colours(const unsigned long long* __restrict__ local_key,
-                                                             const unsigned long long* __restrict__ global_key,
-                                                             long n, int rank, float* __restrict__ colours) {
+// multi-GPU winner selection: after the all-reduce(MAX) of the packed keys every rank that holds the winning key
+// nominates itself (k_key_owner); an all-reduce(MIN) of the nominations elects exactly ONE rank per Gaussian -- several
+// ranks hold the same key after an earlier exchange or a rebase --, the others zero their colours
+// (k_keep_winner_colours), and the all-reduce(SUM) of the colours has exactly one non-zero term per Gaussian whatever
+// was exchanged before: the exchange is idempotent.
+__global__ __launch_bounds__(RA_T) void k_key_owner(const unsigned long long* __restrict__ local_key,
+                                                   const unsigned long long* __restrict__ global_key, long n, int rank,
+                                                   int32_t* __restrict__ owner) {
     long i = (long)blockIdx.x * RA_T + threadIdx.x;
     if (i >= n) return;
-    unsigned long long g = global_key[i];
-    // keys rebased after an earlier exchange (order 0) are identical on every rank, and so are their colours:
-    // only rank 0 contributes them to the sum
-    const bool from_earlier_epoch = (uint32_t)g == 0xFFFFFFFFu;
-    if ((g >> 32) == 0ull || local_key[i] != g || (from_earlier_epoch && rank != 0)) {
-        colours[3 * i + 0] = 0.0f; colours[3 * i + 1] = 0.0f; colours[3 * i + 2] = 0.0f;
-    }
+    const unsigned long long g = global_key[i];
+    owner[i] = ((g >> 32) != 0ull && local_key[i] == g) ? rank : 0x7FFFFFFF;
+}
+__global__ __launch_bounds__(RA_T) void k_keep_winner_colours(const int32_t* __restrict__ owner, long n, int rank,
+                                                             float* __restrict__ colours) {
+    long i = (long)blockIdx.x * RA_T + threadIdx.x;
+    if (i >= n) return;
+    if (owner[i] != rank) { colours[3 * i + 0] = 0.0f; colours[3 * i + 1] = 0.0f; colours[3 * i + 2] = 0.0f; }
 }
 
 __global__ __launch_bounds__(RA_T) void k_contributions(const unsigned long long* __restrict__ best_key, long n,
@@ -1450,13 +1454,22 @@ int g2pc_raster_rebase_keys(unsigned long long* best_key, int64_t n, void* strea
     return check_launch("g2pc_raster_rebase_keys");
 }
 
-int g2pc_raster_keep_winner_colours(const unsigned long long* local_key, const unsigned long long* global_key,
-                                    int64_t n, int32_t rank, float* colours, void* stream) {
+int g2pc_raster_key_owner(const unsigned long long* local_key, const unsigned long long* global_key, int64_t n,
+                          int32_t rank, int32_t* owner, void* stream) {
     using namespace g2pc;
     if (n <= 0) return G2PC_OK;
-    G2PC_REQUIRE(local_key && global_key && colours, G2PC_ERR_ARG, "null pointer");
-    hipLaunchKernelGGL(k_keep_winner_colours, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, (hipStream_t)stream, local_key,
-                       global_key, (long)n, (int)rank, colours);
+    G2PC_REQUIRE(local_key && global_key && owner, G2PC_ERR_ARG, "null pointer");
+    hipLaunchKernelGGL(k_key_owner, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, (hipStream_t)stream, local_key, global_key, (long)n,
+                       (int)rank, owner);
+    return check_launch("g2pc_raster_key_owner");
+}
+
+int g2pc_raster_keep_winner_colours(const int32_t* owner, int64_t n, int32_t rank, float* colours, void* stream) {
+    using namespace g2pc;
+    if (n <= 0) return G2PC_OK;
+    G2PC_REQUIRE(owner && colours, G2PC_ERR_ARG, "null pointer");
+    hipLaunchKernelGGL(k_keep_winner_colours, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, (hipStream_t)stream, owner, (long)n,
+                       (int)rank, colours);
     return check_launch("g2pc_raster_keep_winner_colours");
 }
 

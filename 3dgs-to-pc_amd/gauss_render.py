@@ -74,7 +74,8 @@ nv._RASTER_PROTOS.update({
     "g2pc_raster_rebase_keys": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "g2pc_raster_debug_chunk_work": (C.c_int, [C.c_void_p]),
     "g2pc_set_blend_variant": (C.c_int, [C.c_int]),
-    "g2pc_raster_keep_winner_colours": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "g2pc_raster_key_owner": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "g2pc_raster_keep_winner_colours": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "g2pc_raster_contributions": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
 })
 if nv._LIB is not None:
@@ -343,6 +344,7 @@ class GaussHipRenderer():
         self.rerendered = 0           # cameras that overflowed their graph's capacity and went through the two-call path
         self.layouts = {}
         self.last_stats = []          # (instances L, tile-sort passes, W*H) per rendered camera
+        self._dirty = False           # rendered since the last all_reduce_visibility
 
     def state_ptrs(self):
         return nv.ptr(self.best_key), nv.ptr(self.gaussian_colours)
@@ -407,23 +409,33 @@ class GaussHipRenderer():
         # tile layouts depend only on the image size and tiling: built and uploaded once per process and device
         key = (width, height, self.MAX_TILE_SIZE, BLEND_SUBBLOCKS, self.tile_shard, str(self.device))
         if key not in _LAYOUT_CACHE:
-            _LAYOUT_CACHE[key] = _DeviceLayout(tiles.python_quadtree_layout(width, height, self.MAX_TILE_SIZE, BLEND_SUBBLOCKS,
-                                                                             self.tile_shard), self.device)
+            host = tiles.python_quadtree_layout(width, height, self.MAX_TILE_SIZE, BLEND_SUBBLOCKS, self.tile_shard)
+            if host["nx"] * host["ny"] > 4096 or host["nx"] > 256 or host["ny"] > 256:
+                # 12-bit tile field of the packed visibility keys / 8-bit tile-interval ranges of the per-Gaussian rects
+                raise NotImplementedError("%dx%d at max_tile_size=%d needs %d quad-tree leaves; the python-semantics rasteriser "
+                                          "supports at most 4096 (images up to 3840 px wide): lower --colour_quality"
+                                          % (width, height, self.MAX_TILE_SIZE, host["nx"] * host["ny"]))
+            _LAYOUT_CACHE[key] = _DeviceLayout(host, self.device)
         return _LAYOUT_CACHE[key]
 
     def all_reduce_visibility(self, group=None):
         """Multi-GPU (cameras sharded over ranks): combine the running state of all ranks.  all-reduce MAX of the
-        packed (contribution, ~order) keys -- exact and order-free -- then every rank zeroes the colours it did
-        not win and an all-reduce SUM delivers the winners' colours (one non-zero term per Gaussian)."""
+        packed (contribution, ~order) keys -- exact and order-free --, an all-reduce MIN elects ONE rank among
+        those holding the winning key (several do after an earlier exchange), every other rank zeroes its colour and an
+        all-reduce SUM delivers the winners' colours: one non-zero term per Gaussian, so calling this twice is harmless."""
         import torch.distributed as dist
         self.flush()
         if not dist.is_initialized() or dist.get_world_size(group) == 1:
             return
         global_key = self.best_key.clone()
         dist.all_reduce(global_key, op=dist.ReduceOp.MAX, group=group)
-        nv.check(nv.lib().g2pc_raster_keep_winner_colours(nv.ptr(self.best_key), nv.ptr(global_key), self.n,
-                                                          dist.get_rank(group), nv.ptr(self.gaussian_colours),
-                                                          nv.stream_handle(self.device)),
+        rank = dist.get_rank(group)
+        owner = torch.empty((self.n,), dtype=torch.int32, device=self.device)
+        st = nv.stream_handle(self.device)
+        nv.check(nv.lib().g2pc_raster_key_owner(nv.ptr(self.best_key), nv.ptr(global_key), self.n, rank, nv.ptr(owner), st),
+                 "key_owner")
+        dist.all_reduce(owner, op=dist.ReduceOp.MIN, group=group)          # exactly one rank per Gaussian keeps its colour
+        nv.check(nv.lib().g2pc_raster_keep_winner_colours(nv.ptr(owner), self.n, rank, nv.ptr(self.gaussian_colours), st),
                  "keep_winner_colours")
         dist.all_reduce(self.gaussian_colours, op=dist.ReduceOp.SUM, group=group)
         self.best_key.copy_(global_key)            # in place: the captured graphs hold this tensor's address
@@ -611,6 +623,7 @@ class GaussHipRenderer():
     def __call__(self, camera, return_image=True, slot=None, **kwargs):
         W, H = int(camera.image_width), int(camera.image_height)
         lay = self._layout(W, H)
+        self._dirty = True
         if slot is not None:                       # caller-assigned global camera order (multi-GPU camera sharding)
             if not (1 <= slot <= 255):
                 raise ValueError("camera slot must be in [1, 255]")

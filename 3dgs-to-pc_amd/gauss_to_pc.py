@@ -426,6 +426,11 @@ def config_parser(argv=None):
     if args.camera_skip_rate < 0:
         raise AttributeError(f"The camera skip rate must be larger than 0")
 
+    if args.generate_mesh:
+        from mesh_handler import open3d_available
+        if not open3d_available():
+            raise AttributeError("--generate_mesh needs Open3D (Poisson surface reconstruction), which is not installed: "
+                                 "refusing before the render / sampling work is spent")
     if args.generate_mesh and args.no_calculate_normals:
         raise AttributeError(f"Normals are required for accurate meshing")
 

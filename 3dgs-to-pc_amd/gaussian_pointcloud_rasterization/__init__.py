@@ -227,6 +227,7 @@ class GaussianRasterizer(nn.Module):
         self._camera_counter = int(cam_index) + 1
         rs = raster_settings
         cam, campos, mask = self._camera(rs)
+        self._dirty = True
         n = self.n
         if discard_images and PIPELINE_STREAMS > 1 and self.device.type == "cuda" and not nv.emulated():
             if not self._pipe:
@@ -238,6 +239,12 @@ class GaussianRasterizer(nn.Module):
             if not self._pending:
                 for other in self._pipe:
                     other.stream.wait_stream(torch.cuda.current_stream(self.device))
+            if mask is not None:
+                # the mask was produced (copied / converted) on the CURRENT stream but is read by the blend on sc.stream,
+                # possibly several cameras later: order the side stream behind its producer and keep the allocator from
+                # handing the block to the next camera's mask while that blend is still queued
+                sc.stream.wait_stream(torch.cuda.current_stream(self.device))
+                mask.record_stream(sc.stream)
             self._front(sc, cam, campos, rs.sh_degree)
             sc.front_done.record(sc.stream)
             self._pending.append((sc, cam, mask, int(cam_index)))
@@ -318,15 +325,25 @@ class GaussianRasterizer(nn.Module):
             return
         gmax = self.gaussian_max_contribution.clone()
         dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
-        # earliest camera among the ranks that reached the global maximum (strict > in the reference = first wins)
+        # earliest camera among the ranks that reached the global maximum (strict > in the reference = first wins) ...
         none = torch.full_like(self._winner_cam, 1 << 30)
         cand = torch.where((self.gaussian_max_contribution == gmax) & (gmax > 0), self._winner_cam, none)
         first = cand.clone()
         dist.all_reduce(first, op=dist.ReduceOp.MIN, group=group)
-        mine = (cand == first) & (first < (1 << 30))
+        # ... and ONE rank among those holding it (after an earlier exchange every rank does): the exchange is idempotent
+        rank = dist.get_rank(group)
+        owner = torch.where((cand == first) & (first < (1 << 30)), torch.full_like(first, rank), none)
+        dist.all_reduce(owner, op=dist.ReduceOp.MIN, group=group)
+        mine = owner == rank
         self.gaussian_colours = torch.where(mine.unsqueeze(1), self.gaussian_colours, torch.zeros_like(self.gaussian_colours))
         dist.all_reduce(self.gaussian_colours, op=dist.ReduceOp.SUM, group=group)
-        dist.all_reduce(self.gaussian_total_contribution, op=dist.ReduceOp.SUM, group=group)
+        # running SUM: only what this rank added since the previous exchange travels; the part every rank already shares
+        # (the previous exchange's result) is added back afterwards
+        base = getattr(self, "_total_base", None)
+        new = self.gaussian_total_contribution - base if base is not None else self.gaussian_total_contribution.clone()
+        dist.all_reduce(new, op=dist.ReduceOp.SUM, group=group)
+        self.gaussian_total_contribution = new + base if base is not None else new
+        self._total_base = self.gaussian_total_contribution.clone()
         dist.all_reduce(self.gaussian_min_surface_distance, op=dist.ReduceOp.MIN, group=group)
         self._winner_cam = first
         self.gaussian_max_contribution = gmax

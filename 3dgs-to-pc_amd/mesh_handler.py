@@ -166,7 +166,30 @@ def clean_point_cloud(points, colours, normals, std_ratio=10, device="cuda:0"):
     return pts, cols, nrm
 
 
+def open3d_available():
+    try:
+        import open3d  # noqa: F401
+        return True
+    except Exception:
+        return False
+
+
 def generate_mesh(points, colours, normals, output_path, depth=12, laplacian_iters=10, std_ratio=3):
-    """mesh_handler.py:66-87 -- Open3D's Poisson reconstruction; not part of the hot path and not rebuilt here."""
-    raise NotImplementedError("--generate_mesh needs Open3D's Poisson surface reconstruction, which is outside the scope of "
-                              "this package; convert_3dgs_to_pc still returns the surface point cloud it would consume")
+    """mesh_handler.py:66-87 -- Open3D's Poisson reconstruction + Laplacian smoothing.  The meshing algorithm is Open3D's
+    own (a third-party CPU library after the hot path): when Open3D is installed this delegates to it
+    with the reference's parameters, otherwise it raises -- and `main()` refuses --generate_mesh up front."""
+    if not open3d_available():
+        raise NotImplementedError("--generate_mesh needs Open3D's Poisson surface reconstruction (not installed); "
+                                  "convert_3dgs_to_pc still returns the surface point cloud it would consume")
+    import numpy as np
+    import open3d as o3d
+    pcd = o3d.geometry.PointCloud()
+    pcd.points = o3d.utility.Vector3dVector(points.detach().cpu().double().numpy())
+    pcd.colors = o3d.utility.Vector3dVector(np.clip(colours.detach().cpu().double().numpy(), 0, 255) / 255.0)
+    pcd.normals = o3d.utility.Vector3dVector(normals.detach().cpu().double().numpy())
+    pcd, _ = pcd.remove_statistical_outlier(nb_neighbors=20, std_ratio=std_ratio)
+    mesh, _ = o3d.geometry.TriangleMesh.create_from_point_cloud_poisson(pcd, depth=depth)
+    mesh = mesh.filter_smooth_laplacian(number_of_iterations=laplacian_iters)
+    mesh.compute_vertex_normals()
+    o3d.io.write_triangle_mesh(output_path, mesh)
+    return mesh

@@ -412,7 +412,7 @@ def main():
             out["parity"] = {k: full.get(k) for k in (
                 "mask_flips", "near_threshold_1e-5", "contrib_max", "contrib_frac_gt_1e-4", "colour_max", "colour_frac_gt_1e-4",
                 "image_max", "image_frac_gt_1e-4", "culled_equal", "ppg_mismatch_given_ref_contrib", "ppg_mismatch_end_to_end",
-                "sample_points", "sample_points_ref", "sample_xyz_max", "sample_rgb_max", "sample_rows_compared", "cameras",
+                "sample_points", "sample_points_ref", "sample_xyz_max", "sample_rgb_max", "sample_rows_compared", "sample_rows_unmatched", "cameras",
                 "gaussians", "resolution", "t_floor", "oracle", "check_seconds")}
             out["parity"]["ppg_equal"] = full.get("ppg_mismatch_given_ref_contrib") == 0
     if not a.no_cpu_baseline and world == 1:          # the CPU baseline is a 1-GPU companion figure (rank 0, N = 1 only)

@@ -344,11 +344,13 @@ int g2pc_raster_back_cu(const G2pcCamera* cam, const int32_t* mask, int64_t n, i
                         int32_t* winner_cam, int32_t cam_index, float* cur_contrib, int32_t* cur_pixels, float* cur_surf,
                         int phases, void* ws, size_t ws_bytes, void* stream);
 
-/* multi-GPU (no counterpart in the reference): zero colours[i,:] unless local_key[i] == global_key[i] != 0, so that an
- * all-reduce(SUM) over ranks after an all-reduce(MAX) of the keys reproduces "earliest camera wins" exactly.  Keys that
- * were rebased after an earlier exchange are shared by all ranks: only `rank` 0 keeps their colour. */
-int g2pc_raster_keep_winner_colours(const unsigned long long* local_key, const unsigned long long* global_key,
-                                    int64_t n, int32_t rank, float* colours, void* stream);
+/* Multi-GPU exchange of the python-semantics state (cameras sharded over ranks): all-reduce MAX of best_key, then
+ * g2pc_raster_key_owner (owner[i] = rank where this rank holds the winning key, INT32_MAX elsewhere), all-reduce MIN of
+ * owner, g2pc_raster_keep_winner_colours (zero the colours of every Gaussian another rank was elected for), all-reduce
+ * SUM of the colours: exactly one non-zero term per Gaussian, also for keys several ranks share after an earlier exchange. */
+int g2pc_raster_key_owner(const unsigned long long* local_key, const unsigned long long* global_key, int64_t n,
+                          int32_t rank, int32_t* owner, void* stream);
+int g2pc_raster_keep_winner_colours(const int32_t* owner, int64_t n, int32_t rank, float* colours, void* stream);
 /* _C.mark_visible (rasterize_points.h:43-46, unused by the reference's own pipeline): present[i] = the Gaussian centre is
  * in front of the near plane of the native rasteriser (z_view > 0.2, auxiliary.h:166).  viewmatrix: HOST float[16] as in
  * G2pcCamera.view. */

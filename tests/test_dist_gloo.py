@@ -169,3 +169,77 @@ def test_tile_shards_partition_the_chunk_list():
         sizes = [len(p["chunk_tile"]) for p in parts]
         assert max(sizes) - min(sizes) <= 8                                   # one tile's worth of chunks at most
         assert all(np.array_equal(p["tile_seq"], full["tile_seq"]) for p in parts)   # keys mean the same on every rank
+
+
+def _run_exchange_twice(rank, world, port, out_dir, renderer):
+    for p in (os.path.join(ROOT, "3dgs-to-pc_amd"), os.path.join(ROOT, "oracle"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from g2pc import _native as nv
+    nv._inject_for_tests(os.path.join(HERE, "hipemu", "libg2pc_emu.so"))
+    from g2pc.synth import make_scene, make_cameras
+    from gauss_handler import Gaussians
+    import camera_handler
+    import gauss_render
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sc = make_scene(800, 93, scale_lo=0.01, scale_hi=0.06)
+    transforms, intr = make_cameras(4, width=120, height=68, focal=100.0)
+    G = Gaussians(sc.xyz, sc.scales, sc.rots, sc.colours, sc.opacities)
+    R = gauss_render.get_renderer(renderer, G.xyz, G.opacities.unsqueeze(1), G.colours, G.covariances,
+                                  visible_gaussian_threshold=0.05, surface_distance_std=2.0 if renderer == "cuda" else None,
+                                  calculate_surface_distance=renderer == "cuda")
+    states = []
+    for half in (0, 1):                     # two cameras, exchange, exchange AGAIN, two more cameras, exchange
+        for ci, name in list(enumerate(sorted(transforms)))[2 * half:2 * half + 2]:
+            if ci % world == rank:
+                cam = camera_handler.get_camera(renderer, torch.tensor(transforms[name]), intr[name])
+                R(cam, return_image=False, slot=ci + 1)
+        R.all_reduce_visibility()
+        first = (R.get_gaussian_colours().clone(), R.get_total_gaussian_contributions().clone())
+        R.all_reduce_visibility()           # nothing rendered in between: must not change anything
+        second = (R.get_gaussian_colours().clone(), R.get_total_gaussian_contributions().clone())
+        assert torch.equal(first[0], second[0]) and torch.equal(first[1], second[1])
+        states.append(second)
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "twice_%s.npz" % renderer), colours=states[-1][0].numpy(), total=states[-1][1].numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("renderer", ["python", "cuda"])
+def test_visibility_exchange_is_idempotent(tmp_path, renderer):
+    """all_reduce_visibility called twice in a row (and again after more cameras) equals the single-process state: one
+    rank per Gaussian is elected for the colour SUM, and the running total only ships what was added since the last
+    exchange."""
+    from emu_util import build_emu
+    build_emu()
+    port = 33500 + (os.getpid() % 2000) + (7 if renderer == "cuda" else 0)
+    mp.spawn(_run_exchange_twice, args=(2, port, str(tmp_path), renderer), nprocs=2, join=True)
+    got = np.load(tmp_path / ("twice_%s.npz" % renderer))
+    # single process, same four cameras
+    for p in (os.path.join(ROOT, "3dgs-to-pc_amd"), os.path.join(ROOT, "oracle"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from g2pc import _native as nv
+    saved = (nv._LIB, nv._EMULATED)
+    nv._inject_for_tests(os.path.join(HERE, "hipemu", "libg2pc_emu.so"))
+    try:
+        from g2pc.synth import make_scene, make_cameras
+        from gauss_handler import Gaussians
+        import camera_handler
+        import gauss_render
+        sc = make_scene(800, 93, scale_lo=0.01, scale_hi=0.06)
+        transforms, intr = make_cameras(4, width=120, height=68, focal=100.0)
+        G = Gaussians(sc.xyz, sc.scales, sc.rots, sc.colours, sc.opacities)
+        R = gauss_render.get_renderer(renderer, G.xyz, G.opacities.unsqueeze(1), G.colours, G.covariances,
+                                      visible_gaussian_threshold=0.05, surface_distance_std=2.0 if renderer == "cuda" else None,
+                                      calculate_surface_distance=renderer == "cuda")
+        for name in sorted(transforms):
+            R(camera_handler.get_camera(renderer, torch.tensor(transforms[name]), intr[name]), return_image=False)
+        assert np.array_equal(R.get_gaussian_colours().numpy(), got["colours"])
+        np.testing.assert_allclose(R.get_total_gaussian_contributions().numpy(), got["total"], rtol=1e-5, atol=1e-6)
+    finally:
+        nv._LIB, nv._EMULATED = saved

@@ -17,5 +17,5 @@ def test_parity_checker_on_mini_job(emu):
     assert r["mask_flips"] == 0 and r["culled_equal"] and r["keep_equal"]
     assert r["contrib_max"] < 1e-4 and r["colour_max"] < 1e-4 and r["image_max"] < 1e-4
     assert r["ppg_mismatch_given_ref_contrib"] == 0
-    assert r["sample_points"] == r["sample_points_ref"] and r["sample_xyz_rows_gt_1e-4"] == 0
+    assert r["sample_points"] == r["sample_points_ref"] and r["sample_rows_unmatched"] == 0
     assert r["sample_xyz_max"] < 1e-4 and r["sample_rgb_max"] < 1e-4
