@@ -49,6 +49,7 @@ _PROTOS = {
     "g2pc_sampler_count": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _i32, _i32, _u64, _u64, _vp,
                                      _vp, _vp, _vp]),
 }
+_PROTOS["g2pc_scatter_ones_u8"] = (C.c_int, [_vp, _i64, _vp, _i64, _vp])
 _PROTOS["g2pc_sampler_partition"] = (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _sz, _vp])
 _PROTOS["g2pc_sampler_scan_workspace"] = (_sz, [_i64, _i32])
 _PROTOS["g2pc_sampler_scan_counts"] = (C.c_int, [_vp, _vp, _i64, _i32, _vp, _sz, _vp])

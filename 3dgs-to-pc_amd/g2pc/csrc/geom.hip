@@ -377,6 +377,28 @@ int g2pc_gather_rows(const void* src, const uint32_t* index, int64_t m, int32_t 
 }
 }
 
+namespace g2pc {
+__global__ __launch_bounds__(GEO_T) void k_scatter_ones_u8(const uint32_t* __restrict__ index, long m, uint8_t* __restrict__ dst,
+                                                          long n) {
+    long i = (long)blockIdx.x * GEO_T + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t j = index[i];
+    if ((long)j < n) dst[j] = 1;
+}
+}  // namespace g2pc
+
+extern "C" {
+/* dst[index[i]] = 1 for i < m (uint8 mask of n entries; out-of-range positions are ignored) */
+int g2pc_scatter_ones_u8(const uint32_t* index, int64_t m, uint8_t* dst, int64_t n, void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(m >= 0 && n >= 0, G2PC_ERR_ARG, "negative size");
+    if (m == 0) return G2PC_OK;
+    G2PC_REQUIRE(index && dst, G2PC_ERR_ARG, "null pointer");
+    hipLaunchKernelGGL(k_scatter_ones_u8, dim3(cdiv(m, GEO_T)), dim3(GEO_T), 0, (hipStream_t)stream, index, (long)m, dst, (long)n);
+    return check_launch("g2pc_scatter_ones_u8");
+}
+}
+
 extern "C" {
 int g2pc_pack_ply_vertices(const float* points, const float* normals, const float* colours, int64_t m, void* out,
                            void* stream) {

@@ -42,6 +42,28 @@ def sort_pairs_u32(keys: torch.Tensor, vals: torch.Tensor, bit_lo: int = 0, bit_
     return ko, vo
 
 
+def argsort_f64_nonnegative(x: torch.Tensor) -> torch.Tensor:
+    """Stable ascending argsort (int32) of non-negative float64 values: their IEEE bit patterns order like unsigned
+    64-bit integers, sorted least-significant word first with two stable 32-bit radix sorts."""
+    x = x.to(torch.float64).contiguous()
+    n = x.shape[0]
+    words = x.view(torch.int32).reshape(n, 2)                    # little endian: [:, 0] low word, [:, 1] high word
+    idx = torch.arange(n, dtype=torch.int32, device=x.device)
+    _, order_lo = sort_pairs_u32(words[:, 0].contiguous(), idx)
+    hi_in_lo_order = gather_rows(words[:, 1].contiguous(), order_lo)
+    _, order = sort_pairs_u32(hi_in_lo_order, order_lo)
+    return order
+
+
+def scatter_ones_u8(dst_u8: torch.Tensor, index_i32: torch.Tensor) -> torch.Tensor:
+    """dst[index] = 1 (uint8 destination, int32 positions)."""
+    m = index_i32.numel()
+    if m:
+        nv.check(nv.lib().g2pc_scatter_ones_u8(nv.ptr(index_i32.contiguous()), m, nv.ptr(dst_u8), dst_u8.numel(),
+                                               nv.stream_handle(dst_u8.device)), "scatter_ones_u8")
+    return dst_u8
+
+
 # ------------------------------------------------------------------------------------------ geometry
 def build_covariances(log_scales: torch.Tensor, rots: torch.Tensor, scaling_modifier: float = 1.0,
                       want_cov6: bool = False, want_normals: bool = False, want_rotmat: bool = False):
@@ -186,6 +208,7 @@ class SampledCloud(NamedTuple):
 
 
 WAVE_MODE_MIN_DRAWS = 32   # quota-1 at and above which one Gaussian is sampled by a whole wave64
+HIST_GUESS = 8192          # histogram length used before max(points per Gaussian) is known on the host
 ATTEMPT_CHUNK = 8
 
 
@@ -221,9 +244,10 @@ def _pinned_i64(device, n=2):
 
 
 def sample_pointcloud(xyz: torch.Tensor, cov: torch.Tensor, colours: torch.Tensor,
-                      normals: Optional[torch.Tensor], ppg_i32: torch.Tensor, max_ppg: int, *, exact: bool,
+                      normals: Optional[torch.Tensor], ppg_i32: torch.Tensor, max_ppg: Optional[int], *, exact: bool,
                       std: float, attempts: int, seed: int, gid_base: int = 0, want_index: bool = False,
-                      bins: Optional[list] = None, emit_means: bool = True) -> SampledCloud:
+                      bins: Optional[list] = None, emit_means: bool = True,
+                      stats: Optional[torch.Tensor] = None) -> SampledCloud:
     """The bin loop of generate_pointcloud (gauss_to_pc.py:308-371) + create_new_gaussian_points
     (gauss_to_pc.py:157-275) for all bins at once, in the reference's output order.
     `bins` overrides the bin table ((start, end, quota) triples); emit_means=False drops the centre points
@@ -240,7 +264,18 @@ def sample_pointcloud(xyz: torch.Tensor, cov: torch.Tensor, colours: torch.Tenso
     normals = _f32c(normals) if normals is not None else None
     G = xyz.shape[0]
 
-    hist = bincount(ppg_i32, int(max_ppg) + 1).cpu().numpy().astype(np.int64)          # round trip #1
+    if max_ppg is None:
+        # the caller hands over distribute_points' device-side stats instead of reading max(ppg) back first: histogram
+        # with a generous fixed length, ONE read-back for both (falls back to the exact length if some Gaussian got more
+        # than HIST_GUESS points)
+        hist_dev = bincount(ppg_i32, HIST_GUESS)
+        both = torch.cat([stats.to(torch.int64), hist_dev.to(torch.int64)]).cpu().numpy()            # round trip #1
+        max_ppg = int(both[3])
+        hist = both[4:4 + max_ppg + 1] if max_ppg < HIST_GUESS else None
+    else:
+        hist = None
+    if hist is None:
+        hist = bincount(ppg_i32, int(max_ppg) + 1).cpu().numpy().astype(np.int64)      # round trip #1
     if bins is None:
         bins = bin_table_from_hist(hist, exact)
     B = len(bins)

@@ -107,7 +107,8 @@ class Gaussians():
         keep = ops.validate_covariances_(cov, regularise=regularise, reg_eps=5e-7, eps=epsilon,
                                          min_eps=min_ps_epsilon, iters=num_clamp_iters)
         self.covariances = cov
-        if bool((~keep).any()):
+        self.last_validate_culled = bool((~keep).any())
+        if self.last_validate_culled:
             self.add_gaussians_to_cull(keep)
             self.filter_gaussians()
         return keep
@@ -119,6 +120,7 @@ class Gaussians():
         """gauss_handler.py:171-193 -- stream compaction (scan + row gathers in HIP)."""
         filter_indices = torch.clone(self.filter_indices)
         index = ops.compact_index(filter_indices)
+        self.last_filter_index = index        # int32 positions of the survivors: select(per_gaussian_tensor) reuses it
 
         self.xyz = ops.gather_rows(self.xyz, index)
         self.scales = ops.gather_rows(self.scales, index)
@@ -138,6 +140,11 @@ class Gaussians():
 
         return filter_indices
 
+    def select(self, per_gaussian):
+        """per_gaussian[mask of the LAST filter_gaussians()] as a row gather on the compaction index that filter already
+        built (what the reference writes as tensor[culled_indices], gauss_to_pc.py:503,513)."""
+        return ops.gather_rows(per_gaussian.contiguous(), self.last_filter_index)
+
     def apply_min_opacity(self, min_opacity):
         """gauss_handler.py:195-204."""
         if min_opacity > 0.0:
@@ -154,14 +161,16 @@ class Gaussians():
         self.filter_indices = m.to(torch.bool)
 
     def cull_large_gaussians(self, cull_gauss_size_percent):
-        """gauss_handler.py:235-250 (intent: drop the largest `cull_gauss_size_percent` of the Gaussians)."""
+        """gauss_handler.py:235-250.  The reference's line `filter_indices & culled_gaussians` ANDs a bool mask with int64
+        INDICES (a shape / dtype error as written); the intent -- keep the floor(n * (1 - p)) smallest Gaussians by
+        get_gaussian_magnitudes(), ties in index order -- is what runs here, ranked by the library's stable radix sort."""
         if cull_gauss_size_percent > 0.0:
             gaussian_sizes = self.get_gaussian_magnitudes()
             cull_index = floor(gaussian_sizes.shape[0] * (1 - cull_gauss_size_percent))
-            sorted_sizes, sorted_indices = torch.sort(gaussian_sizes)
-            keep = torch.zeros_like(self.filter_indices)
-            keep[sorted_indices[:cull_index]] = True
-            self.filter_indices = self.filter_indices & keep
+            order = ops.argsort_f64_nonnegative(gaussian_sizes)
+            keep = torch.zeros((gaussian_sizes.shape[0],), dtype=torch.uint8, device=gaussian_sizes.device)
+            ops.scatter_ones_u8(keep, order[:cull_index])
+            self.filter_indices = self.filter_indices & keep.to(torch.bool)
 
     def get_gaussian_magnitudes(self, contributions=None):
         """gauss_handler.py:252-279 -- sqrt(ellipsoid area) x (contributions or opacities), float64."""

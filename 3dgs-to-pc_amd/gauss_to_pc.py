@@ -136,10 +136,11 @@ def generate_pointcloud(gaussians, num_points, contributions=None, mahalanobis_d
 
     # Assign points to gaussians
     _, points_per_gaussian, stats = ops.distribute_points(gaussian_sizes, num_points)
-    max_ppg = int(stats[3].item())
+    max_ppg = None                      # read back together with the histogram (one host round trip, ops.sample_pointcloud)
 
     bins = None
     if shard is not None and shard[1] > 1:
+        max_ppg = int(stats[3].item())
         rank, world = shard
         g_total = points_per_gaussian.shape[0]
         lo, hi = (g_total * rank) // world, (g_total * (rank + 1)) // world
@@ -155,7 +156,7 @@ def generate_pointcloud(gaussians, num_points, contributions=None, mahalanobis_d
     out = ops.sample_pointcloud(gaussians.xyz, gaussians.covariances, gaussians.colours,
                                 gaussians.normals if calculate_normals else None, points_per_gaussian, max_ppg,
                                 exact=bool(exact_num_points), std=mahalanobis_distance_std,
-                                attempts=num_sample_attempts, seed=seed, gid_base=gid_base, bins=bins)
+                                attempts=num_sample_attempts, seed=seed, gid_base=gid_base, bins=bins, stats=stats)
     return _finish_dtypes(out.points, out.colours, out.normals)
 
 
@@ -252,10 +253,10 @@ def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, poin
 
         if s.generate_mesh:
             surface_gaussian_idxs = gaussian_renderer.get_predicted_surface_gaussians(predicted_surface_std=1.0)
-            surface_gaussian_idxs = surface_gaussian_idxs[culled_indices]
+            surface_gaussian_idxs = gaussians.select(surface_gaussian_idxs)
 
         if s.prioritise_visible_gaussians:
-            total_gaussian_contributions = gaussian_renderer.get_total_gaussian_contributions()[culled_indices]
+            total_gaussian_contributions = gaussians.select(gaussian_renderer.get_total_gaussian_contributions())
 
         del gaussian_renderer
         if not keep_render_context:
@@ -275,8 +276,8 @@ def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, poin
 
     invalid_gaussian_indices = gaussians.validate_covariances()
 
-    if total_gaussian_contributions is not None:
-        total_gaussian_contributions = total_gaussian_contributions[invalid_gaussian_indices]
+    if total_gaussian_contributions is not None and gaussians.last_validate_culled:
+        total_gaussian_contributions = gaussians.select(total_gaussian_contributions)      # [invalid_gaussian_indices]
 
     num_sample_attempts = 5 if not s.exact_num_points else 100
 
@@ -303,7 +304,8 @@ def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, poin
             print("Starting Point Cloud Generation for Surface Gaussians")
             print()
 
-        surface_gaussian_idxs = surface_gaussian_idxs[invalid_gaussian_indices]
+        if gaussians.last_validate_culled:
+            surface_gaussian_idxs = gaussians.select(surface_gaussian_idxs)                  # [invalid_gaussian_indices]
         gaussians.add_gaussians_to_cull(surface_gaussian_idxs)
         gaussians.filter_gaussians()
 
@@ -312,7 +314,7 @@ def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, poin
 
         points, colours, normals = generate_pointcloud(gaussians, total_mesh_points, exact_num_points=s.exact_num_points,
                                                        num_sample_attempts=num_sample_attempts,
-                                                       contributions=total_gaussian_contributions[surface_gaussian_idxs],
+                                                       contributions=gaussians.select(total_gaussian_contributions),
                                                        device=s.device, quiet=s.quiet, seed=seed, shard=(rank, world))
 
         surface_point_cloud = PointCloudData(points=points, colours=colours, normals=normals)

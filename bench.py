@@ -35,7 +35,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default=None, choices=[None, "render", "sample", "render_cuda"])
+    ap.add_argument("--workload", default=None, choices=[None, "render", "sample", "render_cuda", "config4"],
+                    help="render = configs[2] (default), sample = configs[1], render_cuda = configs[4], config4 = configs[3] "
+                         "(5M Gaussians, 200 cameras, 50M points: the 8-GPU job, also runnable on one GPU)")
     ap.add_argument("--gaussians", type=int, default=1_000_000)
     ap.add_argument("--points", type=int, default=10_000_000)
     ap.add_argument("--cameras", type=int, default=50)
@@ -263,6 +265,11 @@ def main():
     nv.lib()
     import gauss_render  # noqa: F401  (registers the rasteriser prototypes)
     workload = a.workload or ("render" if have_renderer() else "sample")
+    config4 = workload == "config4"
+    if config4:                                   # configs[3]: same pipeline as "render", BASELINE's 8-GPU sizes
+        workload = "render"
+        if (a.gaussians, a.cameras, a.points) == (1_000_000, 50, 10_000_000):
+            a.gaussians, a.cameras, a.points = 5_000_000, 200, 50_000_000
     global GATHER_OUTPUT
     GATHER_OUTPUT = a.gather
     import gauss_render
@@ -384,7 +391,8 @@ def main():
         "metric": "coloured points/sec", "value": points_all / dt_all, "unit": "points/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt_all / a.steps * 1e3, "higher_is_better": True,
         "scaling": a.scaling if world > 1 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": {"render": "configs[2]: 1M Gaussians, 50 cameras 1280x720, 10M points, python-renderer semantics",
+        "config": {"workload": "configs[3]: 5M Gaussians, 200 cameras 1280x720, 50M points, python-renderer semantics" if config4 else
+                               {"render": "configs[2]: 1M Gaussians, 50 cameras 1280x720, 10M points, python-renderer semantics",
                                 "render_cuda": "configs[4]: 1M Gaussians, 50 cameras, native-rasteriser semantics, SH degree 3, "
                                                "surface_distance_std=2.0, exact_num_points, 10M points",
                                 "sample": "configs[1]: 1M Gaussians, no_render_colours, 10M points (sampling pipeline)"}[workload],
@@ -398,7 +406,7 @@ def main():
         "regions_ms_per_step": {k: v[1] / a.steps for k, v in sorted(prof.items())},
         "first_job_ms": first_job_ms,
     }
-    if world == 1 and workload == "render" and not a.no_extra and not a.camera_subset:
+    if world == 1 and workload == "render" and not config4 and not a.no_extra and not a.camera_subset:
         out["extra_workloads"] = {"sample": extra_sample_line(a, device)}
     if world == 1 and workload == "render" and not a.no_parity:
         # parity gates, outside the timed region: the same scene, cameras 0 and 17 of the same rig, against

@@ -93,6 +93,8 @@ size_t g2pc_compact_workspace(int64_t n);
 int g2pc_compact_index(const uint8_t* mask, int64_t n, uint32_t* index, uint32_t* count, void* ws, size_t ws_bytes,
                        void* stream);
 int g2pc_gather_rows(const void* src, const uint32_t* index, int64_t m, int32_t row_bytes, void* dst, void* stream);
+/* dst[index[i]] = 1 for i < m (uint8 mask of n entries): the keep mask of cull_large_gaussians (gauss_handler.py:235-250) */
+int g2pc_scatter_ones_u8(const uint32_t* index, int64_t m, uint8_t* dst, int64_t n, void* stream);
 
 /* --- clean_point_cloud (mesh_handler.py:89-94), "next" row f4 -----------------------------------------------------
  * The reference hands the cloud to Open3D (not vendored, version unpinned): PointCloud::RemoveStatisticalOutliers(

@@ -36,3 +36,8 @@ def test_mark_visible_is_the_near_plane_test(emu):
     z = (V[0, 2] * x[:, 0] + V[1, 2] * x[:, 1] + V[2, 2] * x[:, 2] + V[3, 2]).astype(np.float32)
     assert vis.dtype == np.bool_ and np.array_equal(vis, z > np.float32(0.2))
     assert 0 < vis.sum() < vis.size                                               # both sides of the plane are present
+
+
+def test_generate_mesh_surface_point_cloud(emu):
+    from mesh_surface_checks import check_surface_cloud
+    print(check_surface_cloud())

@@ -128,3 +128,27 @@ def test_tile_overflow_is_reported(emu, monkeypatch):
     monkeypatch.setattr(gauss_render, "STRICT_TILE_LOAD", True)
     with pytest.raises(NotImplementedError, match="max_gaussians_per_tile"):
         R.get_gaussian_colours()
+
+
+def test_cull_large_gaussians_drops_the_largest(emu):
+    """gauss_handler.py:235-250 (intent; the reference's own line is a dtype error): the floor(n (1 - p)) smallest
+    Gaussians by get_gaussian_magnitudes() survive, ties in index order."""
+    import numpy as np
+    import torch
+    from gauss_handler import Gaussians
+    from g2pc import ops
+    from g2pc.synth import make_scene
+    sc = make_scene(3000, 17)
+    G = Gaussians(sc.xyz, sc.scales, sc.rots, sc.colours, sc.opacities)
+    mags = G.get_gaussian_magnitudes().numpy()
+    order = ops.argsort_f64_nonnegative(torch.from_numpy(mags)).numpy()
+    assert np.array_equal(order, np.argsort(mags, kind="stable"))
+    G.cull_large_gaussians(0.1)
+    keep = G.filter_indices.numpy()
+    assert int(keep.sum()) == 2700
+    assert mags[keep].max() <= mags[~keep].min()
+    kept = G.filter_gaussians()
+    assert G.xyz.shape[0] == 2700 and torch.equal(G.select(torch.from_numpy(mags)), torch.from_numpy(mags[kept.numpy()]))
+    # exact ties: the stable sort keeps index order
+    t = torch.tensor([3.0, 1.0, 3.0, 0.0, 1.0, 3.0], dtype=torch.float64)
+    assert ops.argsort_f64_nonnegative(t).tolist() == [3, 1, 4, 0, 2, 5]

@@ -58,3 +58,8 @@ def test_config5_pipeline_cuda_semantics_surface_cull_exact_points():
     assert cloud.colours.shape == (m, 3) and cloud.normals.shape == (m, 3)
     assert float(cloud.colours.min()) >= 0.0 and float(cloud.colours.max()) <= 255.0 * 1.0001
     assert torch.isfinite(cloud.points).all()
+
+
+def test_generate_mesh_surface_point_cloud():
+    from mesh_surface_checks import check_surface_cloud
+    print(check_surface_cloud("cuda:0", n=20000, ncam=4, num_points=400000))
