@@ -168,7 +168,7 @@ __device__ __forceinline__ void sym3_clamp(double A[6], const double e[3], doubl
 // LAPACK solver on the float32 matrix; here: closed-form fp64 eigenvalues of the symmetrised matrix.
 __global__ __launch_bounds__(GEO_T) void k_validate_cov(float* __restrict__ cov9, long n, int regularise,
                                                        float reg_eps, float eps, float min_eps, int iters,
-                                                       uint8_t* __restrict__ keep) {
+                                                       uint8_t* __restrict__ keep, uint32_t* __restrict__ culled_count) {
     long i = (long)blockIdx.x * GEO_T + threadIdx.x;
     if (i >= n) return;
     float* c = cov9 + 9 * i;
@@ -192,7 +192,9 @@ __global__ __launch_bounds__(GEO_T) void k_validate_cov(float* __restrict__ cov9
     const double Af[6] = {(double)m[0], 0.5 * ((double)m[1] + (double)m[3]), 0.5 * ((double)m[2] + (double)m[6]),
                           (double)m[4], 0.5 * ((double)m[5] + (double)m[7]), (double)m[8]};
     sym3_eigvals(Af[0], Af[1], Af[2], Af[3], Af[4], Af[5], e);
-    keep[i] = (sym3_min_eig(Af, e, (double)min_eps) <= (double)min_eps) ? 0 : 1;   // NaN compares false -> kept, as in the reference
+    const bool cull = sym3_min_eig(Af, e, (double)min_eps) <= (double)min_eps;    // NaN compares false -> kept, as in the reference
+    keep[i] = cull ? 0 : 1;
+    if (cull && culled_count) atomicAdd(culled_count, 1u);                        // rare: no contention in practice
     if (dirty) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) c[k] = m[k];
@@ -306,14 +308,19 @@ int g2pc_build_covariances(const float* log_scales, const float* rots, float sca
     return check_launch("g2pc_build_covariances");
 }
 
-int g2pc_validate_covariances(float* cov9, int64_t n, int regularise, float reg_eps, float eps, float min_eps,
-                              int iters, uint8_t* keep, void* stream) {
+int g2pc_validate_covariances_counted(float* cov9, int64_t n, int regularise, float reg_eps, float eps, float min_eps,
+                                      int iters, uint8_t* keep, uint32_t* culled_count, void* stream) {
     using namespace g2pc;
     G2PC_REQUIRE(n >= 0 && (n == 0 || (cov9 && keep)), G2PC_ERR_ARG, "null input");
     if (n == 0) return G2PC_OK;
     hipLaunchKernelGGL(k_validate_cov, dim3(cdiv(n, GEO_T)), dim3(GEO_T), 0, (hipStream_t)stream, cov9, (long)n,
-                       regularise, reg_eps, eps, min_eps, iters, keep);
+                       regularise, reg_eps, eps, min_eps, iters, keep, culled_count);
     return check_launch("g2pc_validate_covariances");
+}
+
+int g2pc_validate_covariances(float* cov9, int64_t n, int regularise, float reg_eps, float eps, float min_eps,
+                              int iters, uint8_t* keep, void* stream) {
+    return g2pc_validate_covariances_counted(cov9, n, regularise, reg_eps, eps, min_eps, iters, keep, nullptr, stream);
 }
 
 int g2pc_gaussian_magnitudes(const float* cov9, const float* weights, int64_t n, double* sizes, void* stream) {

@@ -260,6 +260,20 @@ __device__ __forceinline__ uint32_t block_search_le(const uint32_t* __restrict__
     return lo;
 }
 
+// 64 consecutive 12-byte rows of one wave -> global memory as three fully coalesced dword stores per array (a lane
+// writing its own row would touch 12 cache lines per store instruction, a third of each)
+__device__ __forceinline__ void wave_store_rows3(float* __restrict__ s_rows /* [192] wave-private */, float a, float b, float c,
+                                                 bool valid, unsigned lane, unsigned cnt, float* __restrict__ dst /* row base */) {
+    if (valid) { s_rows[3 * lane + 0] = a; s_rows[3 * lane + 1] = b; s_rows[3 * lane + 2] = c; }
+    wave_sync();
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const unsigned idx = j * 64 + lane;
+        if (idx < 3 * cnt) dst[idx] = s_rows[idx];
+    }
+    wave_sync();
+}
+
 __global__ __launch_bounds__(ER_T) void k_emit_rows(
     const float* __restrict__ means, const float* __restrict__ cov9, const float* __restrict__ colours,
     const float* __restrict__ normals, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ bin_start, int B,
@@ -267,6 +281,9 @@ __global__ __launch_bounds__(ER_T) void k_emit_rows(
     const uint32_t* __restrict__ dscan, const int64_t* __restrict__ sec_base, float* __restrict__ out_points,
     float* __restrict__ out_colours, float* __restrict__ out_normals, int32_t* __restrict__ out_gauss) {
     __shared__ uint32_t s_win[ER_WIN + 1];
+    __shared__ float s_rows[ER_T / kWave][192];
+    __shared__ int s_cnt;
+    const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int S = B * (1 + A);
     const long M = (long)sec_base[S];
     const long row0 = (long)blockIdx.x * ER_ROWS;
@@ -275,7 +292,6 @@ __global__ __launch_bounds__(ER_T) void k_emit_rows(
     // first section that ends after row0 (the sections ending at or before row0 form a prefix of the table)
     int before = 0;
     for (int i = threadIdx.x; i < S; i += ER_T) before += (sec_base[i + 1] <= (int64_t)row0) ? 1 : 0;
-    __shared__ int s_cnt;
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
     if (before) atomicAdd(&s_cnt, before);
@@ -288,53 +304,62 @@ __global__ __launch_bounds__(ER_T) void k_emit_rows(
         const long r_lo = sb > row0 ? sb : row0, r_hi = se < row1 ? se : row1;
         const int b = si / (1 + A), sct = si % (1 + A);
         const uint32_t bs0 = bin_start[b], bs1 = bin_start[b + 1];
-        if (sct == 0) {                             // the means of the bin's members, in member order
-            for (long r = r_lo + threadIdx.x; r < r_hi; r += ER_T) {
-                const unsigned g = perm[bs0 + (uint32_t)(r - sb)];
-                const size_t o = (size_t)r;
-                out_points[3 * o + 0] = means[3 * (size_t)g]; out_points[3 * o + 1] = means[3 * (size_t)g + 1]; out_points[3 * o + 2] = means[3 * (size_t)g + 2];
-                out_colours[3 * o + 0] = colours[3 * (size_t)g]; out_colours[3 * o + 1] = colours[3 * (size_t)g + 1]; out_colours[3 * o + 2] = colours[3 * (size_t)g + 2];
-                if (out_normals) { out_normals[3 * o + 0] = normals[3 * (size_t)g]; out_normals[3 * o + 1] = normals[3 * (size_t)g + 1]; out_normals[3 * o + 2] = normals[3 * (size_t)g + 2]; }
-                if (out_gauss) out_gauss[o] = (int32_t)g;
-            }
-            continue;
+        const uint32_t* sc = nullptr;
+        uint32_t sc0 = 0, p_first = 0, wlen = 0, win_end = 0;
+        if (sct > 0) {
+            sc = dscan + (size_t)(sct - 1) * (size_t)(gv + 1);
+            sc0 = sc[bs0];
+            // owner of the first row, then a window of the scan from there (relative to the section)
+            const uint32_t t_first = sc0 + (uint32_t)(r_lo - sb);
+            p_first = block_search_le(sc, bs0, bs1, t_first);
+            wlen = (bs1 - p_first) < (uint32_t)ER_WIN ? (bs1 - p_first) : (uint32_t)ER_WIN;
+            __syncthreads();                        // previous section's readers are done with the window
+            for (uint32_t j = threadIdx.x; j <= wlen; j += ER_T) s_win[j] = sc[p_first + j];
+            __syncthreads();
+            win_end = s_win[wlen];                  // first scan value NOT covered by the window's owners
         }
-        const int a = sct - 1;
-        const uint32_t* sc = dscan + (size_t)a * (size_t)(gv + 1);
-        const uint32_t sc0 = sc[bs0];
-        // owner of the first row, then a window of the scan from there (relative to the section)
-        const uint32_t t_first = sc0 + (uint32_t)(r_lo - sb);
-        const uint32_t p_first = block_search_le(sc, bs0, bs1, t_first);
-        const uint32_t wlen = (bs1 - p_first) < (uint32_t)ER_WIN ? (bs1 - p_first) : (uint32_t)ER_WIN;
-        __syncthreads();                            // previous section's readers are done with the window
-        for (uint32_t j = threadIdx.x; j <= wlen; j += ER_T) s_win[j] = sc[p_first + j];
-        __syncthreads();
-        const uint32_t win_end = s_win[wlen];       // first scan value NOT covered by the window's owners
-        for (long r = r_lo + threadIdx.x; r < r_hi; r += ER_T) {
-            const uint32_t t = sc0 + (uint32_t)(r - sb);
-            uint32_t p, start;
-            if (t < win_end) {                      // largest j in [0, wlen) with s_win[j] <= t
-                uint32_t lo = 0, hi = wlen;
-                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_win[mid] <= t) lo = mid; else hi = mid; }
-                p = p_first + lo; start = s_win[lo];
-            } else {                                // long runs of finished Gaussians (d = 0): search the global scan
-                uint32_t lo = p_first + wlen, hi = bs1;
-                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sc[mid] <= t) lo = mid; else hi = mid; }
-                p = lo; start = sc[lo];
+        // every wave takes 64 consecutive rows per step; lanes past the section's end idle but join the staged stores
+        for (long rb = r_lo + 64 * (long)w; rb < r_hi; rb += ER_T) {
+            const long r = rb + lane;
+            const bool valid = r < r_hi;
+            const unsigned cnt = (unsigned)((r_hi - rb) < 64 ? (r_hi - rb) : 64);
+            unsigned g = 0;
+            float x = 0.f, y = 0.f, z = 0.f;
+            if (valid) {
+                if (sct == 0) {                     // the means of the bin's members, in member order
+                    g = perm[bs0 + (uint32_t)(r - sb)];
+                    x = means[3 * (size_t)g]; y = means[3 * (size_t)g + 1]; z = means[3 * (size_t)g + 2];
+                } else {
+                    const uint32_t t = sc0 + (uint32_t)(r - sb);
+                    uint32_t p, start;
+                    if (t < win_end) {              // largest j in [0, wlen) with s_win[j] <= t
+                        uint32_t lo = 0, hi = wlen;
+                        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_win[mid] <= t) lo = mid; else hi = mid; }
+                        p = p_first + lo; start = s_win[lo];
+                    } else {                        // long runs of finished Gaussians (d = 0): search the global scan
+                        uint32_t lo = p_first + wlen, hi = bs1;
+                        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sc[mid] <= t) lo = mid; else hi = mid; }
+                        p = lo; start = sc[lo];
+                    }
+                    const unsigned k = t - start;
+                    g = perm[p];
+                    GaussChol s;
+                    load_chol(means, cov9, g, s);
+                    const uint64_t gid = gid_base + g;
+                    const Normal3 e = keyed_normal3(seed_lo, seed_hi, (unsigned)gid, (unsigned)(gid >> 32),
+                                                    (unsigned)(attempt0 + sct - 1), k);
+                    x = s.mx + s.l00 * e.x;
+                    y = s.my + (s.l10 * e.x + s.l11 * e.y);
+                    z = s.mz + (s.l20 * e.x + s.l21 * e.y + s.l22 * e.z);
+                }
             }
-            const unsigned k = t - start;
-            const unsigned g = perm[p];
-            GaussChol s;
-            load_chol(means, cov9, g, s);
-            const uint64_t gid = gid_base + g;
-            const Normal3 e = keyed_normal3(seed_lo, seed_hi, (unsigned)gid, (unsigned)(gid >> 32), (unsigned)(attempt0 + a), k);
-            const size_t o = (size_t)r;
-            out_points[3 * o + 0] = s.mx + s.l00 * e.x;
-            out_points[3 * o + 1] = s.my + (s.l10 * e.x + s.l11 * e.y);
-            out_points[3 * o + 2] = s.mz + (s.l20 * e.x + s.l21 * e.y + s.l22 * e.z);
-            out_colours[3 * o + 0] = colours[3 * (size_t)g]; out_colours[3 * o + 1] = colours[3 * (size_t)g + 1]; out_colours[3 * o + 2] = colours[3 * (size_t)g + 2];
-            if (out_normals) { out_normals[3 * o + 0] = normals[3 * (size_t)g]; out_normals[3 * o + 1] = normals[3 * (size_t)g + 1]; out_normals[3 * o + 2] = normals[3 * (size_t)g + 2]; }
-            if (out_gauss) out_gauss[o] = (int32_t)g;
+            wave_store_rows3(s_rows[w], x, y, z, valid, lane, cnt, out_points + 3 * (size_t)rb);
+            wave_store_rows3(s_rows[w], valid ? colours[3 * (size_t)g] : 0.f, valid ? colours[3 * (size_t)g + 1] : 0.f,
+                             valid ? colours[3 * (size_t)g + 2] : 0.f, valid, lane, cnt, out_colours + 3 * (size_t)rb);
+            if (out_normals)
+                wave_store_rows3(s_rows[w], valid ? normals[3 * (size_t)g] : 0.f, valid ? normals[3 * (size_t)g + 1] : 0.f,
+                                 valid ? normals[3 * (size_t)g + 2] : 0.f, valid, lane, cnt, out_normals + 3 * (size_t)rb);
+            if (out_gauss && valid) out_gauss[(size_t)r] = (int32_t)g;
         }
     }
 }

@@ -127,14 +127,20 @@ def gather_rows(src: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
 
 
 def validate_covariances_(cov: torch.Tensor, regularise: bool = True, reg_eps: float = 5e-7, eps: float = 1e-7,
-                          min_eps: float = 1e-8, iters: int = 3) -> torch.Tensor:
-    """In-place gauss_handler.py:142-166; returns the keep mask (bool[n])."""
+                          min_eps: float = 1e-8, iters: int = 3, want_count: bool = False):
+    """In-place gauss_handler.py:142-166; returns the keep mask (bool[n]); want_count=True also returns the number of
+    culled rows as a python int (ONE 4-byte read-back -- the caller's `if anything was culled`)."""
     assert cov.dtype == torch.float32 and cov.is_contiguous()
     n = cov.shape[0]
     keep = torch.empty((n,), dtype=torch.uint8, device=cov.device)
-    nv.check(nv.lib().g2pc_validate_covariances(nv.ptr(cov), n, int(regularise), reg_eps, eps, min_eps, iters,
-                                                nv.ptr(keep), nv.stream_handle(cov.device)), "validate_covariances")
-    return keep.to(torch.bool)
+    count = torch.zeros((1,), dtype=torch.int32, device=cov.device) if want_count else None
+    nv.check(nv.lib().g2pc_validate_covariances_counted(nv.ptr(cov), n, int(regularise), reg_eps, eps, min_eps, iters,
+                                                        nv.ptr(keep), nv.ptr(count), nv.stream_handle(cov.device)),
+             "validate_covariances")
+    keep = keep.view(torch.bool)                       # 0 / 1 bytes: a reinterpretation, not a conversion kernel
+    if want_count:
+        return keep, int(count.item())
+    return keep
 
 
 def gaussian_magnitudes(cov: torch.Tensor, weights: torch.Tensor) -> torch.Tensor:

@@ -67,7 +67,17 @@ class Gaussians():
         self.set_default_filter()
 
     def set_default_filter(self):
-        self.filter_indices = torch.full((self.xyz.shape[0],), True, dtype=torch.bool, device=self.xyz.device)
+        self._filter = None                       # "keep everything": materialised on first use (filter_indices)
+
+    @property
+    def filter_indices(self):
+        if self._filter is None:
+            self._filter = torch.full((self.xyz.shape[0],), True, dtype=torch.bool, device=self.xyz.device)
+        return self._filter
+
+    @filter_indices.setter
+    def filter_indices(self, value):
+        self._filter = value
 
     def calculate_normals(self):
         """gauss_handler.py:89-106 -- the axis of the smallest scale, rotated by R."""
@@ -104,17 +114,17 @@ class Gaussians():
         """gauss_handler.py:142-166 -- one fused kernel: regularise, up to num_clamp_iters clamp rounds,
         final test; culls what is still not positive definite and returns the keep mask."""
         cov = self.covariances.to(torch.float32).contiguous()
-        keep = ops.validate_covariances_(cov, regularise=regularise, reg_eps=5e-7, eps=epsilon,
-                                         min_eps=min_ps_epsilon, iters=num_clamp_iters)
+        keep, culled = ops.validate_covariances_(cov, regularise=regularise, reg_eps=5e-7, eps=epsilon,
+                                                 min_eps=min_ps_epsilon, iters=num_clamp_iters, want_count=True)
         self.covariances = cov
-        self.last_validate_culled = bool((~keep).any())
+        self.last_validate_culled = culled > 0
         if self.last_validate_culled:
             self.add_gaussians_to_cull(keep)
             self.filter_gaussians()
         return keep
 
     def add_gaussians_to_cull(self, indices_to_cull):
-        self.filter_indices = self.filter_indices & indices_to_cull
+        self.filter_indices = indices_to_cull.clone() if self._filter is None else self._filter & indices_to_cull
 
     def filter_gaussians(self):
         """gauss_handler.py:171-193 -- stream compaction (scan + row gathers in HIP)."""

@@ -57,6 +57,7 @@ def parse():
                     help="diagnostic: Gaussian scale range of the synthetic scene (default 0.002 0.02 = SURVEY.md's)")
     ap.add_argument("--no-context-pool", action="store_true", help="tuning aid: every job captures its camera graphs anew")
     ap.add_argument("--streams", type=int, default=0, help="tuning aid: cameras in flight (HIP streams) of the renderer")
+    ap.add_argument("--no-front-priority", action="store_true", help="tuning aid: camera heads on the slot's normal stream, inside one graph with the blend")
     ap.add_argument("--camera-subset", type=int, default=0, help="profiling aid: render only the first k cameras of the rig")
     ap.add_argument("--t-floor", type=float, default=None, help="blend transmittance floor (default: gauss_render.DEFAULT_T_FLOOR)")
     return ap.parse_args()
@@ -162,8 +163,20 @@ def cpu_baseline(workload, full_n, full_cams, full_points, n=200_000, pts=1_000_
     import ref_render as RR
     from np_philox import keyed_normals
     from g2pc.synth import make_scene, make_cameras
-    threads = max(1, os.cpu_count() or 1)
+    # torch's CPU kernels on batches of 3x3 / per-tile tensors stop scaling (and with hundreds of threads collapse) beyond
+    # a few tens of threads: cap at 32
+    threads = max(1, min(32, os.cpu_count() or 1))
     torch.set_num_threads(threads)
+    if workload != "sample" and n > 20_000:
+        # bound the wall time whatever the host: a 20 k-Gaussian camera first, the full sample only if that projects to < 25 s
+        sc0 = make_scene(20_000, 1234 + 3)
+        tr0, intr0 = make_cameras(50)
+        R0 = RR.PythonRendererOracle(sc0.xyz, sc0.opacities.unsqueeze(1), sc0.colours.double(), RG.covariances(sc0.scales, sc0.rots), threshold=0.05)
+        tp = time.perf_counter()
+        R0(RR.get_camera(torch.tensor(tr0[sorted(tr0)[17]]), intr0[sorted(tr0)[17]], colour_resolution=1280))
+        probe = time.perf_counter() - tp
+        while n > 20_000 and probe * (n / 20_000) > 25.0:
+            n //= 2
     sc = make_scene(n, 1234 + 3)
     t0 = time.perf_counter()
     cov = RG.covariances(sc.scales, sc.rots)
@@ -264,6 +277,11 @@ def main():
     from g2pc.synth import make_scene, make_cameras
     nv.lib()
     import gauss_render  # noqa: F401  (registers the rasteriser prototypes)
+    if os.environ.get("G2PC_PREALLOC_GB") and not emulate:
+        # experiment: let torch's caching allocator obtain ONE large device block first, so that everything the first job
+        # allocates is carved out of it instead of coming from many separate hipMalloc calls
+        big = torch.empty((int(float(os.environ["G2PC_PREALLOC_GB"]) * (1 << 30)),), dtype=torch.uint8, device=device)
+        del big
     workload = a.workload or ("render" if have_renderer() else "sample")
     config4 = workload == "config4"
     if config4:                                   # configs[3]: same pipeline as "render", BASELINE's 8-GPU sizes
@@ -282,6 +300,8 @@ def main():
     nv.check(nv.lib().g2pc_set_blend_variant(a.blend_variant), "set_blend_variant")
     if a.streams:
         gauss_render.PIPELINE_STREAMS = a.streams
+    if a.no_front_priority:
+        gauss_render.FRONT_PRIORITY = False
     if a.no_context_pool:
         gauss_render.CONTEXT_POOL_SIZE = 0
 

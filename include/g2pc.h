@@ -77,6 +77,10 @@ int g2pc_build_covariances(const float* log_scales, const float* rots, float sca
  * keep[i] = (min eig > min_eps).  cov9 f32[n,3,3] in/out, keep u8[n] out. */
 int g2pc_validate_covariances(float* cov9, int64_t n, int regularise, float reg_eps, float eps, float min_eps,
                               int iters, uint8_t* keep, void* stream);
+/* the same; culled_count (optional, device u32, zeroed by the caller) += number of rows culled, so that the caller's
+ * `if any culled: filter` needs one 4-byte read-back instead of a reduction over the mask */
+int g2pc_validate_covariances_counted(float* cov9, int64_t n, int regularise, float reg_eps, float eps, float min_eps,
+                                      int iters, uint8_t* keep, uint32_t* culled_count, void* stream);
 
 /* get_gaussian_magnitudes (gauss_handler.py:252-279): Knud-Thomsen ellipsoid area from the eigenvalues,
  * sqrt, times weights (contributions or opacities) -> f64[n]. */

@@ -13,6 +13,7 @@ DEV = "cuda:0"
     (6000, 320, 180, 275.0, 3, False, True, False),
     (4000, 333, 187, 280.0, 2, True, True, True),          # partial edge tiles + SH degree 3 + mask
     (60000, 1280, 720, 1100.0, 2, False, True, False),     # configs[4]-shaped camera (reduced N for the CPU oracle)
+    (60000, 1280, 720, 1100.0, 1, True, True, False),      # ... with SH degree 3 evaluated in the rasteriser (configs[4])
 ])
 def test_cuda_semantics_vs_oracle(n, w, h, f, ncam, sh, surf, mask):
     rep = run_cuda_case(n, 40 + n, w, h, f, ncam, device=DEV, with_sh=sh, surf=surf, use_mask=mask)
