@@ -1204,7 +1204,7 @@ __global__ __launch_bounds__(RA_T) void k_fill_u32(uint32_t* __restrict__ p, lon
 }
 
 static uint32_t* g_chunk_work = nullptr;      // diagnostics hook (g2pc_raster_debug_chunk_work)
-static int g_blend_variant = 1;               // 0 = first-generation kernels, 1 = k_blend_py_v2, 2 = v2 without the adaptive width
+static int g_blend_variant = 0;               // 0 = k_blend_py_pk (default), 1 = k_blend_py_v2, 2 = v2 without the adaptive width
 
 static Cam to_cam(const G2pcCamera* c) {
     Cam k;

@@ -206,7 +206,7 @@ class _Scratch:
 # The packed-key atomicMax makes the blends of different cameras commutative, so camera c+1's small sort / scan
 # kernels (which leave most CUs idle) and even its blend overlap camera c's blend.
 PIPELINE_STREAMS = 4
-FRONT_PRIORITY = True             # see _GraphSlot
+FRONT_PRIORITY = False            # see _GraphSlot (measured: 30.7 ms per job with the split against 23.6 without)
 PIPELINE_IN_EMULATOR = False      # tests: drive the capture / replay path through the CPU emulator too
 CAPACITY_HEADROOM = 1.25          # instance capacity of the captured graphs relative to the largest count seen so far
 MIN_CAPACITY = 1 << 16
@@ -220,11 +220,12 @@ class _GraphSlot:
         self.on_gpu = on_gpu
         self.stream = torch.cuda.Stream(device) if on_gpu else None
         self.stream_ptr = C.c_void_p(self.stream.cuda_stream) if on_gpu else C.c_void_p(1)   # the emulator ignores streams
-        # FRONT_PRIORITY: the latency-bound head of a camera (preprocess, depth sort, binning: ~30 small launches) runs
-        # on a HIGH-priority stream of its own, the blend on the slot's normal one.  Under four cameras in flight the
-        # blends' 8 192 single-wave blocks fill every wave slot of the chip and a 39 us preprocess launch took 270 us to get
-        # through (profiles/r02a_render_s4_kernel_stats.csv): the head of the next camera then queues behind the body
-        # of the others although it needs a few per cent of the machine.
+        # FRONT_PRIORITY (experiment, off): the latency-bound head of a camera (preprocess, depth sort, binning: ~30 small
+        # launches) on a HIGH-priority stream of its own, the blend on the slot's normal one behind an event.  Motivation:
+        # under four cameras in flight the blends' 8 192 single-wave blocks fill every wave slot of the chip and a 39 us
+        # preprocess launch takes 270 us to get through (profiles/r02a_render_s4_kernel_stats.csv).  Result on MI355X:
+        # 30.7 ms per job against 23.6 ms with everything in one graph on one stream (profiles/r02b_ab_*.json) -- the
+        # cross-stream hand-over and the blend leaving the graph cost more than the head gains.
         self.stream_hi = torch.cuda.Stream(device, priority=-1) if (on_gpu and FRONT_PRIORITY) else None
         self.stream_hi_ptr = C.c_void_p(self.stream_hi.cuda_stream) if self.stream_hi is not None else self.stream_ptr
         self.front_done = torch.cuda.Event() if self.stream_hi is not None else None

@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--sort-bits", type=int, default=0, help="tuning aid: wide radix digit bits (8 or 11)")
     ap.add_argument("--sort-small", type=int, default=2 << 20, help="tuning aid: inputs up to this many keys use 4 keys/thread")
     ap.add_argument("--blend-subblocks", type=int, default=0, help="tuning aid: 8x8 sub-blocks per blend wave (1, 2, 4)")
-    ap.add_argument("--blend-variant", type=int, default=1, help="tuning aid: 0 = first-generation blend kernel, 1 = k_blend_py_v2, 2 = v2 without adaptive width")
+    ap.add_argument("--blend-variant", type=int, default=0, help="tuning aid: 0 = first-generation blend kernel, 1 = k_blend_py_v2, 2 = v2 without adaptive width")
     ap.add_argument("--scene-scales", type=float, nargs=2, default=None, metavar=("LO", "HI"),
                     help="diagnostic: Gaussian scale range of the synthetic scene (default 0.002 0.02 = SURVEY.md's)")
     ap.add_argument("--no-context-pool", action="store_true", help="tuning aid: every job captures its camera graphs anew")

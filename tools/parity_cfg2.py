@@ -92,7 +92,9 @@ def run(device="cuda:0", t_floor=None, sampler=True, tag="1m"):
     out["visible"] = int(ref_vis.sum())
     cols = (R.get_gaussian_colours().cpu().numpy() / 255.0)[::16]
     ref_cols = g["colours_s16"] / 255.0
-    seen = ref_c[::16] > max(R.t_floor, 0.0)            # below the floor a Gaussian may stay colourless
+    # below the floor a Gaussian may stay colourless; with floor 0 the same holds where the transmittance is at the edge of
+    # fp32 (contributions < 1e-12: T underflows to 0 a few list entries earlier or later than the reference's cumprod)
+    seen = ref_c[::16] > max(R.t_floor, 1e-12)
     dcol = np.abs(cols - ref_cols)[seen]
     out["colour_max"], out["colour_frac_gt_1e-4"] = float(dcol.max()), float((dcol.max(axis=1) > 1e-4).mean())
 
