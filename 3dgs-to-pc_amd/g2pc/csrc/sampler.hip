@@ -324,11 +324,13 @@ __global__ __launch_bounds__(ER_T) void k_emit_rows(
             const bool valid = r < r_hi;
             const unsigned cnt = (unsigned)((r_hi - rb) < 64 ? (r_hi - rb) : 64);
             unsigned g = 0;
-            float x = 0.f, y = 0.f, z = 0.f;
+            float x = 0.f, y = 0.f, z = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
             if (valid) {
                 if (sct == 0) {                     // the means of the bin's members, in member order
                     g = perm[bs0 + (uint32_t)(r - sb)];
                     x = means[3 * (size_t)g]; y = means[3 * (size_t)g + 1]; z = means[3 * (size_t)g + 2];
+                    c0 = colours[3 * (size_t)g]; c1 = colours[3 * (size_t)g + 1]; c2 = colours[3 * (size_t)g + 2];
+                    if (out_normals) { n0 = normals[3 * (size_t)g]; n1 = normals[3 * (size_t)g + 1]; n2 = normals[3 * (size_t)g + 2]; }
                 } else {
                     const uint32_t t = sc0 + (uint32_t)(r - sb);
                     uint32_t p, start;
@@ -343,6 +345,9 @@ __global__ __launch_bounds__(ER_T) void k_emit_rows(
                     }
                     const unsigned k = t - start;
                     g = perm[p];
+                    // every per-Gaussian input is requested before the first is used: one round trip, not one per field
+                    c0 = colours[3 * (size_t)g]; c1 = colours[3 * (size_t)g + 1]; c2 = colours[3 * (size_t)g + 2];
+                    if (out_normals) { n0 = normals[3 * (size_t)g]; n1 = normals[3 * (size_t)g + 1]; n2 = normals[3 * (size_t)g + 2]; }
                     GaussChol s;
                     load_chol(means, cov9, g, s);
                     const uint64_t gid = gid_base + g;
@@ -354,11 +359,8 @@ __global__ __launch_bounds__(ER_T) void k_emit_rows(
                 }
             }
             wave_store_rows3(s_rows[w], x, y, z, valid, lane, cnt, out_points + 3 * (size_t)rb);
-            wave_store_rows3(s_rows[w], valid ? colours[3 * (size_t)g] : 0.f, valid ? colours[3 * (size_t)g + 1] : 0.f,
-                             valid ? colours[3 * (size_t)g + 2] : 0.f, valid, lane, cnt, out_colours + 3 * (size_t)rb);
-            if (out_normals)
-                wave_store_rows3(s_rows[w], valid ? normals[3 * (size_t)g] : 0.f, valid ? normals[3 * (size_t)g + 1] : 0.f,
-                                 valid ? normals[3 * (size_t)g + 2] : 0.f, valid, lane, cnt, out_normals + 3 * (size_t)rb);
+            wave_store_rows3(s_rows[w], c0, c1, c2, valid, lane, cnt, out_colours + 3 * (size_t)rb);
+            if (out_normals) wave_store_rows3(s_rows[w], n0, n1, n2, valid, lane, cnt, out_normals + 3 * (size_t)rb);
             if (out_gauss && valid) out_gauss[(size_t)r] = (int32_t)g;
         }
     }
