@@ -230,20 +230,6 @@ __global__ __launch_bounds__(SEC_T) void k_sections(const uint32_t* __restrict__
 // are gathered straight from global memory: neighbouring rows share their Gaussian, so a wave touches a handful of lines.
 constexpr int ER_T = 256, ER_ROWS = 1024, ER_WIN = 1024;
 
-struct GaussChol { float mx, my, mz, l00, l10, l11, l20, l21, l22; };
-__device__ __forceinline__ void load_chol(const float* __restrict__ means, const float* __restrict__ cov9, unsigned g,
-                                          GaussChol& s) {
-    s.mx = means[3 * (size_t)g + 0]; s.my = means[3 * (size_t)g + 1]; s.mz = means[3 * (size_t)g + 2];
-    const float* c = cov9 + 9 * (size_t)g;
-    const float a00 = c[0], a10 = c[3], a11 = c[4], a20 = c[6], a21 = c[7], a22 = c[8];   // the lower triangle, as load_gauss
-    s.l00 = sqrtf(a00);
-    s.l10 = a10 / s.l00;
-    s.l20 = a20 / s.l00;
-    s.l11 = sqrtf(a11 - s.l10 * s.l10);
-    s.l21 = (a21 - s.l20 * s.l10) / s.l11;
-    s.l22 = sqrtf(a22 - s.l20 * s.l20 - s.l21 * s.l21);
-}
-
 // largest p in [lo, hi) with sc[p] <= t, for a non-decreasing sc with sc[lo] <= t (all threads of the block, same
 // arguments, same result): 256-way narrowing, one probe per thread and step
 __device__ __forceinline__ uint32_t block_search_le(const uint32_t* __restrict__ sc, uint32_t lo, uint32_t hi, uint32_t t) {
@@ -318,50 +304,85 @@ __global__ __launch_bounds__(ER_T) void k_emit_rows(
             __syncthreads();
             win_end = s_win[wlen];                  // first scan value NOT covered by the window's owners
         }
-        // every wave takes 64 consecutive rows per step; lanes past the section's end idle but join the staged stores
-        for (long rb = r_lo + 64 * (long)w; rb < r_hi; rb += ER_T) {
-            const long r = rb + lane;
-            const bool valid = r < r_hi;
-            const unsigned cnt = (unsigned)((r_hi - rb) < 64 ? (r_hi - rb) : 64);
-            unsigned g = 0;
-            float x = 0.f, y = 0.f, z = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
-            if (valid) {
-                if (sct == 0) {                     // the means of the bin's members, in member order
-                    g = perm[bs0 + (uint32_t)(r - sb)];
-                    x = means[3 * (size_t)g]; y = means[3 * (size_t)g + 1]; z = means[3 * (size_t)g + 2];
-                    c0 = colours[3 * (size_t)g]; c1 = colours[3 * (size_t)g + 1]; c2 = colours[3 * (size_t)g + 2];
-                    if (out_normals) { n0 = normals[3 * (size_t)g]; n1 = normals[3 * (size_t)g + 1]; n2 = normals[3 * (size_t)g + 2]; }
-                } else {
-                    const uint32_t t = sc0 + (uint32_t)(r - sb);
-                    uint32_t p, start;
-                    if (t < win_end) {              // largest j in [0, wlen) with s_win[j] <= t
-                        uint32_t lo = 0, hi = wlen;
-                        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_win[mid] <= t) lo = mid; else hi = mid; }
-                        p = p_first + lo; start = s_win[lo];
-                    } else {                        // long runs of finished Gaussians (d = 0): search the global scan
-                        uint32_t lo = p_first + wlen, hi = bs1;
-                        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sc[mid] <= t) lo = mid; else hi = mid; }
-                        p = lo; start = sc[lo];
+        // Every wave takes ER_G groups of 64 consecutive rows per step and walks them PHASE by phase (owner search for
+        // all groups, then all index loads, then all per-Gaussian loads, then the draws, then the stores): a row costs three
+        // dependent memory round trips, and with one row per lane in flight the kernel was bound by their latency
+        // (223 us for 10 M rows at full occupancy); ER_G independent chains per lane divide that by ER_G.
+        constexpr int ER_G = 4;
+        for (long rb0 = r_lo + (long)(64 * ER_G) * w; rb0 < r_hi; rb0 += (long)ER_T * ER_G) {
+            bool valid[ER_G];
+            unsigned g[ER_G], k[ER_G], p[ER_G];
+#pragma unroll
+            for (int j = 0; j < ER_G; ++j) {
+                const long r = rb0 + 64 * j + lane;
+                valid[j] = r < r_hi;
+                g[j] = 0; k[j] = 0; p[j] = bs0;
+                if (valid[j]) {
+                    if (sct == 0) {
+                        p[j] = bs0 + (uint32_t)(r - sb);
+                    } else {
+                        const uint32_t t = sc0 + (uint32_t)(r - sb);
+                        uint32_t start;
+                        if (t < win_end) {          // largest i in [0, wlen) with s_win[i] <= t
+                            uint32_t lo = 0, hi = wlen;
+                            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_win[mid] <= t) lo = mid; else hi = mid; }
+                            p[j] = p_first + lo; start = s_win[lo];
+                        } else {                    // long runs of finished Gaussians (d = 0): search the global scan
+                            uint32_t lo = p_first + wlen, hi = bs1;
+                            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sc[mid] <= t) lo = mid; else hi = mid; }
+                            p[j] = lo; start = sc[lo];
+                        }
+                        k[j] = t - start;
                     }
-                    const unsigned k = t - start;
-                    g = perm[p];
-                    // every per-Gaussian input is requested before the first is used: one round trip, not one per field
-                    c0 = colours[3 * (size_t)g]; c1 = colours[3 * (size_t)g + 1]; c2 = colours[3 * (size_t)g + 2];
-                    if (out_normals) { n0 = normals[3 * (size_t)g]; n1 = normals[3 * (size_t)g + 1]; n2 = normals[3 * (size_t)g + 2]; }
-                    GaussChol s;
-                    load_chol(means, cov9, g, s);
-                    const uint64_t gid = gid_base + g;
-                    const Normal3 e = keyed_normal3(seed_lo, seed_hi, (unsigned)gid, (unsigned)(gid >> 32),
-                                                    (unsigned)(attempt0 + sct - 1), k);
-                    x = s.mx + s.l00 * e.x;
-                    y = s.my + (s.l10 * e.x + s.l11 * e.y);
-                    z = s.mz + (s.l20 * e.x + s.l21 * e.y + s.l22 * e.z);
                 }
             }
-            wave_store_rows3(s_rows[w], x, y, z, valid, lane, cnt, out_points + 3 * (size_t)rb);
-            wave_store_rows3(s_rows[w], c0, c1, c2, valid, lane, cnt, out_colours + 3 * (size_t)rb);
-            if (out_normals) wave_store_rows3(s_rows[w], n0, n1, n2, valid, lane, cnt, out_normals + 3 * (size_t)rb);
-            if (out_gauss && valid) out_gauss[(size_t)r] = (int32_t)g;
+#pragma unroll
+            for (int j = 0; j < ER_G; ++j) if (valid[j]) g[j] = perm[p[j]];
+            float mx[ER_G], my[ER_G], mz[ER_G], a00[ER_G], a10[ER_G], a11[ER_G], a20[ER_G], a21[ER_G], a22[ER_G];
+            float c0[ER_G], c1[ER_G], c2[ER_G], n0[ER_G], n1[ER_G], n2[ER_G];
+#pragma unroll
+            for (int j = 0; j < ER_G; ++j) {
+                mx[j] = my[j] = mz[j] = 0.f; a00[j] = a11[j] = a22[j] = 1.f; a10[j] = a20[j] = a21[j] = 0.f;
+                c0[j] = c1[j] = c2[j] = n0[j] = n1[j] = n2[j] = 0.f;
+                if (valid[j]) {
+                    const size_t gg = (size_t)g[j];
+                    mx[j] = means[3 * gg]; my[j] = means[3 * gg + 1]; mz[j] = means[3 * gg + 2];
+                    c0[j] = colours[3 * gg]; c1[j] = colours[3 * gg + 1]; c2[j] = colours[3 * gg + 2];
+                    if (out_normals) { n0[j] = normals[3 * gg]; n1[j] = normals[3 * gg + 1]; n2[j] = normals[3 * gg + 2]; }
+                    if (sct > 0) {
+                        const float* c = cov9 + 9 * gg;                   // the lower triangle, as load_gauss reads it
+                        a00[j] = c[0]; a10[j] = c[3]; a11[j] = c[4]; a20[j] = c[6]; a21[j] = c[7]; a22[j] = c[8];
+                    }
+                }
+            }
+            float x[ER_G], y[ER_G], z[ER_G];
+#pragma unroll
+            for (int j = 0; j < ER_G; ++j) {
+                x[j] = mx[j]; y[j] = my[j]; z[j] = mz[j];
+                if (sct > 0 && valid[j]) {
+                    const float l00 = sqrtf(a00[j]);
+                    const float l10 = a10[j] / l00, l20 = a20[j] / l00;
+                    const float l11 = sqrtf(a11[j] - l10 * l10);
+                    const float l21 = (a21[j] - l20 * l10) / l11;
+                    const float l22 = sqrtf(a22[j] - l20 * l20 - l21 * l21);
+                    const uint64_t gid = gid_base + g[j];
+                    const Normal3 e = keyed_normal3(seed_lo, seed_hi, (unsigned)gid, (unsigned)(gid >> 32),
+                                                    (unsigned)(attempt0 + sct - 1), k[j]);
+                    x[j] = mx[j] + l00 * e.x;
+                    y[j] = my[j] + (l10 * e.x + l11 * e.y);
+                    z[j] = mz[j] + (l20 * e.x + l21 * e.y + l22 * e.z);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < ER_G; ++j) {
+                const long rb = rb0 + 64 * j;
+                if (rb >= r_hi) break;                                    // wave-uniform
+                const unsigned cnt = (unsigned)((r_hi - rb) < 64 ? (r_hi - rb) : 64);
+                wave_store_rows3(s_rows[w], x[j], y[j], z[j], valid[j], lane, cnt, out_points + 3 * (size_t)rb);
+                wave_store_rows3(s_rows[w], c0[j], c1[j], c2[j], valid[j], lane, cnt, out_colours + 3 * (size_t)rb);
+                if (out_normals) wave_store_rows3(s_rows[w], n0[j], n1[j], n2[j], valid[j], lane, cnt, out_normals + 3 * (size_t)rb);
+                if (out_gauss && valid[j]) out_gauss[(size_t)(rb + lane)] = (int32_t)g[j];
+            }
         }
     }
 }
