@@ -57,6 +57,44 @@ __device__ __forceinline__ void load_gauss(const float* __restrict__ means, cons
     s.i22 = c22 * id;
 }
 
+// ---- bin-ordered records ---------------------------------------------------------------------------------------------
+// After the partition, position p of the bin order holds Gaussian perm[p].  The count pass and every section of the
+// emission visit the Gaussians in POSITION order; gathering xyz / cov / colour / normal through perm there costs a whole
+// cache line per 12..36-byte field and Gaussian (1 M Gaussians x 4 arrays x 3 sections = 1.5 GB of line traffic for a
+// 0.36 GB cloud: the emission ran at 250 us).  One pass instead reads the inputs SEQUENTIALLY by Gaussian index and
+// writes one 64-byte record to the Gaussian's position (full-line stores):
+//   rec[p] = { mean.xyz, cov[0..8], colour.rgb, bits(g) }   (+ nrec[p] = { normal.xyz, 0 } when normals are wanted)
+constexpr int REC_F = 16;
+__global__ __launch_bounds__(SM_T) void k_invperm(const uint32_t* __restrict__ perm, long gv, uint32_t* __restrict__ inv) {
+    long p = (long)blockIdx.x * SM_T + threadIdx.x;
+    if (p < gv) inv[perm[p]] = (uint32_t)p;
+}
+__global__ __launch_bounds__(SM_T) void k_records(const float* __restrict__ means, const float* __restrict__ cov9,
+                                                 const float* __restrict__ colours, const float* __restrict__ normals,
+                                                 const uint32_t* __restrict__ inv, long g_count, float4* __restrict__ rec,
+                                                 float4* __restrict__ nrec) {
+    long g = (long)blockIdx.x * SM_T + threadIdx.x;
+    if (g >= g_count) return;
+    const uint32_t p = inv[g];
+    if (p == 0xFFFFFFFFu) return;                   // not a member of any bin
+    const float* c = cov9 + 9 * (size_t)g;
+    float4* r = rec + 4 * (size_t)p;
+    r[0] = make_float4(means[3 * (size_t)g], means[3 * (size_t)g + 1], means[3 * (size_t)g + 2], c[0]);
+    r[1] = make_float4(c[1], c[2], c[3], c[4]);
+    r[2] = make_float4(c[5], c[6], c[7], c[8]);
+    r[3] = make_float4(colours[3 * (size_t)g], colours[3 * (size_t)g + 1], colours[3 * (size_t)g + 2], __uint_as_float((uint32_t)g));
+    if (nrec) nrec[p] = make_float4(normals[3 * (size_t)g], normals[3 * (size_t)g + 1], normals[3 * (size_t)g + 2], 0.f);
+}
+
+// the record at position p -> sampling parameters (the arithmetic of load_gauss, fed from the record) + Gaussian index
+__device__ __forceinline__ unsigned load_gauss_rec(const float4* __restrict__ rec, long p, GaussSample& s) {
+    const float4 r0 = rec[4 * (size_t)p], r1 = rec[4 * (size_t)p + 1], r2 = rec[4 * (size_t)p + 2], r3 = rec[4 * (size_t)p + 3];
+    const float cc[9] = {r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+    const float m[3] = {r0.x, r0.y, r0.z};
+    load_gauss(m, cc, 0u, s);
+    return __float_as_uint(r3.w);
+}
+
 // draw k of (gid, attempt): sample point and accept flag
 __device__ __forceinline__ bool draw(const GaussSample& s, unsigned seed_lo, unsigned seed_hi, unsigned gid_lo,
                                      unsigned gid_hi, unsigned attempt, unsigned k, float std_limit, float& px,
@@ -88,9 +126,7 @@ __global__ __launch_bounds__(SM_T) void k_bin_keys(const int32_t* __restrict__ p
 }
 
 // ---- counting pass ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(SM_T) void k_count_thread(const float* __restrict__ means,
-                                                      const float* __restrict__ cov9,
-                                                      const uint32_t* __restrict__ perm,
+__global__ __launch_bounds__(SM_T) void k_count_thread(const float4* __restrict__ rec,
                                                       const uint32_t* __restrict__ pbin,
                                                       const int32_t* __restrict__ quota, long p_end, long gv,
                                                       float std_limit, int attempt0, int num_attempts,
@@ -99,7 +135,6 @@ __global__ __launch_bounds__(SM_T) void k_count_thread(const float* __restrict__
                                                       uint32_t* __restrict__ remaining) {
     long p = (long)blockIdx.x * SM_T + threadIdx.x;
     if (p >= p_end) return;
-    const unsigned g = perm[p];
     const int n = quota[pbin[p]] - 1;
     unsigned have = added[p];
     if (n <= 0 || have >= (unsigned)n) {
@@ -107,7 +142,7 @@ __global__ __launch_bounds__(SM_T) void k_count_thread(const float* __restrict__
         return;
     }
     GaussSample s;
-    load_gauss(means, cov9, g, s);
+    const unsigned g = load_gauss_rec(rec, p, s);
     const uint64_t gid = gid_base + g;
     const unsigned gid_lo = (unsigned)gid, gid_hi = (unsigned)(gid >> 32);
     for (int a = 0; a < num_attempts; ++a) {
@@ -128,9 +163,7 @@ __global__ __launch_bounds__(SM_T) void k_count_thread(const float* __restrict__
     if (have < (unsigned)n) atomicAdd(remaining, 1u);
 }
 
-__global__ __launch_bounds__(SM_T) void k_count_wave(const float* __restrict__ means,
-                                                    const float* __restrict__ cov9,
-                                                    const uint32_t* __restrict__ perm,
+__global__ __launch_bounds__(SM_T) void k_count_wave(const float4* __restrict__ rec,
                                                     const uint32_t* __restrict__ pbin,
                                                     const int32_t* __restrict__ quota, long p_begin, long gv,
                                                     float std_limit, int attempt0, int num_attempts,
@@ -140,7 +173,6 @@ __global__ __launch_bounds__(SM_T) void k_count_wave(const float* __restrict__ m
     const unsigned lane = threadIdx.x & 63;
     long p = p_begin + (long)blockIdx.x * (SM_T / kWave) + (threadIdx.x >> 6);
     if (p >= gv) return;                                   // whole wave leaves together
-    const unsigned g = perm[p];
     const int n = quota[pbin[p]] - 1;
     unsigned have = added[p];
     if (n <= 0 || have >= (unsigned)n) {
@@ -148,7 +180,7 @@ __global__ __launch_bounds__(SM_T) void k_count_wave(const float* __restrict__ m
         return;
     }
     GaussSample s;
-    load_gauss(means, cov9, g, s);
+    const unsigned g = load_gauss_rec(rec, p, s);
     const uint64_t gid = gid_base + g;
     const unsigned gid_lo = (unsigned)gid, gid_hi = (unsigned)(gid >> 32);
     for (int a = 0; a < num_attempts; ++a) {
@@ -261,8 +293,7 @@ __device__ __forceinline__ void wave_store_rows3(float* __restrict__ s_rows /* [
 }
 
 __global__ __launch_bounds__(ER_T) void k_emit_rows(
-    const float* __restrict__ means, const float* __restrict__ cov9, const float* __restrict__ colours,
-    const float* __restrict__ normals, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ bin_start, int B,
+    const float4* __restrict__ rec, const float4* __restrict__ nrec, const uint32_t* __restrict__ bin_start, int B,
     int A, long gv, int attempt0, unsigned seed_lo, unsigned seed_hi, uint64_t gid_base,
     const uint32_t* __restrict__ dscan, const int64_t* __restrict__ sec_base, float* __restrict__ out_points,
     float* __restrict__ out_colours, float* __restrict__ out_normals, int32_t* __restrict__ out_gauss) {
@@ -336,23 +367,19 @@ __global__ __launch_bounds__(ER_T) void k_emit_rows(
                     }
                 }
             }
-#pragma unroll
-            for (int j = 0; j < ER_G; ++j) if (valid[j]) g[j] = perm[p[j]];
             float mx[ER_G], my[ER_G], mz[ER_G], a00[ER_G], a10[ER_G], a11[ER_G], a20[ER_G], a21[ER_G], a22[ER_G];
             float c0[ER_G], c1[ER_G], c2[ER_G], n0[ER_G], n1[ER_G], n2[ER_G];
 #pragma unroll
             for (int j = 0; j < ER_G; ++j) {
                 mx[j] = my[j] = mz[j] = 0.f; a00[j] = a11[j] = a22[j] = 1.f; a10[j] = a20[j] = a21[j] = 0.f;
                 c0[j] = c1[j] = c2[j] = n0[j] = n1[j] = n2[j] = 0.f;
-                if (valid[j]) {
-                    const size_t gg = (size_t)g[j];
-                    mx[j] = means[3 * gg]; my[j] = means[3 * gg + 1]; mz[j] = means[3 * gg + 2];
-                    c0[j] = colours[3 * gg]; c1[j] = colours[3 * gg + 1]; c2[j] = colours[3 * gg + 2];
-                    if (out_normals) { n0[j] = normals[3 * gg]; n1[j] = normals[3 * gg + 1]; n2[j] = normals[3 * gg + 2]; }
-                    if (sct > 0) {
-                        const float* c = cov9 + 9 * gg;                   // the lower triangle, as load_gauss reads it
-                        a00[j] = c[0]; a10[j] = c[3]; a11[j] = c[4]; a20[j] = c[6]; a21[j] = c[7]; a22[j] = c[8];
-                    }
+                if (valid[j]) {                                            // neighbouring rows share their record's line
+                    const float4* r = rec + 4 * (size_t)p[j];
+                    const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+                    mx[j] = r0.x; my[j] = r0.y; mz[j] = r0.z;
+                    a00[j] = r0.w; a10[j] = r1.z; a11[j] = r1.w; a20[j] = r2.y; a21[j] = r2.z; a22[j] = r2.w;   // the lower triangle
+                    c0[j] = r3.x; c1[j] = r3.y; c2[j] = r3.z; g[j] = __float_as_uint(r3.w);
+                    if (out_normals) { const float4 nn = nrec[p[j]]; n0[j] = nn.x; n1[j] = nn.y; n2[j] = nn.z; }
                 }
             }
             float x[ER_G], y[ER_G], z[ER_G];
@@ -484,24 +511,46 @@ int g2pc_sampler_partition(const int32_t* ppg, int64_t g, const int32_t* bin_of_
     return check_launch("g2pc_sampler_partition");
 }
 
-int g2pc_sampler_count(const float* means, const float* cov9, const uint32_t* perm, const uint32_t* pbin,
+size_t g2pc_sampler_records_workspace(int64_t g) { return g2pc::align_up((size_t)(g > 0 ? g : 1) * 4) + 256; }
+
+/* Bin-ordered records (see k_records): rec f32[gv,16] = {mean, cov[9], colour, bits(Gaussian index)} at the Gaussian's
+ * position of the partition; nrec f32[gv,4] = {normal, 0} (optional).  ws: u32[g] scratch (inverse permutation). */
+int g2pc_sampler_records(const float* means, const float* cov9, const float* colours, const float* normals,
+                         const uint32_t* perm, int64_t gv, int64_t g, float* rec, float* nrec, void* ws, size_t ws_bytes,
+                         void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(gv >= 0 && g >= gv, G2PC_ERR_ARG, "bad sizes");
+    if (gv == 0) return G2PC_OK;
+    G2PC_REQUIRE(means && cov9 && colours && perm && rec && ws, G2PC_ERR_ARG, "null pointer");
+    G2PC_REQUIRE(!nrec || normals, G2PC_ERR_ARG, "normals requested but not given");
+    G2PC_REQUIRE(ws_bytes >= (size_t)g * 4, G2PC_ERR_WORKSPACE, "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t* inv = (uint32_t*)ws;
+    G2PC_REQUIRE(hipMemsetAsync(inv, 0xFF, (size_t)g * 4, s) == hipSuccess, G2PC_ERR_LAUNCH, "memset failed");
+    hipLaunchKernelGGL(k_invperm, dim3(cdiv(gv, SM_T)), dim3(SM_T), 0, s, perm, (long)gv, inv);
+    hipLaunchKernelGGL(k_records, dim3(cdiv(g, SM_T)), dim3(SM_T), 0, s, means, cov9, colours, normals, inv, (long)g,
+                       (float4*)rec, (float4*)nrec);
+    return check_launch("g2pc_sampler_records");
+}
+
+int g2pc_sampler_count(const float* rec, const uint32_t* pbin,
                        const int32_t* quota, int64_t gv, int64_t p_wave_begin, float std_limit, int32_t attempt0,
                        int32_t num_attempts, uint64_t seed, uint64_t gid_base, uint32_t* added, uint32_t* dcount,
                        uint32_t* remaining, void* stream) {
     using namespace g2pc;
-    G2PC_REQUIRE(gv >= 0 && means && cov9 && perm && pbin && quota && added && dcount && remaining, G2PC_ERR_ARG,
+    G2PC_REQUIRE(gv >= 0 && rec && pbin && quota && added && dcount && remaining, G2PC_ERR_ARG,
                  "bad arguments");
     if (gv == 0) return G2PC_OK;
     if (p_wave_begin < 0 || p_wave_begin > gv) p_wave_begin = gv;
     hipStream_t s = (hipStream_t)stream;
     unsigned slo = (unsigned)seed, shi = (unsigned)(seed >> 32);
     if (p_wave_begin > 0)
-        hipLaunchKernelGGL(k_count_thread, dim3(cdiv(p_wave_begin, SM_T)), dim3(SM_T), 0, s, means, cov9, perm, pbin,
+        hipLaunchKernelGGL(k_count_thread, dim3(cdiv(p_wave_begin, SM_T)), dim3(SM_T), 0, s, (const float4*)rec, pbin,
                            quota, (long)p_wave_begin, (long)gv, std_limit, (int)attempt0, (int)num_attempts, slo, shi,
                            gid_base, added, dcount, remaining);
     if (p_wave_begin < gv)
-        hipLaunchKernelGGL(k_count_wave, dim3(cdiv(gv - p_wave_begin, SM_T / kWave)), dim3(SM_T), 0, s, means, cov9,
-                           perm, pbin, quota, (long)p_wave_begin, (long)gv, std_limit, (int)attempt0,
+        hipLaunchKernelGGL(k_count_wave, dim3(cdiv(gv - p_wave_begin, SM_T / kWave)), dim3(SM_T), 0, s, (const float4*)rec,
+                           pbin, quota, (long)p_wave_begin, (long)gv, std_limit, (int)attempt0,
                            (int)num_attempts, slo, shi, gid_base, added, dcount, remaining);
     return check_launch("g2pc_sampler_count");
 }
@@ -544,19 +593,17 @@ int g2pc_sampler_sections(const uint32_t* bin_start, const int32_t* quota, int32
 
 /* Row-balanced emission of the whole cloud (means and every attempt's rows) in one launch: `rows_capacity` >= M is the
  * size the output arrays were allocated for (the launch covers it; blocks beyond the real M, read from sec_base, exit). */
-int g2pc_sampler_emit_rows(const float* means, const float* cov9, const float* colours, const float* normals,
-                           const uint32_t* perm, const uint32_t* bin_start, int32_t num_bins, int32_t attempt0,
-                           int32_t attempts, int64_t gv, uint64_t seed, uint64_t gid_base, const uint32_t* dscan,
-                           const int64_t* sec_base, int64_t rows_capacity, float* out_points, float* out_colours,
-                           float* out_normals, int32_t* out_gauss, void* stream) {
+int g2pc_sampler_emit_rows(const float* rec, const float* nrec, const uint32_t* bin_start, int32_t num_bins,
+                           int32_t attempt0, int32_t attempts, int64_t gv, uint64_t seed, uint64_t gid_base,
+                           const uint32_t* dscan, const int64_t* sec_base, int64_t rows_capacity, float* out_points,
+                           float* out_colours, float* out_normals, int32_t* out_gauss, void* stream) {
     using namespace g2pc;
-    G2PC_REQUIRE(means && cov9 && colours && perm && bin_start && sec_base && out_points && out_colours, G2PC_ERR_ARG,
-                 "bad arguments");
-    G2PC_REQUIRE(!out_normals || normals, G2PC_ERR_ARG, "normals requested but not given");
+    G2PC_REQUIRE(rec && bin_start && sec_base && out_points && out_colours, G2PC_ERR_ARG, "bad arguments");
+    G2PC_REQUIRE(!out_normals || nrec, G2PC_ERR_ARG, "normals requested but not given");
     G2PC_REQUIRE(attempts == 0 || dscan, G2PC_ERR_ARG, "missing scans");
     if (rows_capacity <= 0 || num_bins <= 0) return G2PC_OK;
-    hipLaunchKernelGGL(k_emit_rows, dim3(cdiv(rows_capacity, ER_ROWS)), dim3(ER_T), 0, (hipStream_t)stream, means, cov9, colours,
-                       normals, perm, bin_start, (int)num_bins, (int)attempts, (long)gv, (int)attempt0, (unsigned)seed,
+    hipLaunchKernelGGL(k_emit_rows, dim3(cdiv(rows_capacity, ER_ROWS)), dim3(ER_T), 0, (hipStream_t)stream, (const float4*)rec,
+                       (const float4*)nrec, bin_start, (int)num_bins, (int)attempts, (long)gv, (int)attempt0, (unsigned)seed,
                        (unsigned)(seed >> 32), gid_base, dscan, sec_base, out_points, out_colours, out_normals, out_gauss);
     return check_launch("g2pc_sampler_emit_rows");
 }
