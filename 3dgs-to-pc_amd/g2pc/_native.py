@@ -47,17 +47,16 @@ _PROTOS = {
     "g2pc_bincount_i32": (C.c_int, [_vp, _i64, _vp, _i64, _vp]),
     "g2pc_sampler_plan_workspace": (_sz, [_i64]),
     "g2pc_sampler_plan": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "g2pc_sampler_records_workspace": (_sz, [_i64]),
-    "g2pc_sampler_records": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
-    "g2pc_sampler_count": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _f32, _i32, _i32, _u64, _u64, _vp, _vp, _vp, _vp]),
+    "g2pc_sampler_count": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _i32, _i32, _u64, _u64, _vp,
+                                     _vp, _vp, _vp]),
 }
 _PROTOS["g2pc_scatter_ones_u8"] = (C.c_int, [_vp, _i64, _vp, _i64, _vp])
 _PROTOS["g2pc_sampler_partition"] = (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _sz, _vp])
 _PROTOS["g2pc_sampler_scan_workspace"] = (_sz, [_i64, _i32])
 _PROTOS["g2pc_sampler_scan_counts"] = (C.c_int, [_vp, _vp, _i64, _i32, _vp, _sz, _vp])
 _PROTOS["g2pc_sampler_sections"] = (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i64, C.c_int, _vp, _vp, _vp, _vp])
-_PROTOS["g2pc_sampler_emit_rows"] = (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _u64, _u64, _vp, _vp, _i64, _vp, _vp,
-                                               _vp, _vp, _vp])
+_PROTOS["g2pc_sampler_emit_rows"] = (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _u64, _u64, _vp, _vp,
+                                               _i64, _vp, _vp, _vp, _vp, _vp])
 _PROTOS["g2pc_eval_sh"] = (C.c_int, [_i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp])
 _PROTOS["g2pc_build_covariance_2d"] = (C.c_int, [_vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _vp, _vp])
 _PROTOS["g2pc_projection_ndc"] = (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp])

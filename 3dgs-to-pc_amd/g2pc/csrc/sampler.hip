@@ -57,44 +57,6 @@ __device__ __forceinline__ void load_gauss(const float* __restrict__ means, cons
     s.i22 = c22 * id;
 }
 
-// ---- bin-ordered records ---------------------------------------------------------------------------------------------
-// After the partition, position p of the bin order holds Gaussian perm[p].  The count pass and every section of the
-// emission visit the Gaussians in POSITION order; gathering xyz / cov / colour / normal through perm there costs a whole
-// cache line per 12..36-byte field and Gaussian (1 M Gaussians x 4 arrays x 3 sections = 1.5 GB of line traffic for a
-// 0.36 GB cloud: the emission ran at 250 us).  One pass instead reads the inputs SEQUENTIALLY by Gaussian index and
-// writes one 64-byte record to the Gaussian's position (full-line stores):
-//   rec[p] = { mean.xyz, cov[0..8], colour.rgb, bits(g) }   (+ nrec[p] = { normal.xyz, 0 } when normals are wanted)
-constexpr int REC_F = 16;
-__global__ __launch_bounds__(SM_T) void k_invperm(const uint32_t* __restrict__ perm, long gv, uint32_t* __restrict__ inv) {
-    long p = (long)blockIdx.x * SM_T + threadIdx.x;
-    if (p < gv) inv[perm[p]] = (uint32_t)p;
-}
-__global__ __launch_bounds__(SM_T) void k_records(const float* __restrict__ means, const float* __restrict__ cov9,
-                                                 const float* __restrict__ colours, const float* __restrict__ normals,
-                                                 const uint32_t* __restrict__ inv, long g_count, float4* __restrict__ rec,
-                                                 float4* __restrict__ nrec) {
-    long g = (long)blockIdx.x * SM_T + threadIdx.x;
-    if (g >= g_count) return;
-    const uint32_t p = inv[g];
-    if (p == 0xFFFFFFFFu) return;                   // not a member of any bin
-    const float* c = cov9 + 9 * (size_t)g;
-    float4* r = rec + 4 * (size_t)p;
-    r[0] = make_float4(means[3 * (size_t)g], means[3 * (size_t)g + 1], means[3 * (size_t)g + 2], c[0]);
-    r[1] = make_float4(c[1], c[2], c[3], c[4]);
-    r[2] = make_float4(c[5], c[6], c[7], c[8]);
-    r[3] = make_float4(colours[3 * (size_t)g], colours[3 * (size_t)g + 1], colours[3 * (size_t)g + 2], __uint_as_float((uint32_t)g));
-    if (nrec) nrec[p] = make_float4(normals[3 * (size_t)g], normals[3 * (size_t)g + 1], normals[3 * (size_t)g + 2], 0.f);
-}
-
-// the record at position p -> sampling parameters (the arithmetic of load_gauss, fed from the record) + Gaussian index
-__device__ __forceinline__ unsigned load_gauss_rec(const float4* __restrict__ rec, long p, GaussSample& s) {
-    const float4 r0 = rec[4 * (size_t)p], r1 = rec[4 * (size_t)p + 1], r2 = rec[4 * (size_t)p + 2], r3 = rec[4 * (size_t)p + 3];
-    const float cc[9] = {r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
-    const float m[3] = {r0.x, r0.y, r0.z};
-    load_gauss(m, cc, 0u, s);
-    return __float_as_uint(r3.w);
-}
-
 // draw k of (gid, attempt): sample point and accept flag
 __device__ __forceinline__ bool draw(const GaussSample& s, unsigned seed_lo, unsigned seed_hi, unsigned gid_lo,
                                      unsigned gid_hi, unsigned attempt, unsigned k, float std_limit, float& px,
@@ -126,7 +88,9 @@ __global__ __launch_bounds__(SM_T) void k_bin_keys(const int32_t* __restrict__ p
 }
 
 // ---- counting pass ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(SM_T) void k_count_thread(const float4* __restrict__ rec,
+__global__ __launch_bounds__(SM_T) void k_count_thread(const float* __restrict__ means,
+                                                      const float* __restrict__ cov9,
+                                                      const uint32_t* __restrict__ perm,
                                                       const uint32_t* __restrict__ pbin,
                                                       const int32_t* __restrict__ quota, long p_end, long gv,
                                                       float std_limit, int attempt0, int num_attempts,
@@ -135,6 +99,7 @@ __global__ __launch_bounds__(SM_T) void k_count_thread(const float4* __restrict_
                                                       uint32_t* __restrict__ remaining) {
     long p = (long)blockIdx.x * SM_T + threadIdx.x;
     if (p >= p_end) return;
+    const unsigned g = perm[p];
     const int n = quota[pbin[p]] - 1;
     unsigned have = added[p];
     if (n <= 0 || have >= (unsigned)n) {
@@ -142,7 +107,7 @@ __global__ __launch_bounds__(SM_T) void k_count_thread(const float4* __restrict_
         return;
     }
     GaussSample s;
-    const unsigned g = load_gauss_rec(rec, p, s);
+    load_gauss(means, cov9, g, s);
     const uint64_t gid = gid_base + g;
     const unsigned gid_lo = (unsigned)gid, gid_hi = (unsigned)(gid >> 32);
     for (int a = 0; a < num_attempts; ++a) {
@@ -163,7 +128,9 @@ __global__ __launch_bounds__(SM_T) void k_count_thread(const float4* __restrict_
     if (have < (unsigned)n) atomicAdd(remaining, 1u);
 }
 
-__global__ __launch_bounds__(SM_T) void k_count_wave(const float4* __restrict__ rec,
+__global__ __launch_bounds__(SM_T) void k_count_wave(const float* __restrict__ means,
+                                                    const float* __restrict__ cov9,
+                                                    const uint32_t* __restrict__ perm,
                                                     const uint32_t* __restrict__ pbin,
                                                     const int32_t* __restrict__ quota, long p_begin, long gv,
                                                     float std_limit, int attempt0, int num_attempts,
@@ -173,6 +140,7 @@ __global__ __launch_bounds__(SM_T) void k_count_wave(const float4* __restrict__ 
     const unsigned lane = threadIdx.x & 63;
     long p = p_begin + (long)blockIdx.x * (SM_T / kWave) + (threadIdx.x >> 6);
     if (p >= gv) return;                                   // whole wave leaves together
+    const unsigned g = perm[p];
     const int n = quota[pbin[p]] - 1;
     unsigned have = added[p];
     if (n <= 0 || have >= (unsigned)n) {
@@ -180,7 +148,7 @@ __global__ __launch_bounds__(SM_T) void k_count_wave(const float4* __restrict__ 
         return;
     }
     GaussSample s;
-    const unsigned g = load_gauss_rec(rec, p, s);
+    load_gauss(means, cov9, g, s);
     const uint64_t gid = gid_base + g;
     const unsigned gid_lo = (unsigned)gid, gid_hi = (unsigned)(gid >> 32);
     for (int a = 0; a < num_attempts; ++a) {
@@ -262,6 +230,20 @@ __global__ __launch_bounds__(SEC_T) void k_sections(const uint32_t* __restrict__
 // are gathered straight from global memory: neighbouring rows share their Gaussian, so a wave touches a handful of lines.
 constexpr int ER_T = 256, ER_ROWS = 1024, ER_WIN = 1024;
 
+struct GaussChol { float mx, my, mz, l00, l10, l11, l20, l21, l22; };
+__device__ __forceinline__ void load_chol(const float* __restrict__ means, const float* __restrict__ cov9, unsigned g,
+                                          GaussChol& s) {
+    s.mx = means[3 * (size_t)g + 0]; s.my = means[3 * (size_t)g + 1]; s.mz = means[3 * (size_t)g + 2];
+    const float* c = cov9 + 9 * (size_t)g;
+    const float a00 = c[0], a10 = c[3], a11 = c[4], a20 = c[6], a21 = c[7], a22 = c[8];   // the lower triangle, as load_gauss
+    s.l00 = sqrtf(a00);
+    s.l10 = a10 / s.l00;
+    s.l20 = a20 / s.l00;
+    s.l11 = sqrtf(a11 - s.l10 * s.l10);
+    s.l21 = (a21 - s.l20 * s.l10) / s.l11;
+    s.l22 = sqrtf(a22 - s.l20 * s.l20 - s.l21 * s.l21);
+}
+
 // largest p in [lo, hi) with sc[p] <= t, for a non-decreasing sc with sc[lo] <= t (all threads of the block, same
 // arguments, same result): 256-way narrowing, one probe per thread and step
 __device__ __forceinline__ uint32_t block_search_le(const uint32_t* __restrict__ sc, uint32_t lo, uint32_t hi, uint32_t t) {
@@ -293,7 +275,8 @@ __device__ __forceinline__ void wave_store_rows3(float* __restrict__ s_rows /* [
 }
 
 __global__ __launch_bounds__(ER_T) void k_emit_rows(
-    const float4* __restrict__ rec, const float4* __restrict__ nrec, const uint32_t* __restrict__ bin_start, int B,
+    const float* __restrict__ means, const float* __restrict__ cov9, const float* __restrict__ colours,
+    const float* __restrict__ normals, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ bin_start, int B,
     int A, long gv, int attempt0, unsigned seed_lo, unsigned seed_hi, uint64_t gid_base,
     const uint32_t* __restrict__ dscan, const int64_t* __restrict__ sec_base, float* __restrict__ out_points,
     float* __restrict__ out_colours, float* __restrict__ out_normals, int32_t* __restrict__ out_gauss) {
@@ -335,81 +318,50 @@ __global__ __launch_bounds__(ER_T) void k_emit_rows(
             __syncthreads();
             win_end = s_win[wlen];                  // first scan value NOT covered by the window's owners
         }
-        // Every wave takes ER_G groups of 64 consecutive rows per step and walks them PHASE by phase (owner search for
-        // all groups, then all index loads, then all per-Gaussian loads, then the draws, then the stores): a row costs three
-        // dependent memory round trips, and with one row per lane in flight the kernel was bound by their latency
-        // (223 us for 10 M rows at full occupancy); ER_G independent chains per lane divide that by ER_G.
-        constexpr int ER_G = 4;
-        for (long rb0 = r_lo + (long)(64 * ER_G) * w; rb0 < r_hi; rb0 += (long)ER_T * ER_G) {
-            bool valid[ER_G];
-            unsigned g[ER_G], k[ER_G], p[ER_G];
-#pragma unroll
-            for (int j = 0; j < ER_G; ++j) {
-                const long r = rb0 + 64 * j + lane;
-                valid[j] = r < r_hi;
-                g[j] = 0; k[j] = 0; p[j] = bs0;
-                if (valid[j]) {
-                    if (sct == 0) {
-                        p[j] = bs0 + (uint32_t)(r - sb);
-                    } else {
-                        const uint32_t t = sc0 + (uint32_t)(r - sb);
-                        uint32_t start;
-                        if (t < win_end) {          // largest i in [0, wlen) with s_win[i] <= t
-                            uint32_t lo = 0, hi = wlen;
-                            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_win[mid] <= t) lo = mid; else hi = mid; }
-                            p[j] = p_first + lo; start = s_win[lo];
-                        } else {                    // long runs of finished Gaussians (d = 0): search the global scan
-                            uint32_t lo = p_first + wlen, hi = bs1;
-                            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sc[mid] <= t) lo = mid; else hi = mid; }
-                            p[j] = lo; start = sc[lo];
-                        }
-                        k[j] = t - start;
+        // every wave takes 64 consecutive rows per step; lanes past the section's end idle but join the staged stores
+        for (long rb = r_lo + 64 * (long)w; rb < r_hi; rb += ER_T) {
+            const long r = rb + lane;
+            const bool valid = r < r_hi;
+            const unsigned cnt = (unsigned)((r_hi - rb) < 64 ? (r_hi - rb) : 64);
+            unsigned g = 0;
+            float x = 0.f, y = 0.f, z = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
+            if (valid) {
+                if (sct == 0) {                     // the means of the bin's members, in member order
+                    g = perm[bs0 + (uint32_t)(r - sb)];
+                    x = means[3 * (size_t)g]; y = means[3 * (size_t)g + 1]; z = means[3 * (size_t)g + 2];
+                    c0 = colours[3 * (size_t)g]; c1 = colours[3 * (size_t)g + 1]; c2 = colours[3 * (size_t)g + 2];
+                    if (out_normals) { n0 = normals[3 * (size_t)g]; n1 = normals[3 * (size_t)g + 1]; n2 = normals[3 * (size_t)g + 2]; }
+                } else {
+                    const uint32_t t = sc0 + (uint32_t)(r - sb);
+                    uint32_t p, start;
+                    if (t < win_end) {              // largest j in [0, wlen) with s_win[j] <= t
+                        uint32_t lo = 0, hi = wlen;
+                        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_win[mid] <= t) lo = mid; else hi = mid; }
+                        p = p_first + lo; start = s_win[lo];
+                    } else {                        // long runs of finished Gaussians (d = 0): search the global scan
+                        uint32_t lo = p_first + wlen, hi = bs1;
+                        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sc[mid] <= t) lo = mid; else hi = mid; }
+                        p = lo; start = sc[lo];
                     }
-                }
-            }
-            float mx[ER_G], my[ER_G], mz[ER_G], a00[ER_G], a10[ER_G], a11[ER_G], a20[ER_G], a21[ER_G], a22[ER_G];
-            float c0[ER_G], c1[ER_G], c2[ER_G], n0[ER_G], n1[ER_G], n2[ER_G];
-#pragma unroll
-            for (int j = 0; j < ER_G; ++j) {
-                mx[j] = my[j] = mz[j] = 0.f; a00[j] = a11[j] = a22[j] = 1.f; a10[j] = a20[j] = a21[j] = 0.f;
-                c0[j] = c1[j] = c2[j] = n0[j] = n1[j] = n2[j] = 0.f;
-                if (valid[j]) {                                            // neighbouring rows share their record's line
-                    const float4* r = rec + 4 * (size_t)p[j];
-                    const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
-                    mx[j] = r0.x; my[j] = r0.y; mz[j] = r0.z;
-                    a00[j] = r0.w; a10[j] = r1.z; a11[j] = r1.w; a20[j] = r2.y; a21[j] = r2.z; a22[j] = r2.w;   // the lower triangle
-                    c0[j] = r3.x; c1[j] = r3.y; c2[j] = r3.z; g[j] = __float_as_uint(r3.w);
-                    if (out_normals) { const float4 nn = nrec[p[j]]; n0[j] = nn.x; n1[j] = nn.y; n2[j] = nn.z; }
-                }
-            }
-            float x[ER_G], y[ER_G], z[ER_G];
-#pragma unroll
-            for (int j = 0; j < ER_G; ++j) {
-                x[j] = mx[j]; y[j] = my[j]; z[j] = mz[j];
-                if (sct > 0 && valid[j]) {
-                    const float l00 = sqrtf(a00[j]);
-                    const float l10 = a10[j] / l00, l20 = a20[j] / l00;
-                    const float l11 = sqrtf(a11[j] - l10 * l10);
-                    const float l21 = (a21[j] - l20 * l10) / l11;
-                    const float l22 = sqrtf(a22[j] - l20 * l20 - l21 * l21);
-                    const uint64_t gid = gid_base + g[j];
+                    const unsigned k = t - start;
+                    g = perm[p];
+                    // every per-Gaussian input is requested before the first is used: one round trip, not one per field
+                    c0 = colours[3 * (size_t)g]; c1 = colours[3 * (size_t)g + 1]; c2 = colours[3 * (size_t)g + 2];
+                    if (out_normals) { n0 = normals[3 * (size_t)g]; n1 = normals[3 * (size_t)g + 1]; n2 = normals[3 * (size_t)g + 2]; }
+                    GaussChol s;
+                    load_chol(means, cov9, g, s);
+                    const uint64_t gid = gid_base + g;
                     const Normal3 e = keyed_normal3(seed_lo, seed_hi, (unsigned)gid, (unsigned)(gid >> 32),
-                                                    (unsigned)(attempt0 + sct - 1), k[j]);
-                    x[j] = mx[j] + l00 * e.x;
-                    y[j] = my[j] + (l10 * e.x + l11 * e.y);
-                    z[j] = mz[j] + (l20 * e.x + l21 * e.y + l22 * e.z);
+                                                    (unsigned)(attempt0 + sct - 1), k);
+                    x = s.mx + s.l00 * e.x;
+                    y = s.my + (s.l10 * e.x + s.l11 * e.y);
+                    z = s.mz + (s.l20 * e.x + s.l21 * e.y + s.l22 * e.z);
                 }
             }
-#pragma unroll
-            for (int j = 0; j < ER_G; ++j) {
-                const long rb = rb0 + 64 * j;
-                if (rb >= r_hi) break;                                    // wave-uniform
-                const unsigned cnt = (unsigned)((r_hi - rb) < 64 ? (r_hi - rb) : 64);
-                wave_store_rows3(s_rows[w], x[j], y[j], z[j], valid[j], lane, cnt, out_points + 3 * (size_t)rb);
-                wave_store_rows3(s_rows[w], c0[j], c1[j], c2[j], valid[j], lane, cnt, out_colours + 3 * (size_t)rb);
-                if (out_normals) wave_store_rows3(s_rows[w], n0[j], n1[j], n2[j], valid[j], lane, cnt, out_normals + 3 * (size_t)rb);
-                if (out_gauss && valid[j]) out_gauss[(size_t)(rb + lane)] = (int32_t)g[j];
-            }
+            wave_store_rows3(s_rows[w], x, y, z, valid, lane, cnt, out_points + 3 * (size_t)rb);
+            wave_store_rows3(s_rows[w], c0, c1, c2, valid, lane, cnt, out_colours + 3 * (size_t)rb);
+            if (out_normals) wave_store_rows3(s_rows[w], n0, n1, n2, valid, lane, cnt, out_normals + 3 * (size_t)rb);
+            if (out_gauss && valid) out_gauss[(size_t)r] = (int32_t)g;
         }
     }
 }
@@ -511,46 +463,24 @@ int g2pc_sampler_partition(const int32_t* ppg, int64_t g, const int32_t* bin_of_
     return check_launch("g2pc_sampler_partition");
 }
 
-size_t g2pc_sampler_records_workspace(int64_t g) { return g2pc::align_up((size_t)(g > 0 ? g : 1) * 4) + 256; }
-
-/* Bin-ordered records (see k_records): rec f32[gv,16] = {mean, cov[9], colour, bits(Gaussian index)} at the Gaussian's
- * position of the partition; nrec f32[gv,4] = {normal, 0} (optional).  ws: u32[g] scratch (inverse permutation). */
-int g2pc_sampler_records(const float* means, const float* cov9, const float* colours, const float* normals,
-                         const uint32_t* perm, int64_t gv, int64_t g, float* rec, float* nrec, void* ws, size_t ws_bytes,
-                         void* stream) {
-    using namespace g2pc;
-    G2PC_REQUIRE(gv >= 0 && g >= gv, G2PC_ERR_ARG, "bad sizes");
-    if (gv == 0) return G2PC_OK;
-    G2PC_REQUIRE(means && cov9 && colours && perm && rec && ws, G2PC_ERR_ARG, "null pointer");
-    G2PC_REQUIRE(!nrec || normals, G2PC_ERR_ARG, "normals requested but not given");
-    G2PC_REQUIRE(ws_bytes >= (size_t)g * 4, G2PC_ERR_WORKSPACE, "workspace too small");
-    hipStream_t s = (hipStream_t)stream;
-    uint32_t* inv = (uint32_t*)ws;
-    G2PC_REQUIRE(hipMemsetAsync(inv, 0xFF, (size_t)g * 4, s) == hipSuccess, G2PC_ERR_LAUNCH, "memset failed");
-    hipLaunchKernelGGL(k_invperm, dim3(cdiv(gv, SM_T)), dim3(SM_T), 0, s, perm, (long)gv, inv);
-    hipLaunchKernelGGL(k_records, dim3(cdiv(g, SM_T)), dim3(SM_T), 0, s, means, cov9, colours, normals, inv, (long)g,
-                       (float4*)rec, (float4*)nrec);
-    return check_launch("g2pc_sampler_records");
-}
-
-int g2pc_sampler_count(const float* rec, const uint32_t* pbin,
+int g2pc_sampler_count(const float* means, const float* cov9, const uint32_t* perm, const uint32_t* pbin,
                        const int32_t* quota, int64_t gv, int64_t p_wave_begin, float std_limit, int32_t attempt0,
                        int32_t num_attempts, uint64_t seed, uint64_t gid_base, uint32_t* added, uint32_t* dcount,
                        uint32_t* remaining, void* stream) {
     using namespace g2pc;
-    G2PC_REQUIRE(gv >= 0 && rec && pbin && quota && added && dcount && remaining, G2PC_ERR_ARG,
+    G2PC_REQUIRE(gv >= 0 && means && cov9 && perm && pbin && quota && added && dcount && remaining, G2PC_ERR_ARG,
                  "bad arguments");
     if (gv == 0) return G2PC_OK;
     if (p_wave_begin < 0 || p_wave_begin > gv) p_wave_begin = gv;
     hipStream_t s = (hipStream_t)stream;
     unsigned slo = (unsigned)seed, shi = (unsigned)(seed >> 32);
     if (p_wave_begin > 0)
-        hipLaunchKernelGGL(k_count_thread, dim3(cdiv(p_wave_begin, SM_T)), dim3(SM_T), 0, s, (const float4*)rec, pbin,
+        hipLaunchKernelGGL(k_count_thread, dim3(cdiv(p_wave_begin, SM_T)), dim3(SM_T), 0, s, means, cov9, perm, pbin,
                            quota, (long)p_wave_begin, (long)gv, std_limit, (int)attempt0, (int)num_attempts, slo, shi,
                            gid_base, added, dcount, remaining);
     if (p_wave_begin < gv)
-        hipLaunchKernelGGL(k_count_wave, dim3(cdiv(gv - p_wave_begin, SM_T / kWave)), dim3(SM_T), 0, s, (const float4*)rec,
-                           pbin, quota, (long)p_wave_begin, (long)gv, std_limit, (int)attempt0,
+        hipLaunchKernelGGL(k_count_wave, dim3(cdiv(gv - p_wave_begin, SM_T / kWave)), dim3(SM_T), 0, s, means, cov9,
+                           perm, pbin, quota, (long)p_wave_begin, (long)gv, std_limit, (int)attempt0,
                            (int)num_attempts, slo, shi, gid_base, added, dcount, remaining);
     return check_launch("g2pc_sampler_count");
 }
@@ -593,17 +523,19 @@ int g2pc_sampler_sections(const uint32_t* bin_start, const int32_t* quota, int32
 
 /* Row-balanced emission of the whole cloud (means and every attempt's rows) in one launch: `rows_capacity` >= M is the
  * size the output arrays were allocated for (the launch covers it; blocks beyond the real M, read from sec_base, exit). */
-int g2pc_sampler_emit_rows(const float* rec, const float* nrec, const uint32_t* bin_start, int32_t num_bins,
-                           int32_t attempt0, int32_t attempts, int64_t gv, uint64_t seed, uint64_t gid_base,
-                           const uint32_t* dscan, const int64_t* sec_base, int64_t rows_capacity, float* out_points,
-                           float* out_colours, float* out_normals, int32_t* out_gauss, void* stream) {
+int g2pc_sampler_emit_rows(const float* means, const float* cov9, const float* colours, const float* normals,
+                           const uint32_t* perm, const uint32_t* bin_start, int32_t num_bins, int32_t attempt0,
+                           int32_t attempts, int64_t gv, uint64_t seed, uint64_t gid_base, const uint32_t* dscan,
+                           const int64_t* sec_base, int64_t rows_capacity, float* out_points, float* out_colours,
+                           float* out_normals, int32_t* out_gauss, void* stream) {
     using namespace g2pc;
-    G2PC_REQUIRE(rec && bin_start && sec_base && out_points && out_colours, G2PC_ERR_ARG, "bad arguments");
-    G2PC_REQUIRE(!out_normals || nrec, G2PC_ERR_ARG, "normals requested but not given");
+    G2PC_REQUIRE(means && cov9 && colours && perm && bin_start && sec_base && out_points && out_colours, G2PC_ERR_ARG,
+                 "bad arguments");
+    G2PC_REQUIRE(!out_normals || normals, G2PC_ERR_ARG, "normals requested but not given");
     G2PC_REQUIRE(attempts == 0 || dscan, G2PC_ERR_ARG, "missing scans");
     if (rows_capacity <= 0 || num_bins <= 0) return G2PC_OK;
-    hipLaunchKernelGGL(k_emit_rows, dim3(cdiv(rows_capacity, ER_ROWS)), dim3(ER_T), 0, (hipStream_t)stream, (const float4*)rec,
-                       (const float4*)nrec, bin_start, (int)num_bins, (int)attempts, (long)gv, (int)attempt0, (unsigned)seed,
+    hipLaunchKernelGGL(k_emit_rows, dim3(cdiv(rows_capacity, ER_ROWS)), dim3(ER_T), 0, (hipStream_t)stream, means, cov9, colours,
+                       normals, perm, bin_start, (int)num_bins, (int)attempts, (long)gv, (int)attempt0, (unsigned)seed,
                        (unsigned)(seed >> 32), gid_base, dscan, sec_base, out_points, out_colours, out_normals, out_gauss);
     return check_launch("g2pc_sampler_emit_rows");
 }

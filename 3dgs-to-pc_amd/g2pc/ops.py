@@ -306,16 +306,10 @@ def sample_pointcloud(xyz: torch.Tensor, cov: torch.Tensor, colours: torch.Tenso
 
     perm = torch.empty((G,), dtype=torch.int32, device=dev)
     pbin = torch.empty((G,), dtype=torch.int32, device=dev)
-    ws_bytes = max(L.g2pc_sampler_plan_workspace(G), L.g2pc_sampler_records_workspace(G))
+    ws_bytes = L.g2pc_sampler_plan_workspace(G)
     ws = nv.workspace(ws_bytes, dev)
     nv.check(L.g2pc_sampler_partition(nv.ptr(ppg_i32), G, nv.ptr(lut_d), lut.shape[0], B, nv.ptr(perm), nv.ptr(pbin),
                                       nv.ptr(ws), ws_bytes, st), "sampler_partition")
-    # bin-ordered 64-byte records: what the count pass and the emission read (contiguous) instead of four gathers via perm
-    rec = torch.empty((max(gv, 1), 16), dtype=torch.float32, device=dev)
-    nrec = torch.empty((max(gv, 1), 4), dtype=torch.float32, device=dev) if normals is not None else None
-    rb = L.g2pc_sampler_records_workspace(G)
-    nv.check(L.g2pc_sampler_records(nv.ptr(xyz), nv.ptr(cov), nv.ptr(colours), nv.ptr(normals), nv.ptr(perm), gv, G,
-                                    nv.ptr(rec), nv.ptr(nrec), nv.ptr(ws), max(ws_bytes, rb), st), "sampler_records")
     wave_bins = [b for b in range(B) if quota[b] - 1 >= WAVE_MODE_MIN_DRAWS and members[b] > 0]
     p_wave = int(bs_host[wave_bins[0]]) if wave_bins else gv
 
@@ -346,7 +340,7 @@ def sample_pointcloud(xyz: torch.Tensor, cov: torch.Tensor, colours: torch.Tenso
         if a0 > 0:
             remaining.zero_()
         with nv.region("sampler_count", dev):
-            nv.check(L.g2pc_sampler_count(nv.ptr(rec), nv.ptr(pbin), nv.ptr(quota_d), gv,
+            nv.check(L.g2pc_sampler_count(nv.ptr(xyz), nv.ptr(cov), nv.ptr(perm), nv.ptr(pbin), nv.ptr(quota_d), gv,
                                           p_wave, float(std), a0, na, int(seed), int(gid_base), nv.ptr(added),
                                           nv.ptr(dcount), nv.ptr(remaining), st), "sampler_count")
         counts.append(dcount)
@@ -367,7 +361,7 @@ def sample_pointcloud(xyz: torch.Tensor, cov: torch.Tensor, colours: torch.Tenso
     pts, cols, nrm, gidx = outputs(rows_ub)
     if rows_ub > 0 and gv > 0 and B > 0:
         with nv.region("sampler_emit", dev):
-            nv.check(L.g2pc_sampler_emit_rows(nv.ptr(rec), nv.ptr(nrec),
+            nv.check(L.g2pc_sampler_emit_rows(nv.ptr(xyz), nv.ptr(cov), nv.ptr(colours), nv.ptr(normals), nv.ptr(perm),
                                               nv.ptr(bin_start), B, 0, A, gv, int(seed), int(gid_base), nv.ptr(dscan),
                                               nv.ptr(sec_base), rows_ub, nv.ptr(pts), nv.ptr(cols), nv.ptr(nrm),
                                               nv.ptr(gidx), st), "sampler_emit_rows")

@@ -158,23 +158,15 @@ size_t g2pc_sampler_plan_workspace(int64_t g);
 int g2pc_sampler_plan(const int32_t* ppg, int64_t g, const int32_t* bin_of_ppg, int64_t lut_len, int32_t num_bins,
                       uint32_t* perm, uint32_t* pbin, uint32_t* bin_start, void* ws, size_t ws_bytes, void* stream);
 
-/* Stage 1b: bin-ordered records.  rec f32[gv,16] = {mean.xyz, cov[0..8], colour.rgb, bits(Gaussian index)} and
- * (optional) nrec f32[gv,4] = {normal.xyz, 0} at every Gaussian's POSITION of the partition: the count pass and every
- * section of the emission then read their inputs as contiguous 64-byte records instead of gathering four arrays
- * through perm (a cache line per field).  ws: g2pc_sampler_records_workspace(g) bytes. */
-size_t g2pc_sampler_records_workspace(int64_t g);
-int g2pc_sampler_records(const float* means, const float* cov9, const float* colours, const float* normals,
-                         const uint32_t* perm, int64_t gv, int64_t g, float* rec, float* nrec, void* ws, size_t ws_bytes,
-                         void* stream);
 /* Stage 2: attempts [attempt0, attempt0 + num_attempts) of create_new_gaussian_points
- * (gauss_to_pc.py:157-275) for every bin at once, counting only.  rec = the bin-ordered records;
- * quota i32[num_bins] = points per Gaussian of the bin (the mean counts as the
+ * (gauss_to_pc.py:157-275) for every bin at once, counting only.  means f32[*,3], cov9 f32[*,3,3]
+ * indexed by Gaussian; quota i32[num_bins] = points per Gaussian of the bin (the mean counts as the
  * first one, gauss_to_pc.py:352-361); added u32[gv] in/out (zero before attempt 0);
  * dcount u32[num_attempts, gv] out = points emitted per (attempt, sorted position);
  * remaining u32[1] out (+= number of Gaussians still short after the last attempt; caller zeroes).
  * Sorted positions < p_wave_begin run one Gaussian per lane, the rest one Gaussian per wave64 (pick the
  * first position whose quota-1 >= 32; quotas ascend with the bin index). */
-int g2pc_sampler_count(const float* rec, const uint32_t* pbin,
+int g2pc_sampler_count(const float* means, const float* cov9, const uint32_t* perm, const uint32_t* pbin,
                        const int32_t* quota, int64_t gv, int64_t p_wave_begin, float std_limit, int32_t attempt0,
                        int32_t num_attempts, uint64_t seed, uint64_t gid_base, uint32_t* added, uint32_t* dcount,
                        uint32_t* remaining, void* stream);
@@ -196,10 +188,11 @@ int g2pc_sampler_scan_counts(const uint32_t* dcount, uint32_t* dscan, int64_t gv
 int g2pc_sampler_sections(const uint32_t* bin_start, const int32_t* quota, int32_t num_bins, int32_t attempts,
                           const uint32_t* dscan, int64_t gv, int emit_means, int64_t* sec_base, int64_t* info_host,
                           const uint32_t* remaining, void* stream);
-int g2pc_sampler_emit_rows(const float* rec, const float* nrec, const uint32_t* bin_start, int32_t num_bins,
-                           int32_t attempt0, int32_t attempts, int64_t gv, uint64_t seed, uint64_t gid_base,
-                           const uint32_t* dscan, const int64_t* sec_base, int64_t rows_capacity, float* out_points,
-                           float* out_colours, float* out_normals, int32_t* out_gauss, void* stream);
+int g2pc_sampler_emit_rows(const float* means, const float* cov9, const float* colours, const float* normals,
+                           const uint32_t* perm, const uint32_t* bin_start, int32_t num_bins, int32_t attempt0,
+                           int32_t attempts, int64_t gv, uint64_t seed, uint64_t gid_base, const uint32_t* dscan,
+                           const int64_t* sec_base, int64_t rows_capacity, float* out_points, float* out_colours,
+                           float* out_normals, int32_t* out_gauss, void* stream);
 
 /* --- stand-alone helpers of the python renderer (the reference's public gauss_render functions) ------------------
  * eval_sh (gauss_render.py:43-99): sh f32[n, channels, coeffs] (coefficient index on the LAST axis, as the
