@@ -980,7 +980,8 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_cu(Cam cam, int grid_x, int
 // for the surface distance, each guarded by a cheap "can any lane improve the staged value" ballot.
 constexpr int CU_T = 256;
 
-__global__ __launch_bounds__(CU_T) void k_blend_cu(int W, int H, int grid_x, const uint32_t* __restrict__ tile_start,
+__global__ __launch_bounds__(CU_T) void k_blend_cu(int W, int H, int grid_x, int tile_first, int tile_step,
+                                                  const uint32_t* __restrict__ tile_start,
                                                   const uint32_t* __restrict__ inst_g, const float4* __restrict__ rec,
                                                   const int32_t* __restrict__ mask, float3 bg, int calc_surf,
                                                   unsigned long long* __restrict__ cam_key,
@@ -991,7 +992,7 @@ __global__ __launch_bounds__(CU_T) void k_blend_cu(int W, int H, int grid_x, con
     __shared__ float4 s_p2[CU_T];
     __shared__ uint32_t s_g[CU_T];
     __shared__ uint32_t s_surf[CU_T];             // surface distance known when the batch was staged (filter only)
-    const int tile = blockIdx.x;
+    const int tile = tile_first + (int)blockIdx.x * tile_step;       // (first, step) != (0, 1): this rank's share of the tiles
     const int tx = tile % grid_x, ty = tile / grid_x;
     const unsigned t = threadIdx.x, lane = t & 63;
     const int x = tx * 16 + (int)(t & 15), y = ty * 16 + (int)(t >> 4);
@@ -1532,18 +1533,20 @@ int g2pc_raster_front_cu(const G2pcCamera* cam, const float* means3D, const floa
 // CU semantics, back half: duplicate -> tile sort -> ranges -> blend -> running-state update.
 // out_color f32[3,H,W], out_depth / out_invdepth f32[H,W] are zero-filled here.  cam_key u64[n], cam_surf u32[n] are
 // per-camera scratch.  cur_* (optional) receive this camera's gauss_contributions / gauss_pixels / surface distances.
-int g2pc_raster_back_cu(const G2pcCamera* cam, const int32_t* mask, int64_t n, int64_t num_instances, const float* rec,
+int g2pc_raster_back_cu_tiles(const G2pcCamera* cam, const int32_t* mask, int64_t n, int64_t num_instances, const float* rec,
                         const uint32_t* rect, const uint32_t* sorted_idx, const uint32_t* offsets, int calculate_surface_distance, unsigned long long* cam_key,
                         uint32_t* cam_surf, float* out_color, float* out_depth, float* out_invdepth,
                         float* max_contrib, float* total_contrib, float* colours, float* min_surf,
                         int32_t* winner_cam, int32_t cam_index, float* cur_contrib, int32_t* cur_pixels, float* cur_surf,
-                        int phases, void* ws, size_t ws_bytes, void* stream) {
+                        int phases, int32_t tile_first, int32_t tile_step, void* ws, size_t ws_bytes, void* stream) {
     using namespace g2pc;
     G2PC_REQUIRE(cam && rec && rect && sorted_idx && offsets && cam_key && cam_surf && out_color &&
                      out_depth && out_invdepth && max_contrib && total_contrib && colours && min_surf && ws && n > 0,
                  G2PC_ERR_ARG, "bad arguments");
     const int W = cam->width, H = cam->height;
     const int gx = (W + 15) / 16, gy = (H + 15) / 16, T = gx * gy;
+    G2PC_REQUIRE(tile_step >= 1 && tile_first >= 0 && tile_first < tile_step, G2PC_ERR_ARG, "bad tile shard");
+    const bool sharded = tile_step > 1;                 // the images then hold this rank's tiles only (zero elsewhere)
     hipStream_t s = (hipStream_t)stream;
     const long L = num_instances;
     Arena ar(ws, ws_bytes);
@@ -1561,7 +1564,7 @@ int g2pc_raster_back_cu(const G2pcCamera* cam, const int32_t* mask, int64_t n, i
     if (phases & 1) {
     hipMemsetAsync(tile_start, 0, (size_t)(T + 2) * 4, s);
     hipMemsetAsync(cam_key, 0, (size_t)n * 8, s);
-    if (mask) {                                   // without a mask every pixel is written by the blend kernel
+    if (mask || sharded) {                        // without a mask every pixel is written by the blend kernel
         hipMemsetAsync(out_color, 0, (size_t)3 * W * H * 4, s);
         hipMemsetAsync(out_depth, 0, (size_t)W * H * 4, s);
         hipMemsetAsync(out_invdepth, 0, (size_t)W * H * 4, s);
@@ -1577,13 +1580,26 @@ int g2pc_raster_back_cu(const G2pcCamera* cam, const int32_t* mask, int64_t n, i
     (void)scan_ws; (void)scan_bytes;
     hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T)), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start, (const uint32_t*)nullptr);
     }
-    if (phases & 2)
-    hipLaunchKernelGGL(k_blend_cu, dim3((unsigned)T), dim3(CU_T), 0, s, W, H, gx, tile_start, g_sorted, (const float4*)rec,
+    if ((phases & 2) && tile_first < T)
+    hipLaunchKernelGGL(k_blend_cu, dim3((unsigned)((T - tile_first + tile_step - 1) / tile_step)), dim3(CU_T), 0, s, W, H, gx,
+                       (int)tile_first, (int)tile_step, tile_start, g_sorted, (const float4*)rec,
                        mask, make_float3(cam->bg[0], cam->bg[1], cam->bg[2]),
                        calculate_surface_distance, cam_key, cam_surf, out_color, out_depth, out_invdepth);
     if (phases & 4)
     hipLaunchKernelGGL(k_update_cu, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, cam_key, cam_surf, (long)n, W, H, out_color,
                        max_contrib, total_contrib, colours, min_surf, winner_cam, cam_index, cur_contrib, cur_pixels, cur_surf);
     return check_launch("g2pc_raster_back_cu");
+}
+
+int g2pc_raster_back_cu(const G2pcCamera* cam, const int32_t* mask, int64_t n, int64_t num_instances, const float* rec,
+                        const uint32_t* rect, const uint32_t* sorted_idx, const uint32_t* offsets, int calculate_surface_distance,
+                        unsigned long long* cam_key, uint32_t* cam_surf, float* out_color, float* out_depth, float* out_invdepth,
+                        float* max_contrib, float* total_contrib, float* colours, float* min_surf, int32_t* winner_cam,
+                        int32_t cam_index, float* cur_contrib, int32_t* cur_pixels, float* cur_surf, int phases, void* ws,
+                        size_t ws_bytes, void* stream) {
+    return g2pc_raster_back_cu_tiles(cam, mask, n, num_instances, rec, rect, sorted_idx, offsets, calculate_surface_distance,
+                                     cam_key, cam_surf, out_color, out_depth, out_invdepth, max_contrib, total_contrib, colours,
+                                     min_surf, winner_cam, cam_index, cur_contrib, cur_pixels, cur_surf, phases, 0, 1, ws,
+                                     ws_bytes, stream);
 }
 }

@@ -681,12 +681,12 @@ def get_renderer(renderer_type: str, xyz, opacities, colours, covariances, shs=N
             return GaussianPCRasterizer(xyz.to(torch.float), means2D, opacities.type(torch.float),
                                         colors_precomp=colours.to(torch.float), cov3D_precomp=strip_symmetric(covariances).to(torch.float),
                                         visible_gaussian_threshold=visible_gaussian_threshold, surface_distance_std=surface_distance_std,
-                                        calculate_surface_distance=calculate_surface_distance)
+                                        calculate_surface_distance=calculate_surface_distance, tile_shard=tile_shard)
         else:
             return GaussianPCRasterizer(xyz.to(torch.float), means2D, opacities.type(torch.float),
                                         shs=shs.to(torch.float), cov3D_precomp=strip_symmetric(covariances).to(torch.float),
                                         visible_gaussian_threshold=visible_gaussian_threshold, surface_distance_std=surface_distance_std,
-                                        calculate_surface_distance=calculate_surface_distance)
+                                        calculate_surface_distance=calculate_surface_distance, tile_shard=tile_shard)
 
     elif renderer_type == "python":
         return GaussHipRenderer(xyz, opacities, colours, covariances, semantics="python",

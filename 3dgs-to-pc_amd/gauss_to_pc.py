@@ -186,9 +186,9 @@ def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, poin
         if not s.quiet:
             print("Rendering Gaussian Colours")
 
-        # fewer cameras than ranks: split every camera's TILES over the ranks instead of the cameras (python semantics;
-        # the native-rasteriser path keeps the camera split and leaves the surplus ranks idle)
-        split_tiles = (world > 1 and transforms is not None and len(transforms) < world and s.renderer_type == "python")
+        # fewer cameras than ranks: split every camera's TILES over the ranks instead of the cameras (both semantics: the
+        # python-semantics renderer merges once after the loop, the native-rasteriser one camera by camera)
+        split_tiles = (world > 1 and transforms is not None and len(transforms) < world)
         extra = dict(tile_shard=(rank, world)) if split_tiles else {}
         gaussian_renderer = get_renderer(s.renderer_type, gaussians.xyz, torch.unsqueeze(torch.clone(gaussians.opacities), 1),
                                          gaussians.colours, gaussians.covariances,
@@ -197,6 +197,9 @@ def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, poin
                                          surface_distance_std=s.surface_distance_std,
                                          calculate_surface_distance=True if (s.surface_distance_std is not None or s.generate_mesh) else False,
                                          **extra)
+
+        if split_tiles and hasattr(gaussian_renderer, "tile_group"):
+            gaussian_renderer.tile_group = group
 
         if transforms is None:
             raise Exception("Transforms are required to render colours")

@@ -50,6 +50,8 @@ nv._RASTER_PROTOS.update({
                              [_vp] * 7 + [C.c_size_t, _vp]),
     "g2pc_raster_back_cu": (C.c_int, [C.POINTER(_Camera), _vp, C.c_int64, C.c_int64] + [_vp] * 4 + [C.c_int] + [_vp] * 10 +
                             [C.c_int32] + [_vp] * 3 + [C.c_int, _vp, C.c_size_t, _vp]),
+    "g2pc_raster_back_cu_tiles": (C.c_int, [C.POINTER(_Camera), _vp, C.c_int64, C.c_int64] + [_vp] * 4 + [C.c_int] + [_vp] * 10 +
+                                  [C.c_int32] + [_vp] * 3 + [C.c_int, C.c_int32, C.c_int32, _vp, C.c_size_t, _vp]),
     "g2pc_mark_visible": (C.c_int, [_vp, C.c_int64, C.POINTER(C.c_float * 16), _vp, _vp]),
 })
 if nv._LIB is not None:
@@ -97,8 +99,12 @@ class GaussianRasterizer(nn.Module):
 
     def __init__(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                  cov3D_precomp=None, visible_gaussian_threshold=0.0, surface_distance_std=None,
-                 calculate_surface_distance=False):
+                 calculate_surface_distance=False, tile_shard=None):
         super().__init__()
+        # (rank, world): multi-GPU jobs with fewer cameras than ranks -- every rank renders every camera but blends only
+        # tiles rank, rank + world, ...; the per-camera results are merged across ranks inside forward() (see _exchange_camera)
+        self.tile_shard = tuple(tile_shard) if tile_shard is not None and tile_shard[1] > 1 else None
+        self.tile_group = None
 
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception('Please provide excatly one of either SHs or precomputed colors!')
@@ -182,14 +188,28 @@ class GaussianRasterizer(nn.Module):
                 sc.depths = torch.empty((1, H, W), dtype=torch.float32, device=self.device)
                 sc.invdepths = torch.empty((1, H, W), dtype=torch.float32, device=self.device)
         with nv.region(name, self.device, sc.stream):
-            nv.check(L.g2pc_raster_back_cu(
+            first, step = self.tile_shard if self.tile_shard is not None else (0, 1)
+            nv.check(L.g2pc_raster_back_cu_tiles(
                 C.byref(cam), nv.ptr(mask), self.n, num_rendered, nv.ptr(sc.rec), nv.ptr(sc.rect), nv.ptr(sc.sorted),
                 nv.ptr(sc.offsets), 1 if self.calculate_surface_distance else 0,
                 nv.ptr(sc.cam_key), nv.ptr(sc.cam_surf), nv.ptr(sc.colour), nv.ptr(sc.depths), nv.ptr(sc.invdepths),
                 nv.ptr(self.gaussian_max_contribution), nv.ptr(self.gaussian_total_contribution),
                 nv.ptr(self.gaussian_colours), nv.ptr(self.gaussian_min_surface_distance), nv.ptr(self._winner_cam),
-                int(cam_index), nv.ptr(cur[0]), nv.ptr(cur[1]), nv.ptr(cur[2]), phases, nv.ptr(sc.back_ws), sc.back_bytes,
-                self._stream_ptr(sc)), "raster_back_cu")
+                int(cam_index), nv.ptr(cur[0]), nv.ptr(cur[1]), nv.ptr(cur[2]), phases, int(first), int(step),
+                nv.ptr(sc.back_ws), sc.back_bytes, self._stream_ptr(sc)), "raster_back_cu")
+
+    def _exchange_camera(self, sc):
+        """Tile-split mode, between the blend and the running-state update of ONE camera: merge what the ranks found in their
+        tiles -- MAX of the packed (contribution, ~pixel) keys, MIN of the surface distances, SUM of the images (every pixel
+        was written by exactly one rank, zero elsewhere).  Afterwards the camera's data, and so the running state, is
+        identical on every rank."""
+        import torch.distributed as dist
+        dist.all_reduce(sc.cam_key, op=dist.ReduceOp.MAX, group=self.tile_group)
+        if self.calculate_surface_distance:
+            dist.all_reduce(sc.cam_surf, op=dist.ReduceOp.MIN, group=self.tile_group)     # non-negative floats order like their bits
+        dist.all_reduce(sc.colour, op=dist.ReduceOp.SUM, group=self.tile_group)
+        dist.all_reduce(sc.depths, op=dist.ReduceOp.SUM, group=self.tile_group)
+        dist.all_reduce(sc.invdepths, op=dist.ReduceOp.SUM, group=self.tile_group)
 
     def _finish(self, entry):
         sc, cam, mask, cam_index = entry
@@ -229,6 +249,19 @@ class GaussianRasterizer(nn.Module):
         cam, campos, mask = self._camera(rs)
         self._dirty = True
         n = self.n
+        if self.tile_shard is not None:
+            # tile split: one camera at a time, with the cross-rank merge between its blend and its state update
+            self.flush()
+            sc = self._sync
+            self._front(sc, cam, campos, rs.sh_degree)
+            num_rendered = int(sc.offsets[n].item())
+            sc.colour = None
+            self._back(sc, cam, mask, num_rendered, cam_index, 3, "raster_bin+blend_cu")
+            self._exchange_camera(sc)
+            self._back(sc, cam, mask, num_rendered, cam_index, 4, "raster_update_cu")
+            if discard_images:
+                return None, None, None, None
+            return sc.colour, sc.radii.clone(), sc.invdepths, sc.depths
         if discard_images and PIPELINE_STREAMS > 1 and self.device.type == "cuda" and not nv.emulated():
             if not self._pipe:
                 self._pipe = [_CuScratch(n, self.device, torch.cuda.Stream(self.device)) for _ in range(PIPELINE_STREAMS)]
@@ -322,6 +355,8 @@ class GaussianRasterizer(nn.Module):
         import torch.distributed as dist
         self.flush()
         if not dist.is_initialized() or dist.get_world_size(group) == 1:
+            return
+        if self.tile_shard is not None:       # tile split: the state was merged camera by camera and is already global
             return
         gmax = self.gaussian_max_contribution.clone()
         dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)

@@ -349,6 +349,16 @@ int g2pc_raster_back_cu(const G2pcCamera* cam, const int32_t* mask, int64_t n, i
                         float* max_contrib, float* total_contrib, float* colours, float* min_surf,
                         int32_t* winner_cam, int32_t cam_index, float* cur_contrib, int32_t* cur_pixels, float* cur_surf,
                         int phases, void* ws, size_t ws_bytes, void* stream);
+/* The same with a tile shard: only tiles tile_first, tile_first + tile_step, ... are blended (multi-GPU jobs with fewer
+ * cameras than ranks split every camera's 16x16 tiles over the ranks); the images hold zeros elsewhere, cam_key / cam_surf
+ * cover this rank's tiles only and are merged by the caller (MAX / MIN over ranks, SUM of the images) before phase 4. */
+int g2pc_raster_back_cu_tiles(const G2pcCamera* cam, const int32_t* mask, int64_t n, int64_t num_instances, const float* rec,
+                              const uint32_t* rect, const uint32_t* sorted_idx, const uint32_t* offsets,
+                              int calculate_surface_distance, unsigned long long* cam_key, uint32_t* cam_surf,
+                              float* out_color, float* out_depth, float* out_invdepth, float* max_contrib,
+                              float* total_contrib, float* colours, float* min_surf, int32_t* winner_cam, int32_t cam_index,
+                              float* cur_contrib, int32_t* cur_pixels, float* cur_surf, int phases, int32_t tile_first,
+                              int32_t tile_step, void* ws, size_t ws_bytes, void* stream);
 
 /* Multi-GPU exchange of the python-semantics state (cameras sharded over ranks): all-reduce MAX of best_key, then
  * g2pc_raster_key_owner (owner[i] = rank where this rank holds the winning key, INT32_MAX elsewhere), all-reduce MIN of

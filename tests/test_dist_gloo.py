@@ -157,6 +157,22 @@ def test_two_ranks_one_camera_split_the_tiles(tmp_path):
     assert np.array_equal(ca[np.lexsort(ca.T[::-1])], cb[np.lexsort(cb.T[::-1])])
 
 
+def test_two_ranks_one_camera_split_the_tiles_cuda_semantics(tmp_path):
+    """The same for the native-rasteriser semantics: the ranks blend alternate 16x16 tiles of the single camera and merge
+    the camera's keys / surface distances / image before the running-state update, so every rank ends with the
+    single-process state exactly (MAX / MIN / one-writer SUM are order-free)."""
+    from emu_util import build_emu
+    build_emu()
+    _run(0, 1, 0, str(tmp_path), "cuda", 255, 1)
+    port = 39500 + (os.getpid() % 2000)
+    mp.spawn(_run, args=(2, port, str(tmp_path), "cuda", 255, 1), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "cuda_w1_e255.npz"), np.load(tmp_path / "cuda_w2_e255.npz")
+    rows = lambda d: np.concatenate([d["points"], d["colours"], d["normals"]], axis=1)
+    ca, cb = rows(a), rows(b)
+    assert ca.shape == cb.shape and ca.shape[0] > 5000
+    assert np.array_equal(ca[np.lexsort(ca.T[::-1])], cb[np.lexsort(cb.T[::-1])])
+
+
 def test_tile_shards_partition_the_chunk_list():
     sys.path.insert(0, os.path.join(ROOT, "3dgs-to-pc_amd"))
     from g2pc import tiles
