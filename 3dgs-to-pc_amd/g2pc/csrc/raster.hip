@@ -397,7 +397,7 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_pk(Layout lay, const int32_t*
                                                      unsigned long long* __restrict__ best_key, uint32_t order_base,
                                                      float t_floor, float bg, float* __restrict__ tilebuf,
                                                      uint32_t* __restrict__ chunk_work,
-                                                     const G2pcCameraJob* __restrict__ job) {
+                                                     const G2pcCameraJob* __restrict__ job, uint32_t walk_cap) {
     if (job) { order_base = job->camera_slot << 24; t_floor = job->t_floor; bg = job->cam.bg[0]; }
     __shared__ float4 s_p0[BL_BATCH + 4];
     __shared__ float4 s_p1[BL_BATCH + 4];
@@ -428,7 +428,9 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_pk(Layout lay, const int32_t*
     pk2 T = pk_make(Ts[0], Ts[1]);
     pk2 cr = pk_splat(0.f), cg = pk_splat(0.f), cb = pk_splat(0.f);
 
-    const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
+    const uint32_t start = tile_start[tile];
+    uint32_t end = tile_start[tile + 1];
+    if (walk_cap && end - start > walk_cap) end = start + walk_cap;     // DIAGNOSTIC ONLY (g2pc_debug_blend_walk_cap): wrong images
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t g_cur = 0, g_nxt = 0;
     bool v_cur = (start + lane) < end, v_nxt = (start + BL_BATCH + lane) < end;
@@ -1205,6 +1207,7 @@ __global__ __launch_bounds__(RA_T) void k_fill_u32(uint32_t* __restrict__ p, lon
 }
 
 static uint32_t* g_chunk_work = nullptr;      // diagnostics hook (g2pc_raster_debug_chunk_work)
+static uint32_t g_blend_walk_cap = 0;         // diagnostics: truncate every tile list to this many entries (0 = off)
 static int g_blend_variant = 0;               // 0 = k_blend_py_pk (default), 1 = k_blend_py_v2, 2 = v2 without the adaptive width
 
 static Cam to_cam(const G2pcCamera* c) {
@@ -1310,7 +1313,9 @@ static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t*
                 else if (v2) G2PC_BLEND_V2(k_blend_py_v2<4, false>);
 #undef G2PC_BLEND_V2
                 else
-                    G2PC_BLEND(k_blend_py_pk<4>);
+                    hipLaunchKernelGGL((k_blend_py_pk<4>), dim3((unsigned)layout->num_chunks), dim3(BL_T), 0, s, lay, layout->chunk_tile,
+                                       layout->chunk_pix0, tile_start, g_sorted, (const float4*)fb.rec, best_key, ba.camera_slot << 24,
+                                       ba.t_floor, ba.bg, tilebuf, g_chunk_work, ba.job, g_blend_walk_cap);
                 break;
             case 4: G2PC_BLEND(k_blend_py<4, 1>); break;
             default: set_error("raster_back_py", "chunk_subblocks must be 1, 2 or 4"); return G2PC_ERR_ARG;
@@ -1440,6 +1445,10 @@ int g2pc_raster_camera_update_py(const G2pcTileLayout* layout, int64_t n, uint32
 
 /* diagnostics: when set, the PY blend writes (list length, entries walked) per chunk into u32[2*num_chunks] */
 int g2pc_raster_debug_chunk_work(uint32_t* buf) { g2pc::g_chunk_work = buf; return G2PC_OK; }
+
+/* DIAGNOSTIC: truncate every tile's list to `cap` entries in k_blend_py_pk (0 = off).  Produces WRONG images; it exists to
+ * measure how much of a launch is the few never-saturating walks (tools/gpu_round2_h.sh). */
+int g2pc_debug_blend_walk_cap(uint32_t cap) { g2pc::g_blend_walk_cap = cap; return G2PC_OK; }
 
 /* tuning / A-B aid: 0 = first-generation blend kernels (k_blend_py_pk), 1 = k_blend_py_v2 (default) */
 int g2pc_set_blend_variant(int variant) {

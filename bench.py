@@ -57,6 +57,7 @@ def parse():
                     help="diagnostic: Gaussian scale range of the synthetic scene (default 0.002 0.02 = SURVEY.md's)")
     ap.add_argument("--no-context-pool", action="store_true", help="tuning aid: every job captures its camera graphs anew")
     ap.add_argument("--streams", type=int, default=0, help="tuning aid: cameras in flight (HIP streams) of the renderer")
+    ap.add_argument("--debug-walk-cap", type=int, default=0, help="DIAGNOSTIC (wrong images): truncate every tile list to this many entries")
     ap.add_argument("--no-front-priority", action="store_true", help="tuning aid: camera heads on the slot's normal stream, inside one graph with the blend")
     ap.add_argument("--camera-subset", type=int, default=0, help="profiling aid: render only the first k cameras of the rig")
     ap.add_argument("--t-floor", type=float, default=None, help="blend transmittance floor (default: gauss_render.DEFAULT_T_FLOOR)")
@@ -298,6 +299,8 @@ def main():
     if a.blend_subblocks:
         gauss_render.BLEND_SUBBLOCKS = a.blend_subblocks
     nv.check(nv.lib().g2pc_set_blend_variant(a.blend_variant), "set_blend_variant")
+    if a.debug_walk_cap:
+        nv.lib().g2pc_debug_blend_walk_cap(a.debug_walk_cap)
     if a.streams:
         gauss_render.PIPELINE_STREAMS = a.streams
     if a.no_front_priority:

@@ -321,6 +321,8 @@ int g2pc_raster_debug_chunk_work(uint32_t* buf);
  * (k_blend_py_pk), 1 = k_blend_py_v2 (default: LDS reads one trip ahead, 10-dword staged records, packed -> scalar
  * width once one 8x8 sub-block is below the floor).  Same results above the transmittance floor, bit for bit. */
 int g2pc_set_blend_variant(int variant);
+/* DIAGNOSTIC ONLY: truncate every tile list to `cap` entries in the default blend kernel (0 = off); wrong images. */
+int g2pc_debug_blend_walk_cap(uint32_t cap);
 /* --- native-rasteriser ("cuda") semantics: _C.rasterize_gaussians (rasterize_points.h:18-41) ----------------------
  * Deterministic spec of SURVEY.md §8(a.5): 16x16 tiles, near cull z_view <= 0.2, radius ceil(3 sqrt(lambda_max)),
  * stable (tile, depth) order, alpha rules (power > 0 skip, min(0.99, .), alpha < 1/255 skip, T(1-alpha) < 1e-4 stop),
