@@ -233,6 +233,34 @@ __global__ __launch_bounds__(RS_T) void k_radix_hist(const uint32_t* __restrict_
     for (unsigned d = threadIdx.x; d <= mask; d += RS_T) ghist[(size_t)d * nb + blockIdx.x] = hist[d];
 }
 
+// One launch instead of the generic two-kernel scan over the (digit, block) matrix: block d turns row d of ghist (the
+// per-tile counts of digit d, nb entries) into its exclusive prefix IN PLACE and leaves the row total in gtot[d]; the
+// scatter kernel adds the exclusive scan of the <= 2048 row totals itself (a few hundred LDS operations per block).
+__global__ __launch_bounds__(SCAN_T) void k_radix_rowscan(uint32_t* __restrict__ ghist, unsigned nb, uint32_t* __restrict__ gtot) {
+    __shared__ uint32_t wsum[SCAN_T / kWave];
+    __shared__ uint32_t carry;
+    uint32_t* row = ghist + (size_t)blockIdx.x * nb;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (unsigned base = 0; base < nb; base += SCAN_T) {
+        const unsigned i = base + threadIdx.x;
+        const uint32_t v = i < nb ? row[i] : 0u;
+        const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const uint32_t incl = wave_incl_scan_u32(v);
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        uint32_t woff = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_T / kWave; ++k) { const uint32_t t = wsum[k]; if (k < (int)w) woff += t; total += t; }
+        const uint32_t c = carry;
+        if (i < nb) row[i] = c + woff + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) gtot[blockIdx.x] = carry;
+}
+
 template <int BITS, int ITEMS>
 __global__ __launch_bounds__(RS_T) void k_radix_scatter(const uint32_t* __restrict__ keys_in,
                                                        const uint32_t* __restrict__ vals_in,
@@ -240,10 +268,12 @@ __global__ __launch_bounds__(RS_T) void k_radix_scatter(const uint32_t* __restri
                                                        uint32_t* __restrict__ vals_out, long n, int shift,
                                                        unsigned mask, int nbits,
                                                        const uint32_t* __restrict__ goffs, unsigned nb,
-                                                       const uint32_t* __restrict__ n_dev) {
+                                                       const uint32_t* __restrict__ n_dev,
+                                                       const uint32_t* __restrict__ gtot) {
     constexpr int BINS = 1 << BITS, TILE = RS_T * ITEMS;
     __shared__ uint32_t whist[RS_W][BINS];      // per-wave running digit counts, then exclusive offsets
     __shared__ uint32_t gbase[BINS];
+    __shared__ uint32_t dsum[RS_T / kWave];
     if (n_dev) {
         const long m = (long)*n_dev;
         n = m < n ? m : n;
@@ -251,7 +281,30 @@ __global__ __launch_bounds__(RS_T) void k_radix_scatter(const uint32_t* __restri
     }
     const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < RS_W * BINS; i += RS_T) (&whist[0][0])[i] = 0;
-    for (unsigned d = threadIdx.x; d <= mask; d += RS_T) gbase[d] = goffs[(size_t)d * nb + blockIdx.x];
+    {   // gbase[d] = (number of keys with a smaller digit) + (keys with digit d in the tiles before this one):
+        // exclusive scan of the row totals, BINS / RS_T digits per thread
+        constexpr int PER = (BINS + RS_T - 1) / RS_T;
+        uint32_t tv[PER], tsum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const unsigned d = threadIdx.x * PER + k;
+            tv[k] = d <= mask ? gtot[d] : 0u;
+            tsum += tv[k];
+        }
+        const uint32_t incl = wave_incl_scan_u32(tsum);
+        if (lane == 63) dsum[w] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+#pragma unroll
+        for (int k = 0; k < RS_T / kWave; ++k) if (k < (int)w) woff += dsum[k];
+        uint32_t run = woff + incl - tsum;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const unsigned d = threadIdx.x * PER + k;
+            if (d <= mask) gbase[d] = run + goffs[(size_t)d * nb + blockIdx.x];
+            run += tv[k];
+        }
+    }
     __syncthreads();
 
     const long wbase = (long)blockIdx.x * TILE + (long)w * (TILE / RS_W);
@@ -309,7 +362,7 @@ size_t sort_workspace(long n) {
     long nb = (n + RS_T * 4 - 1) / (RS_T * 4);
     if (nb < 1) nb = 1;
     size_t entries = (size_t)2048 * nb + 1;
-    return align_up(entries * sizeof(uint32_t)) + scan_workspace((long)entries) + 512;
+    return align_up(entries * sizeof(uint32_t)) + scan_workspace((long)entries) + 2048 * sizeof(uint32_t) + 512;
 }
 
 template <int BITS, int ITEMS>
@@ -318,10 +371,11 @@ static void radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout,
                        const uint32_t* n_dev) {
     unsigned mask = (1u << nbits) - 1u;
     hipLaunchKernelGGL((k_radix_hist<BITS, ITEMS>), dim3(nb), dim3(RS_T), 0, s, kin, n, bit, mask, ghist, nb, n_dev);
-    rc = scan_exclusive_u32(ghist, ghist, (long)(mask + 1) * nb, scan_ws, scan_bytes, s);
-    if (rc) return;
+    uint32_t* gtot = (uint32_t*)scan_ws;                       // (mask + 1) row totals
+    if (scan_bytes < (size_t)(mask + 1) * sizeof(uint32_t)) { set_error("sort", "workspace too small"); rc = G2PC_ERR_WORKSPACE; return; }
+    hipLaunchKernelGGL(k_radix_rowscan, dim3(mask + 1), dim3(SCAN_T), 0, s, ghist, nb, gtot);
     hipLaunchKernelGGL((k_radix_scatter<BITS, ITEMS>), dim3(nb), dim3(RS_T), 0, s, kin, vin, kout, vout, n, bit, mask, nbits,
-                       ghist, nb, n_dev);
+                       ghist, nb, n_dev, gtot);
 }
 
 int sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
@@ -348,7 +402,7 @@ int sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* k
     Arena ar(ws, ws_bytes);
     size_t entries = ((size_t)1 << maxbits) * nb + 1;
     uint32_t* ghist = ar.get<uint32_t>(entries);
-    size_t scan_bytes = scan_workspace((long)entries);
+    size_t scan_bytes = scan_workspace((long)entries) + 2048 * sizeof(uint32_t);     // holds the per-digit row totals
     char* scan_ws = ar.get<char>(scan_bytes);
     if (!ar.ok()) { set_error("sort", "workspace too small"); return G2PC_ERR_WORKSPACE; }
     // ping-pong so that the last pass lands in *_out
