@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--no-parity", action="store_true", help="skip the parity block (reference fixtures at the benchmark's scale)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_workloads lines (configs[1] sampling job)")
     ap.add_argument("--sort-bits", type=int, default=0, help="tuning aid: wide radix digit bits (8 or 11)")
+    ap.add_argument("--sort-single-pass-bits", type=int, default=0, help="tuning aid: sorts of at most this many key bits (8..11) run as one pass")
     ap.add_argument("--sort-small", type=int, default=2 << 20, help="tuning aid: inputs up to this many keys use 4 keys/thread")
     ap.add_argument("--blend-subblocks", type=int, default=0, help="tuning aid: 8x8 sub-blocks per blend wave (1, 2, 4)")
     ap.add_argument("--blend-variant", type=int, default=0, help="tuning aid: 0 = first-generation blend kernel, 1 = k_blend_py_v2, 2 = v2 without adaptive width")
@@ -296,6 +297,8 @@ def main():
         gauss_render.DEFAULT_T_FLOOR = a.t_floor
     if a.sort_bits:
         nv.lib().g2pc_set_sort_tuning(a.sort_bits, a.sort_small)
+    if a.sort_single_pass_bits:
+        nv.check(nv.lib().g2pc_set_sort_single_pass_bits(a.sort_single_pass_bits), "set_sort_single_pass_bits")
     if a.blend_subblocks:
         gauss_render.BLEND_SUBBLOCKS = a.blend_subblocks
     nv.check(nv.lib().g2pc_set_blend_variant(a.blend_variant), "set_blend_variant")

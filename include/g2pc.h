@@ -46,6 +46,8 @@ int g2pc_scan_exclusive_u32(const uint32_t* in, uint32_t* out, int64_t n, void* 
 size_t g2pc_sort_workspace(int64_t n);
 /* tuning: digit width (8 or 11 bits) for sorts of more than 8 bits; inputs up to small_input_keys use 4 keys/thread */
 int g2pc_set_sort_tuning(int wide_digit_bits, int64_t small_input_keys);
+/* tuning aid: key ranges of at most `bits` bits (8..11) are sorted in ONE pass with 2^bits bins */
+int g2pc_set_sort_single_pass_bits(int bits);
 
 /* --- hipGraph capture of a sequence of g2pc_* calls --------------------------------------------------------------------
  * Every g2pc_* entry point only queues work on `stream` (no allocation, no synchronisation), so whatever is called
