@@ -356,12 +356,7 @@ __global__ __launch_bounds__(RS_T) void k_radix_scatter(const uint32_t* __restri
 static int g_radix_wide_bits = 8;          // 8 or 11: digit width used when more than 8 bits are sorted (tuning knob)
 static long g_radix_small_n = 2L << 20;    // inputs up to this size use 4 keys per thread
 static inline int radix_items(long n) { return n <= g_radix_small_n ? 4 : 8; }
-static int g_radix_single_pass_bits = 8;   // sorts of at most this many key bits run as ONE pass (<= 11; tuning knob)
-static inline int radix_maxbits(int total_bits) {
-    if (total_bits <= 8) return 8;
-    if (total_bits <= g_radix_single_pass_bits) return 11;
-    return g_radix_wide_bits;
-}
+static inline int radix_maxbits(int total_bits) { return total_bits <= 8 ? 8 : g_radix_wide_bits; }
 
 size_t sort_workspace(long n) {
     long nb = (n + RS_T * 4 - 1) / (RS_T * 4);
@@ -446,14 +441,6 @@ __global__ __launch_bounds__(64) void k_selftest_wave_reduce(const uint32_t* __r
 extern "C" {
 const char* g2pc_last_error(void) { return g2pc::g_err.c_str(); }
 int g2pc_abi_version(void) { return G2PC_ABI_VERSION; }
-
-/* tuning aid: key ranges of at most `bits` bits (8..11) are sorted in ONE pass with 2^bits bins (e.g. the 10-bit tile ids
- * of a 1 024-leaf layout) instead of two narrower passes */
-int g2pc_set_sort_single_pass_bits(int bits) {
-    if (bits < 8 || bits > 11) return G2PC_ERR_ARG;
-    g2pc::g_radix_single_pass_bits = bits;
-    return G2PC_OK;
-}
 
 int g2pc_set_sort_tuning(int wide_digit_bits, int64_t small_input_keys) {
     if (wide_digit_bits != 8 && wide_digit_bits != 11) return G2PC_ERR_ARG;

@@ -397,7 +397,7 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_pk(Layout lay, const int32_t*
                                                      unsigned long long* __restrict__ best_key, uint32_t order_base,
                                                      float t_floor, float bg, float* __restrict__ tilebuf,
                                                      uint32_t* __restrict__ chunk_work,
-                                                     const G2pcCameraJob* __restrict__ job, uint32_t walk_cap) {
+                                                     const G2pcCameraJob* __restrict__ job) {
     if (job) { order_base = job->camera_slot << 24; t_floor = job->t_floor; bg = job->cam.bg[0]; }
     __shared__ float4 s_p0[BL_BATCH + 4];
     __shared__ float4 s_p1[BL_BATCH + 4];
@@ -428,9 +428,7 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_pk(Layout lay, const int32_t*
     pk2 T = pk_make(Ts[0], Ts[1]);
     pk2 cr = pk_splat(0.f), cg = pk_splat(0.f), cb = pk_splat(0.f);
 
-    const uint32_t start = tile_start[tile];
-    uint32_t end = tile_start[tile + 1];
-    if (walk_cap && end - start > walk_cap) end = start + walk_cap;     // DIAGNOSTIC ONLY (g2pc_debug_blend_walk_cap): wrong images
+    const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t g_cur = 0, g_nxt = 0;
     bool v_cur = (start + lane) < end, v_nxt = (start + BL_BATCH + lane) < end;
@@ -522,235 +520,6 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_pk(Layout lay, const int32_t*
             }
         }
         if (__all((T[0] <= t_floor && T[1] <= t_floor) ? 1 : 0)) break;      // see k_blend_py
-    }
-    if (chunk_work && lane == 0) {
-        chunk_work[2 * blockIdx.x] = end - start;
-        chunk_work[2 * blockIdx.x + 1] = processed;
-    }
-    float* out = tilebuf + 3 * (size_t)lay.tile_pix_off[tile];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        if (pix[j] >= 0) {
-            out[3 * (size_t)pix[j] + 0] = fmaf(T[j], bg, cr[j]);
-            out[3 * (size_t)pix[j] + 1] = fmaf(T[j], bg, cg[j]);
-            out[3 * (size_t)pix[j] + 2] = fmaf(T[j], bg, cb[j]);
-        }
-    }
-}
-
-// K6 (PY), second generation of the packed kernel.  Same arithmetic per (pixel, Gaussian) pair, bit for bit; what changes is
-// how a wave spends its time:
-//  * the per-Gaussian parameters a trip needs are read from LDS ONE TRIP AHEAD into registers, so a wave that is alone on
-//    its SIMD (the long tile-silhouette walks that set the launch's length) no longer stalls on ds_read latency every trip;
-//  * the staged record shrinks from 12 to 10 dwords per Gaussian (b128 + b128 + b64 broadcast reads: 10 instead of 12
-//    LDS cycles per Gaussian and wave; depth and radius were staged but never read);
-//  * ADAPTIVE WIDTH: once every pixel of ONE of the two 8x8 sub-blocks is below the floor (or was never valid: the
-//    odd 15th sub-block of a tile, rows 23.. of a 23-row tile) the wave drops to a scalar body on the live sub-block:
-//    16 plain VALU per Gaussian instead of 11 packed + 8 plain.  The dead half's later terms are all below the floor
-//    (exactly 0 for floor 0), i.e. inside what the floor already discards.
-//  * the leaf-overflow check (k_check_tile_load) is folded in: one compare per wave.
-template <int U, bool ADAPT>
-__global__ __launch_bounds__(BL_T) void k_blend_py_v2(Layout lay, const int32_t* __restrict__ chunk_tile,
-                                                     const int32_t* __restrict__ chunk_pix0,
-                                                     const uint32_t* __restrict__ tile_start,
-                                                     const uint32_t* __restrict__ inst_g,
-                                                     const float4* __restrict__ rec,
-                                                     unsigned long long* __restrict__ best_key, uint32_t order_base,
-                                                     float t_floor, float bg, float* __restrict__ tilebuf,
-                                                     uint32_t* __restrict__ chunk_work,
-                                                     const G2pcCameraJob* __restrict__ job, uint32_t max_per_tile,
-                                                     uint32_t* __restrict__ overflow_flag) {
-    if (job) { order_base = job->camera_slot << 24; t_floor = job->t_floor; bg = job->cam.bg[0]; }
-    __shared__ float4 s_pa[BL_BATCH + U];          // mx, my, A, B
-    __shared__ float4 s_pb[BL_BATCH + U];          // C, opacity, r, g
-    __shared__ float2 s_pc[BL_BATCH + U];          // b, max(running maximum, FLT_MIN)
-    __shared__ uint32_t s_g[BL_BATCH];
-    const int tile = chunk_tile[blockIdx.x];
-    const int sb0 = chunk_pix0[blockIdx.x];
-    const int ix = tile % lay.nx, iy = tile / lay.nx;
-    const int x0 = lay.xs[ix], w = lay.ws[ix], y0 = lay.ys[iy], h = lay.hs[iy];
-    const int nsbx = (w + 7) >> 3;
-    const uint32_t order_tile = order_base | ((uint32_t)lay.tile_seq[tile] << 12);
-    const unsigned lane = threadIdx.x;
-    const int lx = lane & 7, ly = lane >> 3;
-
-    int pix[2];
-    float pxs[2], pys[2], Ts[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        int sb = sb0 + j;
-        int x = (sb % nsbx) * 8 + lx, y = (sb / nsbx) * 8 + ly;
-        bool valid = (x < w) && (y < h);
-        pix[j] = valid ? y * w + x : -1;
-        pxs[j] = (float)(x0 + x);
-        pys[j] = (float)(y0 + y);
-        Ts[j] = valid ? 1.0f : 0.0f;
-    }
-    pk2 px = pk_make(pxs[0], pxs[1]), py = pk_make(pys[0], pys[1]);
-    pk2 T = pk_make(Ts[0], Ts[1]);
-    pk2 cr = pk_splat(0.f), cg = pk_splat(0.f), cb = pk_splat(0.f);
-
-    const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
-    if (overflow_flag && max_per_tile && sb0 == 0 && lane == 0 && end - start > max_per_tile) atomicMax(overflow_flag, end - start);
-    if (lane < U) {                                 // the look-ahead of a batch's last trip reads these: keep them finite
-        s_pa[BL_BATCH + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-        s_pb[BL_BATCH + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-        s_pc[BL_BATCH + lane] = make_float2(0.f, 3.0e38f);
-    }
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    uint32_t g_cur = 0, g_nxt = 0;
-    bool v_cur = (start + lane) < end, v_nxt = (start + BL_BATCH + lane) < end;
-    if (v_cur) g_cur = inst_g[start + lane];
-    if (v_nxt) g_nxt = inst_g[start + BL_BATCH + lane];
-    float4 r0 = zero4, r1 = zero4, r2 = zero4;
-    uint32_t gmb = 0x7F000000u;
-    if (v_cur) {
-        r0 = rec[4 * (size_t)g_cur];
-        r1 = rec[4 * (size_t)g_cur + 1];
-        r2 = rec[4 * (size_t)g_cur + 2];
-        gmb = ((const uint32_t*)best_key)[2 * (size_t)g_cur + 1];
-    }
-    uint32_t processed = 0;
-    // which sub-blocks still have a pixel above the floor (wave-uniform); a sub-block that dies stays dead
-    bool live0 = !__all(Ts[0] <= t_floor ? 1 : 0), live1 = !__all(Ts[1] <= t_floor ? 1 : 0);
-    for (uint32_t b = start; b < end && (live0 || live1); b += BL_BATCH) {
-        processed = b + BL_BATCH - start;
-        if (processed == 16 * BL_BATCH) __builtin_amdgcn_s_setprio(2);
-        wave_sync();
-        s_pa[lane] = r0;
-        s_pb[lane] = make_float4(r1.x, r1.y, r2.x, r2.y);
-        s_pc[lane] = make_float2(r2.z, fmaxf(__uint_as_float(gmb), 1.17549435e-38f));
-        s_g[lane] = g_cur;
-        g_cur = g_nxt;
-        v_cur = v_nxt;
-        v_nxt = (b + 2 * BL_BATCH + lane) < end;
-        g_nxt = 0;
-        if (v_nxt) g_nxt = inst_g[b + 2 * BL_BATCH + lane];
-        r0 = zero4; r1 = zero4; r2 = zero4; gmb = 0x7F000000u;
-        if (v_cur) {
-            r0 = rec[4 * (size_t)g_cur];
-            r1 = rec[4 * (size_t)g_cur + 1];
-            r2 = rec[4 * (size_t)g_cur + 2];
-            gmb = ((const uint32_t*)best_key)[2 * (size_t)g_cur + 1];
-        }
-        wave_sync();
-        const int cnt = (end - b) < (uint32_t)BL_BATCH ? (int)(end - b) : BL_BATCH;
-        float4 na[U], nb[U];
-        float2 nc[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) { na[u] = s_pa[u]; nb[u] = s_pb[u]; nc[u] = s_pc[u]; }
-        if (!ADAPT || (live0 && live1)) {
-            for (int k0 = 0; k0 < cnt; k0 += U) {
-                float4 a[U], q[U];
-                float2 c[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) { a[u] = na[u]; q[u] = nb[u]; c[u] = nc[u]; }
-#pragma unroll
-                for (int u = 0; u < U; ++u) { na[u] = s_pa[k0 + U + u]; nb[u] = s_pb[k0 + U + u]; nc[u] = s_pc[k0 + U + u]; }
-                pk2 alpha[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const pk2 dx = px - a[u].x, dy = py - a[u].y;
-                    const pk2 power = pk_fma(dx, pk_fma(pk_splat(a[u].w), dy, a[u].z * dx), (q[u].x * dy) * dy);
-                    const pk2 wgt = pk_make(__builtin_amdgcn_exp2f(power[0]), __builtin_amdgcn_exp2f(power[1]));
-                    const pk2 al = wgt * q[u].y;
-                    alpha[u] = pk_make(fminf(al[0], 0.99f), fminf(al[1], 0.99f));
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) G2PC_PIN(alpha[u]);
-                pk2 contrib[U];
-                bool any_cand = false;
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    contrib[u] = T * alpha[u];
-                    cr = pk_fma(contrib[u], pk_splat(q[u].z), cr);
-                    cg = pk_fma(contrib[u], pk_splat(q[u].w), cg);
-                    cb = pk_fma(contrib[u], pk_splat(c[u].x), cb);
-                    T = T - contrib[u];
-                    any_cand = any_cand || (fmaxf(contrib[u][0], contrib[u][1]) >= c[u].y);
-                }
-                if (__any(any_cand ? 1 : 0)) {
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const float best = fmaxf(contrib[u][0], contrib[u][1]);
-                        if (__any(best >= c[u].y)) {
-                            uint32_t bits = __float_as_uint(best);
-                            uint32_t m = wave_max_u32_dpp(bits);
-                            const unsigned long long at0 = __ballot(__float_as_uint(contrib[u][0]) == m);
-                            const unsigned long long at1 = __ballot(__float_as_uint(contrib[u][1]) == m);
-                            const uint32_t pa = at0 ? (uint32_t)__builtin_amdgcn_readlane(pix[0], __ffsll(at0) - 1) : 0xFFFFFFFFu;
-                            const uint32_t pb = at1 ? (uint32_t)__builtin_amdgcn_readlane(pix[1], __ffsll(at1) - 1) : 0xFFFFFFFFu;
-                            const uint32_t pm = pa < pb ? pa : pb;
-                            if (lane == 0) {
-                                unsigned long long key = ((unsigned long long)m << 32) | (unsigned long long)(uint32_t)(~(order_tile | pm));
-                                atomicMax(&best_key[s_g[k0 + u]], key);
-                            }
-                        }
-                    }
-                }
-            }
-            live0 = !__all(T[0] <= t_floor ? 1 : 0);
-            live1 = !__all(T[1] <= t_floor ? 1 : 0);
-            if (ADAPT && live1 && !live0) {         // keep the live sub-block in element 0
-                px = pk_make(px[1], px[0]); py = pk_make(py[1], py[0]); T = pk_make(T[1], T[0]);
-                cr = pk_make(cr[1], cr[0]); cg = pk_make(cg[1], cg[0]); cb = pk_make(cb[1], cb[0]);
-                const int t = pix[0]; pix[0] = pix[1]; pix[1] = t;
-                live0 = true; live1 = false;
-            }
-        } else {
-            if (live1) {                            // only at entry: the first sub-block was never valid
-                px = pk_make(px[1], px[0]); py = pk_make(py[1], py[0]); T = pk_make(T[1], T[0]);
-                cr = pk_make(cr[1], cr[0]); cg = pk_make(cg[1], cg[0]); cb = pk_make(cb[1], cb[0]);
-                const int t = pix[0]; pix[0] = pix[1]; pix[1] = t;
-                live0 = true; live1 = false;
-            }
-            float sx = px[0], sy = py[0], sT = T[0], scr = cr[0], scg = cg[0], scb = cb[0];
-            for (int k0 = 0; k0 < cnt; k0 += U) {
-                float4 a[U], q[U];
-                float2 c[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) { a[u] = na[u]; q[u] = nb[u]; c[u] = nc[u]; }
-#pragma unroll
-                for (int u = 0; u < U; ++u) { na[u] = s_pa[k0 + U + u]; nb[u] = s_pb[k0 + U + u]; nc[u] = s_pc[k0 + U + u]; }
-                float alpha[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const float dx = sx - a[u].x, dy = sy - a[u].y;
-                    const float power = fmaf(dx, fmaf(a[u].w, dy, a[u].z * dx), (q[u].x * dy) * dy);
-                    alpha[u] = fminf(__builtin_amdgcn_exp2f(power) * q[u].y, 0.99f);
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) G2PC_PIN(alpha[u]);
-                float contrib[U];
-                bool any_cand = false;
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    contrib[u] = sT * alpha[u];
-                    scr = fmaf(contrib[u], q[u].z, scr);
-                    scg = fmaf(contrib[u], q[u].w, scg);
-                    scb = fmaf(contrib[u], c[u].x, scb);
-                    sT = sT - contrib[u];
-                    any_cand = any_cand || (contrib[u] >= c[u].y);
-                }
-                if (__any(any_cand ? 1 : 0)) {
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        if (__any(contrib[u] >= c[u].y)) {
-                            uint32_t bits = __float_as_uint(contrib[u]);
-                            uint32_t m = wave_max_u32_dpp(bits);
-                            const unsigned long long at_max = __ballot(bits == m);
-                            const uint32_t pm = (uint32_t)__builtin_amdgcn_readlane(pix[0], __ffsll(at_max) - 1);
-                            if (lane == 0) {
-                                unsigned long long key = ((unsigned long long)m << 32) | (unsigned long long)(uint32_t)(~(order_tile | pm));
-                                atomicMax(&best_key[s_g[k0 + u]], key);
-                            }
-                        }
-                    }
-                }
-            }
-            T = pk_make(sT, T[1]); cr = pk_make(scr, cr[1]); cg = pk_make(scg, cg[1]); cb = pk_make(scb, cb[1]);
-            live0 = !__all(sT <= t_floor ? 1 : 0);
-        }
     }
     if (chunk_work && lane == 0) {
         chunk_work[2 * blockIdx.x] = end - start;
@@ -1207,8 +976,6 @@ __global__ __launch_bounds__(RA_T) void k_fill_u32(uint32_t* __restrict__ p, lon
 }
 
 static uint32_t* g_chunk_work = nullptr;      // diagnostics hook (g2pc_raster_debug_chunk_work)
-static uint32_t g_blend_walk_cap = 0;         // diagnostics: truncate every tile list to this many entries (0 = off)
-static int g_blend_variant = 0;               // 0 = k_blend_py_pk (default), 1 = k_blend_py_v2, 2 = v2 without the adaptive width
 
 static Cam to_cam(const G2pcCamera* c) {
     Cam k;
@@ -1283,7 +1050,6 @@ static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t*
     char* sort_ws = ar.get<char>(sort_bytes);
     if (!ar.ok()) { set_error("raster_back_py", "workspace too small"); return G2PC_ERR_WORKSPACE; }
     Layout lay = to_layout(layout);
-    const bool v2 = g_blend_variant >= 1 && layout->chunk_subblocks == 2;
     if (phases & 1) {
         if (L > 0) {
             hipLaunchKernelGGL(k_duplicate, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, fb.sorted_idx, fb.offsets, fb.rect, n, lay.nx,
@@ -1293,8 +1059,7 @@ static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t*
             if (rc) return rc;
         }
         hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T)), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start, l_eff);
-        // the leaf-overflow check rides in k_blend_py_v2; the first-generation kernels need it as a launch of its own
-        if (overflow_flag && max_per_tile && !(v2 && (phases & 2)))
+        if (overflow_flag && max_per_tile)
             hipLaunchKernelGGL(k_check_tile_load, dim3(cdiv(T, RA_T)), dim3(RA_T), 0, s, tile_start, T, max_per_tile, overflow_flag);
     }
     if (phases & 2) {
@@ -1304,19 +1069,7 @@ static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t*
                        ba.camera_slot << 24, ba.t_floor, ba.bg, tilebuf, g_chunk_work, ba.job)
         switch (layout->chunk_subblocks) {
             case 1: G2PC_BLEND(k_blend_py<1, 4>); break;
-            case 2:
-#define G2PC_BLEND_V2(...)                                                                                              \
-    hipLaunchKernelGGL((__VA_ARGS__), dim3((unsigned)layout->num_chunks), dim3(BL_T), 0, s, lay, layout->chunk_tile,          \
-                       layout->chunk_pix0, tile_start, g_sorted, (const float4*)fb.rec, best_key, ba.camera_slot << 24,       \
-                       ba.t_floor, ba.bg, tilebuf, g_chunk_work, ba.job, (phases & 1) ? max_per_tile : 0u, overflow_flag)
-                if (v2 && g_blend_variant == 1) G2PC_BLEND_V2(k_blend_py_v2<4, true>);
-                else if (v2) G2PC_BLEND_V2(k_blend_py_v2<4, false>);
-#undef G2PC_BLEND_V2
-                else
-                    hipLaunchKernelGGL((k_blend_py_pk<4>), dim3((unsigned)layout->num_chunks), dim3(BL_T), 0, s, lay, layout->chunk_tile,
-                                       layout->chunk_pix0, tile_start, g_sorted, (const float4*)fb.rec, best_key, ba.camera_slot << 24,
-                                       ba.t_floor, ba.bg, tilebuf, g_chunk_work, ba.job, g_blend_walk_cap);
-                break;
+            case 2: G2PC_BLEND(k_blend_py_pk<4>); break;
             case 4: G2PC_BLEND(k_blend_py<4, 1>); break;
             default: set_error("raster_back_py", "chunk_subblocks must be 1, 2 or 4"); return G2PC_ERR_ARG;
         }
@@ -1445,17 +1198,6 @@ int g2pc_raster_camera_update_py(const G2pcTileLayout* layout, int64_t n, uint32
 
 /* diagnostics: when set, the PY blend writes (list length, entries walked) per chunk into u32[2*num_chunks] */
 int g2pc_raster_debug_chunk_work(uint32_t* buf) { g2pc::g_chunk_work = buf; return G2PC_OK; }
-
-/* DIAGNOSTIC: truncate every tile's list to `cap` entries in k_blend_py_pk (0 = off).  Produces WRONG images; it exists to
- * measure how much of a launch is the few never-saturating walks (tools/gpu_round2_h.sh). */
-int g2pc_debug_blend_walk_cap(uint32_t cap) { g2pc::g_blend_walk_cap = cap; return G2PC_OK; }
-
-/* tuning / A-B aid: 0 = first-generation blend kernels (k_blend_py_pk), 1 = k_blend_py_v2 (default) */
-int g2pc_set_blend_variant(int variant) {
-    if (variant < 0 || variant > 2) return G2PC_ERR_ARG;
-    g2pc::g_blend_variant = variant;
-    return G2PC_OK;
-}
 
 int g2pc_raster_rebase_keys(unsigned long long* best_key, int64_t n, void* stream) {
     using namespace g2pc;

@@ -73,8 +73,6 @@ nv._RASTER_PROTOS.update({
     "g2pc_graph_destroy": (C.c_int, [C.c_void_p]),
     "g2pc_raster_rebase_keys": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "g2pc_raster_debug_chunk_work": (C.c_int, [C.c_void_p]),
-    "g2pc_set_blend_variant": (C.c_int, [C.c_int]),
-    "g2pc_debug_blend_walk_cap": (C.c_int, [C.c_uint32]),
     "g2pc_raster_key_owner": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "g2pc_raster_keep_winner_colours": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "g2pc_raster_contributions": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
@@ -207,7 +205,6 @@ class _Scratch:
 # The packed-key atomicMax makes the blends of different cameras commutative, so camera c+1's small sort / scan
 # kernels (which leave most CUs idle) and even its blend overlap camera c's blend.
 PIPELINE_STREAMS = 4
-FRONT_PRIORITY = False            # see _GraphSlot (measured: 30.7 ms per job with the split against 23.6 without)
 PIPELINE_IN_EMULATOR = False      # tests: drive the capture / replay path through the CPU emulator too
 CAPACITY_HEADROOM = 1.25          # instance capacity of the captured graphs relative to the largest count seen so far
 MIN_CAPACITY = 1 << 16
@@ -221,15 +218,6 @@ class _GraphSlot:
         self.on_gpu = on_gpu
         self.stream = torch.cuda.Stream(device) if on_gpu else None
         self.stream_ptr = C.c_void_p(self.stream.cuda_stream) if on_gpu else C.c_void_p(1)   # the emulator ignores streams
-        # FRONT_PRIORITY (experiment, off): the latency-bound head of a camera (preprocess, depth sort, binning: ~30 small
-        # launches) on a HIGH-priority stream of its own, the blend on the slot's normal one behind an event.  Motivation:
-        # under four cameras in flight the blends' 8 192 single-wave blocks fill every wave slot of the chip and a 39 us
-        # preprocess launch takes 270 us to get through (profiles/r02a_render_s4_kernel_stats.csv).  Result on MI355X:
-        # 30.7 ms per job against 23.6 ms with everything in one graph on one stream (profiles/r02b_ab_*.json) -- the
-        # cross-stream hand-over and the blend leaving the graph cost more than the head gains.
-        self.stream_hi = torch.cuda.Stream(device, priority=-1) if (on_gpu and FRONT_PRIORITY) else None
-        self.stream_hi_ptr = C.c_void_p(self.stream_hi.cuda_stream) if self.stream_hi is not None else self.stream_ptr
-        self.front_done = torch.cuda.Event() if self.stream_hi is not None else None
         nbytes = C.sizeof(_Job)
         self.job_host = torch.zeros((nbytes,), dtype=torch.uint8)
         self.count_host = torch.zeros((1,), dtype=torch.int32)
@@ -247,8 +235,6 @@ class _GraphSlot:
         if self.graph:
             if self.on_gpu:
                 self.stream.synchronize()          # never destroy an executable graph that may still be in flight
-                if self.stream_hi is not None:
-                    self.stream_hi.synchronize()
             L.g2pc_graph_destroy(self.graph)
             self.graph, self.graph_key = C.c_void_p(None), None
 
@@ -528,21 +514,20 @@ class GaussHipRenderer():
                 sl.tilebuf = torch.empty((lay.total_pixels * 3,), dtype=torch.float32, device=self.device)
         # run the state-free half once outside the capture: kernels that are launched for the first time INSIDE a stream
         # capture (k_preprocess_py<true>, k_resolve_count, ...) leave a graph that replays ~25 % slower for good
-        front = sl.stream_hi_ptr                   # the graph lives on the slot's high-priority stream when it has one
-        nv.check(self._camera_call(sl, lay, capacity, 1, front), "raster_camera_py (warm-up)")
-        nv.check(L.g2pc_graph_capture_begin(front), "graph_capture_begin")
-        rc = self._camera_call(sl, lay, capacity, key[2], front)
+        nv.check(self._camera_call(sl, lay, capacity, 1), "raster_camera_py (warm-up)")
+        nv.check(L.g2pc_graph_capture_begin(sl.stream_ptr), "graph_capture_begin")
+        rc = self._camera_call(sl, lay, capacity, key[2])
         graph = C.c_void_p(None)
-        rc_end = L.g2pc_graph_capture_end(front, C.byref(graph))
+        rc_end = L.g2pc_graph_capture_end(sl.stream_ptr, C.byref(graph))
         nv.check(rc or rc_end, "raster_camera_py (capture)")
         sl.graph, sl.graph_key = graph, key
 
-    def _camera_call(self, sl, lay, capacity, phases, stream_ptr=None):
+    def _camera_call(self, sl, lay, capacity, phases):
         return nv.lib().g2pc_raster_camera_py(nv.ptr(sl.job_dev), C.c_void_p(sl.job_host.data_ptr()), C.byref(lay.c),
                                               *self.scene_ptrs, self.colour_ptr, self.n, capacity, self.state_ptrs()[0],
                                               nv.ptr(sl.tilebuf), C.c_void_p(sl.count_host.data_ptr()),
                                               self.MAX_GAUSSIANS_PER_TILE, self.overflow_ptr, phases, nv.ptr(sl.ws),
-                                              sl.ws_bytes, stream_ptr if stream_ptr is not None else sl.stream_ptr)
+                                              sl.ws_bytes, sl.stream_ptr)
 
     def _retire(self, sl):
         """The slot's previous camera: wait for it (normally long done), collect its count / timing, queue a re-render
@@ -582,22 +567,14 @@ class GaussHipRenderer():
         if on_gpu and not any(o.inflight for o in self.slots):
             for o in self.slots:
                 o.stream.wait_stream(torch.cuda.current_stream(self.device))      # scene tensors / state are ready
-                if o.stream_hi is not None:
-                    o.stream_hi.wait_stream(torch.cuda.current_stream(self.device))
-        # The graph holds the head of the camera (front + binning) and, unless the blend has to be issued on its own, the
-        # blend.  On its own: when the head runs on the high-priority stream (the blend then follows on the slot's normal
-        # stream behind an event), and when profiling (HIP events around the blend alone; this runtime refuses
-        # event-record nodes inside a captured graph).
-        split = sl.stream_hi is not None
-        key = (id(lay), self.capacity, 1 if (nv.PROFILE is not None or split) else 3)
+        # profiling: HIP events around the blend alone -> the graph stops before it and the blend is issued directly
+        # (this runtime refuses event-record nodes inside a captured graph)
+        key = (id(lay), self.capacity, 1 if nv.PROFILE is not None else 3)
         if sl.graph_key != key:
             self._capture(sl, lay, key)
         self._camera_struct(camera, sl.job.cam)                                    # rewrite the pinned job in place
         sl.job.camera_slot, sl.job.t_floor = slot, self.t_floor
-        nv.check(L.g2pc_graph_launch(sl.graph, sl.stream_hi_ptr), "graph_launch")
-        if split:
-            sl.front_done.record(sl.stream_hi)
-            sl.stream.wait_event(sl.front_done)
+        nv.check(L.g2pc_graph_launch(sl.graph, sl.stream_ptr), "graph_launch")
         if key[2] == 1:
             with nv.region("raster_blend", self.device, sl.stream):
                 nv.check(self._camera_call(sl, lay, key[1], 2), "raster_camera_py (blend)")

@@ -50,16 +50,12 @@ def parse():
     ap.add_argument("--no-parity", action="store_true", help="skip the parity block (reference fixtures at the benchmark's scale)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_workloads lines (configs[1] sampling job)")
     ap.add_argument("--sort-bits", type=int, default=0, help="tuning aid: wide radix digit bits (8 or 11)")
-    ap.add_argument("--sort-single-pass-bits", type=int, default=0, help="tuning aid: sorts of at most this many key bits (8..11) run as one pass")
     ap.add_argument("--sort-small", type=int, default=2 << 20, help="tuning aid: inputs up to this many keys use 4 keys/thread")
     ap.add_argument("--blend-subblocks", type=int, default=0, help="tuning aid: 8x8 sub-blocks per blend wave (1, 2, 4)")
-    ap.add_argument("--blend-variant", type=int, default=0, help="tuning aid: 0 = first-generation blend kernel, 1 = k_blend_py_v2, 2 = v2 without adaptive width")
     ap.add_argument("--scene-scales", type=float, nargs=2, default=None, metavar=("LO", "HI"),
                     help="diagnostic: Gaussian scale range of the synthetic scene (default 0.002 0.02 = SURVEY.md's)")
     ap.add_argument("--no-context-pool", action="store_true", help="tuning aid: every job captures its camera graphs anew")
     ap.add_argument("--streams", type=int, default=0, help="tuning aid: cameras in flight (HIP streams) of the renderer")
-    ap.add_argument("--debug-walk-cap", type=int, default=0, help="DIAGNOSTIC (wrong images): truncate every tile list to this many entries")
-    ap.add_argument("--no-front-priority", action="store_true", help="tuning aid: camera heads on the slot's normal stream, inside one graph with the blend")
     ap.add_argument("--camera-subset", type=int, default=0, help="profiling aid: render only the first k cameras of the rig")
     ap.add_argument("--t-floor", type=float, default=None, help="blend transmittance floor (default: gauss_render.DEFAULT_T_FLOOR)")
     return ap.parse_args()
@@ -114,7 +110,7 @@ def algorithmic_bytes(workload, n, n_kept, m, cams, stats):
 
 PMC_TRAFFIC_FILE = "profiles/r02_pmc_traffic.json"      # tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE passes of THIS command
 PMC_SQ_FILE = "profiles/r02_pmc_sq.json"                # tools/pmc_kernel.py: SQ counter pass of THIS command
-BLEND_KERNELS = {0: "void g2pc::k_blend_py_pk<4>", 1: "void g2pc::k_blend_py_v2<4, true>", 2: "void g2pc::k_blend_py_v2<4, false>"}
+BLEND_KERNEL = "void g2pc::k_blend_py_pk<4>"
 
 
 def _default_config(a):
@@ -131,7 +127,7 @@ def pmc_traffic(region, a):
     the one profiled or the profiled kernel is not the one this build launches.  Corrected as MI355X_MICROARCH.md §HBM
     prescribes for gfx950: FETCH_SIZE counts 16-byte-per-lane loads at half their bytes (doubled), WRITE_SIZE as is."""
     path = os.path.join(ROOT, PMC_TRAFFIC_FILE)
-    kernel = {"raster_blend": BLEND_KERNELS.get(a.blend_variant), "sampler_emit": "g2pc::k_emit_rows"}.get(region)
+    kernel = {"raster_blend": BLEND_KERNEL, "sampler_emit": "g2pc::k_emit_rows"}.get(region)
     if kernel is None or not os.path.isfile(path) or not _default_config(a):
         return None, None
     rec = json.load(open(path)).get(kernel)
@@ -143,7 +139,7 @@ def pmc_valu(region, a):
     path = os.path.join(ROOT, PMC_SQ_FILE)
     if region != "raster_blend" or not os.path.isfile(path) or not _default_config(a):
         return None
-    rec = json.load(open(path)).get(BLEND_KERNELS.get(a.blend_variant, ""))
+    rec = json.load(open(path)).get(BLEND_KERNEL)
     if not rec:
         return None
     return {"insts": rec["SQ_INSTS_VALU"], "cycles_per_inst": 4.0 * rec["SQ_ACTIVE_INST_VALU"] / rec["SQ_INSTS_VALU"],
@@ -297,17 +293,10 @@ def main():
         gauss_render.DEFAULT_T_FLOOR = a.t_floor
     if a.sort_bits:
         nv.lib().g2pc_set_sort_tuning(a.sort_bits, a.sort_small)
-    if a.sort_single_pass_bits:
-        nv.check(nv.lib().g2pc_set_sort_single_pass_bits(a.sort_single_pass_bits), "set_sort_single_pass_bits")
     if a.blend_subblocks:
         gauss_render.BLEND_SUBBLOCKS = a.blend_subblocks
-    nv.check(nv.lib().g2pc_set_blend_variant(a.blend_variant), "set_blend_variant")
-    if a.debug_walk_cap:
-        nv.lib().g2pc_debug_blend_walk_cap(a.debug_walk_cap)
     if a.streams:
         gauss_render.PIPELINE_STREAMS = a.streams
-    if a.no_front_priority:
-        gauss_render.FRONT_PRIORITY = False
     if a.no_context_pool:
         gauss_render.CONTEXT_POOL_SIZE = 0
 

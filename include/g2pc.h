@@ -46,9 +46,6 @@ int g2pc_scan_exclusive_u32(const uint32_t* in, uint32_t* out, int64_t n, void* 
 size_t g2pc_sort_workspace(int64_t n);
 /* tuning: digit width (8 or 11 bits) for sorts of more than 8 bits; inputs up to small_input_keys use 4 keys/thread */
 int g2pc_set_sort_tuning(int wide_digit_bits, int64_t small_input_keys);
-/* tuning aid: key ranges of at most `bits` bits (8..11) are sorted in ONE pass with 2^bits bins */
-int g2pc_set_sort_single_pass_bits(int bits);
-
 /* --- hipGraph capture of a sequence of g2pc_* calls --------------------------------------------------------------------
  * Every g2pc_* entry point only queues work on `stream` (no allocation, no synchronisation), so whatever is called
  * between g2pc_graph_capture_begin(stream) and g2pc_graph_capture_end(stream, &graph) -- on that stream, with fixed
@@ -319,12 +316,6 @@ int g2pc_raster_camera_update_py(const G2pcTileLayout* layout, int64_t n, uint32
 int g2pc_raster_rebase_keys(unsigned long long* best_key, int64_t n, void* stream);
 /* diagnostics: when non-NULL, the PY blend records (tile list length, entries walked) per chunk in u32[2*num_chunks] */
 int g2pc_raster_debug_chunk_work(uint32_t* buf);
-/* tuning / A-B aid: which python-semantics blend kernel 2-sub-block layouts use.  0 = first generation
- * (k_blend_py_pk), 1 = k_blend_py_v2 (default: LDS reads one trip ahead, 10-dword staged records, packed -> scalar
- * width once one 8x8 sub-block is below the floor).  Same results above the transmittance floor, bit for bit. */
-int g2pc_set_blend_variant(int variant);
-/* DIAGNOSTIC ONLY: truncate every tile list to `cap` entries in the default blend kernel (0 = off); wrong images. */
-int g2pc_debug_blend_walk_cap(uint32_t cap);
 /* --- native-rasteriser ("cuda") semantics: _C.rasterize_gaussians (rasterize_points.h:18-41) ----------------------
  * Deterministic spec of SURVEY.md §8(a.5): 16x16 tiles, near cull z_view <= 0.2, radius ceil(3 sqrt(lambda_max)),
  * stable (tile, depth) order, alpha rules (power > 0 skip, min(0.99, .), alpha < 1/255 skip, T(1-alpha) < 1e-4 stop),
