@@ -32,6 +32,8 @@ _PROTOS = {
     "g2pc_scan_exclusive_u32": (C.c_int, [_vp, _vp, _i64, _vp, _sz, _vp]),
     "g2pc_sort_workspace": (_sz, [_i64]),
     "g2pc_set_sort_tuning": (C.c_int, [C.c_int, _i64]),
+    "g2pc_bucket_sort_workspace": (_sz, [_i64]),
+    "g2pc_bucket_sort_u32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
     "g2pc_sort_pairs_u32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, _vp, _sz, _vp]),
     "g2pc_build_covariances": (C.c_int, [_vp, _vp, _f32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "g2pc_cull_mask": (C.c_int, [_vp, _vp, _i64, C.c_int, _f32, _vp, _vp, _vp, _vp]),

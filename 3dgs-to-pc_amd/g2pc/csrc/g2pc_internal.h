@@ -88,6 +88,12 @@ int sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* k
                    uint32_t* keys_tmp, uint32_t* vals_tmp, long n, int bit_lo, int bit_hi, void* ws,
                    size_t ws_bytes, hipStream_t s, const uint32_t* n_dev = nullptr);
 
+// bucket sort of (key, input position) pairs for range-spread float-bit keys (see prims.hip); *overflow_flag points into
+// the workspace afterwards (device u32: non-zero = a bucket overflowed, sort again with sort_pairs_u32)
+size_t bucket_sort_workspace(long n);
+int bucket_sort_u32(const uint32_t* keys, const uint32_t* vals, uint32_t* vals_out, uint32_t* keys_out, long n, void* ws,
+                    size_t ws_bytes, uint32_t** overflow_flag, hipStream_t s);
+
 // Philox4x32-10 keyed standard normals (see oracle/np_philox.py for the definition)
 struct Normal3 { float x, y, z; };
 __device__ __forceinline__ Normal3 keyed_normal3(unsigned seed_lo, unsigned seed_hi, unsigned gid_lo,

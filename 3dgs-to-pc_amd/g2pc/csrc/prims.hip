@@ -428,6 +428,132 @@ int sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* k
     return check_launch("sort");
 }
 
+// ------------------------------------------------------------------------------------------------
+// Bucket sort of (key, input position) pairs -- the depth order of one camera in five launches instead of the twelve
+// of a four-pass LSD radix sort.  Keys are bit patterns of positive floats (monotone as integers) and spread smoothly
+// over their range, so ONE most-significant-digit pass into BK_NB range-normalised buckets leaves ~n / BK_NB keys per
+// bucket, and a bucket is finished by a bitonic sort of its 64-bit (key, position) composites entirely in LDS (32 KB of
+// the CU's 160).  The composite makes the result THE stable ascending order (ties in input order), whatever order the
+// atomics of the scatter left inside a bucket.  Keys 0xFFFFFFFF ("not on screen") go to a tail bucket that is copied,
+// not sorted.  A bucket with more than BK_CAP keys (a scene whose depths pile up in 1/1024 of their range) raises
+// `overflow`: the caller repeats the sort with the radix path.
+// ------------------------------------------------------------------------------------------------
+constexpr int BK_NB = 1024, BK_CAP = 4096, BK_T = 256;
+struct BucketHdr {
+    uint32_t neg_kmin, kmax, overflow, pad;         // max(~key) = ~min(key), max(key): one memset(0) initialises all of it
+    uint32_t count[BK_NB + 2], start[BK_NB + 2], cursor[BK_NB + 2];
+};
+__device__ __forceinline__ unsigned bucket_of(uint32_t key, uint32_t kmin, uint32_t kmax) {
+    if (key == 0xFFFFFFFFu) return BK_NB;
+    const uint32_t span = kmax - kmin;
+    const int shift = span < (uint32_t)BK_NB ? 0 : (32 - __clz(span)) - 10;
+    return (key - kmin) >> shift;
+}
+__global__ __launch_bounds__(BK_T) void k_bk_minmax(const uint32_t* __restrict__ keys, long n, BucketHdr* __restrict__ h) {
+    uint32_t a = 0, b = 0;
+    for (long i = (long)blockIdx.x * BK_T + threadIdx.x; i < n; i += (long)gridDim.x * BK_T) {
+        const uint32_t k = keys[i];
+        if (k != 0xFFFFFFFFu) { a = umax_(a, ~k); b = umax_(b, k); }
+    }
+    a = wave_max_u32(a); b = wave_max_u32(b);
+    if ((threadIdx.x & 63) == 0 && (a | b)) { atomicMax(&h->neg_kmin, a); atomicMax(&h->kmax, b); }
+}
+__global__ __launch_bounds__(BK_T) void k_bk_hist(const uint32_t* __restrict__ keys, long n, BucketHdr* __restrict__ h) {
+    __shared__ uint32_t lh[BK_NB + 1];
+    for (int i = threadIdx.x; i <= BK_NB; i += BK_T) lh[i] = 0;
+    __syncthreads();
+    const uint32_t kmin = ~h->neg_kmin, kmax = h->kmax;
+    for (long i = (long)blockIdx.x * BK_T + threadIdx.x; i < n; i += (long)gridDim.x * BK_T)
+        atomicAdd(&lh[bucket_of(keys[i], kmin, kmax)], 1u);
+    __syncthreads();
+    for (int i = threadIdx.x; i <= BK_NB; i += BK_T) { const uint32_t c = lh[i]; if (c) atomicAdd(&h->count[i], c); }
+}
+__global__ __launch_bounds__(1024) void k_bk_scan(BucketHdr* __restrict__ h) {
+    __shared__ uint32_t wsum[16];
+    const unsigned t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const uint32_t c0 = h->count[t], c1 = t == 0 ? h->count[BK_NB] : 0u;      // 1024 buckets + the tail bucket
+    const uint32_t incl = wave_incl_scan_u32(c0);
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    uint32_t woff = 0, total = 0;
+    for (int k = 0; k < 16; ++k) { const uint32_t v = wsum[k]; if (k < (int)w) woff += v; total += v; }
+    const uint32_t excl = woff + incl - c0;
+    h->start[t] = excl; h->cursor[t] = excl;
+    if (c0 > (uint32_t)BK_CAP) atomicMax(&h->overflow, c0);
+    if (t == 0) { h->start[BK_NB] = total; h->cursor[BK_NB] = total; h->start[BK_NB + 1] = total + c1; }
+}
+__global__ __launch_bounds__(BK_T) void k_bk_scatter(const uint32_t* __restrict__ keys, long n, BucketHdr* __restrict__ h,
+                                                    unsigned long long* __restrict__ items) {
+    const uint32_t kmin = ~h->neg_kmin, kmax = h->kmax;
+    for (long i = (long)blockIdx.x * BK_T + threadIdx.x; i < n; i += (long)gridDim.x * BK_T) {
+        const uint32_t k = keys[i];
+        const uint32_t pos = atomicAdd(&h->cursor[bucket_of(k, kmin, kmax)], 1u);
+        items[pos] = ((unsigned long long)k << 32) | (unsigned long long)(uint32_t)i;
+    }
+}
+__global__ __launch_bounds__(BK_T) void k_bk_sort(const BucketHdr* __restrict__ h, const unsigned long long* __restrict__ items,
+                                                 const uint32_t* __restrict__ vals, uint32_t* __restrict__ vals_out,
+                                                 uint32_t* __restrict__ keys_out) {
+    __shared__ unsigned long long s_it[BK_CAP];
+    const unsigned b = blockIdx.x;
+    const uint32_t s0 = h->start[b], cnt = h->start[b + 1] - s0;
+    if (cnt == 0) return;
+    if (b == (unsigned)BK_NB || cnt > (uint32_t)BK_CAP) {           // tail bucket (or an overflowing one): copy, unsorted
+        for (uint32_t j = threadIdx.x; j < cnt; j += BK_T) {
+            const unsigned long long it = items[s0 + j];
+            vals_out[s0 + j] = vals[(uint32_t)it];
+            if (keys_out) keys_out[s0 + j] = (uint32_t)(it >> 32);
+        }
+        return;
+    }
+    uint32_t np = 2;
+    while (np < cnt) np <<= 1;
+    for (uint32_t j = threadIdx.x; j < np; j += BK_T) s_it[j] = j < cnt ? items[s0 + j] : ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= np; k <<= 1)
+        for (uint32_t jj = k >> 1; jj > 0; jj >>= 1) {
+            for (uint32_t i = threadIdx.x; i < np; i += BK_T) {
+                const uint32_t l = i ^ jj;
+                if (l > i) {
+                    const unsigned long long x = s_it[i], y = s_it[l];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) { s_it[i] = y; s_it[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    for (uint32_t j = threadIdx.x; j < cnt; j += BK_T) {
+        const unsigned long long it = s_it[j];
+        vals_out[s0 + j] = vals[(uint32_t)it];
+        if (keys_out) keys_out[s0 + j] = (uint32_t)(it >> 32);
+    }
+}
+
+size_t bucket_sort_workspace(long n) { return align_up(sizeof(BucketHdr)) + align_up((size_t)(n > 0 ? n : 1) * 8) + 256; }
+
+// vals_out[p] = vals[r_p] (and keys_out[p] = keys[r_p] when given) for the positions r sorted by (keys[r], r) ascending,
+// keys 0xFFFFFFFF last.  *overflow_flag (device u32, optional) receives the size of the largest bucket when one exceeds
+// BK_CAP -- the output is then a permutation in bucket order only and the caller must sort again with sort_pairs_u32.
+int bucket_sort_u32(const uint32_t* keys, const uint32_t* vals, uint32_t* vals_out, uint32_t* keys_out, long n, void* ws,
+                    size_t ws_bytes, uint32_t** overflow_flag, hipStream_t s) {
+    if (n <= 0) return G2PC_OK;
+    Arena ar(ws, ws_bytes);
+    BucketHdr* h = ar.get<BucketHdr>(1);
+    unsigned long long* items = ar.get<unsigned long long>((size_t)n);
+    if (!ar.ok()) { set_error("bucket_sort", "workspace too small"); return G2PC_ERR_WORKSPACE; }
+    if (hipMemsetAsync(h, 0, sizeof(BucketHdr), s) != hipSuccess) { set_error("bucket_sort", "memset failed"); return G2PC_ERR_LAUNCH; }
+    unsigned nb = cdiv(n, BK_T * 8);
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(k_bk_minmax, dim3(nb), dim3(BK_T), 0, s, keys, n, h);
+    hipLaunchKernelGGL(k_bk_hist, dim3(nb), dim3(BK_T), 0, s, keys, n, h);
+    hipLaunchKernelGGL(k_bk_scan, dim3(1), dim3(1024), 0, s, h);
+    hipLaunchKernelGGL(k_bk_scatter, dim3(nb), dim3(BK_T), 0, s, keys, n, h, items);
+    hipLaunchKernelGGL(k_bk_sort, dim3(BK_NB + 1), dim3(BK_T), 0, s, (const BucketHdr*)h, (const unsigned long long*)items, vals,
+                       vals_out, keys_out);
+    if (overflow_flag) *overflow_flag = &h->overflow;
+    return check_launch("bucket_sort");
+}
+
 // self-test of the DPP reductions against the shuffle based ones (tests only)
 __global__ __launch_bounds__(64) void k_selftest_wave_reduce(const uint32_t* __restrict__ in, uint32_t* __restrict__ out) {
     uint32_t v = in[blockIdx.x * 64 + threadIdx.x];
@@ -488,6 +614,26 @@ int g2pc_scan_exclusive_u32(const uint32_t* in, uint32_t* out, int64_t n, void* 
     return g2pc::scan_exclusive_u32(in, out, n, ws, ws_bytes, (hipStream_t)stream, nullptr);
 }
 size_t g2pc_sort_workspace(int64_t n) { return g2pc::sort_workspace(n); }
+size_t g2pc_bucket_sort_workspace(int64_t n) { return g2pc::bucket_sort_workspace(n); }
+/* Stable ascending sort of (key, value) u32 pairs for keys that are bit patterns of positive floats spread over their
+ * range (one camera's depths): range-normalised bucket pass + in-LDS bitonic sort per bucket, five launches.  Keys
+ * 0xFFFFFFFF end up last.  *overflow (device u32, zeroed here) != 0 afterwards means a bucket was too large and the
+ * result is NOT sorted: sort again with g2pc_sort_pairs_u32. */
+int g2pc_bucket_sort_u32(const uint32_t* keys, const uint32_t* vals, uint32_t* keys_out, uint32_t* vals_out, int64_t n,
+                         uint32_t* overflow, void* ws, size_t ws_bytes, void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(n >= 0, G2PC_ERR_ARG, "negative n");
+    if (n == 0) return G2PC_OK;
+    G2PC_REQUIRE(keys && vals && vals_out && ws, G2PC_ERR_ARG, "null pointer");
+    uint32_t* flag = nullptr;
+    int rc = bucket_sort_u32(keys, vals, vals_out, keys_out, (long)n, ws, ws_bytes, &flag, (hipStream_t)stream);
+    if (rc) return rc;
+    if (overflow && hipMemcpyAsync(overflow, flag, 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
+        set_error("bucket_sort", "copy failed");
+        return G2PC_ERR_LAUNCH;
+    }
+    return G2PC_OK;
+}
 int g2pc_sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
                         uint32_t* keys_tmp, uint32_t* vals_tmp, int64_t n, int bit_lo, int bit_hi, void* ws,
                         size_t ws_bytes, void* stream) {

@@ -917,10 +917,11 @@ __global__ __launch_bounds__(RA_T) void k_check_tile_load(const uint32_t* __rest
 // capacity-sized launches: the instance count stays on the device.  l_eff = L if it fits the buffers, else 0 (the
 // camera is then skipped altogether and the host, which receives L asynchronously, renders it again with more room)
 __global__ void k_resolve_count(const uint32_t* __restrict__ total, uint32_t capacity, uint32_t* __restrict__ l_eff,
-                                uint32_t* __restrict__ count_host) {
+                                uint32_t* __restrict__ count_host, const uint32_t* __restrict__ depth_overflow) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        l_eff[0] = total[0] <= capacity ? total[0] : 0u;
-        if (count_host) count_host[0] = total[0];      // pinned host memory, written through its device mapping
+        const uint32_t unsorted = depth_overflow ? *depth_overflow : 0u;       // the depth bucket sort gave up: skip the camera
+        l_eff[0] = (total[0] <= capacity && !unsorted) ? total[0] : 0u;
+        if (count_host) { count_host[0] = total[0]; count_host[1] = unsorted; }   // pinned host memory, through its device mapping
     }
 }
 // the pinned host job -> device memory, by a kernel rather than a copy node (see g2pc_raster_camera_py)
@@ -997,14 +998,19 @@ static int bits_for_tiles(unsigned t) { int b = 1; while ((1u << b) < t && b < 3
 // capture-safe API (count stays on the device, launch geometry fixed by a capacity) -------------------------------
 struct PyFrontBuffers { float4* rec; uint32_t *rect, *sorted_idx, *offsets; };      // rec: 4 x float4 per Gaussian
 
-static size_t py_front_ws(long n) { return align_up((size_t)n * 4) * 6 + sort_workspace(n) + scan_workspace(n) + 4096; }
+static size_t py_front_ws(long n) {
+    return align_up((size_t)n * 4) * 6 + sort_workspace(n) + scan_workspace(n) + bucket_sort_workspace(n) + 4096;
+}
+static int g_depth_bucket_sort = 1;           // captured camera path: 1 = bucket sort of the depth keys, 0 = radix (g2pc_set_depth_sort)
 static size_t py_back_ws(long L, int T) {
     return align_up((size_t)(L + 1) * 4) * 6 + sort_workspace(L) + scan_workspace(T + 1) + align_up((size_t)(T + 2) * 4) + 4096;
 }
 
+// depth_overflow != nullptr: the depth order comes from the bucket sort (prims.hip) and *depth_overflow points at its
+// overflow word afterwards (non-zero = NOT sorted: the caller must discard the camera and repeat it with the radix path)
 static int py_front(const Cam& cam_val, const Cam* cam_dev, const G2pcTileLayout* layout, const float* means3D,
                     const float* cov9, const float* opacity, const float* colours, long n, const PyFrontBuffers& fb,
-                    void* ws, size_t ws_bytes, hipStream_t s) {
+                    void* ws, size_t ws_bytes, hipStream_t s, uint32_t** depth_overflow = nullptr) {
     Arena ar(ws, ws_bytes);
     uint32_t* key_rev = ar.get<uint32_t>((size_t)n);
     uint32_t* idx_rev = ar.get<uint32_t>((size_t)n);
@@ -1015,6 +1021,8 @@ static int py_front(const Cam& cam_val, const Cam* cam_dev, const G2pcTileLayout
     size_t sort_bytes = sort_workspace(n), scan_bytes = scan_workspace(n);
     char* sort_ws = ar.get<char>(sort_bytes);
     char* scan_ws = ar.get<char>(scan_bytes);
+    const size_t bucket_bytes = depth_overflow ? bucket_sort_workspace(n) : 0;
+    char* bucket_ws = ar.get<char>(bucket_bytes);
     if (!ar.ok()) { set_error("raster_front_py", "workspace too small"); return G2PC_ERR_WORKSPACE; }
     if (cam_dev)
         hipLaunchKernelGGL(k_preprocess_py<true>, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, cam_val, cam_dev, to_layout(layout),
@@ -1022,7 +1030,8 @@ static int py_front(const Cam& cam_val, const Cam* cam_dev, const G2pcTileLayout
     else
         hipLaunchKernelGGL(k_preprocess_py<false>, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, cam_val, cam_dev, to_layout(layout),
                            means3D, cov9, opacity, n, key_rev, idx_rev, touched, colours, fb.rec, fb.rect);
-    int rc = sort_pairs_u32(key_rev, idx_rev, key_sorted, fb.sorted_idx, ktmp, vtmp, n, 0, 32, sort_ws, sort_bytes, s);
+    int rc = depth_overflow ? bucket_sort_u32(key_rev, idx_rev, fb.sorted_idx, nullptr, n, bucket_ws, bucket_bytes, depth_overflow, s)
+                            : sort_pairs_u32(key_rev, idx_rev, key_sorted, fb.sorted_idx, ktmp, vtmp, n, 0, 32, sort_ws, sort_bytes, s);
     if (rc) return rc;
     // exclusive scan of the tiles touched, taken in depth order (the gather rides in the scan's first kernel)
     return scan_exclusive_u32(touched, fb.offsets, n, scan_ws, scan_bytes, s, fb.sorted_idx);
@@ -1173,10 +1182,12 @@ int g2pc_raster_camera_py(const G2pcCameraJob* job_dev, const G2pcCameraJob* job
         // per camera for the lifetime of the first buffers a process pinned (25.9 -> 29 ms per 50-camera job).
         if (job_host)
             hipLaunchKernelGGL(k_fetch_job, dim3(1), dim3(64), 0, s, (const uint32_t*)job_host, (uint32_t*)job_dev);
+        uint32_t* depth_overflow = nullptr;
         rc = py_front(Cam{}, (const Cam*)&job_dev->cam, layout, means3D, cov9, opacity, colours, (long)n, fb, front_ws,
-                      front_bytes, s);
+                      front_bytes, s, g_depth_bucket_sort ? &depth_overflow : nullptr);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_resolve_count, dim3(1), dim3(64), 0, s, fb.offsets + n, (uint32_t)capacity, l_eff, count_host);
+        hipLaunchKernelGGL(k_resolve_count, dim3(1), dim3(64), 0, s, fb.offsets + n, (uint32_t)capacity, l_eff, count_host,
+                           (const uint32_t*)depth_overflow);
     }
     PyBlendArgs ba{0u, 0.0f, 0.0f, job_dev};
     rc = py_back(layout, (long)n, (long)capacity, l_eff, ba, 0, 0, fb, best_key, nullptr, tilebuf, nullptr,
@@ -1198,6 +1209,11 @@ int g2pc_raster_camera_update_py(const G2pcTileLayout* layout, int64_t n, uint32
 
 /* diagnostics: when set, the PY blend writes (list length, entries walked) per chunk into u32[2*num_chunks] */
 int g2pc_raster_debug_chunk_work(uint32_t* buf) { g2pc::g_chunk_work = buf; return G2PC_OK; }
+
+/* depth order of the capture-safe camera call: 1 = range-normalised bucket sort + in-LDS bitonic (default), 0 = 4-pass
+ * radix.  Identical results; a camera whose depths pile up (bucket overflow) is skipped and reported through
+ * count_host[1] -- the caller repeats it with g2pc_raster_front_py / _back_py, which always use the radix sort. */
+int g2pc_set_depth_sort(int bucket) { g2pc::g_depth_bucket_sort = bucket ? 1 : 0; return G2PC_OK; }
 
 int g2pc_raster_rebase_keys(unsigned long long* best_key, int64_t n, void* stream) {
     using namespace g2pc;

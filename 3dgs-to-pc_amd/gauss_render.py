@@ -73,6 +73,7 @@ nv._RASTER_PROTOS.update({
     "g2pc_graph_destroy": (C.c_int, [C.c_void_p]),
     "g2pc_raster_rebase_keys": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "g2pc_raster_debug_chunk_work": (C.c_int, [C.c_void_p]),
+    "g2pc_set_depth_sort": (C.c_int, [C.c_int]),
     "g2pc_raster_key_owner": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "g2pc_raster_keep_winner_colours": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "g2pc_raster_contributions": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
@@ -220,7 +221,7 @@ class _GraphSlot:
         self.stream_ptr = C.c_void_p(self.stream.cuda_stream) if on_gpu else C.c_void_p(1)   # the emulator ignores streams
         nbytes = C.sizeof(_Job)
         self.job_host = torch.zeros((nbytes,), dtype=torch.uint8)
-        self.count_host = torch.zeros((1,), dtype=torch.int32)
+        self.count_host = torch.zeros((2,), dtype=torch.int32)      # [instances, depth-bucket-sort overflow]
         if on_gpu:
             self.job_host, self.count_host = self.job_host.pin_memory(), self.count_host.pin_memory()
         self.job = _Job.from_address(self.job_host.data_ptr())
@@ -538,9 +539,12 @@ class GaussHipRenderer():
         sl.inflight = None
         if sl.on_gpu:
             sl.update_done.synchronize()
-        num_inst = int(sl.count_host[0])
-        if num_inst > capacity:
-            self.capacity = max(self.capacity, int(num_inst * CAPACITY_HEADROOM))
+        num_inst, unsorted = int(sl.count_host[0]), int(sl.count_host[1])
+        if num_inst > capacity or unsorted:
+            # did not fit the graph's buffers, or the depth bucket sort met a pile-up of equal depths: the graph skipped
+            # the camera as a whole; render it again through the two-call path (radix depth sort, exact instance count)
+            if num_inst > capacity:
+                self.capacity = max(self.capacity, int(num_inst * CAPACITY_HEADROOM))
             self.redo.append((cam, lay, slot))
             self.rerendered += 1
             return

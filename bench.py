@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--scene-scales", type=float, nargs=2, default=None, metavar=("LO", "HI"),
                     help="diagnostic: Gaussian scale range of the synthetic scene (default 0.002 0.02 = SURVEY.md's)")
     ap.add_argument("--no-context-pool", action="store_true", help="tuning aid: every job captures its camera graphs anew")
+    ap.add_argument("--depth-sort", default=None, choices=[None, "bucket", "radix"], help="tuning aid: depth order of the captured camera path")
     ap.add_argument("--streams", type=int, default=0, help="tuning aid: cameras in flight (HIP streams) of the renderer")
     ap.add_argument("--camera-subset", type=int, default=0, help="profiling aid: render only the first k cameras of the rig")
     ap.add_argument("--t-floor", type=float, default=None, help="blend transmittance floor (default: gauss_render.DEFAULT_T_FLOOR)")
@@ -275,6 +276,10 @@ def main():
     from g2pc.synth import make_scene, make_cameras
     nv.lib()
     import gauss_render  # noqa: F401  (registers the rasteriser prototypes)
+    if os.environ.get("G2PC_DUMMY_STREAMS") and not emulate:
+        # experiment: does the position of the renderer's streams in torch's stream pool (-> hardware queue mapping) explain
+        # the slow first context?
+        _dummy_streams = [torch.cuda.Stream(device) for _ in range(int(os.environ["G2PC_DUMMY_STREAMS"]))]
     if os.environ.get("G2PC_PREALLOC_GB") and not emulate:
         # experiment: let torch's caching allocator obtain ONE large device block first, so that everything the first job
         # allocates is carved out of it instead of coming from many separate hipMalloc calls
@@ -293,6 +298,8 @@ def main():
         gauss_render.DEFAULT_T_FLOOR = a.t_floor
     if a.sort_bits:
         nv.lib().g2pc_set_sort_tuning(a.sort_bits, a.sort_small)
+    if a.depth_sort:
+        nv.lib().g2pc_set_depth_sort(1 if a.depth_sort == "bucket" else 0)
     if a.blend_subblocks:
         gauss_render.BLEND_SUBBLOCKS = a.blend_subblocks
     if a.streams:

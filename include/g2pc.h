@@ -60,6 +60,13 @@ int g2pc_graph_destroy(void* graph_exec);
 int g2pc_sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
                         uint32_t* keys_tmp, uint32_t* vals_tmp, int64_t n, int bit_lo, int bit_hi, void* ws,
                         size_t ws_bytes, void* stream);
+/* Stable ascending sort of (key, value) pairs whose keys are bit patterns of positive floats spread over their range (a
+ * camera's depths): range-normalised bucket pass + in-LDS bitonic sort per bucket (five launches instead of twelve).
+ * Keys 0xFFFFFFFF go last.  *overflow (device u32) != 0 afterwards: a bucket held more than 4096 keys and the result is
+ * NOT sorted -- repeat with g2pc_sort_pairs_u32. */
+size_t g2pc_bucket_sort_workspace(int64_t n);
+int g2pc_bucket_sort_u32(const uint32_t* keys, const uint32_t* vals, uint32_t* keys_out, uint32_t* vals_out, int64_t n,
+                         uint32_t* overflow, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Gaussian model (gauss_handler.py)
@@ -313,6 +320,11 @@ int g2pc_raster_camera_py(const G2pcCameraJob* job_dev, const G2pcCameraJob* job
                           void* stream);
 int g2pc_raster_camera_update_py(const G2pcTileLayout* layout, int64_t n, uint32_t camera_slot,
                                  const unsigned long long* best_key, const float* tilebuf, float* colours_out, void* stream);
+/* depth order inside g2pc_raster_camera_py: 1 = range-normalised bucket sort + in-LDS bitonic sort (default; five
+ * launches), 0 = four-pass radix sort.  Same order bit for bit.  count_host must hold TWO words: [0] = instance count,
+ * [1] != 0 = the bucket sort overflowed (depths piled up in 1/1024 of their range), the camera was skipped as a whole
+ * and has to be rendered again through the two-call path (which always sorts by radix). */
+int g2pc_set_depth_sort(int bucket);
 int g2pc_raster_rebase_keys(unsigned long long* best_key, int64_t n, void* stream);
 /* diagnostics: when non-NULL, the PY blend records (tile list length, entries walked) per chunk in u32[2*num_chunks] */
 int g2pc_raster_debug_chunk_work(uint32_t* buf);

@@ -84,3 +84,35 @@ def test_replayed_graph_with_an_empty_camera(emu, monkeypatch):
         res.append((R.best_key.numpy().copy(), R.get_gaussian_colours().numpy().copy(), [s[0] for s in R.last_stats]))
     assert 0 in res[0][2] and sorted(res[0][2]) == sorted(res[1][2])          # the empty camera really was empty
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
+def test_depth_pile_up_falls_back_to_the_radix_sort(emu, monkeypatch):
+    """6 000 Gaussians on a sheet facing the camera: almost all depths fall into one of the depth bucket sort's 1 024
+    range buckets (> 4 096 keys), the captured graph skips the camera and the host renders it again through the two-call
+    path (radix depth sort).  Result = the synchronous path's, bit for bit."""
+    import gauss_render
+    import camera_handler
+    from gauss_handler import Gaussians
+    monkeypatch.setattr(gauss_render, "BLEND_SUBBLOCKS", 4)
+    monkeypatch.setattr(gauss_render, "PIPELINE_STREAMS", 2)
+    sc = make_scene(6000, 79, scale_lo=0.01, scale_hi=0.05)
+    xyz = sc.xyz.clone()
+    xyz[:, 2] = 0.0                                          # the sheet z = 0 ...
+    xyz[:40, 2] = torch.linspace(-0.9, 0.9, 40)              # ... plus a few Gaussians that stretch the depth range
+    transforms, intr = make_cameras(3, width=160, height=90, focal=140.0)
+    eye = torch.eye(4)
+    eye[2, 3] = 3.5                                          # looking down -z at the sheet, head on: one depth for all of it
+    cams = [eye.clone(), eye.clone(), torch.tensor(transforms[sorted(transforms)[1]])]
+    cams[1][0, 3] = 0.2
+    G = Gaussians(xyz, sc.scales, sc.rots, sc.colours, sc.opacities)
+    res = []
+    for pipelined in (False, True):
+        monkeypatch.setattr(gauss_render, "PIPELINE_IN_EMULATOR", pipelined)
+        R = gauss_render.get_renderer("python", G.xyz, G.opacities.unsqueeze(1), G.colours, G.covariances,
+                                      visible_gaussian_threshold=0.05)
+        for c2w in cams:
+            R(camera_handler.get_camera("python", c2w, intr[sorted(intr)[0]]), return_image=not pipelined)
+        cols = R.get_gaussian_colours().numpy().copy()         # flushes: pending re-renders happen here
+        res.append((R.best_key.numpy().copy(), cols, R.rerendered))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert res[1][2] >= 1                                    # the pile-up really happened and was handled

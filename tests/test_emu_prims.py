@@ -84,3 +84,47 @@ def test_dpp_wave_reductions(emu):
     r = v.reshape(37, 64)
     assert np.array_equal(o[:, 0], r.max(1)) and np.array_equal(o[:, 1], r.min(1))
     assert np.array_equal(o[:, 2], r.max(1)) and np.array_equal(o[:, 3], r.min(1))
+
+
+def _bucket_sort(nv, keys, vals):
+    import ctypes as C
+    L = nv.lib()
+    n = keys.numel()
+    ko, vo = torch.empty_like(keys), torch.empty_like(vals)
+    flag = torch.zeros(1, dtype=torch.int32, device=keys.device)
+    wb = L.g2pc_bucket_sort_workspace(n)
+    ws = torch.empty(wb, dtype=torch.uint8, device=keys.device)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    nv.check(L.g2pc_bucket_sort_u32(p(keys), p(vals), p(ko), p(vo), n, p(flag), p(ws), wb, nv.stream_handle(keys.device)), "bucket_sort")
+    return ko, vo, int(flag.item())
+
+
+@pytest.mark.parametrize("n", [1, 63, 1000, 40_000])
+def test_bucket_sort_equals_stable_argsort(emu, n):
+    """Depth-like keys (bit patterns of positive floats in a narrow range, with exact ties and 'off screen' sentinels):
+    the bucket sort returns the stable ascending order, sentinels last."""
+    rng = np.random.default_rng(n)
+    depth = rng.uniform(2.5, 4.5, size=n).astype(np.float32)
+    depth[rng.integers(0, n, size=max(1, n // 10))] = depth[0]                 # exact ties
+    keys = depth.view(np.uint32).copy()
+    off = rng.random(n) < 0.1
+    keys[off] = 0xFFFFFFFF
+    vals = rng.permutation(n).astype(np.int32)
+    ko, vo, flag = _bucket_sort(emu, torch.from_numpy(keys.view(np.int32)), torch.from_numpy(vals))
+    assert flag == 0
+    order = np.argsort(keys, kind="stable")
+    nvalid = int((~off).sum())
+    assert np.array_equal(ko.numpy().view(np.uint32), keys[order])
+    assert np.array_equal(vo.numpy()[:nvalid], vals[order][:nvalid])              # sorted part: exact stable order
+    assert sorted(vo.numpy()[nvalid:].tolist()) == sorted(vals[order][nvalid:].tolist())    # tail: any order
+
+
+def test_bucket_sort_flags_a_pile_up(emu):
+    """More than 4096 keys in 1/1024 of the key range: the overflow flag is raised (the caller falls back to the radix sort)."""
+    n = 20_000
+    keys = np.full(n, np.float32(3.0)).view(np.uint32).copy()
+    keys[0] = np.float32(2.5).view(np.uint32)
+    keys[1] = np.float32(4.5).view(np.uint32)
+    ko, vo, flag = _bucket_sort(emu, torch.from_numpy(keys.view(np.int32)), torch.arange(n, dtype=torch.int32))
+    assert flag > 4096
+    assert sorted(vo.numpy().tolist()) == list(range(n))                          # still a permutation
