@@ -429,77 +429,175 @@ int sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* k
 }
 
 // ------------------------------------------------------------------------------------------------
-// Bucket sort of (key, input position) pairs -- the depth order of one camera in five launches instead of the twelve
-// of a four-pass LSD radix sort.  Keys are bit patterns of positive floats (monotone as integers) and spread smoothly
-// over their range, so ONE most-significant-digit pass into BK_NB range-normalised buckets leaves ~n / BK_NB keys per
-// bucket, and a bucket is finished by a bitonic sort of its 64-bit (key, position) composites entirely in LDS (32 KB of
-// the CU's 160).  The composite makes the result THE stable ascending order (ties in input order), whatever order the
-// atomics of the scatter left inside a bucket.  Keys 0xFFFFFFFF ("not on screen") go to a tail bucket that is copied,
-// not sorted.  A bucket with more than BK_CAP keys (a scene whose depths pile up in 1/1024 of their range) raises
+// Bucket sort of (key, input position) pairs -- the depth order of one camera in six launches instead of the twelve
+// of a four-pass LSD radix sort, every key moved ONCE.  Keys are bit patterns of positive floats (monotone as integers)
+// and spread smoothly over their range, so one most-significant-digit pass into `nbk` range-normalised buckets
+// (~BK_AVG keys each) leaves buckets that a bitonic sort of 64-bit (key, position) composites finishes entirely in LDS
+// (32 KB of the CU's 160).  The composite makes the result THE stable ascending order (ties in input order), whatever
+// order the scatter left inside a bucket.  Keys 0xFFFFFFFF ("not on screen") go to a tail bucket that is copied, not
+// sorted.  A bucket with more than its room (1024 keys; 4096 when the mean bucket exceeds 256: depths piled up in 1/nbk of their range) raises
 // `overflow`: the caller repeats the sort with the radix path.
+//   k_bk_minmax   per-block (~min, max) partials
+//   k_bk_hist     chunk c of `kpb` keys -> LDS histogram -> column c of table[bucket][chunk]
+//   k_bk_colscan  one wave per bucket: exclusive scan of its row of the table, bucket total -> count[]
+//   k_bk_scan     one block: exclusive scan of the bucket totals -> start[], overflow test
+//   k_bk_scatter  chunk c again: LDS cursors seeded with start[b] + table[b][c]; items[pos] = (key, position)
+//   k_bk_sort     one wave per bucket: bitonic sort in LDS, gather of the values
+// No global atomics and no memset: a first version reserved places with global atomicAdd cursors (1 M returning atomics
+// on 2 K addresses: 0.66 ms per camera, and every co-running kernel slowed 4x) and cleared its header with a
+// hipMemsetAsync, whose graph node this runtime did not order against the kernels around it (replays faulted).
 // ------------------------------------------------------------------------------------------------
-constexpr int BK_NB = 1024, BK_CAP = 4096, BK_T = 256;
+constexpr int BK_MIN = 1024, BK_MAX = 8192, BK_AVG = 256, BK_CAP_SMALL = 1024, BK_CAP_LARGE = 4096, BK_T = 256, BK_MAXCHUNKS = 512, BK_PARTIALS = 256, BK_TAILBLOCKS = 256;
 struct BucketHdr {
-    uint32_t neg_kmin, kmax, overflow, pad;         // max(~key) = ~min(key), max(key): one memset(0) initialises all of it
-    uint32_t count[BK_NB + 2], start[BK_NB + 2], cursor[BK_NB + 2];
+    uint32_t overflow, nbk, nchunks, cap;
+    uint32_t partial[2 * BK_PARTIALS];              // per minmax block: max(~key), max(key)
+    uint32_t count[BK_MAX + 2], start[BK_MAX + 2];
 };
-__device__ __forceinline__ unsigned bucket_of(uint32_t key, uint32_t kmin, uint32_t kmax) {
-    if (key == 0xFFFFFFFFu) return BK_NB;
-    const uint32_t span = kmax - kmin;
-    const int shift = span < (uint32_t)BK_NB ? 0 : (32 - __clz(span)) - 10;
-    return (key - kmin) >> shift;
+struct BucketPlan { uint32_t nbk, kpb, nchunks, nminmax, cap; };
+static BucketPlan bucket_plan(long n) {
+    BucketPlan p;
+    p.nbk = BK_MIN;
+    while (p.nbk < (uint32_t)BK_MAX && (long)p.nbk * BK_AVG < n) p.nbk <<= 1;
+    long kpb = 8192;                                // keys per chunk: at most BK_MAXCHUNKS chunks (the table is nbk x nchunks)
+    while (kpb * BK_MAXCHUNKS < n) kpb += 1024;
+    // room of one bucket in the in-LDS sort: 4x the mean while that fits the small footprint (8 KB per wave, which
+    // squeezes in beside the blend waves of the other cameras), else the large one
+    p.cap = (n + p.nbk - 1) / p.nbk * 4 <= BK_CAP_SMALL ? BK_CAP_SMALL : BK_CAP_LARGE;
+    p.kpb = (uint32_t)kpb;
+    p.nchunks = (uint32_t)cdiv(n, kpb);
+    long nm = cdiv(n, BK_T * 16);
+    p.nminmax = (uint32_t)(nm > BK_PARTIALS ? BK_PARTIALS : nm);
+    return p;
 }
-__global__ __launch_bounds__(BK_T) void k_bk_minmax(const uint32_t* __restrict__ keys, long n, BucketHdr* __restrict__ h) {
+struct BucketMap {                                  // bucket = (key - kmin) * nbk / (span + 1), as a 32.32 fixed-point multiply
+    uint32_t kmin, nbk; unsigned long long mul;
+    __device__ __forceinline__ void set(uint32_t neg_kmin, uint32_t kmax, uint32_t nbk_) {
+        kmin = ~neg_kmin; nbk = nbk_;
+        const unsigned long long span1 = kmax >= kmin ? (unsigned long long)(kmax - kmin) + 1ull : 1ull;
+        mul = ((unsigned long long)nbk << 32) / span1;
+    }
+    __device__ __forceinline__ unsigned of(uint32_t key) const {
+        if (key == 0xFFFFFFFFu) return nbk;
+        return (unsigned)(((unsigned long long)(key - kmin) * mul) >> 32);
+    }
+};
+// block-wide reduction of the minmax partials (every thread returns the same map)
+__device__ __forceinline__ BucketMap bucket_map_from_partials(const BucketHdr* __restrict__ h, uint32_t nminmax, uint32_t* lds2) {
+    uint32_t a = 0, b = 0;
+    for (uint32_t i = threadIdx.x; i < nminmax; i += blockDim.x) { a = umax_(a, h->partial[2 * i]); b = umax_(b, h->partial[2 * i + 1]); }
+    a = wave_max_u32(a); b = wave_max_u32(b);
+    if (threadIdx.x == 0) { lds2[0] = 0; lds2[1] = 0; }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { atomicMax(&lds2[0], a); atomicMax(&lds2[1], b); }
+    __syncthreads();
+    BucketMap m;
+    m.set(lds2[0], lds2[1], h->nbk);
+    return m;
+}
+__global__ __launch_bounds__(BK_T) void k_bk_minmax(const uint32_t* __restrict__ keys, long n, BucketHdr* __restrict__ h, BucketPlan plan) {
+    __shared__ uint32_t red[2];
     uint32_t a = 0, b = 0;
     for (long i = (long)blockIdx.x * BK_T + threadIdx.x; i < n; i += (long)gridDim.x * BK_T) {
         const uint32_t k = keys[i];
         if (k != 0xFFFFFFFFu) { a = umax_(a, ~k); b = umax_(b, k); }
     }
     a = wave_max_u32(a); b = wave_max_u32(b);
-    if ((threadIdx.x & 63) == 0 && (a | b)) { atomicMax(&h->neg_kmin, a); atomicMax(&h->kmax, b); }
+    if (threadIdx.x == 0) { red[0] = 0; red[1] = 0; }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { atomicMax(&red[0], a); atomicMax(&red[1], b); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        h->partial[2 * blockIdx.x] = red[0]; h->partial[2 * blockIdx.x + 1] = red[1];
+        if (blockIdx.x == 0) { h->overflow = 0; h->nbk = plan.nbk; h->nchunks = plan.nchunks; h->cap = plan.cap; }
+    }
 }
-__global__ __launch_bounds__(BK_T) void k_bk_hist(const uint32_t* __restrict__ keys, long n, BucketHdr* __restrict__ h) {
-    __shared__ uint32_t lh[BK_NB + 1];
-    for (int i = threadIdx.x; i <= BK_NB; i += BK_T) lh[i] = 0;
+__global__ __launch_bounds__(BK_T) void k_bk_hist(const uint32_t* __restrict__ keys, long n, const BucketHdr* __restrict__ h,
+                                                 uint32_t* __restrict__ table, BucketPlan plan) {
+    __shared__ uint32_t lh[BK_MAX + 1];
+    __shared__ uint32_t red[2];
+    const uint32_t nbk = plan.nbk;
+    for (uint32_t i = threadIdx.x; i <= nbk; i += BK_T) lh[i] = 0;
+    const BucketMap m = bucket_map_from_partials(h, plan.nminmax, red);   // (its barriers also publish the zeroed histogram)
+    const long base = (long)blockIdx.x * plan.kpb;
+    for (uint32_t j = threadIdx.x; j < plan.kpb; j += BK_T) {
+        const long i = base + j;
+        if (i < n) atomicAdd(&lh[m.of(keys[i])], 1u);
+    }
     __syncthreads();
-    const uint32_t kmin = ~h->neg_kmin, kmax = h->kmax;
-    for (long i = (long)blockIdx.x * BK_T + threadIdx.x; i < n; i += (long)gridDim.x * BK_T)
-        atomicAdd(&lh[bucket_of(keys[i], kmin, kmax)], 1u);
-    __syncthreads();
-    for (int i = threadIdx.x; i <= BK_NB; i += BK_T) { const uint32_t c = lh[i]; if (c) atomicAdd(&h->count[i], c); }
+    for (uint32_t i = threadIdx.x; i <= nbk; i += BK_T) table[(size_t)i * plan.nchunks + blockIdx.x] = lh[i];
+}
+// one wave per bucket (4 per block): table row -> exclusive prefix over the chunks, row total -> count[bucket]
+__global__ __launch_bounds__(BK_T) void k_bk_colscan(BucketHdr* __restrict__ h, uint32_t* __restrict__ table, BucketPlan plan) {
+    const uint32_t b = blockIdx.x * (BK_T / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b > plan.nbk) return;
+    uint32_t* row = table + (size_t)b * plan.nchunks;
+    uint32_t carry = 0;
+    for (uint32_t j0 = 0; j0 < plan.nchunks; j0 += 64) {
+        const uint32_t j = j0 + lane;
+        const uint32_t v = j < plan.nchunks ? row[j] : 0u;
+        const uint32_t incl = wave_incl_scan_u32(v);
+        if (j < plan.nchunks) row[j] = carry + incl - v;
+        carry += (uint32_t)__shfl((int)incl, 63);
+    }
+    if (lane == 0) h->count[b] = carry;
 }
 __global__ __launch_bounds__(1024) void k_bk_scan(BucketHdr* __restrict__ h) {
     __shared__ uint32_t wsum[16];
     const unsigned t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const uint32_t c0 = h->count[t], c1 = t == 0 ? h->count[BK_NB] : 0u;      // 1024 buckets + the tail bucket
-    const uint32_t incl = wave_incl_scan_u32(c0);
+    const uint32_t nbk = h->nbk, per = nbk >> 10;                     // nbk is a multiple of 1024: `per` buckets per thread
+    uint32_t c[BK_MAX / 1024], mine = 0, worst = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < (uint32_t)(BK_MAX / 1024); ++k) {
+        c[k] = k < per ? h->count[t * per + k] : 0u;
+        mine += c[k];
+        worst = umax_(worst, c[k]);
+    }
+    const uint32_t incl = wave_incl_scan_u32(mine);
     if (lane == 63) wsum[w] = incl;
     __syncthreads();
     uint32_t woff = 0, total = 0;
     for (int k = 0; k < 16; ++k) { const uint32_t v = wsum[k]; if (k < (int)w) woff += v; total += v; }
-    const uint32_t excl = woff + incl - c0;
-    h->start[t] = excl; h->cursor[t] = excl;
-    if (c0 > (uint32_t)BK_CAP) atomicMax(&h->overflow, c0);
-    if (t == 0) { h->start[BK_NB] = total; h->cursor[BK_NB] = total; h->start[BK_NB + 1] = total + c1; }
+    uint32_t run = woff + incl - mine;
+#pragma unroll
+    for (uint32_t k = 0; k < (uint32_t)(BK_MAX / 1024); ++k)
+        if (k < per) { h->start[t * per + k] = run; run += c[k]; }
+    if (worst > h->cap) atomicMax(&h->overflow, worst);
+    if (t == 0) { h->start[nbk] = total; h->start[nbk + 1] = total + h->count[nbk]; }   // the tail bucket
 }
-__global__ __launch_bounds__(BK_T) void k_bk_scatter(const uint32_t* __restrict__ keys, long n, BucketHdr* __restrict__ h,
-                                                    unsigned long long* __restrict__ items) {
-    const uint32_t kmin = ~h->neg_kmin, kmax = h->kmax;
-    for (long i = (long)blockIdx.x * BK_T + threadIdx.x; i < n; i += (long)gridDim.x * BK_T) {
-        const uint32_t k = keys[i];
-        const uint32_t pos = atomicAdd(&h->cursor[bucket_of(k, kmin, kmax)], 1u);
-        items[pos] = ((unsigned long long)k << 32) | (unsigned long long)(uint32_t)i;
+__global__ __launch_bounds__(BK_T) void k_bk_scatter(const uint32_t* __restrict__ keys, long n, const BucketHdr* __restrict__ h,
+                                                    const uint32_t* __restrict__ table, unsigned long long* __restrict__ items,
+                                                    BucketPlan plan) {
+    __shared__ uint32_t cur[BK_MAX + 1];
+    __shared__ uint32_t red[2];
+    const uint32_t nbk = plan.nbk;
+    for (uint32_t i = threadIdx.x; i <= nbk; i += BK_T) cur[i] = h->start[i] + table[(size_t)i * plan.nchunks + blockIdx.x];
+    const BucketMap m = bucket_map_from_partials(h, plan.nminmax, red);   // (its barriers also publish the cursors)
+    const long base = (long)blockIdx.x * plan.kpb;
+    for (uint32_t j = threadIdx.x; j < plan.kpb; j += BK_T) {
+        const long i = base + j;
+        if (i < n) {
+            const uint32_t k = keys[i];
+            const uint32_t pos = atomicAdd(&cur[m.of(k)], 1u);
+            items[pos] = ((unsigned long long)k << 32) | (unsigned long long)(uint32_t)i;
+        }
     }
 }
-__global__ __launch_bounds__(BK_T) void k_bk_sort(const BucketHdr* __restrict__ h, const unsigned long long* __restrict__ items,
-                                                 const uint32_t* __restrict__ vals, uint32_t* __restrict__ vals_out,
-                                                 uint32_t* __restrict__ keys_out) {
-    __shared__ unsigned long long s_it[BK_CAP];
-    const unsigned b = blockIdx.x;
+// one WAVE per bucket: a 64-thread block with CAP * 8 bytes of LDS finds a place on a CU whose wave slots and LDS the
+// blend of another camera is holding
+template <int CAP>
+__global__ __launch_bounds__(64) void k_bk_sort(const BucketHdr* __restrict__ h, const unsigned long long* __restrict__ items,
+                                                const uint32_t* __restrict__ vals, uint32_t* __restrict__ vals_out,
+                                                uint32_t* __restrict__ keys_out) {
+    __shared__ unsigned long long s_it[CAP];
+    const unsigned lane = threadIdx.x, nbk = h->nbk;
+    // blocks nbk .. nbk + BK_TAILBLOCKS - 1 share the tail bucket (tens of thousands of off-screen keys: one wave copying
+    // them alone, two dependent loads per trip, took longer than the rest of the sort)
+    const unsigned b = blockIdx.x < nbk ? blockIdx.x : nbk;
+    const unsigned part = blockIdx.x < nbk ? 0u : blockIdx.x - nbk, parts = blockIdx.x < nbk ? 1u : (unsigned)BK_TAILBLOCKS;
     const uint32_t s0 = h->start[b], cnt = h->start[b + 1] - s0;
     if (cnt == 0) return;
-    if (b == (unsigned)BK_NB || cnt > (uint32_t)BK_CAP) {           // tail bucket (or an overflowing one): copy, unsorted
-        for (uint32_t j = threadIdx.x; j < cnt; j += BK_T) {
+    if (b == nbk || cnt > (uint32_t)CAP) {                            // tail bucket (or an overflowing one): copy, unsorted
+        for (uint32_t j = part * 64 + lane; j < cnt; j += parts * 64) {
             const unsigned long long it = items[s0 + j];
             vals_out[s0 + j] = vals[(uint32_t)it];
             if (keys_out) keys_out[s0 + j] = (uint32_t)(it >> 32);
@@ -508,48 +606,55 @@ __global__ __launch_bounds__(BK_T) void k_bk_sort(const BucketHdr* __restrict__ 
     }
     uint32_t np = 2;
     while (np < cnt) np <<= 1;
-    for (uint32_t j = threadIdx.x; j < np; j += BK_T) s_it[j] = j < cnt ? items[s0 + j] : ~0ull;
-    __syncthreads();
+    for (uint32_t j = lane; j < np; j += 64) s_it[j] = j < cnt ? items[s0 + j] : ~0ull;
+    wave_sync();
+    // bitonic network: pair p of step jj is (i, i + jj) with i = 2 jj (p / jj) + p % jj
+    const uint32_t half = np >> 1;
     for (uint32_t k = 2; k <= np; k <<= 1)
         for (uint32_t jj = k >> 1; jj > 0; jj >>= 1) {
-            for (uint32_t i = threadIdx.x; i < np; i += BK_T) {
-                const uint32_t l = i ^ jj;
-                if (l > i) {
-                    const unsigned long long x = s_it[i], y = s_it[l];
-                    const bool up = (i & k) == 0;
-                    if ((x > y) == up) { s_it[i] = y; s_it[l] = x; }
-                }
+            for (uint32_t p = lane; p < half; p += 64) {
+                const uint32_t i = ((p & ~(jj - 1)) << 1) | (p & (jj - 1)), l = i + jj;
+                const unsigned long long x = s_it[i], y = s_it[l];
+                const bool up = (i & k) == 0;
+                if ((x > y) == up) { s_it[i] = y; s_it[l] = x; }
             }
-            __syncthreads();
+            wave_sync();
         }
-    for (uint32_t j = threadIdx.x; j < cnt; j += BK_T) {
+    for (uint32_t j = lane; j < cnt; j += 64) {
         const unsigned long long it = s_it[j];
         vals_out[s0 + j] = vals[(uint32_t)it];
         if (keys_out) keys_out[s0 + j] = (uint32_t)(it >> 32);
     }
 }
 
-size_t bucket_sort_workspace(long n) { return align_up(sizeof(BucketHdr)) + align_up((size_t)(n > 0 ? n : 1) * 8) + 256; }
+size_t bucket_sort_workspace(long n) {
+    const BucketPlan p = bucket_plan(n > 0 ? n : 1);
+    return align_up(sizeof(BucketHdr)) + align_up((size_t)(n > 0 ? n : 1) * 8) + align_up((size_t)(p.nbk + 1) * p.nchunks * 4) + 1024;
+}
 
 // vals_out[p] = vals[r_p] (and keys_out[p] = keys[r_p] when given) for the positions r sorted by (keys[r], r) ascending,
 // keys 0xFFFFFFFF last.  *overflow_flag (device u32, optional) receives the size of the largest bucket when one exceeds
-// BK_CAP -- the output is then a permutation in bucket order only and the caller must sort again with sort_pairs_u32.
+// the room of a bucket (BucketPlan::cap) -- the output is then a permutation in bucket order only and the caller must sort again with sort_pairs_u32.
 int bucket_sort_u32(const uint32_t* keys, const uint32_t* vals, uint32_t* vals_out, uint32_t* keys_out, long n, void* ws,
                     size_t ws_bytes, uint32_t** overflow_flag, hipStream_t s) {
     if (n <= 0) return G2PC_OK;
+    const BucketPlan plan = bucket_plan(n);
     Arena ar(ws, ws_bytes);
     BucketHdr* h = ar.get<BucketHdr>(1);
     unsigned long long* items = ar.get<unsigned long long>((size_t)n);
+    uint32_t* table = ar.get<uint32_t>((size_t)(plan.nbk + 1) * plan.nchunks);
     if (!ar.ok()) { set_error("bucket_sort", "workspace too small"); return G2PC_ERR_WORKSPACE; }
-    if (hipMemsetAsync(h, 0, sizeof(BucketHdr), s) != hipSuccess) { set_error("bucket_sort", "memset failed"); return G2PC_ERR_LAUNCH; }
-    unsigned nb = cdiv(n, BK_T * 8);
-    if (nb > 1024) nb = 1024;
-    hipLaunchKernelGGL(k_bk_minmax, dim3(nb), dim3(BK_T), 0, s, keys, n, h);
-    hipLaunchKernelGGL(k_bk_hist, dim3(nb), dim3(BK_T), 0, s, keys, n, h);
+    hipLaunchKernelGGL(k_bk_minmax, dim3(plan.nminmax), dim3(BK_T), 0, s, keys, n, h, plan);
+    hipLaunchKernelGGL(k_bk_hist, dim3(plan.nchunks), dim3(BK_T), 0, s, keys, n, (const BucketHdr*)h, table, plan);
+    hipLaunchKernelGGL(k_bk_colscan, dim3(cdiv(plan.nbk + 1, BK_T / 64)), dim3(BK_T), 0, s, h, table, plan);
     hipLaunchKernelGGL(k_bk_scan, dim3(1), dim3(1024), 0, s, h);
-    hipLaunchKernelGGL(k_bk_scatter, dim3(nb), dim3(BK_T), 0, s, keys, n, h, items);
-    hipLaunchKernelGGL(k_bk_sort, dim3(BK_NB + 1), dim3(BK_T), 0, s, (const BucketHdr*)h, (const unsigned long long*)items, vals,
-                       vals_out, keys_out);
+    hipLaunchKernelGGL(k_bk_scatter, dim3(plan.nchunks), dim3(BK_T), 0, s, keys, n, (const BucketHdr*)h, (const uint32_t*)table, items, plan);
+    if (plan.cap == (uint32_t)BK_CAP_SMALL)
+        hipLaunchKernelGGL(k_bk_sort<BK_CAP_SMALL>, dim3(plan.nbk + BK_TAILBLOCKS), dim3(64), 0, s, (const BucketHdr*)h,
+                           (const unsigned long long*)items, vals, vals_out, keys_out);
+    else
+        hipLaunchKernelGGL(k_bk_sort<BK_CAP_LARGE>, dim3(plan.nbk + BK_TAILBLOCKS), dim3(64), 0, s, (const BucketHdr*)h,
+                           (const unsigned long long*)items, vals, vals_out, keys_out);
     if (overflow_flag) *overflow_flag = &h->overflow;
     return check_launch("bucket_sort");
 }

@@ -22,6 +22,26 @@ import numpy as np
 SUBBLOCKS_PER_CHUNK = 2      # 8x8-pixel sub-blocks per blend wave (1, 2 or 4 pixels per lane; 2 = packed-f32 kernel)
 
 
+def _chunks_of_tile(nsbx: int, nsby: int, subblocks: int):
+    """chunk_pix0 entries of one tile of nsbx x nsby 8x8 sub-blocks (numbered row-major).  1 or 4 sub-blocks per chunk:
+    the first sub-block of each run of consecutive ones.  2 (the packed kernel): pairs of ADJACENT sub-blocks `a | b << 16`
+    (b = 0xFFFF: none) -- side by side along each row, the odd last column paired downwards -- so that a chunk is a
+    compact 16x8 / 8x16 pixel rectangle and far-away Gaussians can be culled per chunk (k_blend_py_pk)."""
+    if subblocks != 2:
+        return list(range(0, nsbx * nsby, subblocks))
+    out = []
+    for r in range(nsby):
+        for c in range(0, nsbx - 1, 2):
+            out.append((r * nsbx + c) | ((r * nsbx + c + 1) << 16))
+    if nsbx % 2:
+        c = nsbx - 1
+        for r in range(0, nsby - 1, 2):
+            out.append((r * nsbx + c) | (((r + 1) * nsbx + c) << 16))
+        if nsby % 2:
+            out.append(((nsby - 1) * nsbx + c) | (0xFFFF << 16))
+    return out
+
+
 def _finish(xs, ws, ys, hs, seq_of, subblocks=None, tile_shard=None) -> Dict[str, np.ndarray]:
     subblocks = SUBBLOCKS_PER_CHUNK if subblocks is None else subblocks
     nx, ny = len(xs), len(ys)
@@ -59,7 +79,7 @@ def _finish(xs, ws, ys, hs, seq_of, subblocks=None, tile_shard=None) -> Dict[str
     chunk_tile, chunk_pix0 = [], []
     for g0 in range(0, len(order_t), 8):
         group = order_t[g0:g0 + 8]
-        per_tile = [list(range(0, ((ws[t % nx] + 7) // 8) * ((hs[t // nx] + 7) // 8), subblocks)) for t in group]
+        per_tile = [_chunks_of_tile((ws[t % nx] + 7) // 8, (hs[t // nx] + 7) // 8, subblocks) for t in group]
         for c in range(max(len(p) for p in per_tile)):
             for k, t in enumerate(group):
                 if c < len(per_tile[k]):
@@ -68,7 +88,7 @@ def _finish(xs, ws, ys, hs, seq_of, subblocks=None, tile_shard=None) -> Dict[str
     return dict(nx=nx, ny=ny, xs=np.asarray(xs, np.int32), ws=np.asarray(ws, np.int32),
                 ys=np.asarray(ys, np.int32), hs=np.asarray(hs, np.int32), tile_seq=rank, seq_tile=seq_tile,
                 tile_pix_off=off.astype(np.int32), chunk_tile=np.asarray(chunk_tile, np.int32),
-                chunk_pix0=np.asarray(chunk_pix0, np.int32), total_pixels=int(off[-1]), chunk_subblocks=int(subblocks))
+                chunk_pix0=np.asarray(chunk_pix0, np.int64).astype(np.uint32).view(np.int32), total_pixels=int(off[-1]), chunk_subblocks=int(subblocks))
 
 
 def python_quadtree_layout(width: int, height: int, max_tile_size: int = 60, subblocks=None,

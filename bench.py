@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--scene-scales", type=float, nargs=2, default=None, metavar=("LO", "HI"),
                     help="diagnostic: Gaussian scale range of the synthetic scene (default 0.002 0.02 = SURVEY.md's)")
     ap.add_argument("--no-context-pool", action="store_true", help="tuning aid: every job captures its camera graphs anew")
+    ap.add_argument("--blend-variant", type=int, default=None, choices=[None, 0, 1], help="tuning aid: 1 = dual-list blend kernel, 0 = packed kernel")
     ap.add_argument("--depth-sort", default=None, choices=[None, "bucket", "radix"], help="tuning aid: depth order of the captured camera path")
     ap.add_argument("--streams", type=int, default=0, help="tuning aid: cameras in flight (HIP streams) of the renderer")
     ap.add_argument("--camera-subset", type=int, default=0, help="profiling aid: render only the first k cameras of the rig")
@@ -298,6 +299,8 @@ def main():
         gauss_render.DEFAULT_T_FLOOR = a.t_floor
     if a.sort_bits:
         nv.lib().g2pc_set_sort_tuning(a.sort_bits, a.sort_small)
+    if a.blend_variant is not None:
+        nv.lib().g2pc_set_blend_variant(a.blend_variant)
     if a.depth_sort:
         nv.lib().g2pc_set_depth_sort(1 if a.depth_sort == "bucket" else 0)
     if a.blend_subblocks:

@@ -254,7 +254,7 @@ typedef struct G2pcTileLayout {      /* HOST struct of DEVICE pointers: tiles = 
     const int32_t* tile_pix_off;     /* [ny*nx+1] pixel offset of every tile inside the per-tile colour buffer */
     int32_t num_chunks;              /* blend work list: one wave64 per chunk = chunk_subblocks consecutive 8x8 pixel */
     const int32_t* chunk_tile;       /* [num_chunks]    sub-blocks of a tile (sub-blocks row-major inside the tile)   */
-    const int32_t* chunk_pix0;       /* [num_chunks] first sub-block of the chunk */
+    const int32_t* chunk_pix0;       /* [num_chunks] first sub-block of the chunk; chunk_subblocks = 2: a | b << 16, two adjacent sub-blocks (b = 0xFFFF: none) */
     int32_t chunk_subblocks;         /* 1, 2 or 4 (pixels per lane) */
 } G2pcTileLayout;
 
@@ -325,6 +325,8 @@ int g2pc_raster_camera_update_py(const G2pcTileLayout* layout, int64_t n, uint32
  * [1] != 0 = the bucket sort overflowed (depths piled up in 1/1024 of their range), the camera was skipped as a whole
  * and has to be rendered again through the two-call path (which always sorts by radix). */
 int g2pc_set_depth_sort(int bucket);
+/* tuning aid: blend kernel of the python-semantics rasteriser for 2 sub-blocks per wave: 1 = dual-list (default), 0 = packed */
+int g2pc_set_blend_variant(int variant);
 int g2pc_raster_rebase_keys(unsigned long long* best_key, int64_t n, void* stream);
 /* diagnostics: when non-NULL, the PY blend records (tile list length, entries walked) per chunk in u32[2*num_chunks] */
 int g2pc_raster_debug_chunk_work(uint32_t* buf);

@@ -83,6 +83,10 @@ def run_vs_oracle(n, seed, width, height, focal, ncam, device="cpu", scale=(0.00
     seen = O.max_contribution > (t_floor if t_floor > 0 else -1.0)
     worst["colour"] = float(dcol[seen].max())
     worst["colour_frac_off"] = float((dcol[seen] > 1e-4).float().mean())
+    # Gaussians whose colour is off: each is one flipped arg-max between pixels whose contributions tie to ~1e-6 (the
+    # colour is the rendered colour of the winning pixel), image and contributions unaffected
+    worst["colour_off_gaussians"] = int((dcol[seen] > 1e-4).any(dim=1).sum())
+    worst["seen_gaussians"] = int(seen.sum())
     flips = (R.get_visible_gaussians().cpu() != O.get_visible_gaussians())
     worst["flips"] = int(flips.sum())
     worst["near_threshold"] = int(((O.max_contribution - 0.05).abs() < 1e-5).sum())

@@ -71,7 +71,8 @@ def test_render_vs_oracle_other_sizes(n, w, h, f, res):
     # The bulk agrees to ~1e-6.  Isolated outliers are inherent: tile membership is a strict float comparison of
     # mean +- radius against integer tile edges (gauss_render.py:308-310), so a 1-ulp difference in a projected
     # mean moves a Gaussian in or out of one tile and changes that tile's pixels by up to exp(-4.5)*opacity.
-    assert r["image_frac_off"] < 1e-4 and r["contribution_frac_off"] < 1e-4 and r["colour_frac_off"] < 1e-4, r
+    assert r["image_frac_off"] < 1e-4 and r["contribution_frac_off"] < 1e-4, r
+    assert r["colour_off_gaussians"] <= max(1, 1e-4 * r["seen_gaussians"]), r       # at most one flipped arg-max in 10 000
     assert r["image"] < 2e-2 and r["contribution"] < 2e-2, r
     assert r["flips"] <= r["near_threshold"] + 1, r   # a mask may only flip where the oracle sits within 1e-5 of 0.05
 
@@ -105,7 +106,8 @@ def test_render_100k_gaussians_vs_oracle():
     from render_checks import run_vs_oracle
     r = run_vs_oracle(100_000, 1239, 1280, 720, 1100.0, 1, device=DEV, scale=(0.002, 0.02), t_floor=1e-6)
     print(r)
-    assert r["image_frac_off"] < 1e-4 and r["contribution_frac_off"] < 1e-4 and r["colour_frac_off"] < 1e-4, r
+    assert r["image_frac_off"] < 1e-4 and r["contribution_frac_off"] < 1e-4, r
+    assert r["colour_off_gaussians"] <= max(1, 1e-4 * r["seen_gaussians"]), r       # at most one flipped arg-max in 10 000
     assert r["image"] < 2e-2 and r["contribution"] < 2e-2, r
     assert r["flips"] <= r["near_threshold"] + 1, r
 
