@@ -71,3 +71,19 @@ for _ in range(24):
             for k, thr in (("skip3e-8", 3e-8), ("skip1e-6", 1e-6), ("skip1e-5", 1e-5), ("skip1e-4", 1e-4)):
                 tot[k] += int((amax < thr).sum())
 print({k: v for k, v in tot.items()}, {k: round(v / tot["visits"], 3) for k, v in tot.items()})
+
+# ---- tile-level: instances (Gaussian, tile) whose alpha stays below 2^-25 on the whole tile
+tot_i = cul_i = 0
+for _ in range(24):
+    x0 = int(rng.integers(4, W // tw - 4)) * tw; y0 = int(rng.integers(4, 28)) * th
+    m = (rmaxx.clip(max=x0 + tw - 1) > rminx.clip(min=x0)) & (rmaxy.clip(max=y0 + th - 1) > rminy.clip(min=y0))
+    idx = m.nonzero()[:, 0]
+    if idx.numel() < 64: continue
+    idx = idx[torch.randperm(idx.numel())[:3000]]
+    ys, xs = torch.meshgrid(torch.arange(y0, y0 + th), torch.arange(x0, x0 + tw), indexing="ij")
+    dx = xs.reshape(-1, 1).float() - mx[idx][None]; dy = ys.reshape(-1, 1).float() - my[idx][None]
+    cn = conic[idx]
+    a = torch.exp(-0.5 * (dx * dx * cn[:, 0, 0] + dy * dy * cn[:, 1, 1] + 2 * dx * dy * cn[:, 0, 1])) * op[idx][None]
+    amax = a.max(0).values
+    tot_i += idx.numel(); cul_i += int((amax < 2.0 ** -25).sum())
+print("tile-level: instances sampled", tot_i, "with alpha < 2^-25 on the whole tile:", cul_i, round(cul_i / max(tot_i, 1), 3))
