@@ -91,6 +91,7 @@ int sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* k
 // bucket sort of (key, input position) pairs for range-spread float-bit keys (see prims.hip); *overflow_flag points into
 // the workspace afterwards (device u32: non-zero = a bucket overflowed, sort again with sort_pairs_u32)
 size_t bucket_sort_workspace(long n);
+bool bucket_sort_pays(long n);          // measured on MI355X: 90 vs 101 us (radix) at 1 M keys, 533 vs 278 us at 5 M
 int bucket_sort_u32(const uint32_t* keys, const uint32_t* vals, uint32_t* vals_out, uint32_t* keys_out, long n, void* ws,
                     size_t ws_bytes, uint32_t** overflow_flag, hipStream_t s);
 

@@ -627,6 +627,9 @@ __global__ __launch_bounds__(64) void k_bk_sort(const BucketHdr* __restrict__ h,
     }
 }
 
+// the per-bucket sort is one wave per bucket: it pays while buckets stay small (the 8 KB footprint)
+bool bucket_sort_pays(long n) { return n > 0 && bucket_plan(n).cap == (uint32_t)BK_CAP_SMALL; }
+
 size_t bucket_sort_workspace(long n) {
     const BucketPlan p = bucket_plan(n > 0 ? n : 1);
     return align_up(sizeof(BucketHdr)) + align_up((size_t)(n > 0 ? n : 1) * 8) + align_up((size_t)(p.nbk + 1) * p.nchunks * 4) + 1024;

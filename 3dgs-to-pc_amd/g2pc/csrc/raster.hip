@@ -821,200 +821,6 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_dl(Layout lay, const int32_t*
     }
 }
 
-// K6 (PY), two-wave variant of the dual-list kernel: one 128-thread block per chunk, wave w blends sub-block w.  A
-// batch is 128 list entries (one per thread, each tested against BOTH sub-blocks and appended -- in depth order: wave
-// 0's survivors first -- to the lists it can touch), then every wave walks only its own list.  Same loads, tests and
-// (pixel, Gaussian) pairs as k_blend_py_dl, but a chunk's serial chain -- batches to stage, entries to walk -- is half
-// as long, and the launch has twice the waves to fill the SIMDs during its long tail (average residency of the
-// single-wave kernels: ~2 waves per SIMD, which is why they sit at ~30 % of the VALU issue rate).
-template <int U>
-__global__ __launch_bounds__(2 * BL_T) void k_blend_py_2w(Layout lay, const int32_t* __restrict__ chunk_tile,
-                                                         const int32_t* __restrict__ chunk_pix0,
-                                                         const uint32_t* __restrict__ tile_start,
-                                                         const uint32_t* __restrict__ inst_g,
-                                                         const float4* __restrict__ rec,
-                                                         unsigned long long* __restrict__ best_key, uint32_t order_base,
-                                                         float t_floor, float bg, float* __restrict__ tilebuf,
-                                                         uint32_t* __restrict__ chunk_work,
-                                                         const G2pcCameraJob* __restrict__ job) {
-    if (job) { order_base = job->camera_slot << 24; t_floor = job->t_floor; bg = job->cam.bg[0]; }
-    constexpr int NB = 2 * BL_BATCH;                // list entries per batch
-    __shared__ float4 s_a[2][NB + 4];               // A, B, C, Lu
-    __shared__ float4 s_b[2][NB + 4];               // Lv, K, red, green
-    __shared__ float2 s_c[2][NB + 4];               // blue, max(running maximum, FLT_MIN)
-    __shared__ uint32_t s_g[2][NB];
-    __shared__ int s_cnt[2][2];                     // [wave][list] survivors of the current batch
-    __shared__ int s_done[2];                       // sub-block saturated (or absent)
-    const int tile = chunk_tile[blockIdx.x];
-    const uint32_t sbpair = (uint32_t)chunk_pix0[blockIdx.x];    // a | b << 16, b = 0xFFFF: none
-    const int ix = tile % lay.nx, iy = tile / lay.nx;
-    const int x0 = lay.xs[ix], w = lay.ws[ix], y0 = lay.ys[iy], h = lay.hs[iy];
-    const int nsbx = (w + 7) >> 3;
-    const uint32_t order_tile = order_base | ((uint32_t)lay.tile_seq[tile] << 12);
-    const unsigned tid = threadIdx.x, lane = tid & 63;
-    const int wv = (int)(tid >> 6);                 // this wave's sub-block / list
-    const int lx = lane & 7, ly = lane >> 3;
-    const float uu = (float)lx - 3.5f, vv = (float)ly - 3.5f;
-
-    float ox[2], oy[2], rx1[2], ry1[2];
-    bool dn[2];                                     // block-uniform view of s_done, one batch old
-    int mypix = -1;
-    float T = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int sb = (int)((sbpair >> (16 * j)) & 0xFFFFu);
-        const bool present = sb != 0xFFFF;
-        const int sx = present ? (sb % nsbx) * 8 : 0, sy = present ? (sb / nsbx) * 8 : 0;
-        ox[j] = (float)(x0 + sx) + 3.5f;
-        oy[j] = (float)(y0 + sy) + 3.5f;
-        rx1[j] = (float)(x0 + (sx + 7 > w - 1 ? w - 1 : sx + 7));   // the cull rectangle stops at the tile's edge
-        ry1[j] = (float)(y0 + (sy + 7 > h - 1 ? h - 1 : sy + 7));
-        dn[j] = !present;
-        if (j == wv) {
-            const int x = sx + lx, y = sy + ly;
-            const bool valid = present && (x < w) && (y < h);
-            mypix = valid ? y * w + x : -1;
-            T = valid ? 1.0f : 0.0f;
-        }
-    }
-    bool mydone = dn[wv];
-    if (lane == 0) s_done[wv] = mydone ? 1 : 0;
-    const bool cull = t_floor > 0.0f;        // t_floor = 0 is the to-the-letter mode: nothing is skipped
-
-    const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    uint32_t g_cur = 0, g_nxt = 0;
-    bool v_cur = (start + tid) < end, v_nxt = (start + NB + tid) < end;
-    if (v_cur) g_cur = inst_g[start + tid];
-    if (v_nxt) g_nxt = inst_g[start + NB + tid];
-    float4 r0 = zero4, r1 = zero4, r2 = zero4;
-    uint32_t gmb = 0x7F000000u;
-    if (v_cur) {
-        r0 = rec[4 * (size_t)g_cur];
-        r1 = rec[4 * (size_t)g_cur + 1];
-        r2 = rec[4 * (size_t)g_cur + 2];
-        gmb = ((const uint32_t*)best_key)[2 * (size_t)g_cur + 1];   // live running maximum
-    }
-    uint32_t processed = 0;
-    for (uint32_t b = start; b < end; b += NB) {
-        processed = b + NB - start;
-        if (processed == 16 * NB) __builtin_amdgcn_s_setprio(2);
-        // (1) test this thread's entry against both sub-blocks (chunk_may_touch), count the survivors per wave
-        bool keep[2];
-        unsigned long long kept[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            keep[j] = !dn[j] && v_cur && (!cull || chunk_may_touch(r0, r1, r2.w, ox[j] - 3.5f, rx1[j], oy[j] - 3.5f, ry1[j]));
-            kept[j] = __ballot(keep[j] ? 1 : 0);
-        }
-        if (lane == 0) { s_cnt[wv][0] = __popcll(kept[0]); s_cnt[wv][1] = __popcll(kept[1]); }
-        __syncthreads();                    // counts and s_done published; every wave has left the previous batch's lists
-        dn[0] = s_done[0] != 0;
-        dn[1] = s_done[1] != 0;
-        if (dn[0] && dn[1]) break;          // block-uniform
-        int total[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int c0 = s_cnt[0][j];
-            total[j] = c0 + s_cnt[1][j];
-            if (keep[j]) {
-                const int pos = (wv ? c0 : 0) + __popcll(kept[j] & ((1ull << lane) - 1ull));
-                const float mx = r0.x - ox[j], my = r0.y - oy[j];
-                const float A = r0.z, B = r0.w, C = r1.x;
-                const float h1 = fmaf(A, mx, B * my);                                     // A mx + B my
-                const float Lu = -(fmaf(A, mx, h1)), Lv = -(fmaf(2.0f * C, my, B * mx));
-                const float K = fmaf(h1, mx, fmaf(C * my, my, -25.5f - r2.w));            // ... + log2(opacity)
-                s_a[j][pos] = make_float4(A, B, C, Lu);
-                s_b[j][pos] = make_float4(Lv, K, r2.x, r2.y);
-                s_c[j][pos] = make_float2(r2.z, fmaxf(__uint_as_float(gmb), 1.17549435e-38f));
-                s_g[j][pos] = g_cur;
-            }
-            if (wv == j && lane < (unsigned)U) {            // the last trip reads up to U - 1 entries past the end: alpha = 0 ones
-                s_a[j][total[j] + lane] = zero4;
-                s_b[j][total[j] + lane] = make_float4(0.f, -INFINITY, 0.f, 0.f);
-                s_c[j][total[j] + lane] = make_float2(0.f, 1.17549435e-38f);
-            }
-        }
-        // loads of the next batch (parameters) and the one after (ids): they complete under this batch's walk
-        g_cur = g_nxt;
-        v_cur = v_nxt;
-        v_nxt = (b + 2 * NB + tid) < end;
-        g_nxt = 0;
-        if (v_nxt) g_nxt = inst_g[b + 2 * NB + tid];
-        r0 = zero4; r1 = zero4; r2 = zero4; gmb = 0x7F000000u;
-        if (v_cur) {
-            r0 = rec[4 * (size_t)g_cur];
-            r1 = rec[4 * (size_t)g_cur + 1];
-            r2 = rec[4 * (size_t)g_cur + 2];
-            gmb = ((const uint32_t*)best_key)[2 * (size_t)g_cur + 1];   // live running maximum
-        }
-        __syncthreads();                    // lists complete
-        // (2) this wave walks its own list
-        if (!mydone) {
-            const int cnt = total[wv];
-            for (int k0 = 0; k0 < cnt; k0 += U) {
-                float alpha[U], contrib[U];
-                float4 qb[U];
-                float2 qc[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const float4 a = s_a[wv][k0 + u];
-                    qb[u] = s_b[wv][k0 + u];
-                    qc[u] = s_c[wv][k0 + u];
-                    float t1 = fmaf(a.x, uu, a.w);
-                    t1 = fmaf(a.y, vv, t1);
-                    const float t2 = fmaf(a.z, vv, qb[u].x);
-                    float pw = fmaf(uu, t1, qb[u].y);
-                    pw = fmaf(vv, t2, pw);
-                    alpha[u] = fminf(__builtin_amdgcn_exp2f(pw), 0.99f);
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    G2PC_PIN(alpha[u]);
-                    G2PC_PIN(qb[u].z); G2PC_PIN(qb[u].w); G2PC_PIN(qc[u].x); G2PC_PIN(qc[u].y);
-                }
-                bool any_cand = false;
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    contrib[u] = T * alpha[u];
-                    cr = fmaf(contrib[u], qb[u].z, cr);
-                    cg = fmaf(contrib[u], qb[u].w, cg);
-                    cb = fmaf(contrib[u], qc[u].x, cb);
-                    T -= contrib[u];
-                    any_cand = any_cand || (contrib[u] >= qc[u].y);
-                }
-                if (__any(any_cand ? 1 : 0)) {
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        if (__any(contrib[u] >= qc[u].y)) {
-                            const uint32_t bits = __float_as_uint(contrib[u]);
-                            const uint32_t m = wave_max_u32_dpp(bits);
-                            const unsigned long long at_max = __ballot(bits == m);      // lowest lane = lowest pixel index
-                            const uint32_t pm = (uint32_t)__builtin_amdgcn_readlane(mypix, __ffsll(at_max) - 1);
-                            if (lane == 0) {
-                                unsigned long long key = ((unsigned long long)m << 32) | (unsigned long long)(uint32_t)(~(order_tile | pm));
-                                atomicMax(&best_key[s_g[wv][k0 + u]], key);
-                            }
-                        }
-                    }
-                }
-            }
-            mydone = __all(T <= t_floor ? 1 : 0) != 0;      // see k_blend_py
-            if (mydone && lane == 0) s_done[wv] = 1;         // read by both waves after the next barrier
-        }
-    }
-    if (chunk_work && tid == 0) {
-        chunk_work[2 * blockIdx.x] = end - start;
-        chunk_work[2 * blockIdx.x + 1] = processed;
-    }
-    if (mypix >= 0) {
-        float* out = tilebuf + 3 * (size_t)lay.tile_pix_off[tile];
-        out[3 * (size_t)mypix + 0] = fmaf(T, bg, cr);
-        out[3 * (size_t)mypix + 1] = fmaf(T, bg, cg);
-        out[3 * (size_t)mypix + 2] = fmaf(T, bg, cb);
-    }
-}
-
 // K7 (PY): running update of the per-Gaussian colour: Gaussians whose best key was set by this camera slot take
 // the colour of the winning (tile, pixel) from that tile's own rendered colours (gauss_render.py:387-395).
 __global__ __launch_bounds__(RA_T) void k_update_colours_py(Layout lay, const unsigned long long* __restrict__ best_key,
@@ -1480,8 +1286,7 @@ struct PyFrontBuffers { float4* rec; uint32_t *rect, *sorted_idx, *offsets; };  
 static size_t py_front_ws(long n) {
     return align_up((size_t)n * 4) * 6 + sort_workspace(n) + scan_workspace(n) + bucket_sort_workspace(n) + 4096;
 }
-static int g_blend_extra_lds = 0;             // EXPERIMENT: unused dynamic LDS per blend block (caps the blend waves per CU)
-static int g_blend_variant = 1;               // 2 sub-blocks per chunk: 2 = two-wave dual-list kernel (k_blend_py_2w), 1 = dual-list kernel (k_blend_py_dl), 0 = packed kernel (k_blend_py_pk)
+static int g_blend_variant = 1;               // 2 sub-blocks per wave: 1 = dual-list kernel (k_blend_py_dl), 0 = packed kernel (k_blend_py_pk)
 static int g_depth_bucket_sort = 1;           // captured camera path: 1 = bucket sort of the depth keys, 0 = radix (g2pc_set_depth_sort)
 static size_t py_back_ws(long L, int T) {
     return align_up((size_t)(L + 1) * 4) * 6 + sort_workspace(L) + scan_workspace(T + 1) + align_up((size_t)(T + 2) * 4) + 4096;
@@ -1554,17 +1359,13 @@ static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t*
     }
     if (phases & 2) {
 #define G2PC_BLEND(...)                                                                                                 \
-    hipLaunchKernelGGL((__VA_ARGS__), dim3((unsigned)layout->num_chunks), dim3(BL_T), (size_t)g_blend_extra_lds, s, lay, layout->chunk_tile, \
+    hipLaunchKernelGGL((__VA_ARGS__), dim3((unsigned)layout->num_chunks), dim3(BL_T), 0, s, lay, layout->chunk_tile,          \
                        layout->chunk_pix0, tile_start, g_sorted, (const float4*)fb.rec, best_key,                      \
                        ba.camera_slot << 24, ba.t_floor, ba.bg, tilebuf, g_chunk_work, ba.job)
         switch (layout->chunk_subblocks) {
             case 1: G2PC_BLEND(k_blend_py<1, 4>); break;
             case 2:
-                if (g_blend_variant == 2)
-                    hipLaunchKernelGGL((k_blend_py_2w<4>), dim3((unsigned)layout->num_chunks), dim3(2 * BL_T), 0, s, lay, layout->chunk_tile,
-                                       layout->chunk_pix0, tile_start, g_sorted, (const float4*)fb.rec, best_key,
-                                       ba.camera_slot << 24, ba.t_floor, ba.bg, tilebuf, g_chunk_work, ba.job);
-                else if (g_blend_variant == 1) G2PC_BLEND(k_blend_py_dl<4>);
+                if (g_blend_variant == 1) G2PC_BLEND(k_blend_py_dl<4>);
                 else G2PC_BLEND(k_blend_py_pk<4>);
                 break;
             case 4: G2PC_BLEND(k_blend_py<4, 1>); break;
@@ -1672,7 +1473,7 @@ int g2pc_raster_camera_py(const G2pcCameraJob* job_dev, const G2pcCameraJob* job
             hipLaunchKernelGGL(k_fetch_job, dim3(1), dim3(64), 0, s, (const uint32_t*)job_host, (uint32_t*)job_dev);
         uint32_t* depth_overflow = nullptr;
         rc = py_front(Cam{}, (const Cam*)&job_dev->cam, layout, means3D, cov9, opacity, colours, (long)n, fb, front_ws,
-                      front_bytes, s, g_depth_bucket_sort ? &depth_overflow : nullptr);
+                      front_bytes, s, (g_depth_bucket_sort && bucket_sort_pays((long)n)) ? &depth_overflow : nullptr);
         if (rc) return rc;
         hipLaunchKernelGGL(k_resolve_count, dim3(1), dim3(64), 0, s, fb.offsets + n, (uint32_t)capacity, l_eff, count_host,
                            (const uint32_t*)depth_overflow);
@@ -1701,7 +1502,6 @@ int g2pc_raster_debug_chunk_work(uint32_t* buf) { g2pc::g_chunk_work = buf; retu
 /* depth order of the capture-safe camera call: 1 = range-normalised bucket sort + in-LDS bitonic (default), 0 = 4-pass
  * radix.  Identical results; a camera whose depths pile up (bucket overflow) is skipped and reported through
  * count_host[1] -- the caller repeats it with g2pc_raster_front_py / _back_py, which always use the radix sort. */
-int g2pc_set_blend_extra_lds(int bytes) { g2pc::g_blend_extra_lds = bytes; return G2PC_OK; }
 int g2pc_set_blend_variant(int variant) { g2pc::g_blend_variant = variant; return G2PC_OK; }
 int g2pc_set_depth_sort(int bucket) { g2pc::g_depth_bucket_sort = bucket ? 1 : 0; return G2PC_OK; }
 

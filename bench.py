@@ -55,8 +55,7 @@ def parse():
     ap.add_argument("--scene-scales", type=float, nargs=2, default=None, metavar=("LO", "HI"),
                     help="diagnostic: Gaussian scale range of the synthetic scene (default 0.002 0.02 = SURVEY.md's)")
     ap.add_argument("--no-context-pool", action="store_true", help="tuning aid: every job captures its camera graphs anew")
-    ap.add_argument("--blend-variant", type=int, default=None, choices=[None, 0, 1, 2], help="tuning aid: 2 = two-wave dual-list, 1 = dual-list blend kernel, 0 = packed kernel")
-    ap.add_argument("--blend-extra-lds", type=int, default=None, help="experiment: unused dynamic LDS bytes per blend block")
+    ap.add_argument("--blend-variant", type=int, default=None, choices=[None, 0, 1], help="tuning aid: 1 = dual-list blend kernel, 0 = packed kernel")
     ap.add_argument("--depth-sort", default=None, choices=[None, "bucket", "radix"], help="tuning aid: depth order of the captured camera path")
     ap.add_argument("--streams", type=int, default=0, help="tuning aid: cameras in flight (HIP streams) of the renderer")
     ap.add_argument("--camera-subset", type=int, default=0, help="profiling aid: render only the first k cameras of the rig")
@@ -111,9 +110,9 @@ def algorithmic_bytes(workload, n, n_kept, m, cams, stats):
     return b
 
 
-PMC_TRAFFIC_FILE = "profiles/r02_pmc_traffic.json"      # tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE passes of THIS command
-PMC_SQ_FILE = "profiles/r02_pmc_sq.json"                # tools/pmc_kernel.py: SQ counter pass of THIS command
-BLEND_KERNEL = "void g2pc::k_blend_py_pk<4>"
+PMC_TRAFFIC_FILE = "profiles/r02w_pmc_traffic.json"      # tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE passes of THIS command
+PMC_SQ_FILE = "profiles/r02w_pmc_sq.json"               # tools/pmc_kernel.py: SQ counter pass of THIS command
+BLEND_KERNEL = "void g2pc::k_blend_py_dl<4>"
 
 
 def _default_config(a):
@@ -302,10 +301,6 @@ def main():
         nv.lib().g2pc_set_sort_tuning(a.sort_bits, a.sort_small)
     if a.blend_variant is not None:
         nv.lib().g2pc_set_blend_variant(a.blend_variant)
-    if a.blend_extra_lds is not None:
-        import ctypes as _C
-        nv.lib().g2pc_set_blend_extra_lds.argtypes = [_C.c_int]
-        nv.lib().g2pc_set_blend_extra_lds(a.blend_extra_lds)
     if a.depth_sort:
         nv.lib().g2pc_set_depth_sort(1 if a.depth_sort == "bucket" else 0)
     if a.blend_subblocks:
