@@ -1260,6 +1260,12 @@ __global__ __launch_bounds__(RA_T) void k_fill_u32(uint32_t* __restrict__ p, lon
     long i = (long)blockIdx.x * RA_T + threadIdx.x;
     if (i < n) p[i] = v;
 }
+// per-camera state of the native-semantics blend in one launch: packed (contribution, ~pixel) keys = 0, surface distance = FLT_MAX
+__global__ __launch_bounds__(RA_T) void k_init_camera_state_cu(unsigned long long* __restrict__ cam_key, uint32_t* __restrict__ cam_surf,
+                                                              long n) {
+    long i = (long)blockIdx.x * RA_T + threadIdx.x;
+    if (i < n) { cam_key[i] = 0ull; cam_surf[i] = 0x7F7FFFFFu; }
+}
 
 static uint32_t* g_chunk_work = nullptr;      // diagnostics hook (g2pc_raster_debug_chunk_work)
 
@@ -1619,14 +1625,13 @@ int g2pc_raster_back_cu_tiles(const G2pcCamera* cam, const int32_t* mask, int64_
     char* scan_ws = ar.get<char>(scan_bytes);
     G2PC_REQUIRE(ar.ok(), G2PC_ERR_WORKSPACE, "workspace too small");
     if (phases & 1) {
-    hipMemsetAsync(tile_start, 0, (size_t)(T + 2) * 4, s);
-    hipMemsetAsync(cam_key, 0, (size_t)n * 8, s);
+    // (k_tile_ranges writes every entry of tile_start: no memset)
     if (mask || sharded) {                        // without a mask every pixel is written by the blend kernel
         hipMemsetAsync(out_color, 0, (size_t)3 * W * H * 4, s);
         hipMemsetAsync(out_depth, 0, (size_t)W * H * 4, s);
         hipMemsetAsync(out_invdepth, 0, (size_t)W * H * 4, s);
     }
-    hipLaunchKernelGGL(k_fill_u32, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, cam_surf, (long)n, 0x7F7FFFFFu);   // FLT_MAX (k_update_cu reads it)
+    hipLaunchKernelGGL(k_init_camera_state_cu, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, (unsigned long long*)cam_key, (uint32_t*)cam_surf, (long)n);
     if (L > 0) {
         hipLaunchKernelGGL(k_duplicate, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, sorted_idx, offsets, rect, (long)n, gx,
                            inst_tile, inst_g, (const uint32_t*)nullptr);
