@@ -213,18 +213,22 @@ constexpr int BL_T = 64, BL_BATCH = 64;
 // -B / 2A, from k_preprocess_py); cth = -25.5 - log2(opacity).  Below 2^-25, T * (1 - alpha) == T bit for bit in fp32 (here
 // and in the reference's cumprod) and the colour / contribution terms are < 3e-8: the visit is dropped and the survivors
 // of a batch are compacted in depth order.  On the bench scene that is ~40 % of all visits.  NaNs compare false: kept.
-__device__ __forceinline__ bool chunk_may_touch(const float4& r0, const float4& r1, float cth, float rx0, float rx1,
-                                                float ry0, float ry1) {
-    const float ax = rx0 - r0.x, bx = rx1 - r0.x, ay = ry0 - r0.y, by = ry1 - r0.y;
+__device__ __forceinline__ bool rect_may_touch(float mx, float my, float A, float B, float C, float slope_y, float slope_x,
+                                               float cth, float rx0, float rx1, float ry0, float ry1) {
+    const float ax = rx0 - mx, bx = rx1 - mx, ay = ry0 - my, by = ry1 - my;
     const bool xout = ax > 0.f || bx < 0.f, yout = ay > 0.f || by < 0.f;
     const float ex = ax > 0.f ? ax : bx, ey = ay > 0.f ? ay : by;
-    const float dyc = fminf(fmaxf(ex * r1.z, ay), by), dxc = fminf(fmaxf(ey * r1.w, ax), bx);
-    const float vx = ex * (r0.z * ex + r0.w * dyc) + (r1.x * dyc) * dyc;
-    const float vy = ey * (r1.x * ey + r0.w * dxc) + (r0.z * dxc) * dxc;
+    const float dyc = fminf(fmaxf(ex * slope_y, ay), by), dxc = fminf(fmaxf(ey * slope_x, ax), bx);
+    const float vx = ex * (A * ex + B * dyc) + (C * dyc) * dyc;
+    const float vy = ey * (C * ey + B * dxc) + (A * dxc) * dxc;
     float peak = 0.0f;
     if (xout) peak = vx;
     if (yout) peak = xout ? fmaxf(vx, vy) : vy;
     return !(peak < cth);
+}
+__device__ __forceinline__ bool chunk_may_touch(const float4& r0, const float4& r1, float cth, float rx0, float rx1,
+                                                float ry0, float ry1) {
+    return rect_may_touch(r0.x, r0.y, r0.z, r0.w, r1.x, r1.z, r1.w, cth, rx0, rx1, ry0, ry1);
 }
 
 // Pixels of a tile are grouped in 8x8 sub-blocks (row-major inside the tile); a chunk = PPT consecutive sub-blocks,
@@ -982,8 +986,12 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_cu(Cam cam, int grid_x, int
                 key = __float_as_uint(tz0);
                 rad = r;
                 const float sc = LOG2E;
-                rec[4 * i + 0] = make_float4(px, py, -0.5f * sc * kx, -sc * ky);        // one 64-byte record per Gaussian,
-                rec[4 * i + 1] = make_float4(-0.5f * sc * kz, opacity[i], tz0, my_radius);   // as on the PY path
+                const float qa = -0.5f * sc * kx, qb = -sc * ky, qc = -0.5f * sc * kz;
+                rec[4 * i + 0] = make_float4(px, py, qa, qb);                           // one 64-byte record per Gaussian,
+                rec[4 * i + 1] = make_float4(qc, opacity[i], tz0, my_radius);           // as on the PY path
+                // per-wave cull of k_blend_cu (rect_may_touch): slopes of the exponent's edge maxima and the exponent below
+                // which alpha < 1/255 (with a 0.7 % margin for the different rounding of the bound)
+                rec[4 * i + 3] = make_float4(-qb / (2.0f * qc), -qb / (2.0f * qa), -8.00435f - log2f(opacity[i]), 0.0f);
                 float cr, cg, cb;
                 if (colours_precomp) {
                     cr = colours_precomp[3 * i]; cg = colours_precomp[3 * i + 1]; cb = colours_precomp[3 * i + 2];
@@ -1043,14 +1051,16 @@ __global__ __launch_bounds__(CU_T) void k_blend_cu(int W, int H, int grid_x, int
                                                   unsigned long long* __restrict__ cam_key,
                                                   uint32_t* __restrict__ cam_surf, float* __restrict__ out_color,
                                                   float* __restrict__ out_depth, float* __restrict__ out_invdepth) {
-    __shared__ float4 s_p0[CU_T];
-    __shared__ float4 s_p1[CU_T];
-    __shared__ float4 s_p2[CU_T];
-    __shared__ uint32_t s_g[CU_T];
+    __shared__ float4 s_p0[CU_T + 1];             // slot CU_T: a neutral entry (opacity 0) the per-wave lists are padded with
+    __shared__ float4 s_p1[CU_T + 1];
+    __shared__ float4 s_p2[CU_T + 1];
+    __shared__ uint32_t s_g[CU_T + 1];
     __shared__ uint32_t s_surf[CU_T];             // surface distance known when the batch was staged (filter only)
+    __shared__ unsigned short s_list[4][CU_T + 4];   // per wave: the batch entries that can reach its 16x4 pixels, in depth order
+    __shared__ int s_wc[4][4];                    // [list][staging wave] survivors
     const int tile = tile_first + (int)blockIdx.x * tile_step;       // (first, step) != (0, 1): this rank's share of the tiles
     const int tx = tile % grid_x, ty = tile / grid_x;
-    const unsigned t = threadIdx.x, lane = t & 63;
+    const unsigned t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int x = tx * 16 + (int)(t & 15), y = ty * 16 + (int)(t >> 4);
     const bool inside = (x < W) && (y < H);
     const bool masked = inside && mask && (mask[(size_t)W * y + x] == 0);
@@ -1062,17 +1072,37 @@ __global__ __launch_bounds__(CU_T) void k_blend_cu(int W, int H, int grid_x, int
     float T = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, E = 0.f, Ei = 0.f;
     const uint32_t* key_hi = (const uint32_t*)cam_key + 1;
     const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
+    // pixel rectangle of wave w inside the image (the four waves of a tile own four 16x4 strips)
+    const float rx0 = (float)(tx * 16), rx1 = (float)min(tx * 16 + 15, W - 1);
+    if (t == 0) {
+        s_p0[CU_T] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s_p1[CU_T] = make_float4(0.f, 0.f, 1.f, 0.f);
+        s_p2[CU_T] = make_float4(0.f, 0.f, 0.f, 3.0e38f);
+        s_g[CU_T] = 0;
+    }
     for (uint32_t b = start; b < end; b += CU_T) {
         if (__syncthreads_and(done ? 1 : 0)) break;                       // forward.cu:373-375 (also: LDS is free again)
+        // Stage entry t and decide, for each of the tile's four waves, whether this Gaussian's alpha can reach 1/255 on
+        // that wave's pixels (rect_may_touch).  Below it the reference's loop body does nothing for the pixel (forward.cu:
+        // 411-413 `continue`), so a Gaussian that fails for all 64 pixels of a wave is not walked by that wave at all --
+        // same results bit for bit, ~half the (pixel, Gaussian) pairs of a 16x16 tile never evaluated.
+        bool keep[4] = {false, false, false, false};
         if (b + t < end) {
             uint32_t g = inst_g[b + t];
-            s_p0[t] = rec[4 * (size_t)g];
-            s_p1[t] = rec[4 * (size_t)g + 1];
+            const float4 r0 = rec[4 * (size_t)g], r1 = rec[4 * (size_t)g + 1], r3 = rec[4 * (size_t)g + 3];
+            s_p0[t] = r0;
+            s_p1[t] = r1;
             const float4 c3 = rec[4 * (size_t)g + 2];
             float gm = fmaxf(__uint_as_float(key_hi[2 * (size_t)g]), 1.17549435e-38f);
             s_p2[t] = make_float4(c3.x, c3.y, c3.z, gm);
             s_g[t] = g;
             if (calc_surf) s_surf[t] = cam_surf[g];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int wy0 = ty * 16 + 4 * w;
+                keep[w] = wy0 < H && rect_may_touch(r0.x, r0.y, r0.z, r0.w, r1.x, r3.x, r3.y, r3.z, rx0, rx1, (float)wy0,
+                                                    (float)min(wy0 + 3, H - 1));
+            }
         } else {                                   // padding: opacity 0 -> alpha 0 < 1/255 -> skipped
             s_p0[t] = make_float4(0.f, 0.f, 0.f, 0.f);
             s_p1[t] = make_float4(0.f, 0.f, 1.f, 0.f);
@@ -1080,17 +1110,39 @@ __global__ __launch_bounds__(CU_T) void k_blend_cu(int W, int H, int grid_x, int
             s_g[t] = 0;
             s_surf[t] = 0;
         }
+        unsigned long long kept[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            kept[w] = __ballot(keep[w] ? 1 : 0);
+            if (lane == 0) s_wc[w][wv] = __popcll(kept[w]);
+        }
+        __syncthreads();
+        int lcnt = 0;                                                   // survivors on this wave's list
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            int off = 0, tot = 0;
+#pragma unroll
+            for (int sw = 0; sw < 4; ++sw) { const int c = s_wc[w][sw]; if (sw < (int)wv) off += c; tot += c; }
+            if (keep[w]) s_list[w][off + __popcll(kept[w] & ((1ull << lane) - 1ull))] = (unsigned short)t;
+            if ((int)wv == w) {
+                lcnt = tot;
+                if (lane < 4) s_list[w][tot + lane] = (unsigned short)CU_T;      // the last trip reads up to 3 entries past the end
+            }
+        }
         __syncthreads();
         const int cnt = (end - b) < (uint32_t)CU_T ? (int)(end - b) : CU_T;
         // wave-uniform early out inside the batch: nothing left to blend for these 64 pixels
-        for (int k0 = 0; k0 < cnt && !__all(done ? 1 : 0); k0 += 4) {
+        for (int i0 = 0; i0 < lcnt && !__all(done ? 1 : 0); i0 += 4) {
             float alpha[4], power[4], dep[4];
             float4 cc[4];
+            int kk[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) cc[u] = s_p2[k0 + u];       // read with the rest: the serial part never waits on LDS
+            for (int u = 0; u < 4; ++u) kk[u] = (int)s_list[wv][i0 + u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cc[u] = s_p2[kk[u]];       // read with the rest: the serial part never waits on LDS
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float4 a = s_p0[k0 + u], q = s_p1[k0 + u];
+                const float4 a = s_p0[kk[u]], q = s_p1[kk[u]];
                 float dx = a.x - px, dy = a.y - py;
                 power[u] = fmaf(dx, fmaf(a.w, dy, a.z * dx), (q.x * dy) * dy);
                 alpha[u] = fminf(0.99f, q.y * __builtin_amdgcn_exp2f(power[u]));
@@ -1124,7 +1176,7 @@ __global__ __launch_bounds__(CU_T) void k_blend_cu(int W, int H, int grid_x, int
                     const uint32_t pm = (uint32_t)__builtin_amdgcn_readlane((int)pixid, __ffsll(__ballot(bits == m)) - 1);
                     if (lane == 0) {
                         unsigned long long key = ((unsigned long long)m << 32) | (unsigned long long)(uint32_t)(~pm);
-                        atomicMax(&cam_key[s_g[k0 + u]], key);
+                        atomicMax(&cam_key[s_g[kk[u]]], key);
                     }
                 }
             }
@@ -1295,7 +1347,7 @@ static size_t py_front_ws(long n) {
 static int g_blend_variant = 1;               // 2 sub-blocks per wave: 1 = dual-list kernel (k_blend_py_dl), 0 = packed kernel (k_blend_py_pk)
 static int g_depth_bucket_sort = 1;           // captured camera path: 1 = bucket sort of the depth keys, 0 = radix (g2pc_set_depth_sort)
 static size_t py_back_ws(long L, int T) {
-    return align_up((size_t)(L + 1) * 4) * 6 + sort_workspace(L) + scan_workspace(T + 1) + align_up((size_t)(T + 2) * 4) + 4096;
+    return align_up((size_t)(L + 1) * 4) * 6 + sort_workspace(L) + scan_workspace(T + 1) + align_up((size_t)(T + 2) * 4) + 4096 + 256;
 }
 
 // depth_overflow != nullptr: the depth order comes from the bucket sort (prims.hip) and *depth_overflow points at its
@@ -1651,6 +1703,60 @@ int g2pc_raster_back_cu_tiles(const G2pcCamera* cam, const int32_t* mask, int64_
     hipLaunchKernelGGL(k_update_cu, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, cam_key, cam_surf, (long)n, W, H, out_color,
                        max_contrib, total_contrib, colours, min_surf, winner_cam, cam_index, cur_contrib, cur_pixels, cur_surf);
     return check_launch("g2pc_raster_back_cu");
+}
+
+// CU semantics, bin + blend of one camera WITHOUT the host in the loop (the python-semantics path's scheme): the launches are
+// sized for `capacity` instances, the true count stays on the device (k_resolve_count -> l_eff; the L-dependent kernels
+// read it) and travels to the pinned count_host[0] on its own.  A camera that does not fit is skipped as a whole (empty
+// tile lists: every pixel gets the background, no Gaussian a contribution) and the caller, who sees count_host[0] >
+// capacity later, renders it again with g2pc_raster_back_cu[_tiles].  Follow with g2pc_raster_back_cu_tiles(phases = 4,
+// num_instances = capacity) for the running-state update.
+int g2pc_raster_back_cu_dev(const G2pcCamera* cam, const int32_t* mask, int64_t n, int64_t capacity, const float* rec,
+                            const uint32_t* rect, const uint32_t* sorted_idx, const uint32_t* offsets,
+                            int calculate_surface_distance, unsigned long long* cam_key, uint32_t* cam_surf, float* out_color,
+                            float* out_depth, float* out_invdepth, uint32_t* count_host, int32_t tile_first, int32_t tile_step,
+                            void* ws, size_t ws_bytes, void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(cam && rec && rect && sorted_idx && offsets && cam_key && cam_surf && out_color && out_depth && out_invdepth &&
+                     ws && n > 0 && capacity > 0, G2PC_ERR_ARG, "bad arguments");
+    const int W = cam->width, H = cam->height;
+    const int gx = (W + 15) / 16, gy = (H + 15) / 16, T = gx * gy;
+    G2PC_REQUIRE(tile_step >= 1 && tile_first >= 0 && tile_first < tile_step, G2PC_ERR_ARG, "bad tile shard");
+    const bool sharded = tile_step > 1;
+    hipStream_t s = (hipStream_t)stream;
+    const long L = capacity;
+    Arena ar(ws, ws_bytes);
+    uint32_t* inst_tile = ar.get<uint32_t>((size_t)L + 1);
+    uint32_t* inst_g = ar.get<uint32_t>((size_t)L + 1);
+    uint32_t* tile_sorted = ar.get<uint32_t>((size_t)L + 1);
+    uint32_t* g_sorted = ar.get<uint32_t>((size_t)L + 1);
+    uint32_t* tile_tmp = ar.get<uint32_t>((size_t)L + 1);
+    uint32_t* g_tmp = ar.get<uint32_t>((size_t)L + 1);
+    uint32_t* tile_start = ar.get<uint32_t>((size_t)T + 2);
+    size_t sort_bytes = sort_workspace(L);
+    char* sort_ws = ar.get<char>(sort_bytes);
+    uint32_t* l_eff = ar.get<uint32_t>(1);
+    G2PC_REQUIRE(ar.ok(), G2PC_ERR_WORKSPACE, "workspace too small");
+    hipLaunchKernelGGL(k_resolve_count, dim3(1), dim3(64), 0, s, offsets + n, (uint32_t)capacity, l_eff, count_host,
+                       (const uint32_t*)nullptr);
+    if (mask || sharded) {                        // without a mask every pixel is written by the blend kernel
+        hipMemsetAsync(out_color, 0, (size_t)3 * W * H * 4, s);
+        hipMemsetAsync(out_depth, 0, (size_t)W * H * 4, s);
+        hipMemsetAsync(out_invdepth, 0, (size_t)W * H * 4, s);
+    }
+    hipLaunchKernelGGL(k_init_camera_state_cu, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, (unsigned long long*)cam_key, (uint32_t*)cam_surf, (long)n);
+    hipLaunchKernelGGL(k_duplicate, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, sorted_idx, offsets, rect, (long)n, gx, inst_tile, inst_g,
+                       (const uint32_t*)l_eff);
+    int rc = sort_pairs_u32(inst_tile, inst_g, tile_sorted, g_sorted, tile_tmp, g_tmp, L, 0, bits_for_tiles((unsigned)T), sort_ws,
+                            sort_bytes, s, l_eff);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T)), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start, (const uint32_t*)l_eff);
+    if (tile_first < T)
+        hipLaunchKernelGGL(k_blend_cu, dim3((unsigned)((T - tile_first + tile_step - 1) / tile_step)), dim3(CU_T), 0, s, W, H, gx,
+                           (int)tile_first, (int)tile_step, tile_start, g_sorted, (const float4*)rec, mask,
+                           make_float3(cam->bg[0], cam->bg[1], cam->bg[2]), calculate_surface_distance, cam_key, cam_surf,
+                           out_color, out_depth, out_invdepth);
+    return check_launch("g2pc_raster_back_cu_dev");
 }
 
 int g2pc_raster_back_cu(const G2pcCamera* cam, const int32_t* mask, int64_t n, int64_t num_instances, const float* rec,

@@ -52,6 +52,8 @@ nv._RASTER_PROTOS.update({
                             [C.c_int32] + [_vp] * 3 + [C.c_int, _vp, C.c_size_t, _vp]),
     "g2pc_raster_back_cu_tiles": (C.c_int, [C.POINTER(_Camera), _vp, C.c_int64, C.c_int64] + [_vp] * 4 + [C.c_int] + [_vp] * 10 +
                                   [C.c_int32] + [_vp] * 3 + [C.c_int, C.c_int32, C.c_int32, _vp, C.c_size_t, _vp]),
+    "g2pc_raster_back_cu_dev": (C.c_int, [C.POINTER(_Camera), _vp, C.c_int64, C.c_int64] + [_vp] * 4 + [C.c_int] + [_vp] * 6 +
+                                [C.c_int32, C.c_int32, _vp, C.c_size_t, _vp]),
     "g2pc_mark_visible": (C.c_int, [_vp, C.c_int64, C.POINTER(C.c_float * 16), _vp, _vp]),
 })
 if nv._LIB is not None:
@@ -59,6 +61,9 @@ if nv._LIB is not None:
 
 
 PIPELINE_STREAMS = 4
+PIPELINE_IN_EMULATOR = False      # tests: drive the no-read-back camera path through the CPU emulator too
+CAPACITY_HEADROOM = 1.25          # instance capacity of the pipelined cameras relative to the largest count seen so far
+MIN_CAPACITY = 1 << 16
 
 
 def mark_visible(means3D, viewmatrix, projmatrix=None):
@@ -89,7 +94,9 @@ class _CuScratch:
         self.back_bytes, self.back_ws = 0, None
         self.colour = self.depths = self.invdepths = None
         self.stream = stream
-        self.count_host = torch.empty((1,), dtype=torch.int32).pin_memory() if stream is not None else None
+        self.count_host = torch.zeros((2,), dtype=torch.int32)          # [instances, 0], written by the device
+        if stream is not None:
+            self.count_host = self.count_host.pin_memory()
         self.front_done = torch.cuda.Event() if stream is not None else None
         self.update_done = torch.cuda.Event() if stream is not None else None
 
@@ -142,6 +149,8 @@ class GaussianRasterizer(nn.Module):
 
         self._sync = _CuScratch(n, dev)
         self._pipe, self._pipe_next, self._pending, self._last_update = [], 0, [], None
+        self._capacity = None              # instance capacity of the pipelined cameras (learned from the first camera)
+        self.rerendered = 0                # pipelined cameras that outgrew the capacity and went through the two-call path
         self._winner_cam = torch.full((n,), 1 << 30, dtype=torch.int32, device=dev)
         self._camera_counter = 0
         self.last = {}
@@ -161,7 +170,7 @@ class GaussianRasterizer(nn.Module):
     def _stream_ptr(self, sc):
         return C.c_void_p(sc.stream.cuda_stream) if sc.stream is not None else nv.stream_handle(self.device)
 
-    def _front(self, sc, cam, campos, sh_degree):
+    def _front(self, sc, cam, campos, sh_degree, count_host=True):
         shs = self.shs
         coeffs = int(shs.shape[1]) if shs is not None else 0
         with nv.region("raster_front", self.device, sc.stream):
@@ -170,7 +179,7 @@ class GaussianRasterizer(nn.Module):
                 nv.ptr(self.colors_precomp), nv.ptr(shs), int(sh_degree) if shs is not None else 0, coeffs,
                 C.cast(campos, C.c_void_p), self.n, nv.ptr(sc.rec), nv.ptr(sc.rect), nv.ptr(sc.radii), nv.ptr(sc.sorted),
                 nv.ptr(sc.offsets),
-                C.c_void_p(sc.count_host.data_ptr()) if sc.count_host is not None else None, nv.ptr(sc.front_ws),
+                C.c_void_p(sc.count_host.data_ptr()) if (count_host and sc.count_host is not None) else None, nv.ptr(sc.front_ws),
                 sc.front_bytes, self._stream_ptr(sc)), "raster_front_cu")
 
     def _back(self, sc, cam, mask, num_rendered, cam_index, phases, name, cur=(None, None, None)):
@@ -211,16 +220,65 @@ class GaussianRasterizer(nn.Module):
         dist.all_reduce(sc.depths, op=dist.ReduceOp.SUM, group=self.tile_group)
         dist.all_reduce(sc.invdepths, op=dist.ReduceOp.SUM, group=self.tile_group)
 
+    def _issue(self, sc, cam, campos, mask, sh_degree, cam_index, capacity):
+        """One pipelined camera, no host in the loop: front, then bin + blend sized for `capacity` with the instance count
+        left on the device (g2pc_raster_back_cu_dev), then the running-state update in camera order."""
+        import contextlib
+        L = nv.lib()
+        W, H = cam.width, cam.height
+        tiles_n = ((W + 15) // 16) * ((H + 15) // 16)
+        need = L.g2pc_raster_back_workspace(capacity, tiles_n)
+        with (torch.cuda.stream(sc.stream) if sc.stream is not None else contextlib.nullcontext()):
+            if need > sc.back_bytes:
+                sc.back_bytes = int(need)
+                sc.back_ws = None
+                sc.back_ws = nv.workspace(sc.back_bytes, self.device)
+            if sc.colour is None or sc.colour.shape[1:] != (H, W):
+                sc.colour = torch.empty((3, H, W), dtype=torch.float32, device=self.device)
+                sc.depths = torch.empty((1, H, W), dtype=torch.float32, device=self.device)
+                sc.invdepths = torch.empty((1, H, W), dtype=torch.float32, device=self.device)
+        self._front(sc, cam, campos, sh_degree, count_host=False)
+        first, step = self.tile_shard if self.tile_shard is not None else (0, 1)
+        with nv.region("raster_bin+blend_cu", self.device, sc.stream):
+            nv.check(L.g2pc_raster_back_cu_dev(
+                C.byref(cam), nv.ptr(mask), self.n, capacity, nv.ptr(sc.rec), nv.ptr(sc.rect), nv.ptr(sc.sorted),
+                nv.ptr(sc.offsets), 1 if self.calculate_surface_distance else 0, nv.ptr(sc.cam_key), nv.ptr(sc.cam_surf),
+                nv.ptr(sc.colour), nv.ptr(sc.depths), nv.ptr(sc.invdepths), C.c_void_p(sc.count_host.data_ptr()),
+                int(first), int(step), nv.ptr(sc.back_ws), sc.back_bytes, self._stream_ptr(sc)), "raster_back_cu_dev")
+        if self._last_update is not None and sc.stream is not None:
+            sc.stream.wait_event(self._last_update)
+        self._back(sc, cam, mask, capacity, cam_index, 4, "raster_update_cu")
+        if sc.stream is not None:
+            sc.update_done.record(sc.stream)
+            self._last_update = sc.update_done
+
     def _finish(self, entry):
-        sc, cam, mask, cam_index = entry
-        sc.front_done.synchronize()
+        """Retire a pipelined camera: it is normally long done; one that did not fit its capacity was skipped on the device
+        and is rendered again here through the two-call path (exact instance count)."""
+        sc, cam, campos, mask, sh_degree, cam_index, capacity = entry
+        if sc.stream is not None:
+            sc.update_done.synchronize()
         num_rendered = int(sc.count_host[0])
+        self.last = dict(num_rendered=num_rendered)
+        if num_rendered > capacity:
+            self._capacity = max(self._capacity, int(num_rendered * CAPACITY_HEADROOM))
+            self.rerendered += 1
+            self._render_two_call(sc, cam, campos, mask, sh_degree, cam_index)
+
+    def _render_two_call(self, sc, cam, campos, mask, sh_degree, cam_index):
+        """front -> host reads the instance count -> bin + blend -> ordered update, on the scratch's stream."""
+        self._front(sc, cam, campos, sh_degree, count_host=False)
+        if sc.stream is not None:
+            sc.stream.synchronize()
+        num_rendered = int(sc.offsets[self.n].item())
         self._back(sc, cam, mask, num_rendered, cam_index, 3, "raster_bin+blend_cu")
-        if self._last_update is not None:
+        if self._last_update is not None and sc.stream is not None:
             sc.stream.wait_event(self._last_update)
         self._back(sc, cam, mask, num_rendered, cam_index, 4, "raster_update_cu")
-        sc.update_done.record(sc.stream)
-        self._last_update = sc.update_done
+        if sc.stream is not None:
+            sc.update_done.record(sc.stream)
+            self._last_update = sc.update_done
+        return num_rendered
 
     def flush(self):
         """Complete every camera in flight (pipelined mode) and make the running state visible to the current stream."""
@@ -228,9 +286,10 @@ class GaussianRasterizer(nn.Module):
             return
         while self._pending:
             self._finish(self._pending.pop(0))
-        cur = torch.cuda.current_stream(self.device)
-        for sc in self._pipe:
-            cur.wait_stream(sc.stream)
+        if self.device.type == "cuda" and not nv.emulated():
+            cur = torch.cuda.current_stream(self.device)
+            for sc in self._pipe:
+                cur.wait_stream(sc.stream)
 
     def __del__(self):
         try:
@@ -262,25 +321,30 @@ class GaussianRasterizer(nn.Module):
             if discard_images:
                 return None, None, None, None
             return sc.colour, sc.radii.clone(), sc.invdepths, sc.depths
-        if discard_images and PIPELINE_STREAMS > 1 and self.device.type == "cuda" and not nv.emulated():
+        on_gpu = self.device.type == "cuda" and not nv.emulated()
+        if discard_images and PIPELINE_STREAMS > 1 and (on_gpu or PIPELINE_IN_EMULATOR):
             if not self._pipe:
-                self._pipe = [_CuScratch(n, self.device, torch.cuda.Stream(self.device)) for _ in range(PIPELINE_STREAMS)]
+                self._pipe = [_CuScratch(n, self.device, torch.cuda.Stream(self.device) if on_gpu else None)
+                              for _ in range(PIPELINE_STREAMS)]
             while len(self._pending) >= PIPELINE_STREAMS:
                 self._finish(self._pending.pop(0))
             sc = self._pipe[self._pipe_next]
             self._pipe_next = (self._pipe_next + 1) % PIPELINE_STREAMS
-            if not self._pending:
+            if not self._pending and on_gpu:
                 for other in self._pipe:
                     other.stream.wait_stream(torch.cuda.current_stream(self.device))
-            if mask is not None:
+            if mask is not None and on_gpu:
                 # the mask was produced (copied / converted) on the CURRENT stream but is read by the blend on sc.stream,
                 # possibly several cameras later: order the side stream behind its producer and keep the allocator from
                 # handing the block to the next camera's mask while that blend is still queued
                 sc.stream.wait_stream(torch.cuda.current_stream(self.device))
                 mask.record_stream(sc.stream)
-            self._front(sc, cam, campos, rs.sh_degree)
-            sc.front_done.record(sc.stream)
-            self._pending.append((sc, cam, mask, int(cam_index)))
+            if self._capacity is None:                 # the first camera tells how many instances to expect
+                num_rendered = self._render_two_call(sc, cam, campos, mask, rs.sh_degree, int(cam_index))
+                self._capacity = max(int(num_rendered * CAPACITY_HEADROOM), MIN_CAPACITY)
+                return None, None, None, None
+            self._issue(sc, cam, campos, mask, rs.sh_degree, int(cam_index), self._capacity)
+            self._pending.append((sc, cam, campos, mask, rs.sh_degree, int(cam_index), self._capacity))
             return None, None, None, None
 
         self.flush()

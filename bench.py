@@ -307,6 +307,8 @@ def main():
         gauss_render.BLEND_SUBBLOCKS = a.blend_subblocks
     if a.streams:
         gauss_render.PIPELINE_STREAMS = a.streams
+        import gaussian_pointcloud_rasterization as _gpr
+        _gpr.PIPELINE_STREAMS = a.streams
     if a.no_context_pool:
         gauss_render.CONTEXT_POOL_SIZE = 0
 

@@ -368,6 +368,15 @@ int g2pc_raster_back_cu_tiles(const G2pcCamera* cam, const int32_t* mask, int64_
                               float* total_contrib, float* colours, float* min_surf, int32_t* winner_cam, int32_t cam_index,
                               float* cur_contrib, int32_t* cur_pixels, float* cur_surf, int phases, int32_t tile_first,
                               int32_t tile_step, void* ws, size_t ws_bytes, void* stream);
+/* Bin + blend of one camera with the instance count kept on the device: launches sized for `capacity`, the count goes to
+ * the pinned count_host[0] (count_host[1] = 0) asynchronously; a camera with more instances is skipped as a whole and
+ * must be rendered again through g2pc_raster_back_cu[_tiles].  Removes the host read-back between the halves of a camera
+ * (rasterizer_impl.cu:289 has it).  Follow with g2pc_raster_back_cu_tiles(phases = 4, num_instances = capacity). */
+int g2pc_raster_back_cu_dev(const G2pcCamera* cam, const int32_t* mask, int64_t n, int64_t capacity, const float* rec,
+                            const uint32_t* rect, const uint32_t* sorted_idx, const uint32_t* offsets,
+                            int calculate_surface_distance, unsigned long long* cam_key, uint32_t* cam_surf, float* out_color,
+                            float* out_depth, float* out_invdepth, uint32_t* count_host, int32_t tile_first, int32_t tile_step,
+                            void* ws, size_t ws_bytes, void* stream);
 
 /* Multi-GPU exchange of the python-semantics state (cameras sharded over ranks): all-reduce MAX of best_key, then
  * g2pc_raster_key_owner (owner[i] = rank where this rank holds the winning key, INT32_MAX elsewhere), all-reduce MIN of

@@ -41,3 +41,36 @@ def test_mark_visible_is_the_near_plane_test(emu):
 def test_generate_mesh_surface_point_cloud(emu):
     from mesh_surface_checks import check_surface_cloud
     print(check_surface_cloud())
+
+
+def test_cameras_without_read_back_equal_one_at_a_time(emu, monkeypatch):
+    """The pipelined native-semantics path (instance count kept on the device, launches sized for a capacity,
+    g2pc_raster_back_cu_dev) leaves the same running state as one camera at a time -- including cameras that outgrow the
+    capacity learned from the first one, which are skipped on the device and rendered again through the two-call path."""
+    import torch
+    import camera_handler
+    import gaussian_pointcloud_rasterization as gpr
+    from g2pc.synth import make_scene, make_cameras
+    sc = make_scene(2500, 11, scale_lo=0.01, scale_hi=0.06)
+    tr, intr = make_cameras(5, width=176, height=100, focal=150.0)
+    names = sorted(tr)
+
+    def run(pipelined, headroom):
+        monkeypatch.setattr(gpr, "PIPELINE_IN_EMULATOR", pipelined)
+        monkeypatch.setattr(gpr, "CAPACITY_HEADROOM", headroom)
+        monkeypatch.setattr(gpr, "MIN_CAPACITY", 16)
+        R = gpr.GaussianRasterizer(sc.xyz, torch.zeros_like(sc.xyz), sc.opacities.unsqueeze(1), colors_precomp=sc.colours,
+                                   scales=torch.exp(sc.scales), rotations=sc.rots, visible_gaussian_threshold=0.05,
+                                   surface_distance_std=2.0, calculate_surface_distance=True)
+        for k in names:
+            R(camera_handler.get_camera("cuda", torch.tensor(tr[k]), intr[k]), return_image=False)
+        R.flush()
+        return R, (R.gaussian_max_contribution.clone(), R.gaussian_total_contribution.clone(), R.gaussian_colours.clone(),
+                   R.gaussian_min_surface_distance.clone())
+
+    _, ref = run(False, 1.25)
+    R1, a = run(True, 1.25)
+    R2, b = run(True, 0.6)                 # capacity = 60 % of the first camera's count: the others overflow it
+    assert R1._capacity is not None and R2.rerendered >= 1
+    for x, y, z in zip(ref, a, b):
+        assert torch.equal(x, y) and torch.equal(x, z)
