@@ -315,7 +315,7 @@ __global__ __launch_bounds__(RS_T) void k_radix_scatter(const uint32_t* __restri
         long idx = wbase + (long)r * 64 + lane;
         bool valid = idx < n;
         key[r] = valid ? keys_in[idx] : 0xFFFFFFFFu;
-        val[r] = valid ? vals_in[idx] : 0u;
+        val[r] = (valid && vals_in) ? vals_in[idx] : 0u;          // vals_in == nullptr: keys only
         unsigned d = (key[r] >> shift) & mask;
         // match-any: lanes holding the same digit
         unsigned long long peers = __ballot(valid);
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(RS_T) void k_radix_scatter(const uint32_t* __restri
             unsigned d = (key[r] >> shift) & mask;
             uint32_t pos = gbase[d] + whist[w][d] + rank[r];
             keys_out[pos] = key[r];
-            vals_out[pos] = val[r];
+            if (vals_out) vals_out[pos] = val[r];
         }
     }
 }
@@ -384,15 +384,17 @@ int sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* k
     // n_dev (optional, device): the number of keys actually present (<= n).  The launch geometry then depends on n
     // (a capacity) only, so the same sequence of launches -- e.g. a captured hipGraph -- serves any count.
     if (n <= 0) return G2PC_OK;
-    if (keys_tmp == keys_in || vals_tmp == vals_in || keys_tmp == keys_out || vals_tmp == vals_out ||
-        keys_out == keys_in || vals_out == vals_in) {
+    // vals_in == vals_out == vals_tmp == nullptr: keys only (half the traffic of a pass)
+    const bool keys_only = !vals_in && !vals_out && !vals_tmp;
+    if (keys_tmp == keys_in || keys_tmp == keys_out || keys_out == keys_in ||
+        (!keys_only && (!vals_in || !vals_out || !vals_tmp || vals_tmp == vals_in || vals_tmp == vals_out || vals_out == vals_in))) {
         set_error("sort", "in / out / tmp buffers must be distinct");
         return G2PC_ERR_ARG;
     }
     int total_bits = bit_hi - bit_lo;
     if (total_bits <= 0) {
         hipMemcpyAsync(keys_out, keys_in, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
-        hipMemcpyAsync(vals_out, vals_in, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
+        if (!keys_only) hipMemcpyAsync(vals_out, vals_in, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
         return G2PC_OK;
     }
     const int maxbits = radix_maxbits(total_bits), items = radix_items(n);

@@ -19,7 +19,7 @@ namespace g2pc {
 
 constexpr int RA_T = 256;
 __global__ void k_tile_ranges(const uint32_t* __restrict__ tile_sorted, long L, int T, uint32_t* __restrict__ tile_start,
-                              const uint32_t* __restrict__ l_dev);
+                              const uint32_t* __restrict__ l_dev, int gshift);
 constexpr float LOG2E = 1.4426950408889634f;
 
 struct Cam {            // device copy of G2pcCamera (passed by value as kernel argument)
@@ -182,7 +182,8 @@ __global__ __launch_bounds__(RA_T) void k_duplicate(const uint32_t* __restrict__
                                                    const uint32_t* __restrict__ offsets,
                                                    const uint32_t* __restrict__ rect, long n, int nx,
                                                    uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ inst_g,
-                                                   const uint32_t* __restrict__ l_eff) {
+                                                   const uint32_t* __restrict__ l_eff, int gshift) {
+    // gshift > 0 (inst_g unused): ONE word per instance, tile << gshift | Gaussian -- the tile sort then moves keys only
     long p = (long)blockIdx.x * RA_T + threadIdx.x;
     if (p >= n) return;
     if (l_eff && *l_eff == 0u) return;          // capacity-sized launch: nothing to emit (or more than fits)
@@ -193,8 +194,12 @@ __global__ __launch_bounds__(RA_T) void k_duplicate(const uint32_t* __restrict__
     int ix0 = rc & 255, ix1 = (rc >> 8) & 255, iy0 = (rc >> 16) & 255, iy1 = rc >> 24;
     for (int iy = iy0; iy <= iy1; ++iy)
         for (int ix = ix0; ix <= ix1; ++ix) {
-            inst_tile[off] = (uint32_t)(iy * nx + ix);
-            inst_g[off] = g;
+            if (gshift) {
+                inst_tile[off] = ((uint32_t)(iy * nx + ix) << gshift) | g;
+            } else {
+                inst_tile[off] = (uint32_t)(iy * nx + ix);
+                inst_g[off] = g;
+            }
             ++off;
         }
 }
@@ -239,7 +244,7 @@ template <int PPT, int U>
 __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __restrict__ chunk_tile,
                                                   const int32_t* __restrict__ chunk_pix0,
                                                   const uint32_t* __restrict__ tile_start,
-                                                  const uint32_t* __restrict__ inst_g,
+                                                  const uint32_t* __restrict__ inst_g, uint32_t gmask,
                                                   const float4* __restrict__ rec,
                                                   unsigned long long* __restrict__ best_key, uint32_t order_base,
                                                   float t_floor, float bg, float* __restrict__ tilebuf,
@@ -288,8 +293,8 @@ __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t g_cur = 0, g_nxt = 0;
     bool v_cur = (start + lane) < end, v_nxt = (start + BL_BATCH + lane) < end;
-    if (v_cur) g_cur = inst_g[start + lane];
-    if (v_nxt) g_nxt = inst_g[start + BL_BATCH + lane];
+    if (v_cur) g_cur = inst_g[start + lane] & gmask;
+    if (v_nxt) g_nxt = inst_g[start + BL_BATCH + lane] & gmask;
     // raw loads only (no arithmetic on them before the LDS write, or the compiler waits for the load right here)
     float4 r0 = zero4, r1 = zero4;                       // zero opacity = padding
     float c0 = 0.f, c1 = 0.f, c2 = 0.f, cth = 0.f;
@@ -328,7 +333,7 @@ __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __
         v_cur = v_nxt;
         v_nxt = (b + 2 * BL_BATCH + lane) < end;
         g_nxt = 0;
-        if (v_nxt) g_nxt = inst_g[b + 2 * BL_BATCH + lane];
+        if (v_nxt) g_nxt = inst_g[b + 2 * BL_BATCH + lane] & gmask;
         r0 = zero4; r1 = zero4; c0 = c1 = c2 = 0.f; cth = 0.f; gmb = 0x7F000000u;
         if (v_cur) {
             r0 = rec[4 * (size_t)g_cur];
@@ -442,7 +447,7 @@ template <int U>
 __global__ __launch_bounds__(BL_T) void k_blend_py_pk(Layout lay, const int32_t* __restrict__ chunk_tile,
                                                      const int32_t* __restrict__ chunk_pix0,
                                                      const uint32_t* __restrict__ tile_start,
-                                                     const uint32_t* __restrict__ inst_g,
+                                                     const uint32_t* __restrict__ inst_g, uint32_t gmask,
                                                      const float4* __restrict__ rec,
                                                      unsigned long long* __restrict__ best_key, uint32_t order_base,
                                                      float t_floor, float bg, float* __restrict__ tilebuf,
@@ -492,8 +497,8 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_pk(Layout lay, const int32_t*
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t g_cur = 0, g_nxt = 0;
     bool v_cur = (start + lane) < end, v_nxt = (start + BL_BATCH + lane) < end;
-    if (v_cur) g_cur = inst_g[start + lane];
-    if (v_nxt) g_nxt = inst_g[start + BL_BATCH + lane];
+    if (v_cur) g_cur = inst_g[start + lane] & gmask;
+    if (v_nxt) g_nxt = inst_g[start + BL_BATCH + lane] & gmask;
     float4 r0 = zero4, r1 = zero4;
     float c0 = 0.f, c1 = 0.f, c2 = 0.f, cth = 0.f;
     uint32_t gmb = 0x7F000000u;
@@ -528,7 +533,7 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_pk(Layout lay, const int32_t*
         v_cur = v_nxt;
         v_nxt = (b + 2 * BL_BATCH + lane) < end;
         g_nxt = 0;
-        if (v_nxt) g_nxt = inst_g[b + 2 * BL_BATCH + lane];
+        if (v_nxt) g_nxt = inst_g[b + 2 * BL_BATCH + lane] & gmask;
         r0 = zero4; r1 = zero4; c0 = c1 = c2 = 0.f; cth = 0.f; gmb = 0x7F000000u;
         if (v_cur) {
             r0 = rec[4 * (size_t)g_cur];
@@ -623,7 +628,7 @@ template <int U>
 __global__ __launch_bounds__(BL_T) void k_blend_py_dl(Layout lay, const int32_t* __restrict__ chunk_tile,
                                                      const int32_t* __restrict__ chunk_pix0,
                                                      const uint32_t* __restrict__ tile_start,
-                                                     const uint32_t* __restrict__ inst_g,
+                                                     const uint32_t* __restrict__ inst_g, uint32_t gmask,
                                                      const float4* __restrict__ rec,
                                                      unsigned long long* __restrict__ best_key, uint32_t order_base,
                                                      float t_floor, float bg, float* __restrict__ tilebuf,
@@ -669,8 +674,8 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_dl(Layout lay, const int32_t*
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t g_cur = 0, g_nxt = 0;
     bool v_cur = (start + lane) < end, v_nxt = (start + BL_BATCH + lane) < end;
-    if (v_cur) g_cur = inst_g[start + lane];
-    if (v_nxt) g_nxt = inst_g[start + BL_BATCH + lane];
+    if (v_cur) g_cur = inst_g[start + lane] & gmask;
+    if (v_nxt) g_nxt = inst_g[start + BL_BATCH + lane] & gmask;
     float4 r0 = zero4, r1 = zero4, r2 = zero4;
     uint32_t gmb = 0x7F000000u;
     if (v_cur) {
@@ -713,7 +718,7 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_dl(Layout lay, const int32_t*
         v_cur = v_nxt;
         v_nxt = (b + 2 * BL_BATCH + lane) < end;
         g_nxt = 0;
-        if (v_nxt) g_nxt = inst_g[b + 2 * BL_BATCH + lane];
+        if (v_nxt) g_nxt = inst_g[b + 2 * BL_BATCH + lane] & gmask;
         r0 = zero4; r1 = zero4; r2 = zero4; gmb = 0x7F000000u;
         if (v_cur) {
             r0 = rec[4 * (size_t)g_cur];
@@ -1046,7 +1051,7 @@ constexpr int CU_T = 256;
 
 __global__ __launch_bounds__(CU_T) void k_blend_cu(int W, int H, int grid_x, int tile_first, int tile_step,
                                                   const uint32_t* __restrict__ tile_start,
-                                                  const uint32_t* __restrict__ inst_g, const float4* __restrict__ rec,
+                                                  const uint32_t* __restrict__ inst_g, uint32_t gmask, const float4* __restrict__ rec,
                                                   const int32_t* __restrict__ mask, float3 bg, int calc_surf,
                                                   unsigned long long* __restrict__ cam_key,
                                                   uint32_t* __restrict__ cam_surf, float* __restrict__ out_color,
@@ -1088,7 +1093,7 @@ __global__ __launch_bounds__(CU_T) void k_blend_cu(int W, int H, int grid_x, int
         // same results bit for bit, ~half the (pixel, Gaussian) pairs of a 16x16 tile never evaluated.
         bool keep[4] = {false, false, false, false};
         if (b + t < end) {
-            uint32_t g = inst_g[b + t];
+            uint32_t g = inst_g[b + t] & gmask;
             const float4 r0 = rec[4 * (size_t)g], r1 = rec[4 * (size_t)g + 1], r3 = rec[4 * (size_t)g + 3];
             s_p0[t] = r0;
             s_p1[t] = r1;
@@ -1233,12 +1238,12 @@ __global__ __launch_bounds__(CU_T) void k_blend_cu(int W, int H, int grid_x, int
 // sorted tile ids (rasterizer_impl.cu:115-137 identifyTileRanges), no histogram, no scan.
 __global__ __launch_bounds__(RA_T) void k_tile_ranges(const uint32_t* __restrict__ tile_sorted, long L, int T,
                                                      uint32_t* __restrict__ tile_start,
-                                                     const uint32_t* __restrict__ l_dev) {
+                                                     const uint32_t* __restrict__ l_dev, int gshift) {
     if (l_dev) L = (long)*l_dev;                 // capacity-sized launch, count on the device
     long l = (long)blockIdx.x * RA_T + threadIdx.x;
     if (l > L) return;
-    int prev = l == 0 ? -1 : (int)tile_sorted[l - 1];
-    int cur = l == L ? T : (int)tile_sorted[l];
+    int prev = l == 0 ? -1 : (int)(tile_sorted[l - 1] >> gshift);      // gshift > 0: packed (tile << gshift | Gaussian) instances
+    int cur = l == L ? T : (int)(tile_sorted[l] >> gshift);
     for (int t = prev + 1; t <= cur; ++t) tile_start[t] = (uint32_t)l;      // every t in [0, T] is written exactly once:
     if (l == L) tile_start[T + 1] = (uint32_t)L;                              // no memset of tile_start is needed
 }
@@ -1346,6 +1351,14 @@ static size_t py_front_ws(long n) {
 }
 static int g_blend_variant = 1;               // 2 sub-blocks per wave: 1 = dual-list kernel (k_blend_py_dl), 0 = packed kernel (k_blend_py_pk)
 static int g_depth_bucket_sort = 1;           // captured camera path: 1 = bucket sort of the depth keys, 0 = radix (g2pc_set_depth_sort)
+// Packed tile-sort instances: when the tile id and the Gaussian index share one 32-bit word (tile << gshift | index) the
+// stable sort by tile moves keys only -- half the traffic of the two passes -- and the blend masks the index out.
+// Returns gshift (0: they do not fit, separate arrays as before).
+static int packed_instance_shift(long n, int T) {
+    int gbits = 1;
+    while (((long)1 << gbits) < n) ++gbits;
+    return (gbits + bits_for_tiles((unsigned)T) <= 32) ? gbits : 0;
+}
 static size_t py_back_ws(long L, int T) {
     return align_up((size_t)(L + 1) * 4) * 6 + sort_workspace(L) + scan_workspace(T + 1) + align_up((size_t)(T + 2) * 4) + 4096 + 256;
 }
@@ -1403,22 +1416,27 @@ static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t*
     char* sort_ws = ar.get<char>(sort_bytes);
     if (!ar.ok()) { set_error("raster_back_py", "workspace too small"); return G2PC_ERR_WORKSPACE; }
     Layout lay = to_layout(layout);
+    const int gshift = packed_instance_shift(n, T);
+    const uint32_t gmask = gshift ? ((1u << gshift) - 1u) : 0xFFFFFFFFu;
+    const uint32_t* blend_list = gshift ? tile_sorted : g_sorted;
     if (phases & 1) {
         if (L > 0) {
             hipLaunchKernelGGL(k_duplicate, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, fb.sorted_idx, fb.offsets, fb.rect, n, lay.nx,
-                               inst_tile, inst_g, l_eff);
-            int rc = sort_pairs_u32(inst_tile, inst_g, tile_sorted, g_sorted, tile_tmp, g_tmp, L, 0, bits_for_tiles((unsigned)T),
-                                    sort_ws, sort_bytes, s, l_eff);
+                               inst_tile, inst_g, l_eff, gshift);
+            int rc = gshift ? sort_pairs_u32(inst_tile, nullptr, tile_sorted, nullptr, tile_tmp, nullptr, L, gshift,
+                                             gshift + bits_for_tiles((unsigned)T), sort_ws, sort_bytes, s, l_eff)
+                            : sort_pairs_u32(inst_tile, inst_g, tile_sorted, g_sorted, tile_tmp, g_tmp, L, 0,
+                                             bits_for_tiles((unsigned)T), sort_ws, sort_bytes, s, l_eff);
             if (rc) return rc;
         }
-        hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T)), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start, l_eff);
+        hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T)), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start, l_eff, gshift);
         if (overflow_flag && max_per_tile)
             hipLaunchKernelGGL(k_check_tile_load, dim3(cdiv(T, RA_T)), dim3(RA_T), 0, s, tile_start, T, max_per_tile, overflow_flag);
     }
     if (phases & 2) {
 #define G2PC_BLEND(...)                                                                                                 \
     hipLaunchKernelGGL((__VA_ARGS__), dim3((unsigned)layout->num_chunks), dim3(BL_T), 0, s, lay, layout->chunk_tile,          \
-                       layout->chunk_pix0, tile_start, g_sorted, (const float4*)fb.rec, best_key,                      \
+                       layout->chunk_pix0, tile_start, blend_list, gmask, (const float4*)fb.rec, best_key,             \
                        ba.camera_slot << 24, ba.t_floor, ba.bg, tilebuf, g_chunk_work, ba.job)
         switch (layout->chunk_subblocks) {
             case 1: G2PC_BLEND(k_blend_py<1, 4>); break;
@@ -1676,6 +1694,8 @@ int g2pc_raster_back_cu_tiles(const G2pcCamera* cam, const int32_t* mask, int64_
     char* sort_ws = ar.get<char>(sort_bytes);
     char* scan_ws = ar.get<char>(scan_bytes);
     G2PC_REQUIRE(ar.ok(), G2PC_ERR_WORKSPACE, "workspace too small");
+    const int gshift = packed_instance_shift((long)n, T);
+    const uint32_t gmask = gshift ? ((1u << gshift) - 1u) : 0xFFFFFFFFu;
     if (phases & 1) {
     // (k_tile_ranges writes every entry of tile_start: no memset)
     if (mask || sharded) {                        // without a mask every pixel is written by the blend kernel
@@ -1686,17 +1706,19 @@ int g2pc_raster_back_cu_tiles(const G2pcCamera* cam, const int32_t* mask, int64_
     hipLaunchKernelGGL(k_init_camera_state_cu, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, (unsigned long long*)cam_key, (uint32_t*)cam_surf, (long)n);
     if (L > 0) {
         hipLaunchKernelGGL(k_duplicate, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, sorted_idx, offsets, rect, (long)n, gx,
-                           inst_tile, inst_g, (const uint32_t*)nullptr);
-        int rc = sort_pairs_u32(inst_tile, inst_g, tile_sorted, g_sorted, tile_tmp, g_tmp, L, 0, bits_for_tiles((unsigned)T),
-                                sort_ws, sort_bytes, s);
+                           inst_tile, inst_g, (const uint32_t*)nullptr, gshift);
+        int rc = gshift ? sort_pairs_u32(inst_tile, nullptr, tile_sorted, nullptr, tile_tmp, nullptr, L, gshift,
+                                         gshift + bits_for_tiles((unsigned)T), sort_ws, sort_bytes, s)
+                        : sort_pairs_u32(inst_tile, inst_g, tile_sorted, g_sorted, tile_tmp, g_tmp, L, 0,
+                                         bits_for_tiles((unsigned)T), sort_ws, sort_bytes, s);
         if (rc) return rc;
     }
     (void)scan_ws; (void)scan_bytes;
-    hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T)), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start, (const uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T)), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start, (const uint32_t*)nullptr, gshift);
     }
     if ((phases & 2) && tile_first < T)
     hipLaunchKernelGGL(k_blend_cu, dim3((unsigned)((T - tile_first + tile_step - 1) / tile_step)), dim3(CU_T), 0, s, W, H, gx,
-                       (int)tile_first, (int)tile_step, tile_start, g_sorted, (const float4*)rec,
+                       (int)tile_first, (int)tile_step, tile_start, gshift ? tile_sorted : g_sorted, gmask, (const float4*)rec,
                        mask, make_float3(cam->bg[0], cam->bg[1], cam->bg[2]),
                        calculate_surface_distance, cam_key, cam_surf, out_color, out_depth, out_invdepth);
     if (phases & 4)
@@ -1745,15 +1767,19 @@ int g2pc_raster_back_cu_dev(const G2pcCamera* cam, const int32_t* mask, int64_t 
         hipMemsetAsync(out_invdepth, 0, (size_t)W * H * 4, s);
     }
     hipLaunchKernelGGL(k_init_camera_state_cu, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, (unsigned long long*)cam_key, (uint32_t*)cam_surf, (long)n);
+    const int gshift = packed_instance_shift((long)n, T);
+    const uint32_t gmask = gshift ? ((1u << gshift) - 1u) : 0xFFFFFFFFu;
     hipLaunchKernelGGL(k_duplicate, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, sorted_idx, offsets, rect, (long)n, gx, inst_tile, inst_g,
-                       (const uint32_t*)l_eff);
-    int rc = sort_pairs_u32(inst_tile, inst_g, tile_sorted, g_sorted, tile_tmp, g_tmp, L, 0, bits_for_tiles((unsigned)T), sort_ws,
-                            sort_bytes, s, l_eff);
+                       (const uint32_t*)l_eff, gshift);
+    int rc = gshift ? sort_pairs_u32(inst_tile, nullptr, tile_sorted, nullptr, tile_tmp, nullptr, L, gshift,
+                                     gshift + bits_for_tiles((unsigned)T), sort_ws, sort_bytes, s, l_eff)
+                    : sort_pairs_u32(inst_tile, inst_g, tile_sorted, g_sorted, tile_tmp, g_tmp, L, 0, bits_for_tiles((unsigned)T),
+                                     sort_ws, sort_bytes, s, l_eff);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T)), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start, (const uint32_t*)l_eff);
+    hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T)), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start, (const uint32_t*)l_eff, gshift);
     if (tile_first < T)
         hipLaunchKernelGGL(k_blend_cu, dim3((unsigned)((T - tile_first + tile_step - 1) / tile_step)), dim3(CU_T), 0, s, W, H, gx,
-                           (int)tile_first, (int)tile_step, tile_start, g_sorted, (const float4*)rec, mask,
+                           (int)tile_first, (int)tile_step, tile_start, gshift ? tile_sorted : g_sorted, gmask, (const float4*)rec, mask,
                            make_float3(cam->bg[0], cam->bg[1], cam->bg[2]), calculate_surface_distance, cam_key, cam_surf,
                            out_color, out_depth, out_invdepth);
     return check_launch("g2pc_raster_back_cu_dev");
