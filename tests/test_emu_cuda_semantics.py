@@ -51,26 +51,30 @@ def test_cameras_without_read_back_equal_one_at_a_time(emu, monkeypatch):
     import camera_handler
     import gaussian_pointcloud_rasterization as gpr
     from g2pc.synth import make_scene, make_cameras
-    sc = make_scene(2500, 11, scale_lo=0.01, scale_hi=0.06)
-    tr, intr = make_cameras(5, width=176, height=100, focal=150.0)
+    sc = make_scene(900, 11, scale_lo=0.01, scale_hi=0.06)
+    tr, intr = make_cameras(5, width=112, height=64, focal=96.0)
     names = sorted(tr)
 
-    def run(pipelined, headroom):
+    def run(pipelined, shrink):
         monkeypatch.setattr(gpr, "PIPELINE_IN_EMULATOR", pipelined)
-        monkeypatch.setattr(gpr, "CAPACITY_HEADROOM", headroom)
         monkeypatch.setattr(gpr, "MIN_CAPACITY", 16)
+        monkeypatch.setattr(gpr, "PIPELINE_STREAMS", 2)        # retire early: the capacity grows while cameras are still coming
         R = gpr.GaussianRasterizer(sc.xyz, torch.zeros_like(sc.xyz), sc.opacities.unsqueeze(1), colors_precomp=sc.colours,
                                    scales=torch.exp(sc.scales), rotations=sc.rots, visible_gaussian_threshold=0.05,
                                    surface_distance_std=2.0, calculate_surface_distance=True)
-        for k in names:
+        for i, k in enumerate(names):
             R(camera_handler.get_camera("cuda", torch.tensor(tr[k]), intr[k]), return_image=False)
+            if i == 0 and pipelined:
+                R._capacity = int(R._capacity * shrink)        # what the first camera taught is too small for the next ones
         R.flush()
         return R, (R.gaussian_max_contribution.clone(), R.gaussian_total_contribution.clone(), R.gaussian_colours.clone(),
                    R.gaussian_min_surface_distance.clone())
 
-    _, ref = run(False, 1.25)
-    R1, a = run(True, 1.25)
-    R2, b = run(True, 0.6)                 # capacity = 60 % of the first camera's count: the others overflow it
-    assert R1._capacity is not None and R2.rerendered >= 1
-    for x, y, z in zip(ref, a, b):
-        assert torch.equal(x, y) and torch.equal(x, z)
+    _, ref = run(False, 1.0)
+    R2, b = run(True, 0.7)                 # capacity = 87 % of the first camera's count: the next cameras overflow it
+    assert R2._capacity is not None and 1 <= R2.rerendered < 4       # some cameras outgrew the capacity, later ones fitted the grown one
+    for i, (x, z) in enumerate(zip(ref, b)):
+        if i == 1:      # the running SUM of the per-camera maxima: a re-rendered camera is added out of order (fp32 rounding)
+            assert torch.allclose(x, z, rtol=1e-6, atol=1e-7)
+        else:
+            assert torch.equal(x, z)

@@ -64,3 +64,42 @@ def test_config5_pipeline_cuda_semantics_surface_cull_exact_points():
 def test_generate_mesh_surface_point_cloud():
     from mesh_surface_checks import check_surface_cloud
     print(check_surface_cloud("cuda:0", n=20000, ncam=4, num_points=400000))
+
+
+def test_cameras_without_read_back_equal_one_at_a_time(monkeypatch):
+    """Pipelined native-semantics cameras (4 HIP streams, instance count kept on the device, g2pc_raster_back_cu_dev) leave
+    the running state of one camera at a time -- also when the capacity learned from the first camera is too small for
+    the next ones (skipped on the device, rendered again)."""
+    import camera_handler
+    import gaussian_pointcloud_rasterization as gpr
+    from gauss_handler import Gaussians
+    from g2pc.synth import make_scene, make_cameras
+    sc = make_scene(120_000, 78, device=DEV)
+    G = Gaussians(sc.xyz, sc.scales, sc.rots, sc.colours, sc.opacities)
+    tr, intr = make_cameras(7)
+    names = sorted(tr)
+
+    def run(streams, shrink):
+        monkeypatch.setattr(gpr, "PIPELINE_STREAMS", streams)
+        R = gpr.GaussianRasterizer(G.xyz, torch.zeros_like(G.xyz), G.opacities.unsqueeze(1), colors_precomp=G.colours,
+                                   cov3D_precomp=None, scales=torch.exp(sc.scales), rotations=sc.rots,
+                                   visible_gaussian_threshold=0.05, surface_distance_std=2.0, calculate_surface_distance=True)
+        for i, k in enumerate(names):
+            R(camera_handler.get_camera("cuda", torch.tensor(tr[k]), intr[k], colour_resolution=1280), return_image=False)
+            if i == 0 and streams > 1:
+                R._capacity = int(R._capacity * shrink)
+        R.flush()
+        torch.cuda.synchronize()
+        return R, (R.gaussian_max_contribution.clone(), R.gaussian_total_contribution.clone(), R.gaussian_colours.clone(),
+                   R.gaussian_min_surface_distance.clone())
+
+    _, ref = run(1, 1.0)
+    Ra, a = run(4, 1.0)
+    Rb, b = run(4, 0.7)
+    assert Ra.rerendered == 0 and Rb.rerendered >= 1
+    for got in (a, b):
+        for i, (x, z) in enumerate(zip(ref, got)):
+            if i == 1:      # running SUM: a re-rendered camera is added out of order (fp32 rounding)
+                assert torch.allclose(x, z, rtol=1e-5, atol=1e-6)
+            else:
+                assert torch.equal(x, z)
