@@ -1287,7 +1287,10 @@ __global__ __launch_bounds__(RA_T) void k_update_cu(const unsigned long long* __
     unsigned long long key = cam_key[i];
     float c = __uint_as_float((uint32_t)(key >> 32));
     uint32_t pix = c > 0.0f ? ~(uint32_t)key : 0u;                      // never blended: pixel 0, contribution 0
-    if (c > max_contrib[i]) {
+    // strictly larger wins; a tie goes to the EARLIER camera whatever the order the cameras are applied in (a camera that
+    // outgrew its capacity is rendered again after later ones; multi-GPU ranks apply their shards independently)
+    const float mc = max_contrib[i];
+    if (c > mc || (c == mc && c > 0.0f && winner_cam && cam_index < winner_cam[i])) {
         const size_t plane = (size_t)W * H;
         max_contrib[i] = c;
         if (winner_cam) winner_cam[i] = cam_index;
