@@ -396,7 +396,7 @@ def main():
                     "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(name, a)[0], "traffic_source": pmc_traffic(name, a)[1],
                     "avg_launch_ms": ms / launches,
                     "algorithmic_bytes_per_launch": per_launch,
-                    "note": "k_blend_py is VALU/v_exp bound, not HBM bound (DESIGN.md §3); frac is its HBM share only"
+                    "note": "the blend is bound by VALU issue at low wave residency, not by HBM (DESIGN.md §4); frac is its HBM share only"
                     if name == "raster_blend" else None}
             valu = pmc_valu(name, a)
             if valu is not None:
