@@ -56,14 +56,16 @@ int g2pc_graph_capture_end(void* stream, void** graph_exec);
 int g2pc_graph_launch(void* graph_exec, void* stream);
 int g2pc_graph_destroy(void* graph_exec);
 
-/* stable LSD radix sort of (key,value) pairs on key bits [bit_lo, bit_hi) */
+/* stable LSD radix sort of (key,value) pairs on key bits [bit_lo, bit_hi); vals_in = vals_out = vals_tmp = NULL: keys only */
 int g2pc_sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
                         uint32_t* keys_tmp, uint32_t* vals_tmp, int64_t n, int bit_lo, int bit_hi, void* ws,
                         size_t ws_bytes, void* stream);
 /* Stable ascending sort of (key, value) pairs whose keys are bit patterns of positive floats spread over their range (a
- * camera's depths): range-normalised bucket pass + in-LDS bitonic sort per bucket (five launches instead of twelve).
- * Keys 0xFFFFFFFF go last.  *overflow (device u32) != 0 afterwards: a bucket held more than 4096 keys and the result is
- * NOT sorted -- repeat with g2pc_sort_pairs_u32. */
+ * camera's depths): range-normalised bucket pass (per-chunk histogram table, no global atomics) + one wave per bucket
+ * sorting (key, position) composites in LDS -- six launches, every key moved once.  Keys 0xFFFFFFFF go last.
+ * *overflow (device u32) != 0 afterwards: a bucket held more keys than its room (1024; 4096 when the mean bucket exceeds
+ * 256 keys) and the result is NOT sorted -- repeat with g2pc_sort_pairs_u32.  Pays up to ~2 M keys (MI355X: 90 vs 101 us
+ * at 1 M, 533 vs 278 us at 5 M). */
 size_t g2pc_bucket_sort_workspace(int64_t n);
 int g2pc_bucket_sort_u32(const uint32_t* keys, const uint32_t* vals, uint32_t* keys_out, uint32_t* vals_out, int64_t n,
                          uint32_t* overflow, void* ws, size_t ws_bytes, void* stream);
