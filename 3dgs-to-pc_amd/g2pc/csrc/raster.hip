@@ -251,7 +251,11 @@ __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __
                                                   uint32_t* __restrict__ chunk_work,
                                                   const G2pcCameraJob* __restrict__ job) {
     // one wave64 per block: the LDS stage is wave-private, no s_barrier anywhere
-    if (job) { order_base = job->camera_slot << 24; t_floor = job->t_floor; bg = job->cam.bg[0]; }   // see k_preprocess_py
+    if (job) {
+        order_base = job->camera_slot << 24; t_floor = job->t_floor; bg = job->cam.bg[0];
+        const unsigned long long tb = ((unsigned long long)job->tilebuf_hi << 32) | job->tilebuf_lo;
+        if (tb) tilebuf = (float*)tb;              // one colour buffer per camera (deferred colour resolve)
+    }   // see k_preprocess_py
     __shared__ float4 s_p0[BL_BATCH + 4];
     __shared__ float4 s_p1[BL_BATCH + 4];
     __shared__ float4 s_p2[BL_BATCH + 4];
@@ -453,7 +457,11 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_pk(Layout lay, const int32_t*
                                                      float t_floor, float bg, float* __restrict__ tilebuf,
                                                      uint32_t* __restrict__ chunk_work,
                                                      const G2pcCameraJob* __restrict__ job) {
-    if (job) { order_base = job->camera_slot << 24; t_floor = job->t_floor; bg = job->cam.bg[0]; }
+    if (job) {
+        order_base = job->camera_slot << 24; t_floor = job->t_floor; bg = job->cam.bg[0];
+        const unsigned long long tb = ((unsigned long long)job->tilebuf_hi << 32) | job->tilebuf_lo;
+        if (tb) tilebuf = (float*)tb;              // one colour buffer per camera (deferred colour resolve)
+    }
     __shared__ float4 s_p0[BL_BATCH + 4];
     __shared__ float4 s_p1[BL_BATCH + 4];
     __shared__ float4 s_p2[BL_BATCH + 4];
@@ -634,7 +642,11 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_dl(Layout lay, const int32_t*
                                                      float t_floor, float bg, float* __restrict__ tilebuf,
                                                      uint32_t* __restrict__ chunk_work,
                                                      const G2pcCameraJob* __restrict__ job) {
-    if (job) { order_base = job->camera_slot << 24; t_floor = job->t_floor; bg = job->cam.bg[0]; }
+    if (job) {
+        order_base = job->camera_slot << 24; t_floor = job->t_floor; bg = job->cam.bg[0];
+        const unsigned long long tb = ((unsigned long long)job->tilebuf_hi << 32) | job->tilebuf_lo;
+        if (tb) tilebuf = (float*)tb;              // one colour buffer per camera (deferred colour resolve)
+    }
     __shared__ float4 s_a[2][BL_BATCH + 4];         // A, B, C, Lu
     __shared__ float4 s_b[2][BL_BATCH + 4];         // Lv, K, red, green
     __shared__ float2 s_c[2][BL_BATCH + 4];         // blue, max(running maximum, FLT_MIN)
@@ -844,6 +856,26 @@ __global__ __launch_bounds__(RA_T) void k_update_colours_py(Layout lay, const un
     int seq = (order >> 12) & 0xFFF, pix = order & 0xFFF;
     int tile = lay.seq_tile[seq];
     const float* src = tilebuf + 3 * ((size_t)lay.tile_pix_off[tile] + pix);
+    colours_out[3 * i + 0] = src[0];
+    colours_out[3 * i + 1] = src[1];
+    colours_out[3 * i + 2] = src[2];
+}
+
+// deferred form of K7: every Gaussian takes its colour from the buffer of the camera that holds its key (tilebufs[slot],
+// device addresses; 0 = that camera updated on its own)
+__global__ __launch_bounds__(RA_T) void k_resolve_colours_py(Layout lay, const unsigned long long* __restrict__ best_key,
+                                                            long n, const unsigned long long* __restrict__ tilebufs,
+                                                            float* __restrict__ colours_out) {
+    long i = (long)blockIdx.x * RA_T + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long key = best_key[i];
+    if ((key >> 32) == 0ull) return;
+    uint32_t order = ~(uint32_t)key;
+    const float* tb = (const float*)tilebufs[order >> 24];
+    if (!tb) return;
+    int seq = (order >> 12) & 0xFFF, pix = order & 0xFFF;
+    int tile = lay.seq_tile[seq];
+    const float* src = tb + 3 * ((size_t)lay.tile_pix_off[tile] + pix);
     colours_out[3 * i + 0] = src[0];
     colours_out[3 * i + 1] = src[1];
     colours_out[3 * i + 2] = src[2];
@@ -1573,6 +1605,15 @@ int g2pc_raster_camera_update_py(const G2pcTileLayout* layout, int64_t n, uint32
     hipLaunchKernelGGL(k_update_colours_py, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, (hipStream_t)stream, to_layout(layout),
                        best_key, (long)n, camera_slot, tilebuf, colours_out);
     return check_launch("g2pc_raster_camera_update_py");
+}
+
+int g2pc_raster_resolve_colours_py(const G2pcTileLayout* layout, int64_t n, const unsigned long long* best_key,
+                                   const unsigned long long* tilebufs, float* colours_out, void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(layout && best_key && tilebufs && colours_out && n > 0, G2PC_ERR_ARG, "bad arguments");
+    hipLaunchKernelGGL(k_resolve_colours_py, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, (hipStream_t)stream, to_layout(layout),
+                       best_key, (long)n, tilebufs, colours_out);
+    return check_launch("g2pc_raster_resolve_colours_py");
 }
 
 /* diagnostics: when set, the PY blend writes (list length, entries walked) per chunk into u32[2*num_chunks] */

@@ -46,7 +46,8 @@ class _Camera(C.Structure):
 
 class _Job(C.Structure):
     """G2pcCameraJob: what a captured camera graph reads from device memory."""
-    _fields_ = [("cam", _Camera), ("camera_slot", C.c_uint32), ("t_floor", C.c_float), ("reserved", C.c_uint32 * 3)]
+    _fields_ = [("cam", _Camera), ("camera_slot", C.c_uint32), ("t_floor", C.c_float), ("tilebuf_lo", C.c_uint32),
+                ("tilebuf_hi", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class _Layout(C.Structure):
@@ -73,6 +74,7 @@ nv._RASTER_PROTOS.update({
     "g2pc_graph_destroy": (C.c_int, [C.c_void_p]),
     "g2pc_raster_rebase_keys": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "g2pc_raster_debug_chunk_work": (C.c_int, [C.c_void_p]),
+    "g2pc_raster_resolve_colours_py": (C.c_int, [C.POINTER(_Layout), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "g2pc_set_depth_sort": (C.c_int, [C.c_int]),
     "g2pc_set_blend_variant": (C.c_int, [C.c_int]),
     "g2pc_raster_key_owner": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
@@ -258,11 +260,14 @@ class _RenderContext:
         self.overflow = torch.empty((1,), dtype=torch.int32, device=device)
         self.sync_scratch = _Scratch(n, device)
         self.slots, self.capacity = [], None
+        self.cam_tilebufs = {}        # camera slot -> per-tile colour buffer of the pipelined camera that used it (kept for
+                                      # the deferred colour resolve; reused by the next epoch / job of this context)
 
     def release(self):
         for sl in self.slots:
             sl.release()
         self.slots = []
+        self.cam_tilebufs = {}
 
 
 CONTEXT_POOL_SIZE = 2
@@ -340,8 +345,8 @@ class GaussHipRenderer():
         self.slots = ctx.slots        # _GraphSlot per in-flight camera (created lazily, kept with the context)
         self.slot_next = 0
         self.capacity = ctx.capacity  # instance capacity of the captured graphs (learned from the first camera rendered)
+        self.deferred = {}            # camera slot -> layout of the pipelined cameras whose colours are resolved at flush()
         self.redo = []                # cameras that did not fit their graph's capacity: (camera struct, layout, slot)
-        self.last_update = None       # event after the latest colour update (updates are issued in camera order)
         self.rerendered = 0           # cameras that overflowed their graph's capacity and went through the two-call path
         self.layouts = {}
         self.last_stats = []          # (instances L, tile-sort passes, W*H) per rendered camera
@@ -579,17 +584,23 @@ class GaussHipRenderer():
             self._capture(sl, lay, key)
         self._camera_struct(camera, sl.job.cam)                                    # rewrite the pinned job in place
         sl.job.camera_slot, sl.job.t_floor = slot, self.t_floor
+        # every pipelined camera renders into its OWN per-tile colour buffer (address in the job, not in the graph): the
+        # winners' colours are then resolved in one pass at flush() instead of one update per camera chained in camera
+        # order across the streams
+        tb = self.ctx.cam_tilebufs.get(slot)
+        if tb is None or tb.numel() < lay.total_pixels * 3:
+            import contextlib
+            with (torch.cuda.stream(sl.stream) if on_gpu else contextlib.nullcontext()):       # first written on this stream
+                tb = torch.empty((lay.total_pixels * 3,), dtype=torch.float32, device=self.device)
+            self.ctx.cam_tilebufs[slot] = tb
+        sl.job.tilebuf_lo, sl.job.tilebuf_hi = tb.data_ptr() & 0xFFFFFFFF, tb.data_ptr() >> 32
+        self.deferred[slot] = lay
         nv.check(L.g2pc_graph_launch(sl.graph, sl.stream_ptr), "graph_launch")
         if key[2] == 1:
             with nv.region("raster_blend", self.device, sl.stream):
                 nv.check(self._camera_call(sl, lay, key[1], 2), "raster_camera_py (blend)")
-        if on_gpu and self.last_update is not None:
-            sl.stream.wait_event(self.last_update)
-        nv.check(L.g2pc_raster_camera_update_py(C.byref(lay.c), self.n, slot, self.state_ptrs()[0], nv.ptr(sl.tilebuf),
-                                                self.state_ptrs()[1], sl.stream_ptr), "raster_camera_update_py")
         if on_gpu:
-            sl.update_done.record(sl.stream)
-            self.last_update = sl.update_done
+            sl.update_done.record(sl.stream)               # "this camera's blend is done" (its colours are resolved at flush)
         cam_copy = _Camera.from_buffer_copy(sl.job.cam)
         sl.inflight = (cam_copy, lay, slot, key[1])
 
@@ -605,7 +616,22 @@ class GaussHipRenderer():
                 cur.wait_stream(sl.stream)
         while self.redo:                           # cameras that overflowed their graph: two-call path, original slot
             cam, lay, slot = self.redo.pop(0)
+            self.deferred.pop(slot, None)          # ... which updates the colours it wins at once
             self._render_sync(cam, lay, slot, False)
+        if self.deferred:
+            # deferred colour resolve: one pass per layout over the Gaussians, colour = the winner camera's tile buffer
+            by_layout = {}
+            for slot, lay in self.deferred.items():
+                by_layout.setdefault(id(lay), (lay, []))[1].append(slot)
+            for lay, slots in by_layout.values():
+                table = np.zeros((256,), dtype=np.uint64)
+                for slot in slots:
+                    table[slot] = self.ctx.cam_tilebufs[slot].data_ptr()
+                table_dev = torch.from_numpy(table.view(np.int64)).to(self.device)
+                nv.check(nv.lib().g2pc_raster_resolve_colours_py(C.byref(lay.c), self.n, self.state_ptrs()[0], nv.ptr(table_dev),
+                                                               self.state_ptrs()[1], nv.stream_handle(self.device)),
+                         "raster_resolve_colours_py")
+            self.deferred = {}
 
     def check_tile_load(self):
         """Some leaf tile held more Gaussians than `render()`'s default max_gaussians_per_tile: the reference, run with

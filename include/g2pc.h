@@ -312,7 +312,10 @@ typedef struct G2pcCameraJob {       /* DEVICE (and pinned host staging) struct 
     G2pcCamera cam;
     uint32_t camera_slot;            /* [1,255], see g2pc_raster_back_py */
     float t_floor;
-    uint32_t reserved[3];
+    uint32_t tilebuf_lo, tilebuf_hi; /* != 0: device address of THIS camera's per-tile colour buffer (overrides the tilebuf
+                                      * argument baked into a captured graph) -- lets a caller keep one buffer per camera and
+                                      * resolve the winners' colours once, g2pc_raster_resolve_colours_py */
+    uint32_t reserved;
 } G2pcCameraJob;
 size_t g2pc_raster_camera_workspace(int64_t n, int64_t capacity, int32_t num_tiles);
 int g2pc_raster_camera_py(const G2pcCameraJob* job_dev, const G2pcCameraJob* job_host, const G2pcTileLayout* layout,
@@ -322,6 +325,12 @@ int g2pc_raster_camera_py(const G2pcCameraJob* job_dev, const G2pcCameraJob* job
                           void* stream);
 int g2pc_raster_camera_update_py(const G2pcTileLayout* layout, int64_t n, uint32_t camera_slot,
                                  const unsigned long long* best_key, const float* tilebuf, float* colours_out, void* stream);
+/* Deferred form of the colour update (gauss_render.py:387-395): ONE pass after all blends of an epoch.  tilebufs: DEVICE
+ * array of 256 addresses, [slot] = the per-tile colour buffer camera `slot` rendered into (0: leave the Gaussians won
+ * by that slot untouched -- e.g. cameras that went through g2pc_raster_back_py, which updates at once).  All listed
+ * cameras share `layout`.  Replaces the per-camera update and its camera-order chaining across streams. */
+int g2pc_raster_resolve_colours_py(const G2pcTileLayout* layout, int64_t n, const unsigned long long* best_key,
+                                   const unsigned long long* tilebufs, float* colours_out, void* stream);
 /* depth order inside g2pc_raster_camera_py: 1 = range-normalised bucket sort + in-LDS bitonic sort (default; five
  * launches), 0 = four-pass radix sort.  Same order bit for bit.  count_host must hold TWO words: [0] = instance count,
  * [1] != 0 = the bucket sort overflowed (depths piled up in 1/1024 of their range), the camera was skipped as a whole
