@@ -9,14 +9,14 @@ from np_philox import keyed_normals
 from g2pc.synth import make_scene, make_cameras
 
 
-def check_surface_cloud(device="cpu", n=900, ncam=3, num_points=20000, seed=31):
+def check_surface_cloud(device="cpu", n=1500, ncam=3, num_points=30000, seed=31):
     import camera_handler
     import gauss_render
     from gauss_handler import Gaussians
     from gauss_to_pc import GaussPointCloudSettings, convert_gaussians_to_pc
     dev = torch.device(device)
     sc = make_scene(n, 57, scale_lo=0.01, scale_hi=0.06)
-    tr, intr = make_cameras(ncam, width=144, height=88, focal=122.0)
+    tr, intr = make_cameras(ncam, width=200, height=120, focal=170.0)
     s = GaussPointCloudSettings(
         renderer_type="cuda", num_points=num_points, prioritise_visible_gaussians=True, mahalanobis_distance_std=2.0,
         camera_skip_rate=0, render_colours=True, min_opacity=0.0, bounding_box_min=None, bounding_box_max=None,

@@ -40,8 +40,8 @@ def _run(rank, world, port, out_dir, renderer="python", epoch=255, ncam=3):
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    sc = make_scene(700, 91, scale_lo=0.01, scale_hi=0.06)
-    transforms, intr = make_cameras(ncam, width=128, height=72, focal=110.0)
+    sc = make_scene(1200, 91, scale_lo=0.01, scale_hi=0.06)
+    transforms, intr = make_cameras(ncam, width=180, height=101, focal=155.0)
     G = Gaussians(sc.xyz, sc.scales, sc.rots, sc.colours, sc.opacities)
     cloud, _ = convert_gaussians_to_pc(G, transforms, intr, None, _settings(12000, renderer), seed=5)
     full = gather_pointcloud(cloud, dst=0)

@@ -51,8 +51,8 @@ def test_cameras_without_read_back_equal_one_at_a_time(emu, monkeypatch):
     import camera_handler
     import gaussian_pointcloud_rasterization as gpr
     from g2pc.synth import make_scene, make_cameras
-    sc = make_scene(900, 11, scale_lo=0.01, scale_hi=0.06)
-    tr, intr = make_cameras(5, width=112, height=64, focal=96.0)
+    sc = make_scene(2500, 11, scale_lo=0.01, scale_hi=0.06)
+    tr, intr = make_cameras(6, width=176, height=100, focal=150.0)
     names = sorted(tr)
 
     def run(pipelined, shrink):

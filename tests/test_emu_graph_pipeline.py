@@ -8,7 +8,7 @@ from emu_util import emu  # noqa: F401
 from g2pc.synth import make_scene, make_cameras
 
 
-def _render_all(pipelined, monkeypatch, headroom=None, ncam=5, subblocks=4):
+def _render_all(pipelined, monkeypatch, headroom=None, ncam=6, subblocks=4):
     import gauss_render
     import camera_handler
     from gauss_handler import Gaussians
@@ -18,8 +18,8 @@ def _render_all(pipelined, monkeypatch, headroom=None, ncam=5, subblocks=4):
     if headroom is not None:
         monkeypatch.setattr(gauss_render, "CAPACITY_HEADROOM", headroom)
         monkeypatch.setattr(gauss_render, "MIN_CAPACITY", 1)
-    sc = make_scene(500, 77, scale_lo=0.01, scale_hi=0.07)
-    transforms, intr = make_cameras(ncam, width=144, height=80, focal=122.0)
+    sc = make_scene(700, 77, scale_lo=0.01, scale_hi=0.07)
+    transforms, intr = make_cameras(ncam, width=200, height=112, focal=170.0)
     G = Gaussians(sc.xyz, sc.scales, sc.rots, sc.colours, sc.opacities)
     R = gauss_render.get_renderer("python", G.xyz, G.opacities.unsqueeze(1), G.colours, G.covariances,
                                   visible_gaussian_threshold=0.05)
