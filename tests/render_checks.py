@@ -29,7 +29,7 @@ def run_render_case(golden_dir, device="cpu", t_floor=0.0):
     return g, R, np.stack(images), np.stack(contribs)
 
 
-def assert_render_matches(g, R, images, contribs, tol=1e-4, allow_mask_flips=0):
+def assert_render_matches(g, R, images, contribs, tol=1e-4, allow_mask_flips=0, max_colour_flips=0):
     # images within tol
     d_img = np.abs(images - g["images"]).max()
     assert d_img < tol, "image max abs diff %g" % d_img
@@ -39,15 +39,20 @@ def assert_render_matches(g, R, images, contribs, tol=1e-4, allow_mask_flips=0):
     # per-Gaussian colours (0..255 scale in the API -> compare in 0..1)
     cols = R.get_gaussian_colours().cpu().numpy() / 255.0
     ref_cols = g["colours"] / 255.0
-    d_col = np.abs(cols - ref_cols).max()
-    assert d_col < tol, "colour max abs diff %g" % d_col
+    # a Gaussian's colour IS the rendered colour of its arg-max pixel: two pixels whose contributions tie to ~1e-6 may swap
+    # under any change of rounding (image and contributions, checked above, are unaffected) -> count such Gaussians
+    off = np.abs(cols - ref_cols) >= tol
+    n_off = int(off.any(axis=1).sum())
+    d_col = float(np.abs(cols - ref_cols)[~off].max()) if (~off).any() else 0.0
+    assert n_off <= max_colour_flips, "%d Gaussians with another arg-max pixel's colour (max abs diff %g)" % (
+        n_off, np.abs(cols - ref_cols).max())
     # culling mask: exact, report the margin of anything that flips
     vis = R.get_visible_gaussians().cpu().numpy()
     flips = np.nonzero(vis != g["visible"])[0]
     margins = np.abs(g["contrib_after_cam"][-1][flips] - 0.05)
     assert len(flips) <= allow_mask_flips, "visible-mask flips: %d, margins %s" % (len(flips), margins)
     np.testing.assert_allclose(R.get_total_gaussian_contributions().cpu().numpy(), g["total"], atol=tol)
-    return dict(image=d_img, contribution=d_c, colour=d_col, flips=len(flips))
+    return dict(image=d_img, contribution=d_c, colour=d_col, colour_flips=n_off, flips=len(flips))
 
 
 def run_vs_oracle(n, seed, width, height, focal, ncam, device="cpu", scale=(0.004, 0.04), colour_resolution=None,

@@ -6,12 +6,16 @@ from emu_util import emu  # noqa: F401
 from render_checks import run_render_case, assert_render_matches
 
 
-def test_render_matches_reference_python_renderer(emu, golden_dir, monkeypatch):
+@pytest.mark.parametrize("sub", [2, 4, 1])
+def test_render_matches_reference_python_renderer(emu, golden_dir, monkeypatch, sub):
+    """Outputs of the untouched reference (golden fixture) vs every blend kernel: 2 = the default dual-list kernel
+    (chunk-level cull, expanded exponent), 4 / 1 = the generic kernel with 4 / 1 pixels per lane."""
     import gauss_render
-    monkeypatch.setattr(gauss_render, "BLEND_SUBBLOCKS", 4)      # 4 pixels per lane: 4x fewer emulated waves (speed only;
-    g, R, images, contribs = run_render_case(golden_dir)          # the default 1 px/lane runs in the pipeline golden test)
-    stats = assert_render_matches(g, R, images, contribs)
-    print(stats)
+    monkeypatch.setattr(gauss_render, "BLEND_SUBBLOCKS", sub)
+    g, R, images, contribs = run_render_case(golden_dir)
+    # the dual-list kernel evaluates the exponent in expanded form: at most one arg-max tie of the 6 000 Gaussians may swap
+    stats = assert_render_matches(g, R, images, contribs, max_colour_flips=1 if sub == 2 else 0)
+    print(sub, stats)
 
 
 def test_render_1024_tiles_two_pass_tile_sort_vs_oracle(emu):

