@@ -584,13 +584,66 @@ __global__ __launch_bounds__(BK_T) void k_bk_scatter(const uint32_t* __restrict_
         }
     }
 }
-// one WAVE per bucket: a 64-thread block with CAP * 8 bytes of LDS finds a place on a CU whose wave slots and LDS the
-// blend of another camera is holding
+// Bitonic sort of 64 * R 64-bit items held R per lane (item e = r * 64 + lane): steps with a stride >= 64 exchange
+// registers of the same lane, the others one __shfl_xor per register -- no LDS, no barriers, everything unrolled.
+template <int R>
+__device__ __forceinline__ void wave_bitonic_sort(unsigned long long (&v)[R], unsigned lane) {
+#pragma unroll
+    for (int k = 2; k <= 64 * R; k <<= 1) {
+#pragma unroll
+        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+            if (jj >= 64) {
+                const int jr = jj >> 6;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if ((r & jr) == 0) {
+                        const bool up = ((r << 6) & k) == 0;
+                        const unsigned long long a = v[r], b = v[r | jr];
+                        const unsigned long long lo = a < b ? a : b, hi = a < b ? b : a;
+                        v[r] = up ? lo : hi;
+                        v[r | jr] = up ? hi : lo;
+                    }
+                }
+            } else {
+                const bool lower = (lane & (unsigned)jj) == 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const bool up = k < 64 ? ((lane & (unsigned)k) == 0) : (((r << 6) & k) == 0);
+                    const unsigned long long x = v[r];
+                    const unsigned long long y = __shfl_xor(x, jj);
+                    const unsigned long long lo = x < y ? x : y, hi = x < y ? y : x;
+                    v[r] = (lower == up) ? lo : hi;
+                }
+            }
+        }
+    }
+}
+template <int R>
+__device__ __forceinline__ void bucket_sort_in_registers(const unsigned long long* __restrict__ items, uint32_t s0, uint32_t cnt,
+                                                         const uint32_t* __restrict__ vals, uint32_t* __restrict__ vals_out,
+                                                         uint32_t* __restrict__ keys_out, unsigned lane) {
+    unsigned long long v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { const uint32_t e = (uint32_t)r * 64u + lane; v[r] = e < cnt ? items[s0 + e] : ~0ull; }
+    wave_bitonic_sort<R>(v, lane);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t e = (uint32_t)r * 64u + lane;
+        if (e < cnt) {
+            vals_out[s0 + e] = vals[(uint32_t)v[r]];
+            if (keys_out) keys_out[s0 + e] = (uint32_t)(v[r] >> 32);
+        }
+    }
+}
+
+// one WAVE per bucket (a 64-thread block finds a place on a CU whose wave slots and LDS the blend of another camera is
+// holding).  Buckets of up to 1024 items are sorted in REGISTERS (wave_bitonic_sort; the LDS version of this kernel spent
+// 60-100 us per camera under load in 36 dependent LDS round trips per bucket); larger rooms keep the LDS network.
 template <int CAP>
 __global__ __launch_bounds__(64) void k_bk_sort(const BucketHdr* __restrict__ h, const unsigned long long* __restrict__ items,
                                                 const uint32_t* __restrict__ vals, uint32_t* __restrict__ vals_out,
                                                 uint32_t* __restrict__ keys_out) {
-    __shared__ unsigned long long s_it[CAP];
+    __shared__ unsigned long long s_it[CAP > 1024 ? CAP : 1];
     const unsigned lane = threadIdx.x, nbk = h->nbk;
     // blocks nbk .. nbk + BK_TAILBLOCKS - 1 share the tail bucket (tens of thousands of off-screen keys: one wave copying
     // them alone, two dependent loads per trip, took longer than the rest of the sort)
@@ -604,6 +657,14 @@ __global__ __launch_bounds__(64) void k_bk_sort(const BucketHdr* __restrict__ h,
             vals_out[s0 + j] = vals[(uint32_t)it];
             if (keys_out) keys_out[s0 + j] = (uint32_t)(it >> 32);
         }
+        return;
+    }
+    if (CAP <= 1024) {                                                // wave-uniform dispatch on the bucket's size
+        if (cnt <= 64) bucket_sort_in_registers<1>(items, s0, cnt, vals, vals_out, keys_out, lane);
+        else if (cnt <= 128) bucket_sort_in_registers<2>(items, s0, cnt, vals, vals_out, keys_out, lane);
+        else if (cnt <= 256) bucket_sort_in_registers<4>(items, s0, cnt, vals, vals_out, keys_out, lane);
+        else if (cnt <= 512) bucket_sort_in_registers<8>(items, s0, cnt, vals, vals_out, keys_out, lane);
+        else bucket_sort_in_registers<16>(items, s0, cnt, vals, vals_out, keys_out, lane);
         return;
     }
     uint32_t np = 2;
