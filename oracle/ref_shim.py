@@ -111,3 +111,49 @@ def inject_standard_normal(provider):
         yield
     finally:
         mvn._standard_normal = orig
+
+
+# ---- the reference's NATIVE rasteriser, compiled for the host (oracle/build_ref.py -> oracle/_ref/) ----
+GPR_NAME = "gaussian_pointcloud_rasterization"
+
+
+def load_reference_gpr(variant: str = "synced", fma: bool = True):
+    """The reference's own gaussian_pointcloud_rasterization/__init__.py (unmodified), bound to the `_C` extension that
+    oracle/build_ref.py compiled from the reference's .cu files.  Returned as a module object that is NOT left in
+    sys.modules (the product ships a drop-in package of the same name); use `reference_gpr()` around reference calls
+    that import it by name (gauss_render.get_renderer / camera_handler.get_camera, "cuda" branch)."""
+    import importlib.util
+    import build_ref
+    key = ("gpr", variant, fma)
+    if key in _loaded:
+        return _loaded[key]
+    so_dir = build_ref.build(variant, fma)
+    init = os.path.join(REFERENCE_ROOT, "gaussian-pointcloud-rasterization", GPR_NAME, "__init__.py")
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == GPR_NAME or k.startswith(GPR_NAME + ".")}
+    try:
+        spec = importlib.util.spec_from_file_location(GPR_NAME, init, submodule_search_locations=[so_dir])
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[GPR_NAME] = mod
+        with CudaToCpu():
+            spec.loader.exec_module(mod)          # runs `from . import _C` -> oracle/_ref/<variant>/_C.so
+        assert os.path.dirname(mod._C.__file__) == so_dir, mod._C.__file__
+    finally:
+        for k in [k for k in sys.modules if k == GPR_NAME or k.startswith(GPR_NAME + ".")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+    _loaded[key] = mod
+    return mod
+
+
+@contextlib.contextmanager
+def reference_gpr(variant: str = "synced", fma: bool = True):
+    """Inside the block, `import gaussian_pointcloud_rasterization` resolves to the reference's package on the host build."""
+    mod = load_reference_gpr(variant, fma)
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == GPR_NAME or k.startswith(GPR_NAME + ".")}
+    sys.modules[GPR_NAME] = mod
+    try:
+        with CudaToCpu():
+            yield mod
+    finally:
+        sys.modules.pop(GPR_NAME, None)
+        sys.modules.update(saved)

@@ -1,11 +1,54 @@
-"""Shared parity assertions for the native-rasteriser ("cuda") semantics: HIP GaussianRasterizer vs the C restatement
-oracle/cuda_raster_ref.c (parity UNPINNED against the CUDA reference itself -- it cannot be run here)."""
+"""Shared parity checks for the native-rasteriser ("cuda") semantics.
+
+run_golden_case / assert in cu_golden: the HIP GaussianRasterizer (through the C ABI) against the golden vectors of the
+REFERENCE'S OWN rasteriser compiled for the host (tests/golden/render_cu_*.npz, oracle/build_ref.py).
+run_cuda_case: the same against the C restatement oracle/cuda_raster_ref.c at sizes that have no fixture -- the restatement
+is itself pinned to those fixtures (tests/test_oracle_cuda.py)."""
 import numpy as np
 import torch
 
 import ref_cuda
 import ref_gauss as RG
 from g2pc.synth import make_scene, make_cameras
+
+
+def run_golden_case(name, device="cpu"):
+    """Drives the drop-in exactly like oracle/make_golden_cu.run_case drives the reference; returns (per-camera reports,
+    state report, Case)."""
+    import camera_handler
+    import gauss_render
+    import cu_golden
+    from gauss_handler import Gaussians
+    case = cu_golden.Case(name)
+    r = case.recipe
+    dev = torch.device(device)
+    sc, transforms, intr = case.scene()
+    G = Gaussians(sc.xyz.to(dev), sc.scales.to(dev), sc.rots.to(dev), sc.colours.to(dev), sc.opacities.to(dev))
+    R = gauss_render.get_renderer("cuda", G.xyz, G.opacities.unsqueeze(1), G.colours, G.covariances,
+                                  shs=sc.shs.to(dev) if r["with_sh"] else None, visible_gaussian_threshold=0.05,
+                                  surface_distance_std=2.0 if r["surf"] else None, calculate_surface_distance=r["surf"])
+    reps = []
+    for i, nm in enumerate(transforms):
+        mask = torch.from_numpy(case.mask.copy()) if case.has_mask else None
+        cam = camera_handler.get_camera("cuda", torch.tensor(transforms[nm]), intr[nm], colour_resolution=None, sh_degree=3,
+                                        mask=mask)
+        colour, radii, invd, dep = R.forward(cam, return_per_camera=True)
+        rc = R._sync.rect.cpu().numpy().astype(np.int64)            # x0 | (x1-1) << 8 | y0 << 16 | (y1-1) << 24, 0 = no tile
+        rad = radii.cpu().numpy()
+        touched = np.where(rad > 0, (((rc >> 8) & 255) - (rc & 255) + 1) * (((rc >> 24) & 255) - ((rc >> 16) & 255) + 1), 0)
+        got = dict(radii=rad, num_rendered=R.last["num_rendered"], tiles_touched=touched.astype(np.uint32),
+                   out_color=colour.cpu().numpy(), out_depth=dep.cpu().numpy(), out_invdepth=invd.cpu().numpy(),
+                   gauss_contributions=R.last["contributions"].cpu().numpy(), gauss_pixels=R.last["pixels"].cpu().numpy(),
+                   gauss_surface_distances=R.last["surface_distances"].cpu().numpy())
+        reps.append(cu_golden.compare_camera(case, i, got))
+    st = dict(max_contribution=R.gaussian_max_contribution.cpu().numpy(),
+              total_contribution=R.get_total_gaussian_contributions().cpu().numpy(),
+              min_surface_distance=R.gaussian_min_surface_distance.cpu().numpy(),
+              colours=R.get_gaussian_colours().cpu().numpy(), visible=R.get_visible_gaussians().cpu().numpy())
+    if r["surf"]:
+        st["low_surface_distance"] = R.get_gaussians_with_low_surface_distance().cpu().numpy()
+        st["predicted_surface"] = R.get_predicted_surface_gaussians(0.5).cpu().numpy()
+    return reps, cu_golden.compare_state(case, st), case
 
 
 def run_cuda_case(n, seed, width, height, focal, ncam, device="cpu", with_sh=False, surf=True, scale=(0.004, 0.04),

@@ -1,8 +1,23 @@
-"""Native-rasteriser ("cuda") semantics through the fiber emulator vs oracle/cuda_raster_ref.c."""
+"""Native-rasteriser ("cuda") semantics through the fiber emulator: against the golden vectors of the reference's own
+rasteriser (tests/golden/render_cu_*.npz) and, at other sizes, against the restatement pinned to them."""
+import json
+
 import pytest
 
+import cu_golden
 from emu_util import emu  # noqa: F401
-from cuda_checks import run_cuda_case, assert_cuda_matches
+from cuda_checks import run_cuda_case, assert_cuda_matches, run_golden_case
+
+
+@pytest.mark.parametrize("name", ["n6000_333x187", "n6000_sh3_320x176", "n20000_mask_320x176", "n6000_nosurf_333x187"])
+def test_cuda_semantics_vs_reference_golden(emu, name):
+    """radii / num_rendered / tiles_touched / arg-max pixels bit for bit, floats to 1e-4 (tests/cu_golden.py)."""
+    reps, st, case = run_golden_case(name)
+    for rep in reps:
+        print(json.dumps(rep))
+        cu_golden.assert_camera(rep, case)
+    print(json.dumps(st))
+    cu_golden.assert_state(st, case)
 
 
 def test_cuda_semantics_precomputed_colours_with_surface_distance(emu):

@@ -1,12 +1,29 @@
-"""-m gpu: native-rasteriser ("cuda") semantics on the MI355X vs the C restatement (oracle/cuda_raster_ref.c)."""
+"""-m gpu: native-rasteriser ("cuda") semantics on the MI355X vs the golden vectors of the reference's own rasteriser
+(tests/golden/render_cu_*.npz: its .cu files compiled for the host, oracle/build_ref.py) and, at other sizes, vs the C
+restatement pinned to them (oracle/cuda_raster_ref.c)."""
+import json
+
 import numpy as np
 import pytest
 import torch
 
-from cuda_checks import run_cuda_case, assert_cuda_matches
+import cu_golden
+from cuda_checks import run_cuda_case, assert_cuda_matches, run_golden_case
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("name", cu_golden.CASES)
+def test_cuda_semantics_vs_reference_golden(name):
+    """Through the C ABI on the GPU: radii / num_rendered / tiles_touched / arg-max pixels bit for bit, floats to 1e-4 up
+    to isolated threshold decisions (tests/cu_golden.py states the bars and where the reference disagrees with itself)."""
+    reps, st, case = run_golden_case(name, DEV)
+    for rep in reps:
+        print(json.dumps(rep))
+        cu_golden.assert_camera(rep, case)
+    print(json.dumps(st))
+    cu_golden.assert_state(st, case)
 
 
 @pytest.mark.parametrize("n,w,h,f,ncam,sh,surf,mask", [
