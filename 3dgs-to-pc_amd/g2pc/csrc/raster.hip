@@ -963,6 +963,7 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_cu(Cam cam, int grid_x, int
                                                        uint32_t* __restrict__ index, uint32_t* __restrict__ tiles_touched,
                                                        float4* __restrict__ rec, uint32_t* __restrict__ rect,
                                                        int32_t* __restrict__ radii) {
+#pragma clang fp contract(off)
     long i = (long)blockIdx.x * RA_T + threadIdx.x;
     if (i >= n) return;
     const float x = means3D[3 * i], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
@@ -970,6 +971,13 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_cu(Cam cam, int grid_x, int
     const float* P = cam.P;
     uint32_t key = 0xFFFFFFFFu, touched = 0, rc = 0;
     int rad = 0;
+    // Everything that decides an INTEGER of the reference (radius, tile rectangle, depth bits -> order) is evaluated
+    // below with the reference's own expressions, operation by operation in source order, every operation rounded on its
+    // own (contraction is off for this kernel).  That is the one evaluation of the reference's text that does not depend
+    // on a compiler's choice of which product to fuse (gcc fuses the FIRST product of transformPoint4x3 but the LAST two of
+    // transformPoint4x4, tools/cu_preprocess_exactness.py; nvcc's choices cannot be observed here), and it is what
+    // oracle/_ref -- the reference's .cu files compiled with -ffp-contract=off -- computes: radii, tile rectangles,
+    // num_rendered, depths and projected means equal bit for bit (tests/golden/render_cu_*).
     const float tz0 = V[2] * x + V[6] * y + V[10] * z + V[14];
     if (tz0 > 0.2f) {                                                   // in_frustum (auxiliary.h:166)
         float hx = P[0] * x + P[4] * y + P[8] * z + P[12];
@@ -983,13 +991,14 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_cu(Cam cam, int grid_x, int
         float limx = 1.3f * cam.tan_fovx, limy = 1.3f * cam.tan_fovy;
         tx = fminf(limx, fmaxf(-limx, tx / tz)) * tz;
         ty = fminf(limy, fmaxf(-limy, ty / tz)) * tz;
-        // T = W J (math convention, see oracle/cuda_raster_ref.c): only columns 0 and 1 of T are non-zero
-        float j00 = focal_x / tz, j11 = focal_y / tz, j20 = -(focal_x * tx) / (tz * tz), j21 = -(focal_y * ty) / (tz * tz);
+        // T = W J with glm's column-major constructors (forward.cu:91-101): column 0 of J is (fx/tz, 0, -fx tx/tz^2),
+        // column 1 is (0, fy/tz, -fy ty/tz^2), column 2 is zero.  The products with those zeros add +-0 and are left out.
+        float j00 = focal_x / tz, j11 = focal_y / tz, j02 = -(focal_x * tx) / (tz * tz), j12 = -(focal_y * ty) / (tz * tz);
         float T0[3], T1[3];                                              // columns 0 and 1 of T, indexed by row
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            T0[r] = V[4 * r + 0] * j00 + V[4 * r + 2] * j20;
-            T1[r] = V[4 * r + 1] * j11 + V[4 * r + 2] * j21;
+            T0[r] = V[4 * r + 0] * j00 + V[4 * r + 2] * j02;
+            T1[r] = V[4 * r + 1] * j11 + V[4 * r + 2] * j12;
         }
         const float* c = cov6 + 6 * i;
         float S[3][3] = {{c[0], c[1], c[2]}, {c[1], c[3], c[4]}, {c[2], c[4], c[5]}};

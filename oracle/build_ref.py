@@ -36,11 +36,15 @@ hardware therefore has ONE outcome here:
                   has finished the batch before its result is published, i.e. the one the code intends and the limit a GPU
                   approaches when its warps stay in step.  It pins gauss_contributions, gauss_pixels,
                   gauss_surface_distances and, through the binding, the running max / sum / min state and the colours.
-  Each variant is built twice: with FMA contraction (-mfma -ffp-contract=fast: nvcc's default is -fmad=true) and without.
-  The goldens come from synced+fma; make_golden.py stores how far the other three are from it.
+  Each variant is built twice: WITHOUT floating-point contraction (-ffp-contract=off: every operation of the reference's
+  expressions rounded on its own, in source order -- the one evaluation of its text that no compiler decides) and with it
+  (-mfma -ffp-contract=fast; nvcc's default is -fmad=true, but WHICH products a compiler fuses is its own business: gcc
+  fuses the first product of transformPoint4x3 and the last two of transformPoint4x4, tools/cu_preprocess_exactness.py).
+  The goldens come from synced + no contraction; make_golden_cu.py stores how far the other three land from it -- that
+  spread is how much of the reference's output is decided by its compiler and its races rather than by its source.
 
 Usage:  python oracle/build_ref.py            (builds all four, a few minutes the first time; incremental afterwards)
-        build("synced", fma=True) -> directory holding _C.so, for ref_shim.load_reference_gpr().
+        build("synced", fma=False) -> directory holding _C.so, for ref_shim.load_reference_gpr().
 """
 import hashlib
 import os
@@ -103,7 +107,7 @@ def _torch_flags():
     return inc, link, abi
 
 
-def build(variant: str = "synced", fma: bool = True) -> str:
+def build(variant: str = "synced", fma: bool = False) -> str:
     """Returns the directory that holds the `_C` extension of the requested variant (building what is out of date)."""
     assert variant in ("verbatim", "synced")
     if not available():

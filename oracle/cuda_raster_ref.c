@@ -15,7 +15,7 @@
  * part in anything; out-of-image threads of partial tiles take part in the surface-distance minimum with an
  * expected depth of 0; a Gaussian whose 256-batch is never reached keeps FLT_MAX / 0.
  *
- * Build: gcc -O2 -shared -fPIC -o oracle/_build/libcuda_raster_ref.so oracle/cuda_raster_ref.c -lm
+ * Build: gcc -O2 -ffp-contract=off -shared -fPIC -o oracle/_build/libcuda_raster_ref.so oracle/cuda_raster_ref.c -lm
  */
 #include <float.h>
 #include <math.h>

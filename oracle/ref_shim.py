@@ -117,7 +117,7 @@ def inject_standard_normal(provider):
 GPR_NAME = "gaussian_pointcloud_rasterization"
 
 
-def load_reference_gpr(variant: str = "synced", fma: bool = True):
+def load_reference_gpr(variant: str = "synced", fma: bool = False):
     """The reference's own gaussian_pointcloud_rasterization/__init__.py (unmodified), bound to the `_C` extension that
     oracle/build_ref.py compiled from the reference's .cu files.  Returned as a module object that is NOT left in
     sys.modules (the product ships a drop-in package of the same name); use `reference_gpr()` around reference calls
@@ -146,7 +146,7 @@ def load_reference_gpr(variant: str = "synced", fma: bool = True):
 
 
 @contextlib.contextmanager
-def reference_gpr(variant: str = "synced", fma: bool = True):
+def reference_gpr(variant: str = "synced", fma: bool = False):
     """Inside the block, `import gaussian_pointcloud_rasterization` resolves to the reference's package on the host build."""
     mod = load_reference_gpr(variant, fma)
     saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == GPR_NAME or k.startswith(GPR_NAME + ".")}

@@ -24,7 +24,12 @@ def run_golden_case(name, device="cpu"):
     dev = torch.device(device)
     sc, transforms, intr = case.scene()
     G = Gaussians(sc.xyz.to(dev), sc.scales.to(dev), sc.rots.to(dev), sc.colours.to(dev), sc.opacities.to(dev))
-    R = gauss_render.get_renderer("cuda", G.xyz, G.opacities.unsqueeze(1), G.colours, G.covariances,
+    # the reference's own 3-D covariances (its torch.exp is SLEEF's, within an ulp of -- not equal to -- any other exp): the
+    # rasteriser is compared on identical inputs; Gaussians' own covariance build is held to the geometry fixtures
+    c6 = torch.from_numpy(case.z["state_cov6"])
+    cov = c6[:, [0, 1, 2, 1, 3, 4, 2, 4, 5]].reshape(-1, 3, 3).contiguous().to(dev)
+    assert float((G.covariances - cov).abs().max()) < 1e-6 * float(cov.abs().max())
+    R = gauss_render.get_renderer("cuda", G.xyz, G.opacities.unsqueeze(1), G.colours, cov,
                                   shs=sc.shs.to(dev) if r["with_sh"] else None, visible_gaussian_threshold=0.05,
                                   surface_distance_std=2.0 if r["surf"] else None, calculate_surface_distance=r["surf"])
     reps = []
@@ -36,7 +41,9 @@ def run_golden_case(name, device="cpu"):
         rc = R._sync.rect.cpu().numpy().astype(np.int64)            # x0 | (x1-1) << 8 | y0 << 16 | (y1-1) << 24, 0 = no tile
         rad = radii.cpu().numpy()
         touched = np.where(rad > 0, (((rc >> 8) & 255) - (rc & 255) + 1) * (((rc >> 24) & 255) - ((rc >> 16) & 255) + 1), 0)
+        rec = R._sync.rec.cpu().numpy().reshape(-1, 16)             # (px, py, qa, qb), (qc, opacity, depth, radius), ...
         got = dict(radii=rad, num_rendered=R.last["num_rendered"], tiles_touched=touched.astype(np.uint32),
+                   means2D=rec[:, 0:2], depths=rec[:, 6], conic_scaled=rec[:, 2:5],
                    out_color=colour.cpu().numpy(), out_depth=dep.cpu().numpy(), out_invdepth=invd.cpu().numpy(),
                    gauss_contributions=R.last["contributions"].cpu().numpy(), gauss_pixels=R.last["pixels"].cpu().numpy(),
                    gauss_surface_distances=R.last["surface_distances"].cpu().numpy())

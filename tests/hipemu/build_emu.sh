@@ -12,7 +12,7 @@ for f in prims geom alloc sampler raster clean project; do
   if [ ! -f "$HERE/$f.emu.o" ] || [ "$SRC/$f.hip" -nt "$HERE/$f.emu.o" ] || [ "$SRC/g2pc_internal.h" -nt "$HERE/$f.emu.o" ] \
      || [ "$SRC/g2pc_device.inl" -nt "$HERE/$f.emu.o" ] || [ "$HERE/hip/hip_runtime.h" -nt "$HERE/$f.emu.o" ] \
      || [ "$ROOT/include/g2pc.h" -nt "$HERE/$f.emu.o" ]; then
-    g++ -O1 -g -std=c++17 -fPIC -ffp-contract=off -x c++ -I"$HERE" -I"$ROOT/include" -Wno-attributes \
+    g++ -O1 -g -std=c++17 -fPIC -ffp-contract=off -x c++ -I"$HERE" -I"$ROOT/include" -Wno-attributes -Wno-unknown-pragmas \
         -c "$SRC/$f.hip" -o "$HERE/$f.emu.o"
   fi
   OBJS="$OBJS $HERE/$f.emu.o"

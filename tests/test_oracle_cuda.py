@@ -81,7 +81,7 @@ def test_fixture_is_what_the_reference_sources_compute():
     name = "n6000_nosurf_333x187"
     case = cu_golden.Case(name)
     assert str(case.z["reference_digest"]) == build_ref.source_digest(), "reference changed: regenerate tests/golden/render_cu_*"
-    cams, state, _ = make_golden_cu.run_case(ref_shim.load_reference(), name, "synced", True)
+    cams, state, _ = make_golden_cu.run_case(ref_shim.load_reference(), name, "synced", False)
     for i, d in enumerate(cams):
         assert d["num_rendered"] == int(case.cam(i, "num_rendered"))
         for k in ("radii", "tiles_touched", "ranges", "gauss_contributions", "gauss_pixels", "means2D", "conic_opacity"):
@@ -95,10 +95,10 @@ def test_fixture_spread_is_recorded():
     and under the thread_rank schedule without the two inserted barriers (oracle/build_ref.py): the basis of the bars."""
     for name in cu_golden.CASES:
         sp = cu_golden.Case(name).spread
-        assert set(sp) == {"verbatim_fma", "synced_nofma", "verbatim_nofma"}
-        assert sp["verbatim_fma"]["image_max"] == 0.0 and sp["verbatim_fma"]["radii_mismatch"] == 0     # races touch no pixel
-        assert sp["verbatim_fma"]["contrib_higher"] == 0 and sp["verbatim_fma"]["contrib_lower"] > 0     # lower bounds only
-        assert sp["synced_nofma"]["contrib_frac_gt_1e4"] == 0.0 and sp["synced_nofma"]["visible_flips"] == 0
+        assert set(sp) == {"verbatim_nofma", "synced_fma", "verbatim_fma"}
+        assert sp["verbatim_nofma"]["image_max"] == 0.0 and sp["verbatim_nofma"]["radii_mismatch"] == 0     # races touch no pixel
+        assert sp["verbatim_nofma"]["contrib_higher"] == 0 and sp["verbatim_nofma"]["contrib_lower"] > 0     # lower bounds only
+        assert sp["synced_fma"]["contrib_frac_gt_1e4"] == 0.0 and sp["synced_fma"]["visible_flips"] == 0
 
 
 def test_cuda_oracle_agrees_with_python_renderer_oracle_up_to_semantics():
