@@ -37,6 +37,14 @@ def run_golden_case(name, device="cpu"):
         mask = torch.from_numpy(case.mask.copy()) if case.has_mask else None
         cam = camera_handler.get_camera("cuda", torch.tensor(transforms[nm]), intr[nm], colour_resolution=None, sh_degree=3,
                                         mask=mask)
+        # The camera matrices are host arithmetic (torch.linalg.inv + a 4x4 sgemm: MKL picks its kernel by CPU, and the
+        # products differ in the last bit between the authoring container and the GPU box): the rasteriser is handed the
+        # matrices the reference was handed; get_camera's own result must agree with them to rounding.
+        stored = {k: torch.from_numpy(case.cam(i, k)) for k in ("viewmatrix", "projmatrix", "campos")}
+        for k, v in stored.items():
+            assert torch.allclose(getattr(cam, k), v, rtol=1e-5, atol=1e-6), k
+        assert abs(cam.tanfovx - float(case.cam(i, "tanfovx"))) < 1e-7 and abs(cam.tanfovy - float(case.cam(i, "tanfovy"))) < 1e-7
+        cam = cam._replace(tanfovx=float(case.cam(i, "tanfovx")), tanfovy=float(case.cam(i, "tanfovy")), **stored)
         colour, radii, invd, dep = R.forward(cam, return_per_camera=True)
         rc = R._sync.rect.cpu().numpy().astype(np.int64)            # x0 | (x1-1) << 8 | y0 << 16 | (y1-1) << 24, 0 = no tile
         rad = radii.cpu().numpy()
