@@ -8,6 +8,7 @@
 // exist so that callers of the reference's helper functions find them behind the same names (gauss_render.py of this
 // package) without a torch re-implementation.  All HBM-bound, one Gaussian per lane, AoS rows read as whole rows.
 #include "g2pc_internal.h"
+#include "py_project.inl"
 
 namespace g2pc {
 
@@ -60,46 +61,16 @@ __global__ __launch_bounds__(PJ_T) void k_eval_sh(int deg, const float* __restri
 struct Mat16 { float m[16]; };
 
 // cov2d f32[n,2,2] = (J W S W^T J^T)[:2,:2] + 0.3 I, J W S W^T J^T evaluated left to right (gauss_render.py:144)
-__global__ __launch_bounds__(PJ_T) void k_cov2d_py(Mat16 Vm, float tan_fovx, float tan_fovy, float focal_x, float focal_y,
+__global__ __launch_bounds__(PJ_T) void k_cov2d_py(Mat16 Vm, float lim_x, float lim_y, float focal_x, float focal_y,
                                                   const float* __restrict__ means3D, const float* __restrict__ cov9,
                                                   long n, float* __restrict__ cov2d) {
     long i = (long)blockIdx.x * PJ_T + threadIdx.x;
     if (i >= n) return;
-    const float* V = Vm.m;
-    const float x = means3D[3 * i], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
-    float t0 = (x * V[0] + y * V[4] + z * V[8]) + V[12];
-    float t1 = (x * V[1] + y * V[5] + z * V[9]) + V[13];
-    float t2 = (x * V[2] + y * V[6] + z * V[10]) + V[14];
-    float limx = tan_fovx * 1.3f, limy = tan_fovy * 1.3f;
-    float qx = t0 / t2, qy = t1 / t2;
-    qx = qx < -limx ? -limx : (qx > limx ? limx : qx);
-    qy = qy < -limy ? -limy : (qy > limy ? limy : qy);
-    float tx = qx * t2, ty = qy * t2, tz = t2;
-    float j00 = 1.0f / tz * focal_x, j02 = -tx / (tz * tz) * focal_x;
-    float j11 = 1.0f / tz * focal_y, j12 = -ty / (tz * tz) * focal_y;
-    float M0[3], M1[3];
+    float pv[4], c[4];
+    py_view(Vm.m, means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2], pv);
+    py_cov2d(Vm.m, pv, lim_x, lim_y, focal_x, focal_y, cov9 + 9 * i, c);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        M0[c] = j00 * V[4 * c + 0] + j02 * V[4 * c + 2];
-        M1[c] = j11 * V[4 * c + 1] + j12 * V[4 * c + 2];
-    }
-    const float* S = cov9 + 9 * i;
-    float A0[3], A1[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        A0[c] = M0[0] * S[0 + c] + M0[1] * S[3 + c] + M0[2] * S[6 + c];
-        A1[c] = M1[0] * S[0 + c] + M1[1] * S[3 + c] + M1[2] * S[6 + c];
-    }
-    float B0[3], B1[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        B0[c] = A0[0] * V[0 + c] + A0[1] * V[4 + c] + A0[2] * V[8 + c];
-        B1[c] = A1[0] * V[0 + c] + A1[1] * V[4 + c] + A1[2] * V[8 + c];
-    }
-    cov2d[4 * i + 0] = B0[0] * j00 + B0[2] * j02 + 0.3f;
-    cov2d[4 * i + 1] = B0[1] * j11 + B0[2] * j12;
-    cov2d[4 * i + 2] = B1[0] * j00 + B1[2] * j02;
-    cov2d[4 * i + 3] = B1[1] * j11 + B1[2] * j12 + 0.3f;
+    for (int j = 0; j < 4; ++j) cov2d[4 * i + j] = c[j];
 }
 
 // p_view = [x,1] V; p_hom = p_view P; p_proj = p_hom / (w + 1e-6); in_mask = p_view.z <= -1e-6
@@ -108,14 +79,9 @@ __global__ __launch_bounds__(PJ_T) void k_projection_ndc(Mat16 Vm, Mat16 Pm, con
                                                         uint8_t* __restrict__ in_mask) {
     long i = (long)blockIdx.x * PJ_T + threadIdx.x;
     if (i >= n) return;
-    const float* V = Vm.m;
-    const float* P = Pm.m;
-    const float x = points[3 * i], y = points[3 * i + 1], z = points[3 * i + 2];
     float pv[4], ph[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) pv[j] = x * V[0 + j] + y * V[4 + j] + z * V[8 + j] + V[12 + j];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) ph[j] = pv[0] * P[0 + j] + pv[1] * P[4 + j] + pv[2] * P[8 + j] + pv[3] * P[12 + j];
+    py_view(Vm.m, points[3 * i], points[3 * i + 1], points[3 * i + 2], pv);
+    py_hom(Pm.m, pv, ph);
     const float pw = 1.0f / (ph[3] + 0.000001f);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -128,14 +94,9 @@ __global__ __launch_bounds__(PJ_T) void k_projection_ndc(Mat16 Vm, Mat16 Pm, con
 __global__ __launch_bounds__(PJ_T) void k_radius_py(const float* __restrict__ cov2d, long n, float* __restrict__ radius) {
     long i = (long)blockIdx.x * PJ_T + threadIdx.x;
     if (i >= n) return;
-    const float c00 = cov2d[4 * i], c01 = cov2d[4 * i + 1], c10 = cov2d[4 * i + 2], c11 = cov2d[4 * i + 3];
-    float det = c00 * c11 - c01 * c10;
-    float mid = 0.5f * (c00 + c11);
-    float disc = mid * mid - det;
-    disc = disc < 0.1f ? 0.1f : disc;                   // NaN stays NaN, as torch.clip does
-    float sq = sqrtf(disc);
-    float l1 = mid + sq, l2 = mid - sq;
-    radius[i] = 3.0f * ceilf(sqrtf(l1 > l2 ? l1 : l2));
+    const float c[4] = {cov2d[4 * i], cov2d[4 * i + 1], cov2d[4 * i + 2], cov2d[4 * i + 3]};
+    float det;
+    radius[i] = py_radius(c, det);
 }
 
 __global__ __launch_bounds__(PJ_T) void k_rect_py(const float* __restrict__ pix, const float* __restrict__ radii, long n,
@@ -167,15 +128,15 @@ int g2pc_eval_sh(int32_t deg, const float* sh, const float* dirs, int64_t n, int
     return check_launch("g2pc_eval_sh");
 }
 
-int g2pc_build_covariance_2d(const float* means3D, const float* cov9, int64_t n, const float* viewmatrix, float tan_fovx,
-                             float tan_fovy, float focal_x, float focal_y, float* cov2d, void* stream) {
+int g2pc_build_covariance_2d(const float* means3D, const float* cov9, int64_t n, const float* viewmatrix, float lim_x,
+                             float lim_y, float focal_x, float focal_y, float* cov2d, void* stream) {
     using namespace g2pc;
     G2PC_REQUIRE(n >= 0, G2PC_ERR_ARG, "negative n");
     if (n == 0) return G2PC_OK;
     G2PC_REQUIRE(means3D && cov9 && viewmatrix && cov2d, G2PC_ERR_ARG, "null pointer");
     Mat16 V;
     for (int i = 0; i < 16; ++i) V.m[i] = viewmatrix[i];
-    hipLaunchKernelGGL(k_cov2d_py, dim3(cdiv(n, PJ_T)), dim3(PJ_T), 0, (hipStream_t)stream, V, tan_fovx, tan_fovy, focal_x,
+    hipLaunchKernelGGL(k_cov2d_py, dim3(cdiv(n, PJ_T)), dim3(PJ_T), 0, (hipStream_t)stream, V, lim_x, lim_y, focal_x,
                        focal_y, means3D, cov9, (long)n, cov2d);
     return check_launch("g2pc_build_covariance_2d");
 }

@@ -13,6 +13,7 @@
 //   packed 64-bit (contribution bits << 32 | ~order) atomicMax, which makes the cross-tile / cross-camera
 //   arg-max exact and deterministic (the reference's CUDA kernel races here, SURVEY.md §2.2 defect 3).
 #include "g2pc_internal.h"
+#include "py_project.inl"
 #include <type_traits>
 
 namespace g2pc {
@@ -28,6 +29,7 @@ struct Cam {            // device copy of G2pcCamera (passed by value as kernel 
     float tan_fovx, tan_fovy, focal_x, focal_y;
     int W, H;
     float bg[3];
+    float lim_x, lim_y;
 };
 
 struct Layout {         // device pointers of G2pcTileLayout
@@ -74,67 +76,22 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_py(Cam cam_val, const Cam* 
     const Cam& cam = CAM_ON_DEVICE ? s_cam : cam_val;
     const float x = means3D[3 * i], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
     const float* V = cam.V;
-    // p_view = [x,1] @ V  (gauss_render.py:163)
     float pv[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) pv[j] = x * V[0 + j] + y * V[4 + j] + z * V[8 + j] + V[12 + j];
+    py_view(V, x, y, z, pv);                                         // p_view = [x,1] @ V  (gauss_render.py:163)
     const bool in_mask = pv[2] <= -0.000001f;                       // :167
     uint32_t key = 0xFFFFFFFFu, touched = 0, rc = 0;
     if (in_mask) {
-        // t = mean @ V[:3,:3] + V[3,:3]  (:125)
-        float t0 = (x * V[0] + y * V[4] + z * V[8]) + V[12];
-        float t1 = (x * V[1] + y * V[5] + z * V[9]) + V[13];
-        float t2 = (x * V[2] + y * V[6] + z * V[10]) + V[14];
-        float limx = cam.tan_fovx * 1.3f, limy = cam.tan_fovy * 1.3f;
-        float qx = t0 / t2, qy = t1 / t2;
-        qx = qx < -limx ? -limx : (qx > limx ? limx : qx);
-        qy = qy < -limy ? -limy : (qy > limy ? limy : qy);
-        float tx = qx * t2, ty = qy * t2, tz = t2;
-        // J (:134-138), W = V[:3,:3]^T; cov2d = J W S W^T J^T evaluated left to right (:144)
-        float j00 = 1.0f / tz * cam.focal_x, j02 = -tx / (tz * tz) * cam.focal_x;
-        float j11 = 1.0f / tz * cam.focal_y, j12 = -ty / (tz * tz) * cam.focal_y;
-        // M = J @ W : rows 0,1 (W[k][c] = V[c][k] -> W row k = column k of V)
-        float M0[3], M1[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            M0[c] = j00 * V[4 * c + 0] + j02 * V[4 * c + 2];
-            M1[c] = j11 * V[4 * c + 1] + j12 * V[4 * c + 2];
-        }
-        const float* S = cov9 + 9 * i;
-        float A0[3], A1[3];                                          // (J W) @ Sigma
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            A0[c] = M0[0] * S[0 + c] + M0[1] * S[3 + c] + M0[2] * S[6 + c];
-            A1[c] = M1[0] * S[0 + c] + M1[1] * S[3 + c] + M1[2] * S[6 + c];
-        }
-        float B0[3], B1[3];                                          // ... @ W^T  (W^T[k][c] = V[k][c])
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            B0[c] = A0[0] * V[0 + c] + A0[1] * V[4 + c] + A0[2] * V[8 + c];
-            B1[c] = A1[0] * V[0 + c] + A1[1] * V[4 + c] + A1[2] * V[8 + c];
-        }
-        // ... @ J^T : J^T[k][c] = J[c][k]
-        float c00 = B0[0] * j00 + B0[2] * j02 + 0.3f;
-        float c01 = B0[1] * j11 + B0[2] * j12;
-        float c10 = B1[0] * j00 + B1[2] * j02;
-        float c11 = B1[1] * j11 + B1[2] * j12 + 0.3f;
-        // projection (:160-163)
-        const float* P = cam.P;
-        float ph0 = pv[0] * P[0] + pv[1] * P[4] + pv[2] * P[8] + pv[3] * P[12];
-        float ph1 = pv[0] * P[1] + pv[1] * P[5] + pv[2] * P[9] + pv[3] * P[13];
-        float ph3 = pv[0] * P[3] + pv[1] * P[7] + pv[2] * P[11] + pv[3] * P[15];
-        float pw = 1.0f / (ph3 + 0.000001f);
-        float ndx = ph0 * pw, ndy = ph1 * pw;
+        float cv[4];                                                 // cov2d (:101-148), torch's evaluation order: py_project.inl
+        py_cov2d(V, pv, cam.lim_x, cam.lim_y, cam.focal_x, cam.focal_y, cov9 + 9 * i, cv);
+        const float c00 = cv[0], c01 = cv[1], c10 = cv[2], c11 = cv[3];
+        float ph[4];
+        py_hom(cam.P, pv, ph);                                       // projection (:160-163)
+        float pw = 1.0f / (ph[3] + 0.000001f);
+        float ndx = ph[0] * pw, ndy = ph[1] * pw;
         float mx = ((ndx + 1.0f) * (float)cam.W - 1.0f) * 0.5f;        // gauss_render.py:435-436
         float my = ((ndy + 1.0f) * (float)cam.H - 1.0f) * 0.5f;
-        // radius (:171-180) and rect (:182-193)
-        float det = c00 * c11 - c01 * c10;
-        float mid = 0.5f * (c00 + c11);
-        float disc = mid * mid - det;
-        disc = disc < 0.1f ? 0.1f : disc;
-        float sq = sqrtf(disc);
-        float l1 = mid + sq, l2 = mid - sq;
-        float radius = 3.0f * ceilf(sqrtf(l1 > l2 ? l1 : l2));
+        float det;
+        const float radius = py_radius(cv, det);                     // radius (:171-180) and rect (:182-193)
         float wmax = (float)cam.W - 1.0f, hmax = (float)cam.H - 1.0f;
         float rminx = fminf(fmaxf(mx - radius, 0.0f), wmax), rmaxx = fminf(fmaxf(mx + radius, 0.0f), wmax);
         float rminy = fminf(fmaxf(my - radius, 0.0f), hmax), rmaxy = fminf(fmaxf(my + radius, 0.0f), hmax);
@@ -1376,6 +1333,7 @@ static Cam to_cam(const G2pcCamera* c) {
     k.tan_fovx = c->tan_fovx; k.tan_fovy = c->tan_fovy; k.focal_x = c->focal_x; k.focal_y = c->focal_y;
     k.W = c->width; k.H = c->height;
     k.bg[0] = c->bg[0]; k.bg[1] = c->bg[1]; k.bg[2] = c->bg[2];
+    k.lim_x = c->lim_x; k.lim_y = c->lim_y;
     return k;
 }
 static Layout to_layout(const G2pcTileLayout* l) {

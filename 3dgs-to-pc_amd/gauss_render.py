@@ -41,7 +41,7 @@ RENDER_STATS = []          # (instances L, tile-sort passes, W*H) of every camer
 class _Camera(C.Structure):
     _fields_ = [("view", C.c_float * 16), ("proj", C.c_float * 16), ("tan_fovx", C.c_float), ("tan_fovy", C.c_float),
                 ("focal_x", C.c_float), ("focal_y", C.c_float), ("width", C.c_int32), ("height", C.c_int32),
-                ("bg", C.c_float * 3)]
+                ("bg", C.c_float * 3), ("lim_x", C.c_float), ("lim_y", C.c_float)]
 
 
 class _Job(C.Structure):
@@ -123,7 +123,7 @@ def build_covariance_2d(mean3d, cov3d, viewmatrix, fov_x, fov_y, focal_x, focal_
     n = m.shape[0]
     out = torch.empty((n, 2, 2), dtype=torch.float32, device=m.device)
     nv.check(nv.lib().g2pc_build_covariance_2d(nv.ptr(m), nv.ptr(c), n, C.cast(_host16(viewmatrix), C.c_void_p),
-                                               tan(fov_x * 0.5), tan(fov_y * 0.5), float(focal_x), float(focal_y),
+                                               tan(fov_x * 0.5) * 1.3, tan(fov_y * 0.5) * 1.3, float(focal_x), float(focal_y),
                                                nv.ptr(out), nv.stream_handle(m.device)), "build_covariance_2d")
     return out
 
@@ -204,7 +204,7 @@ class _Scratch:
 
 # Cameras in flight when the caller does not need the image back (the pipeline of gauss_to_pc.py discards it).
 # Each in-flight camera owns a HIP stream, a device-resident G2pcCameraJob and ONE captured hipGraph holding its
-# ~35 launches (preprocess, depth sort, binning, blend): per camera the host rewrites a pinned 192-byte struct and
+# ~35 launches (preprocess, depth sort, binning, blend): per camera the host rewrites a pinned 200-byte struct and
 # issues one graph launch plus the (camera-ordered) colour update -- no read-back, no per-kernel launch cost.
 # The packed-key atomicMax makes the blends of different cameras commutative, so camera c+1's small sort / scan
 # kernels (which leave most CUs idle) and even its blend overlap camera c's blend.
@@ -260,16 +260,24 @@ class _RenderContext:
         self.overflow = torch.empty((1,), dtype=torch.int32, device=device)
         self.sync_scratch = _Scratch(n, device)
         self.slots, self.capacity = [], None
-        self.cam_tilebufs = {}        # camera slot -> per-tile colour buffer of the pipelined camera that used it (kept for
-                                      # the deferred colour resolve; reused by the next epoch / job of this context)
+        self.cam_tilebufs = []        # ring of per-tile colour buffers, one per pipelined camera whose colours are still to be
+                                      # resolved (deferred colour resolve); bounded by DEFERRED_BUDGET_BYTES, reused by the
+                                      # next batch / job of this context
 
     def release(self):
         for sl in self.slots:
             sl.release()
         self.slots = []
-        self.cam_tilebufs = {}
+        self.cam_tilebufs = []
 
 
+# Deferred colour resolve: every pipelined camera keeps a per-tile colour buffer (12 B per pixel) until flush() gives each
+# Gaussian the colour of the camera that holds its key.  The set is bounded: once the buffers of the cameras in flight would
+# exceed this budget (or DEFERRED_MAX cameras) the renderer resolves what it has and recycles the ring -- 64 cameras at
+# 1280x720 (0.7 GB), 20 at 3840x2160, never fewer than 8.
+DEFERRED_BUDGET_BYTES = 2 << 30
+DEFERRED_MAX = 64
+DEFERRED_MIN = 8
 CONTEXT_POOL_SIZE = 2
 import os as _os
 POOL_SKIP_FIRST_JOBS = int(_os.environ.get("G2PC_POOL_SKIP_FIRST_JOBS", "1"))   # contexts of the first job(s) of a process are not kept, see GaussHipRenderer.close
@@ -457,6 +465,8 @@ class GaussHipRenderer():
         cam.view[:] = camera.world_view_transform.reshape(-1).tolist()
         cam.proj[:] = camera.projection_matrix.reshape(-1).tolist()
         cam.tan_fovx, cam.tan_fovy = tan(camera.FoVx * 0.5), tan(camera.FoVy * 0.5)
+        # the frustum clamp of build_covariance_2d: python floats (double) until they meet the f32 tensor (gauss_render.py:128-129)
+        cam.lim_x, cam.lim_y = tan(camera.FoVx * 0.5) * 1.3, tan(camera.FoVy * 0.5) * 1.3
         cam.focal_x, cam.focal_y = camera.focal_x, camera.focal_y
         cam.width, cam.height = int(camera.image_width), int(camera.image_height)
         bgv = 1.0 if self.white_bkgd else 0.0
@@ -587,14 +597,26 @@ class GaussHipRenderer():
         # every pipelined camera renders into its OWN per-tile colour buffer (address in the job, not in the graph): the
         # winners' colours are then resolved in one pass at flush() instead of one update per camera chained in camera
         # order across the streams
-        tb = self.ctx.cam_tilebufs.get(slot)
-        if tb is None or tb.numel() < lay.total_pixels * 3:
+        ring = self.ctx.cam_tilebufs
+        limit = max(DEFERRED_MIN, min(DEFERRED_MAX, DEFERRED_BUDGET_BYTES // (lay.total_pixels * 12)))
+        if len(self.deferred) >= limit:
+            self.flush()                           # resolve the colours of the cameras so far; their buffers are free again
+            del ring[limit:]                       # a smaller image earlier in the job may have grown the ring past this limit
+            if on_gpu:
+                for o in self.slots:
+                    o.stream.wait_stream(torch.cuda.current_stream(self.device))   # ... once the resolve has read them
+        idx = len(self.deferred)
+        if idx >= len(ring) or ring[idx].numel() < lay.total_pixels * 3:
             import contextlib
             with (torch.cuda.stream(sl.stream) if on_gpu else contextlib.nullcontext()):       # first written on this stream
                 tb = torch.empty((lay.total_pixels * 3,), dtype=torch.float32, device=self.device)
-            self.ctx.cam_tilebufs[slot] = tb
+            if idx >= len(ring):
+                ring.append(tb)
+            else:
+                ring[idx] = tb
+        tb = ring[idx]
         sl.job.tilebuf_lo, sl.job.tilebuf_hi = tb.data_ptr() & 0xFFFFFFFF, tb.data_ptr() >> 32
-        self.deferred[slot] = lay
+        self.deferred[slot] = (lay, tb)
         nv.check(L.g2pc_graph_launch(sl.graph, sl.stream_ptr), "graph_launch")
         if key[2] == 1:
             with nv.region("raster_blend", self.device, sl.stream):
@@ -621,12 +643,12 @@ class GaussHipRenderer():
         if self.deferred:
             # deferred colour resolve: one pass per layout over the Gaussians, colour = the winner camera's tile buffer
             by_layout = {}
-            for slot, lay in self.deferred.items():
-                by_layout.setdefault(id(lay), (lay, []))[1].append(slot)
+            for slot, (lay, tb) in self.deferred.items():
+                by_layout.setdefault(id(lay), (lay, []))[1].append((slot, tb))
             for lay, slots in by_layout.values():
                 table = np.zeros((256,), dtype=np.uint64)
-                for slot in slots:
-                    table[slot] = self.ctx.cam_tilebufs[slot].data_ptr()
+                for slot, tb in slots:
+                    table[slot] = tb.data_ptr()
                 table_dev = torch.from_numpy(table.view(np.int64)).to(self.device)
                 nv.check(nv.lib().g2pc_raster_resolve_colours_py(C.byref(lay.c), self.n, self.state_ptrs()[0], nv.ptr(table_dev),
                                                                self.state_ptrs()[1], nv.stream_handle(self.device)),

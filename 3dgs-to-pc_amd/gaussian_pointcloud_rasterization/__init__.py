@@ -39,7 +39,7 @@ class GaussianRasterizationSettings(NamedTuple):
 class _Camera(C.Structure):
     _fields_ = [("view", C.c_float * 16), ("proj", C.c_float * 16), ("tan_fovx", C.c_float), ("tan_fovy", C.c_float),
                 ("focal_x", C.c_float), ("focal_y", C.c_float), ("width", C.c_int32), ("height", C.c_int32),
-                ("bg", C.c_float * 3)]
+                ("bg", C.c_float * 3), ("lim_x", C.c_float), ("lim_y", C.c_float)]
 
 
 _vp = C.c_void_p

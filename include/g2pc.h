@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define G2PC_ABI_VERSION 1
+#define G2PC_ABI_VERSION 2
 
 #define G2PC_OK 0
 #define G2PC_ERR_ARG (-1)
@@ -208,9 +208,11 @@ int g2pc_sampler_emit_rows(const float* means, const float* cov9, const float* c
 int g2pc_eval_sh(int32_t deg, const float* sh, const float* dirs, int64_t n, int32_t channels, int32_t coeffs, float* out,
                  void* stream);
 /* build_covariance_2d (gauss_render.py:101-148): cov2d f32[n,2,2] = (J W S W^T J^T)[:2,:2] + 0.3 I; viewmatrix is
- * the HOST 4x4 world_view_transform (row-vector convention, 16 floats); tan_fov = tan(fov / 2). */
-int g2pc_build_covariance_2d(const float* means3D, const float* cov9, int64_t n, const float* viewmatrix, float tan_fovx,
-                             float tan_fovy, float focal_x, float focal_y, float* cov2d, void* stream);
+ * the HOST 4x4 world_view_transform (row-vector convention, 16 floats); lim = 1.3 * tan(fov / 2), the frustum clamp of
+ * gauss_render.py:128-129, formed by the caller in DOUBLE from the field of view (as the reference forms it from python
+ * floats) and rounded to f32.  Evaluated in the order torch's CPU build evaluates the reference (csrc/py_project.inl). */
+int g2pc_build_covariance_2d(const float* means3D, const float* cov9, int64_t n, const float* viewmatrix, float lim_x,
+                             float lim_y, float focal_x, float focal_y, float* cov2d, void* stream);
 /* projection_ndc (gauss_render.py:151-168): p_proj f32[n,4], p_view f32[n,4], in_mask u8[n] (p_view.z <= -1e-6);
  * viewmatrix / projmatrix are HOST 4x4 matrices (16 floats each). */
 int g2pc_projection_ndc(const float* points, int64_t n, const float* viewmatrix, const float* projmatrix, float* p_proj,
@@ -243,6 +245,8 @@ typedef struct G2pcCamera {          /* HOST struct, passed by value to the kern
     float focal_x, focal_y;
     int32_t width, height;
     float bg[3];
+    float lim_x, lim_y;              /* PY semantics: 1.3 * tan(fov / 2) formed in double (gauss_render.py:128-129); unused by
+                                      * the CUDA semantics (forward.cu:83-84 multiplies in f32) */
 } G2pcCamera;
 
 typedef struct G2pcTileLayout {      /* HOST struct of DEVICE pointers: tiles = x-intervals times y-intervals */

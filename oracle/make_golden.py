@@ -202,6 +202,60 @@ def gen_pipeline(ref):
     print("pipeline: kept", int(culled.sum()), "points", pts.shape[0])
 
 
+def k1_hash8(*arrays):
+    """8-bit fingerprint per Gaussian of f32 columns (projected mean x / y, radius, view depth, ...): lets a 1 M-Gaussian
+    fixture say WHICH Gaussians a candidate projects differently (any bit) at one byte each.  Shared with tools/parity_cfg2.py."""
+    h = np.zeros(arrays[0].shape[0], dtype=np.uint64)
+    for a in arrays:
+        b = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+        h = ((h ^ b) * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)
+        h ^= h >> np.uint64(15)
+    return ((h ^ (h >> np.uint64(8)) ^ (h >> np.uint64(16)) ^ (h >> np.uint64(24))) & np.uint64(0xFF)).astype(np.uint8)
+
+
+class CaptureK1:
+    """Records what the reference's renderer computes per Gaussian before it bins: in_mask and p_view (projection_ndc,
+    gauss_render.py:151-168), the projected means and radii handed to get_rect (:182-193), by wrapping the module-level
+    functions the reference looks up at call time.  Nothing of the reference is modified."""
+
+    def __init__(self, gr):
+        self.gr, self.rec = gr, {}
+
+    def __enter__(self):
+        gr = self.gr
+        self.orig = (gr.projection_ndc, gr.get_rect, gr.build_covariance_2d)
+
+        def projection_ndc(points, viewmatrix, projmatrix):
+            out = self.orig[0](points, viewmatrix, projmatrix)
+            self.rec["in_mask"], self.rec["depth"] = _np(out[2]).copy(), _np(out[1][:, 2]).copy()
+            return out
+
+        def get_rect(pix_coord, radii, width, height):
+            self.rec["means2D"], self.rec["radii"] = _np(pix_coord).copy(), _np(radii).copy()
+            return self.orig[1](pix_coord, radii, width, height)
+
+        def build_covariance_2d(*a, **k):
+            out = self.orig[2](*a, **k)
+            self.rec["cov2d"] = _np(out).copy()
+            return out
+
+        gr.projection_ndc, gr.get_rect, gr.build_covariance_2d = projection_ndc, get_rect, build_covariance_2d
+        return self
+
+    def __exit__(self, *exc):
+        self.gr.projection_ndc, self.gr.get_rect, self.gr.build_covariance_2d = self.orig
+
+    def full(self, n):
+        """Scatter the in_mask subset back to all n Gaussians (zeros elsewhere)."""
+        m = self.rec["in_mask"]
+        out = dict(in_mask=m, depth=self.rec["depth"].astype(np.float32), cov2d=self.rec["cov2d"].reshape(n, 4).astype(np.float32))
+        for k, w in (("means2D", 2), ("radii", 1)):
+            a = np.zeros((n, w), dtype=np.float32)
+            a[m] = self.rec[k].reshape(-1, w)
+            out[k] = a
+        return out
+
+
 def gen_render_big(ref, tag="1m", n=1_000_000, num_points=10_000_000, width=1280, height=720, focal=1100.0):
     """BASELINE configs[2] at FULL size: the bench scene (1 M Gaussians, seed 1234+3), cameras 0 and 17 of the
     50-camera rig at 1280x720, untouched reference python renderer on CPU (~minutes per camera), then the
@@ -220,18 +274,35 @@ def gen_render_big(ref, tag="1m", n=1_000_000, num_points=10_000_000, width=1280
                          sc.opacities.clone())
         R = gr.get_renderer("python", G.xyz, torch.unsqueeze(torch.clone(G.opacities), 1),
                             G.colours, G.covariances, visible_gaussian_threshold=0.05)
-        imgs, contribs, secs = [], [], []
-        for ci in cam_ids:
+        imgs, contribs, secs, k1 = [], [], [], {}
+        for k, ci in enumerate(cam_ids):
             name = names[ci]
             cam = ch.get_camera("python", torch.tensor(transforms[name]), intr[name], colour_resolution=width)
             t0 = time.perf_counter()
-            img, _, _, _ = R(cam)
+            with CaptureK1(gr) as cap:
+                img, _, _, _ = R(cam)
             secs.append(time.perf_counter() - t0)
+            # the camera as the reference built it (host arithmetic: inv + 4x4 products, last bits differ between hosts) and
+            # what it projected: one fingerprint byte per Gaussian over (mean x, mean y, radius, depth), radii exactly,
+            # every 64th Gaussian in full
+            f = cap.full(n)
+            k1.update({"cam%d_view" % k: _np(cam.world_view_transform).astype(np.float32),
+                       "cam%d_proj" % k: _np(cam.projection_matrix).astype(np.float32),
+                       "cam%d_fov_focal" % k: np.array([cam.FoVx, cam.FoVy, cam.focal_x, cam.focal_y], dtype=np.float64),
+                       "cam%d_in_mask_bits" % k: np.packbits(f["in_mask"]),
+                       "cam%d_k1_hash8" % k: k1_hash8(f["means2D"][:, 0], f["means2D"][:, 1], f["radii"][:, 0], f["depth"]),
+                       "cam%d_cov2d_hash8" % k: k1_hash8(*[f["cov2d"][:, j] for j in range(4)]),
+                       "cam%d_radius_div3_u8" % k: np.minimum(f["radii"][:, 0] / 3.0, 255).astype(np.uint8),
+                       "cam%d_means2D_s64" % k: f["means2D"][::64].copy(), "cam%d_depth_s64" % k: f["depth"][::64].copy(),
+                       "cam%d_cov2d_s64" % k: f["cov2d"][::64].copy()})
             print("render_big: camera %d in %.1f s" % (ci, secs[-1]), flush=True)
             imgs.append(_np(img).astype(np.float32)[::4, ::4].copy())
             contribs.append(_np(R.gaussian_max_contribution).copy())
         colours = _np(R.get_gaussian_colours())
         visible = _np(R.get_visible_gaussians())
+        c9 = _np(G.covariances).reshape(n, 9)
+        k1["cov3d_hash8"] = k1_hash8(*[c9[:, j] for j in (0, 1, 2, 4, 5, 8)])
+        k1["cov3d_s64"] = c9[::64].astype(np.float32)
         G.colours = R.get_gaussian_colours()
         G.add_gaussians_to_cull(R.get_visible_gaussians())
         G.apply_min_opacity(0.0)
@@ -264,7 +335,7 @@ def gen_render_big(ref, tag="1m", n=1_000_000, num_points=10_000_000, width=1280
                         images_s4=np.stack(imgs), contrib_cam0_s8=contribs[0][::8].copy(), contrib_final=contribs[1],
                         visible_bits=np.packbits(visible), colours_s16=colours[::16].astype(np.float32),
                         culled_bits=np.packbits(_np(culled)), keep_bits=np.packbits(_np(keep)),
-                        ppg_u16=_np(ppg).astype(np.uint16), ppg_sum=float(ppg.sum()))
+                        ppg_u16=_np(ppg).astype(np.uint16), ppg_sum=float(ppg.sum()), **k1)
     print("render_big: visible", int(visible.sum()), "kept", int(_np(keep).sum()), "ppg sum", float(ppg.sum()),
           "s/camera", secs)
 
@@ -291,7 +362,12 @@ def gen_helpers(ref):
                            ((p_proj[:, 1] + 1.0) * cam.image_height - 1.0) * 0.5], dim=-1)
         rmin, rmax = gr.get_rect(pix, radii, cam.image_width, cam.image_height)
         out.update(cov2d=_np(cov2d), p_proj=_np(p_proj), p_view=_np(p_view), in_mask=_np(in_mask), radii=_np(radii),
-                   pix=_np(pix), rect_min=_np(rmin), rect_max=_np(rmax))
+                   pix=_np(pix), rect_min=_np(rmin), rect_max=_np(rmax),
+                   # the inputs that are host arithmetic (camera: inv + 4x4 products; covariances: torch.exp = MKL's):
+                   # with THESE the helper kernels must reproduce the outputs above bit for bit (csrc/py_project.inl)
+                   cam_view=_np(cam.world_view_transform).astype(np.float32), cam_proj=_np(cam.projection_matrix).astype(np.float32),
+                   cam_fov_focal=np.array([cam.FoVx, cam.FoVy, cam.focal_x, cam.focal_y], dtype=np.float64),
+                   cov3d=_np(G.covariances).astype(np.float32))
         # eval_sh: [n, 3, 25] coefficients, unit directions
         sh = torch.randn((n, 3, 25), generator=g, dtype=torch.float32) * 0.5
         d = torch.randn((n, 3), generator=g, dtype=torch.float32)

@@ -31,6 +31,18 @@ def check_projection_helpers(golden_dir, device="cpu"):
     np.testing.assert_allclose(p_proj.cpu().numpy(), g["p_proj"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(p_view.cpu().numpy(), g["p_view"], rtol=1e-5, atol=1e-6)
     assert in_mask.dtype == torch.bool and np.array_equal(in_mask.cpu().numpy(), g["in_mask"])
+    # ... and BIT FOR BIT when the host-arithmetic inputs are the reference's own (its camera matrices; its covariances, whose
+    # torch.exp is MKL's): the kernels evaluate the reference's matmuls in torch's order (csrc/py_project.inl)
+    view, proj = torch.from_numpy(g["cam_view"]), torch.from_numpy(g["cam_proj"])
+    fovx, fovy, fx, fy = [float(v) for v in g["cam_fov_focal"]]
+    assert torch.allclose(cam.world_view_transform, view, rtol=1e-5, atol=1e-6) and abs(cam.FoVx - fovx) < 1e-12
+    u = lambda a: np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    cov2d_x = gr.build_covariance_2d(G.xyz, torch.from_numpy(g["cov3d"]).to(dev), view, fovx, fovy, fx, fy)
+    assert np.array_equal(u(cov2d_x.cpu().numpy()), u(g["cov2d"]))
+    pp, pv, im = gr.projection_ndc(G.xyz, view, proj)
+    assert np.array_equal(u(pp.cpu().numpy()), u(g["p_proj"])) and np.array_equal(u(pv.cpu().numpy()), u(g["p_view"]))
+    assert np.array_equal(im.cpu().numpy(), g["in_mask"])
+    assert np.array_equal(gr.get_radius(cov2d_x).cpu().numpy(), g["radii"])
     # radius / rect from the REFERENCE's inputs: exact (integer-valued radii, clipped floats)
     radii = gr.get_radius(torch.from_numpy(g["cov2d"]).to(dev))
     assert np.array_equal(radii.cpu().numpy(), g["radii"])

@@ -25,7 +25,8 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     lib.g2pc_abi_version.restype = ctypes.c_int
-    assert lib.g2pc_abi_version() == 1
+    from g2pc import _native as nv
+    assert lib.g2pc_abi_version() == nv.ABI_VERSION == 2
 
 
 def test_no_cpu_fallback():

@@ -116,3 +116,15 @@ def test_depth_pile_up_falls_back_to_the_radix_sort(emu, monkeypatch):
         res.append((R.best_key.numpy().copy(), cols, R.rerendered))
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     assert res[1][2] >= 1                                    # the pile-up really happened and was handled
+
+
+def test_deferred_colour_buffers_are_bounded(emu, monkeypatch):
+    """The per-camera colour buffers of the deferred resolve form a bounded ring: with room for 2 cameras the
+    renderer resolves and recycles every 2 cameras and still leaves the state of the two-call path."""
+    import gauss_render
+    k0, c0, _, _ = _render_all(False, monkeypatch, ncam=7)
+    monkeypatch.setattr(gauss_render, "DEFERRED_MIN", 1)
+    monkeypatch.setattr(gauss_render, "DEFERRED_MAX", 2)
+    k1, c1, _, R = _render_all(True, monkeypatch, ncam=7)
+    assert np.array_equal(k0, k1) and np.array_equal(c0, c1)
+    assert len(R.ctx.cam_tilebufs) <= 2 and not R.deferred

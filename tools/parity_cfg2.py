@@ -17,6 +17,15 @@ SURVEY.md §8(d) asks to be reported with every number:
   ppg_mismatch_end_to_end              the same from our own render (contributions differ by ~1e-6 -> a few +-1)
   sample_*                             the 10 M-point cloud sampled from the reference's kept set with the same keyed
                                        noise: point count, rows compared (every 64th), max |xyz| and |rgb| difference
+  k1_mismatch / radius_mismatch        per camera: Gaussians whose projected mean (x, y), radius or view depth differ IN ANY
+                                       BIT from what the reference's renderer computed (one fingerprint byte per Gaussian in
+                                       the fixture), and whose radius differs; cov3d_rows_differing: rows of the 3-D
+                                       covariance that differ in any bit (torch.exp on the CPU is MKL's, within an ulp of --
+                                       not equal to -- a correctly rounded exp: the one input difference that remains)
+
+The cameras are the reference's: world_view_transform / projection_matrix are host arithmetic (torch.linalg.inv and 4x4
+products whose last bits depend on the host's BLAS kernels), so the fixture carries them and they are injected here; this
+package's own camera_handler.Camera is checked against them to rounding.
 
 Used by tests/test_gpu_parity_scale.py (-m gpu) and by bench.py's `parity` block (outside the timed region).
 Never imported by the product package.
@@ -44,6 +53,38 @@ def _bits(a, n):
     return np.unpackbits(a)[:n].astype(bool)
 
 
+def k1_hash8(*arrays):
+    """Same fingerprint as oracle/make_golden.py::k1_hash8 (the generator of the fixture)."""
+    h = np.zeros(arrays[0].shape[0], dtype=np.uint64)
+    for a in arrays:
+        b = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+        h = ((h ^ b) * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)
+        h ^= h >> np.uint64(15)
+    return ((h ^ (h >> np.uint64(8)) ^ (h >> np.uint64(16)) ^ (h >> np.uint64(24))) & np.uint64(0xFF)).astype(np.uint8)
+
+
+def _k1_report(g, k, cam, xyz, cov, n):
+    """This package's helper entries (the device functions k_preprocess_py itself calls) against the fixture's fingerprints."""
+    import gauss_render
+    cov2d = gauss_render.build_covariance_2d(xyz, cov, cam.world_view_transform, cam.FoVx, cam.FoVy, cam.focal_x, cam.focal_y)
+    ndc, view, in_mask = gauss_render.projection_ndc(xyz, cam.world_view_transform, cam.projection_matrix)
+    rad = gauss_render.get_radius(cov2d)
+    mx = ((ndc[..., 0] + 1) * cam.image_width - 1.0) * 0.5
+    my = ((ndc[..., 1] + 1) * cam.image_height - 1.0) * 0.5
+    m = in_mask.cpu().numpy()
+    ref_m = _bits(g["cam%d_in_mask_bits" % k], n)
+    z = lambda t: np.where(m, t.cpu().numpy(), 0).astype(np.float32)
+    h = k1_hash8(z(mx), z(my), z(rad), view[:, 2].cpu().numpy())
+    r3 = np.minimum(z(rad) / 3.0, 255).astype(np.uint8)
+    c2 = cov2d.reshape(n, 4).cpu().numpy()
+    out = dict(in_mask_flips=int((m != ref_m).sum()), k1_mismatch=int((h != g["cam%d_k1_hash8" % k]).sum()),
+               radius_mismatch=int((r3 != g["cam%d_radius_div3_u8" % k]).sum()),
+               cov2d_mismatch=int((k1_hash8(*[c2[:, j] for j in range(4)]) != g["cam%d_cov2d_hash8" % k]).sum()))
+    s = slice(None, None, 64)
+    out["means2D_s64_bit_mismatch"] = int((np.stack([z(mx), z(my)], 1)[s].view(np.uint32) != g["cam%d_means2D_s64" % k].view(np.uint32)).any(axis=1).sum())
+    return out
+
+
 def run(device="cuda:0", t_floor=None, sampler=True, tag="1m"):
     import camera_handler
     import gauss_render
@@ -68,9 +109,24 @@ def run(device="cuda:0", t_floor=None, sampler=True, tag="1m"):
     out = {"gaussians": n, "cameras": [int(c) for c in g["cam_ids"]], "resolution": "%dx%d" % (width, height),
            "t_floor": float(R.t_floor), "oracle": "untouched reference on CPU (oracle/make_golden.py render_big)"}
     img_max, img_frac = 0.0, 0.0
+    has_k1 = "cam0_view" in g.files
+    if has_k1:
+        c9 = G.covariances.reshape(n, 9).cpu().numpy()
+        out["cov3d_rows_differing"] = int((k1_hash8(*[c9[:, j] for j in (0, 1, 2, 4, 5, 8)]) != g["cov3d_hash8"]).sum())
+        out["k1"] = []
     for k, ci in enumerate(g["cam_ids"]):
         name = names[int(ci)]
         cam = camera_handler.get_camera("python", torch.tensor(transforms[name]), intr[name], colour_resolution=width)
+        if has_k1:
+            view, proj = torch.from_numpy(g["cam%d_view" % k]), torch.from_numpy(g["cam%d_proj" % k])
+            assert torch.allclose(cam.world_view_transform, view, rtol=1e-5, atol=1e-6)
+            assert torch.allclose(cam.projection_matrix, proj, rtol=1e-5, atol=1e-6)
+            out.setdefault("camera_matrix_bits_differing", []).append(
+                int((cam.world_view_transform.numpy().view(np.uint32) != g["cam%d_view" % k].view(np.uint32)).sum() +
+                    (cam.projection_matrix.numpy().view(np.uint32) != g["cam%d_proj" % k].view(np.uint32)).sum()))
+            cam.world_view_transform, cam.projection_matrix = view, proj
+            cam.FoVx, cam.FoVy, cam.focal_x, cam.focal_y = [float(v) for v in g["cam%d_fov_focal" % k]]
+            out["k1"].append(_k1_report(g, k, cam, G.xyz, G.covariances, n))
         img = R(cam)[0]
         d = (img[::4, ::4].cpu().numpy() - g["images_s4"][k])
         img_max = max(img_max, float(np.abs(d).max()))
