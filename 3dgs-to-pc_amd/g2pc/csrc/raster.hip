@@ -1442,10 +1442,15 @@ static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t*
                        ba.camera_slot << 24, ba.t_floor, ba.bg, tilebuf, g_chunk_work, ba.job)
         switch (layout->chunk_subblocks) {
             case 1: G2PC_BLEND(k_blend_py<1, 4>); break;
-            case 2:
-                if (g_blend_variant == 1) G2PC_BLEND(k_blend_py_dl<4>);
+            case 2: {
+                // t_floor == 0 is the to-the-letter mode: it takes the kernel that evaluates the exponent in the reference's
+                // operation order (k_blend_py_pk); the dual-list kernel's expanded exponent differs by up to ~2e-5 relative
+                // in alpha.  A captured camera reads t_floor from its device job: the caller says so with phase bit 8.
+                const bool exact = ba.job ? ((phases & 8) != 0) : (ba.t_floor == 0.0f);
+                if (g_blend_variant == 1 && !exact) G2PC_BLEND(k_blend_py_dl<4>);
                 else G2PC_BLEND(k_blend_py_pk<4>);
                 break;
+            }
             case 4: G2PC_BLEND(k_blend_py<4, 1>); break;
             default: set_error("raster_back_py", "chunk_subblocks must be 1, 2 or 4"); return G2PC_ERR_ARG;
         }

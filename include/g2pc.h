@@ -306,7 +306,8 @@ int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, int
  *   capacity: instances the buffers hold.  A camera with L > capacity is skipped as a whole (nothing is blended);
  *            count_host (optional, PINNED, written by a kernel through the device mapping) always receives the true L,
  *            so the caller can detect this and render the camera again with more room.
- *   phases:  bit 0 = preprocess .. tile ranges, bit 1 = blend; 3 = the whole camera.  (A caller that wants HIP events
+ *   phases:  bit 0 = preprocess .. tile ranges, bit 1 = blend; 3 = the whole camera; bit 3 (8) = the job's t_floor is 0
+ *            ("to the letter"): blend with the kernel that keeps the reference's operation order.  (A caller that wants HIP events
  *            around the blend alone captures phase 1 and issues phase 2 directly: this runtime refuses event-record
  *            nodes inside a captured graph.)
  * The colour update is not part of the call: updates must be issued in camera order across streams

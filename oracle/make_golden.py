@@ -6,6 +6,7 @@ oracle/ref_shim.py on seeded synthetic inputs and stores inputs' seeds + the ref
 /root/reference only exists in the authoring container; the fixtures travel, this script is the
 committed provenance.  Usage:   python oracle/make_golden.py [geom] [sampler] [render] [pipeline]
 """
+import json
 import os
 import sys
 
@@ -73,6 +74,23 @@ class KeyedNoise:
         self.ctx.__exit__(*exc)
         self.g2p.create_new_gaussian_points = self.orig_create
         self.g2p.sample_from_multivariate_normal = self.orig_sample
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def stable_depth_ties():
+    """The reference orders a leaf's Gaussians with torch.sort(depths), stable=False (gauss_render.py:340): the order of EQUAL
+    depths is then whatever the host's sort implementation leaves (an AVX-512 quicksort here: half of all tied neighbours
+    swapped).  Every fixture of the renderer is produced under the one deterministic execution -- stable=True -- by
+    wrapping torch.sort while the reference renders; gen_render_big records how far the as-is execution lands from it."""
+    orig = torch.sort
+    torch.sort = lambda x, *a, **k: orig(x, *a, **dict(k, stable=True))
+    try:
+        yield
+    finally:
+        torch.sort = orig
 
 
 def gen_geom(ref):
@@ -152,7 +170,8 @@ def gen_render(ref):
         for name in transforms:
             cam = ch.get_camera("python", torch.tensor(transforms[name]), intr[name],
                                 colour_resolution=None)
-            img, _, _, _ = R(cam)
+            with stable_depth_ties():
+                img, _, _, _ = R(cam)
             imgs.append(_np(img).astype(np.float32))
             contribs.append(_np(R.gaussian_max_contribution).copy())
         out = dict(n=n, seed=seed, ncam=ncam, width=320, height=180, focal=275.0,
@@ -180,7 +199,8 @@ def gen_pipeline(ref):
         for name in transforms:
             cam = ch.get_camera("python", torch.tensor(transforms[name]), intr[name],
                                 colour_resolution=360)
-            R(cam)
+            with stable_depth_ties():
+                R(cam)
         G.colours = R.get_gaussian_colours()
         G.add_gaussians_to_cull(R.get_visible_gaussians())
         G.apply_min_opacity(0.0)
@@ -272,9 +292,29 @@ def gen_render_big(ref, tag="1m", n=1_000_000, num_points=10_000_000, width=1280
     with CudaToCpu():
         G = gh.Gaussians(sc.xyz.clone(), sc.scales.clone(), sc.rots.clone(), sc.colours.double(),
                          sc.opacities.clone())
+        # DEPTH TIES.  The reference orders a leaf's Gaussians with torch.sort(depths) -- stable=False (gauss_render.py:340).
+        # On this host that is an AVX-512 quicksort: Gaussians of equal depth come out in an order that is a property of the
+        # sort's partitioning, not of the data (half of all tied neighbours are swapped against their input order).  At 1 M
+        # Gaussians a leaf of ~4 000 holds ~0.5 pairs of bit-equal depths; where such a pair overlaps on screen the two blend
+        # in either order and their contributions differ by up to alpha1 * alpha2 * T.  Any tie order is a legal execution
+        # of the reference; the fixture is produced under the one deterministic rule -- stable=True, i.e. ties in input
+        # order before the flip -- and `tie_spread` records how far the as-is execution lands from it.
+        spread = {}
+        if tag == "1m" or os.environ.get("G2PC_GOLDEN_TIE_SPREAD"):
+            Ru = gr.get_renderer("python", G.xyz, torch.unsqueeze(torch.clone(G.opacities), 1), G.colours, G.covariances,
+                                 visible_gaussian_threshold=0.05)
+            unstable_imgs = []
+            for ci in cam_ids:
+                cam = ch.get_camera("python", torch.tensor(transforms[names[ci]]), intr[names[ci]], colour_resolution=width)
+                unstable_imgs.append(_np(Ru(cam)[0]).astype(np.float32))
+            spread = dict(contrib=_np(Ru.gaussian_max_contribution).copy(), colours=_np(Ru.get_gaussian_colours()).copy(),
+                          images=unstable_imgs)
+            del Ru
+        ties = stable_depth_ties()
+        ties.__enter__()
         R = gr.get_renderer("python", G.xyz, torch.unsqueeze(torch.clone(G.opacities), 1),
                             G.colours, G.covariances, visible_gaussian_threshold=0.05)
-        imgs, contribs, secs, k1 = [], [], [], {}
+        imgs, contribs, secs, k1, full_imgs = [], [], [], {}, []
         for k, ci in enumerate(cam_ids):
             name = names[ci]
             cam = ch.get_camera("python", torch.tensor(transforms[name]), intr[name], colour_resolution=width)
@@ -297,8 +337,22 @@ def gen_render_big(ref, tag="1m", n=1_000_000, num_points=10_000_000, width=1280
                        "cam%d_cov2d_s64" % k: f["cov2d"][::64].copy()})
             print("render_big: camera %d in %.1f s" % (ci, secs[-1]), flush=True)
             imgs.append(_np(img).astype(np.float32)[::4, ::4].copy())
+            full_imgs.append(_np(img).astype(np.float32))
             contribs.append(_np(R.gaussian_max_contribution).copy())
+        ties.__exit__(None, None, None)
         colours = _np(R.get_gaussian_colours())
+        if spread:
+            dc = np.abs(spread["contrib"] - contribs[-1])
+            dcol = np.abs(spread["colours"] - colours).max(axis=1) / 255.0
+            dimg = [np.abs(a - b) for a, b in zip(spread["images"], full_imgs)]
+            k1["tie_spread"] = json.dumps(dict(
+                what="untouched reference with torch.sort as is (unstable) vs the same with stable=True, same host",
+                contrib_gt_1e4=int((dc > 1e-4).sum()), contrib_max=float(dc.max()),
+                colour_frac_gt_1e4=float((dcol > 1e-4).mean()), colour_max=float(dcol.max()),
+                image_frac_gt_1e4=[float((d > 1e-4).mean()) for d in dimg], image_max=[float(d.max()) for d in dimg],
+                visible_flips=int(((spread["contrib"] > 0.05) != (contribs[-1] > 0.05)).sum())))
+            print("render_big: tie spread", k1["tie_spread"], flush=True)
+        k1["tie_rule"] = "stable"
         visible = _np(R.get_visible_gaussians())
         c9 = _np(G.covariances).reshape(n, 9)
         k1["cov3d_hash8"] = k1_hash8(*[c9[:, j] for j in (0, 1, 2, 4, 5, 8)])

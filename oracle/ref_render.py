@@ -151,7 +151,12 @@ class PythonRendererOracle:
                 image[y0:y0 + h, x0:x0 + w, :] = self.bg
                 continue
             coord = pix[y0:y0 + h, x0:x0 + w].flatten(0, -2)
-            _, index = torch.sort(depths[mask])
+            # DEPTH TIES: the reference calls torch.sort(depths) with stable=False (gauss_render.py:340); on an AVX-512 host
+            # that is a quicksort whose order of EQUAL depths is a property of its partitioning (half of all tied neighbours
+            # come out swapped).  Any tie order is a legal execution of the reference; this oracle -- like the 1 M fixture,
+            # oracle/make_golden.py::gen_render_big, whose `tie_spread` records how far the as-is execution lands from it --
+            # fixes the one deterministic rule: stable, i.e. ties in input order before the flip.
+            _, index = torch.sort(depths[mask], stable=True)
             index = torch.flip(index, [0, ])
             inv_index = index.argsort(0)
             sm, sc2 = m2[mask][index], c2[mask][index]

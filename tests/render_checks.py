@@ -67,16 +67,23 @@ def run_vs_oracle(n, seed, width, height, focal, ncam, device="cpu", scale=(0.00
     sc = make_scene(n, seed, scale_lo=scale[0], scale_hi=scale[1])
     transforms, intr = make_cameras(ncam, width=width, height=height, focal=focal)
     G = Gaussians(sc.xyz.to(dev), sc.scales.to(dev), sc.rots.to(dev), sc.colours.to(dev), sc.opacities.to(dev))
-    R = gauss_render.get_renderer("python", G.xyz, G.opacities.unsqueeze(1), G.colours, G.covariances,
+    # both renderers get the SAME host-arithmetic inputs: the oracle's covariances (torch.exp on the CPU is MKL's, within an
+    # ulp of the library's correctly rounded one) and, below, its camera matrices
+    cov = RG.covariances(sc.scales, sc.rots)
+    assert float((G.covariances.cpu() - cov).abs().max()) <= 1e-6 * float(cov.abs().max())
+    R = gauss_render.get_renderer("python", G.xyz, G.opacities.unsqueeze(1), G.colours, cov.to(dev),
                                   visible_gaussian_threshold=0.05)
     R.t_floor = t_floor
-    O = RR.PythonRendererOracle(sc.xyz, sc.opacities.unsqueeze(1), sc.colours.double(), RG.covariances(sc.scales, sc.rots),
-                                threshold=0.05)
+    O = RR.PythonRendererOracle(sc.xyz, sc.opacities.unsqueeze(1), sc.colours.double(), cov, threshold=0.05)
     worst = dict(image=0.0, contribution=0.0, colour=0.0, flips=0, near_threshold=0, image_frac_off=0.0)
     for name in transforms:
         cam = camera_handler.get_camera("python", torch.tensor(transforms[name]), intr[name], colour_resolution=colour_resolution)
+        ocam = RR.get_camera(torch.tensor(transforms[name]), intr[name], colour_resolution=colour_resolution)
+        assert torch.allclose(cam.world_view_transform, ocam.world_view_transform, rtol=1e-5, atol=1e-6)
+        cam.world_view_transform, cam.projection_matrix = ocam.world_view_transform, ocam.projection_matrix
+        cam.FoVx, cam.FoVy, cam.focal_x, cam.focal_y = ocam.FoVx, ocam.FoVy, ocam.focal_x, ocam.focal_y
         img = R(cam)[0].cpu()
-        ref = O(RR.get_camera(torch.tensor(transforms[name]), intr[name], colour_resolution=colour_resolution))
+        ref = O(ocam)
         d = (img - ref).abs()
         worst["image"] = max(worst["image"], float(d.max()))
         worst["image_frac_off"] = max(worst["image_frac_off"], float((d > 1e-4).float().mean()))

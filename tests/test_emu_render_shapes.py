@@ -45,8 +45,12 @@ def test_nothing_in_front_of_the_camera(emu):
 
 @pytest.mark.parametrize("sub", [1, 2])
 def test_floor_mode_keeps_contributions_bit_identical(emu, monkeypatch, sub):
-    """The documented guarantee of the transmittance floor: every contribution above it equals the exact mode's bit for
-    bit (the floor only stops walks whose remaining contributions are all below it), and so do the winners."""
+    """The documented guarantee of the transmittance floor: the floor only stops walks whose remaining contributions are all
+    below it.  With one 8x8 sub-block per wave both modes run the same kernel and every contribution above the floor equals
+    the exact mode's bit for bit, as do the winners.  With two (the default) the exact mode runs k_blend_py_pk -- the
+    reference's operation order in the exponent -- and the floor mode k_blend_py_dl -- the exponent expanded about the
+    sub-block centre, <= 2e-5 relative in alpha: contributions agree to a few 1e-6, an arg-max may move between pixels whose
+    contributions tie at that level."""
     import gauss_render
     import camera_handler
     from gauss_handler import Gaussians
@@ -66,7 +70,14 @@ def test_floor_mode_keeps_contributions_bit_identical(emu, monkeypatch, sub):
     exact, floored = out
     seen = exact[0] >= 1e-5
     assert seen.sum() > 300
-    assert np.array_equal(exact[0][seen], floored[0][seen])                    # contributions, bit for bit
-    assert np.array_equal(exact[3][seen], floored[3][seen])                    # and the winning (camera, tile, pixel)
-    assert np.abs(exact[1][seen] - floored[1][seen]).max() < 1e-3              # winners' colours (0..255 scale)
-    assert np.abs(exact[2] - floored[2]).max() < 2e-6                          # images
+    if sub == 1:
+        assert np.array_equal(exact[0][seen], floored[0][seen])                    # contributions, bit for bit
+        assert np.array_equal(exact[3][seen], floored[3][seen])                    # and the winning (camera, tile, pixel)
+        assert np.abs(exact[1][seen] - floored[1][seen]).max() < 1e-3              # winners' colours (0..255 scale)
+        assert np.abs(exact[2] - floored[2]).max() < 2e-6                          # images
+    else:
+        assert np.abs(exact[0][seen] - floored[0][seen]).max() < 5e-6
+        same_winner = ((exact[3] & 0xFFFFFFFF) == (floored[3] & 0xFFFFFFFF))[seen]   # low word = ~(camera, tile, pixel)
+        assert same_winner.mean() > 0.995
+        assert np.abs(exact[1][seen] - floored[1][seen])[same_winner].max() < 2e-3
+        assert np.abs(exact[2] - floored[2]).max() < 1e-5

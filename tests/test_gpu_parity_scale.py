@@ -16,20 +16,20 @@ def test_configs2_scene_two_cameras_against_reference(t_floor):
     assert parity_cfg2.available()
     r = parity_cfg2.run("cuda:0", t_floor=t_floor, sampler=(t_floor is None))
     print(r)
-    # north_star: RGB / xyz within 1e-4, culling indices bit-exact.  Measured on MI355X (profiles/r02b_bench_default.json):
-    # 0 mask flips of 1 M (7 Gaussians sit within 1e-5 of the threshold), 5 contributions of 1 M off by > 1e-4, 6.5e-4 of the
-    # pixels and -- a Gaussian's colour IS a pixel's colour -- 1e-4..5e-4 of the colours.  The outliers are whole terms, not drift: tile membership is a strict float comparison
-    # of mean +- radius against integer tile edges (gauss_render.py:308-310), a last-bit difference in a projected mean
-    # moves one Gaussian in or out of one tile; everything else agrees to ~1e-6.
-    assert r["mask_flips"] <= r["near_threshold_1e-5"], r
-    assert all(m < 1e-5 for m in r["mask_flip_margins"]), r
-    assert r["contrib_frac_gt_1e-4"] < 2e-5 and r["colour_frac_gt_1e-4"] < 2e-3 and r["image_frac_gt_1e-4"] < 2e-3, r
+    # north_star: RGB / xyz within 1e-4, culling indices bit-exact.  Measured on the MI355X (profiles/r03e_parity_1m.json):
+    # image 2.1e-6, contributions 8.3e-7 over all 1 M Gaussians, colours 1.5e-6, 0 mask flips, identical cull, 1 of 35 702
+    # point quotas off by one, 10 001 675 = 10 001 675 points.  The fixture is the reference with depth ties in stable order
+    # (torch.sort is unstable: `reference_tie_spread` in the report is how far the reference lands from ITSELF otherwise --
+    # 4 contributions of 1 M by up to 0.15, 6.7e-4 of the pixels -- exactly what rounds 1-2 read as outliers of this port).
+    assert r["mask_flips"] == 0 and r["culled_equal"], r
+    assert r["contrib_max"] < 1e-5 and r["contrib_frac_gt_1e-4"] == 0.0, r
+    assert r["image_max"] < 1e-4 and r["image_frac_gt_1e-4"] == 0.0, r
+    assert r["colour_max"] < 1e-4 and r["colour_frac_gt_1e-4"] == 0.0, r
+    # projected means / radii / depths: every bit of every Gaussian but the handful whose covariance row differs in the last
+    # bit (the library's exp is correctly rounded, torch's MKL exp is within an ulp of that)
+    assert all(k["in_mask_flips"] == 0 and k["k1_mismatch"] <= 3 and k["radius_mismatch"] <= 3 for k in r["k1"]), r["k1"]
     assert r["keep_equal"] and r["ppg_mismatch_given_ref_contrib"] == 0, r
-    if r["mask_flips"] == 0:
-        assert r["culled_equal"]
-        # our own render -> allocation: contributions agree to ~1e-6, so a few quotas move by one; the handful of Gaussians
-        # whose contribution differs by a whole term (tile-membership flips, above) move by more
-        assert 0 <= r["ppg_mismatch_end_to_end"] <= 0.005 * r["visible"], r
+    assert 0 <= r["ppg_mismatch_end_to_end"] <= 5 and r["ppg_max_abs_diff_end_to_end"] <= 1, r
     if t_floor is None:
         assert abs(r["sample_points"] - r["sample_points_ref"]) <= 16, r          # a flipped accept/reject can cost a point
         assert r["sample_rows_unmatched"] <= max(2, 1e-4 * r["sample_rows_compared"]) and r["sample_xyz_max"] < 1e-4, r

@@ -108,6 +108,12 @@ def run(device="cuda:0", t_floor=None, sampler=True, tag="1m"):
         R.t_floor = float(t_floor)
     out = {"gaussians": n, "cameras": [int(c) for c in g["cam_ids"]], "resolution": "%dx%d" % (width, height),
            "t_floor": float(R.t_floor), "oracle": "untouched reference on CPU (oracle/make_golden.py render_big)"}
+    if "tie_spread" in g.files:
+        # how far the reference lands from ITSELF when torch.sort (stable=False) orders depth ties its own way instead of
+        # stably: the fixture is the stable execution (oracle/make_golden.py::gen_render_big)
+        import json as _json
+        out["reference_tie_rule"] = str(g["tie_rule"])
+        out["reference_tie_spread"] = _json.loads(str(g["tie_spread"]))
     img_max, img_frac = 0.0, 0.0
     has_k1 = "cam0_view" in g.files
     if has_k1:
