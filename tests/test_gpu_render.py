@@ -58,7 +58,8 @@ def test_render_full_size_properties():
     # exponent, <= 2e-5 relative in alpha, visits below 2^-25 dropped, walks stopped below the floor)
     assert float((i0 - i1).abs().max()) < 2e-5                  # the floor changes nothing above ~1e-6
     assert float((c0 - c1).abs().max()) <= 5e-6
-    assert torch.equal(v0, v1)                                   # visibility mask at threshold 0.05 is identical
+    flips = v0 != v1                                             # the visibility mask at threshold 0.05 may only flip where
+    assert int(flips.sum()) <= 3 and bool(((c0[flips] - 0.05).abs() < 1e-5).all())   # the contribution sits ON the threshold
     seen = c0 > 1e-6                                             # below the floor a Gaussian may stay colourless
     assert float((col0 - col1)[seen].abs().max()) < 255e-5
     assert 0.01 < float(v0.float().mean()) < 0.9
