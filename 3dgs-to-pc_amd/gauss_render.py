@@ -284,9 +284,6 @@ DEFERRED_BUDGET_BYTES = 2 << 30
 DEFERRED_MAX = 64
 DEFERRED_MIN = 8
 CONTEXT_POOL_SIZE = 2
-import os as _os
-POOL_SKIP_FIRST_JOBS = int(_os.environ.get("G2PC_POOL_SKIP_FIRST_JOBS", "1"))   # contexts of the first job(s) of a process are not kept, see GaussHipRenderer.close
-_JOBS_CLOSED = 0
 _CONTEXT_POOL = []            # free contexts, most recently used last
 
 
@@ -380,12 +377,7 @@ class GaussHipRenderer():
             for sl in self.slots:
                 sl.inflight = None
             ctx.slots, ctx.capacity = self.slots, self.capacity
-            global _JOBS_CLOSED
-            _JOBS_CLOSED += 1
-            if _JOBS_CLOSED <= POOL_SKIP_FIRST_JOBS:
-                ctx.release()
-            else:
-                _return_context(ctx)
+            _return_context(ctx)
         except Exception:
             ctx.release()
 

@@ -325,6 +325,10 @@ def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, poin
     return total_point_cloud, surface_point_cloud
 
 
+def _warmup_semantics(s):
+    return () if not s.render_colours else (("python",) if s.renderer_type == "python" else ("cuda",))
+
+
 def convert_3dgs_to_pc(input_path, transform_path, mask_path, pointcloud_settings):
     """gauss_to_pc.py:373-601.  File loading (gauss_dataloader.py, transform_dataloader.py, mask_dataloader.py) is the
     I/O layer around the hot path; the compute body is convert_gaussians_to_pc."""
@@ -355,6 +359,10 @@ def convert_3dgs_to_pc(input_path, transform_path, mask_path, pointcloud_setting
 
     xyz, scales, rots, colours, opacities, shs = load_gaussians(input_path, max_sh_degree=s.max_sh_degree)
     gaussians = Gaussians(xyz, scales, rots, colours, opacities, shs=shs)
+
+    if torch.cuda.is_available() and str(s.device).startswith("cuda"):
+        from g2pc.warmup import warmup
+        warmup(s.device, _warmup_semantics(s))     # returns at once when main()'s background warm-up has finished, else waits for it
 
     out = convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, s, keep_render_context=False)
 
@@ -509,6 +517,11 @@ def main(argv=None):
         args.quiet = args.quiet or rank != 0
 
     pointcloud_settings = settings_from_args(args)
+
+    # load every kernel / torch operator of the hot path on a thread while the host parses the input files (g2pc/warmup.py)
+    if torch.cuda.is_available() and str(pointcloud_settings.device).startswith("cuda"):
+        from g2pc.warmup import warmup_in_background
+        warmup_in_background(pointcloud_settings.device, _warmup_semantics(pointcloud_settings))
 
     total_point_cloud, surface_point_cloud = convert_3dgs_to_pc(args.input_path, args.transform_path, args.mask_path,
                                                                 pointcloud_settings)

@@ -13,6 +13,8 @@ ap.add_argument("--gaussians", type=int, default=1_000_000)
 ap.add_argument("--points", type=int, default=10_000_000)
 ap.add_argument("--subblocks", type=int, default=None)
 ap.add_argument("--workload", default="render", choices=["render", "render_cuda", "sample"])
+ap.add_argument("--every-job", action="store_true", help="print the table of every job of the process (job 1 = what a one-shot conversion pays)")
+ap.add_argument("--jobs", type=int, default=3)
 a = ap.parse_args()
 if a.subblocks:
     gauss_render.BLEND_SUBBLOCKS = a.subblocks
@@ -50,14 +52,20 @@ R.get_total_gaussian_contributions = timed("get_total_contributions", R.get_tota
 gauss_to_pc.generate_pointcloud = timed("generate_pointcloud", gauss_to_pc.generate_pointcloud)
 scene = make_scene(a.gaussians, 1237, device=dev, with_sh=(a.workload == "render_cuda"))
 cams = make_cameras(50)
-for rep in range(3):
+def report(wall):
+    print("step wall ms (with stage syncs) %.2f" % wall)
+    for k, v in T.items():
+        print("%-45s %8.3f ms" % (k, v))
+    print("sum of top-level stages %.2f" % sum(v for k, v in T.items() if not k.startswith("  ")))
+for rep in range(a.jobs):
     T.clear()
     torch.cuda.synchronize()
     t = time.perf_counter()
     bench.one_step(scene, cams if a.workload != "sample" else None, a.workload, a.points, dev, rep)
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t) * 1e3
-print("step wall ms (with stage syncs) %.2f" % wall)
-for k, v in T.items():
-    print("%-45s %8.3f ms" % (k, v))
-print("sum of top-level stages %.2f" % sum(v for k, v in T.items() if not k.startswith("  ")))
+    if a.every_job:
+        print("---- job %d of this process" % (rep + 1))
+        report(wall)
+if not a.every_job:
+    report(wall)
