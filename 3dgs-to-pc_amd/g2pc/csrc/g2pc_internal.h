@@ -38,6 +38,15 @@ struct Arena {
     bool ok() const { return off <= cap; }
 };
 
+// ---- camera batching -----------------------------------------------------------------------------
+// A batched launch runs the same kernel for `batch` cameras at once: grid.y = batch, and everything a camera owns lives in
+// ONE contiguous arena, the arenas `cs` bytes apart -- so every per-camera pointer of a kernel moves by the same
+// blockIdx.y * cs bytes.  batch = 1 (grid.y = 1) is the single-camera launch, whatever cs.
+template <typename T> __device__ __forceinline__ T* seg(T* p, size_t cs) {
+    return p ? (T*)((char*)p + (size_t)blockIdx.y * cs) : p;
+}
+struct Batch { int n = 1; size_t cs = 0; };          // host side: number of cameras, arena stride in bytes
+
 // ---- wave-level helpers -------------------------------------------------------------------------
 __device__ __forceinline__ unsigned lane_id() {
     return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -77,7 +86,7 @@ __device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned v) {
 size_t scan_workspace(long n);
 // gather != nullptr: scans in[gather[i]] (in and out must then be distinct)
 int scan_exclusive_u32(const uint32_t* in, uint32_t* out, long n, void* ws, size_t ws_bytes, hipStream_t s,
-                       const uint32_t* gather = nullptr);
+                       const uint32_t* gather = nullptr, Batch b = Batch());
 // `rows` independent scans of n values each (row r: in + r*n -> out + r*(n+1)) in two launches; n <= 2M per row
 size_t scan_rows_workspace(long n, int rows);
 int scan_exclusive_rows_u32(const uint32_t* in, uint32_t* out, long n, int rows, void* ws, size_t ws_bytes, hipStream_t s);
@@ -86,14 +95,14 @@ int scan_exclusive_rows_u32(const uint32_t* in, uint32_t* out, long n, int rows,
 size_t sort_workspace(long n);
 int sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
                    uint32_t* keys_tmp, uint32_t* vals_tmp, long n, int bit_lo, int bit_hi, void* ws,
-                   size_t ws_bytes, hipStream_t s, const uint32_t* n_dev = nullptr);
+                   size_t ws_bytes, hipStream_t s, const uint32_t* n_dev = nullptr, Batch b = Batch());
 
 // bucket sort of (key, input position) pairs for range-spread float-bit keys (see prims.hip); *overflow_flag points into
 // the workspace afterwards (device u32: non-zero = a bucket overflowed, sort again with sort_pairs_u32)
 size_t bucket_sort_workspace(long n);
 bool bucket_sort_pays(long n);          // measured on MI355X: 90 vs 101 us (radix) at 1 M keys, 533 vs 278 us at 5 M
 int bucket_sort_u32(const uint32_t* keys, const uint32_t* vals, uint32_t* vals_out, uint32_t* keys_out, long n, void* ws,
-                    size_t ws_bytes, uint32_t** overflow_flag, hipStream_t s);
+                    size_t ws_bytes, uint32_t** overflow_flag, hipStream_t s, Batch b = Batch());
 
 // Philox4x32-10 keyed standard normals (see oracle/np_philox.py for the definition)
 struct Normal3 { float x, y, z; };

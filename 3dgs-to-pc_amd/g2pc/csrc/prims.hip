@@ -25,8 +25,9 @@ constexpr int SCAN_T = 256, SCAN_I = 4, SCAN_TILE = SCAN_T * SCAN_I;
 // gather (optional): scan in[gather[i]] instead of in[i] (the rasteriser's tiles-touched counts in depth order)
 __global__ __launch_bounds__(SCAN_T) void k_scan_tile(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                      long n, uint32_t* __restrict__ block_sums,
-                                                     const uint32_t* __restrict__ gather) {
+                                                     const uint32_t* __restrict__ gather, size_t cs) {
     __shared__ uint32_t wsum[SCAN_T / kWave];
+    in = seg(in, cs); out = seg(out, cs); block_sums = seg(block_sums, cs); gather = seg(gather, cs);
     const long base = (long)blockIdx.x * SCAN_TILE + (long)threadIdx.x * SCAN_I;
     uint32_t v[SCAN_I];
     uint32_t tsum = 0;
@@ -61,8 +62,9 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_tile(const uint32_t* __restrict
 // second (and last) kernel of the 2-kernel scan: every block sums the block totals in front of it by itself
 // (nb <= 2048 values, L2 resident) instead of a separate scan-of-sums launch; the last block also writes the total.
 __global__ __launch_bounds__(SCAN_T) void k_scan_add_self(uint32_t* __restrict__ out, long n,
-                                                         const uint32_t* __restrict__ block_sums) {
+                                                         const uint32_t* __restrict__ block_sums, size_t cs) {
     __shared__ uint32_t wsum[SCAN_T / kWave];
+    out = seg(out, cs); block_sums = seg(block_sums, cs);
     uint32_t acc = 0;
     for (unsigned i = threadIdx.x; i < blockIdx.x; i += SCAN_T) acc += block_sums[i];
     acc = wave_sum(acc);
@@ -180,17 +182,18 @@ size_t scan_workspace(long n) {
 }
 
 static int scan_rec(const uint32_t* in, uint32_t* out, long n, Arena& ar, hipStream_t s,
-                    const uint32_t* gather = nullptr) {
+                    const uint32_t* gather = nullptr, Batch b = Batch()) {
     long nb = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (nb < 1) nb = 1;
     uint32_t* sums = ar.get<uint32_t>((size_t)nb + 1);
     if (!ar.ok()) { set_error("scan", "workspace too small"); return G2PC_ERR_WORKSPACE; }
-    hipLaunchKernelGGL(k_scan_tile, dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, out, n, sums, gather);
+    hipLaunchKernelGGL(k_scan_tile, dim3((unsigned)nb, (unsigned)b.n), dim3(SCAN_T), 0, s, in, out, n, sums, gather, b.cs);
     if (nb == 1) return check_launch("scan");
     if (nb <= 2048) {
-        hipLaunchKernelGGL(k_scan_add_self, dim3((unsigned)nb), dim3(SCAN_T), 0, s, out, n, sums);
+        hipLaunchKernelGGL(k_scan_add_self, dim3((unsigned)nb, (unsigned)b.n), dim3(SCAN_T), 0, s, out, n, sums, b.cs);
         return check_launch("scan");
     }
+    if (b.n > 1) { set_error("scan", "batched scans support at most 2M values per camera"); return G2PC_ERR_UNSUPPORTED; }
     int rc = scan_rec(sums, sums, nb, ar, s);   // sums[0..nb] = exclusive offsets (+ total)
     if (rc) return rc;
     hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb), dim3(SCAN_T), 0, s, out, n, sums, out + n);
@@ -198,13 +201,13 @@ static int scan_rec(const uint32_t* in, uint32_t* out, long n, Arena& ar, hipStr
 }
 
 int scan_exclusive_u32(const uint32_t* in, uint32_t* out, long n, void* ws, size_t ws_bytes, hipStream_t s,
-                       const uint32_t* gather) {
+                       const uint32_t* gather, Batch b) {
     if (n <= 0) {
         if (hipMemsetAsync(out, 0, sizeof(uint32_t), s) != hipSuccess) { set_error("scan", "memset failed"); return G2PC_ERR_LAUNCH; }
         return G2PC_OK;
     }
     Arena ar(ws, ws_bytes);
-    return scan_rec(in, out, n, ar, s, gather);
+    return scan_rec(in, out, n, ar, s, gather, b);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -217,9 +220,10 @@ constexpr int RS_T = 256, RS_W = RS_T / kWave;
 template <int BITS, int ITEMS>
 __global__ __launch_bounds__(RS_T) void k_radix_hist(const uint32_t* __restrict__ keys, long n, int shift,
                                                     unsigned mask, uint32_t* __restrict__ ghist, unsigned nb,
-                                                    const uint32_t* __restrict__ n_dev) {
+                                                    const uint32_t* __restrict__ n_dev, size_t cs) {
     constexpr int BINS = 1 << BITS, TILE = RS_T * ITEMS;
     __shared__ uint32_t hist[BINS];
+    keys = seg(keys, cs); ghist = seg(ghist, cs); n_dev = seg(n_dev, cs);
     if (n_dev) { const long m = (long)*n_dev; n = m < n ? m : n; }      // device-side count (n = the launch capacity)
     for (int i = threadIdx.x; i < BINS; i += RS_T) hist[i] = 0;
     __syncthreads();
@@ -236,9 +240,11 @@ __global__ __launch_bounds__(RS_T) void k_radix_hist(const uint32_t* __restrict_
 // One launch instead of the generic two-kernel scan over the (digit, block) matrix: block d turns row d of ghist (the
 // per-tile counts of digit d, nb entries) into its exclusive prefix IN PLACE and leaves the row total in gtot[d]; the
 // scatter kernel adds the exclusive scan of the <= 2048 row totals itself (a few hundred LDS operations per block).
-__global__ __launch_bounds__(SCAN_T) void k_radix_rowscan(uint32_t* __restrict__ ghist, unsigned nb, uint32_t* __restrict__ gtot) {
+__global__ __launch_bounds__(SCAN_T) void k_radix_rowscan(uint32_t* __restrict__ ghist, unsigned nb, uint32_t* __restrict__ gtot,
+                                                         size_t cs) {
     __shared__ uint32_t wsum[SCAN_T / kWave];
     __shared__ uint32_t carry;
+    ghist = seg(ghist, cs); gtot = seg(gtot, cs);
     uint32_t* row = ghist + (size_t)blockIdx.x * nb;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
@@ -269,11 +275,13 @@ __global__ __launch_bounds__(RS_T) void k_radix_scatter(const uint32_t* __restri
                                                        unsigned mask, int nbits,
                                                        const uint32_t* __restrict__ goffs, unsigned nb,
                                                        const uint32_t* __restrict__ n_dev,
-                                                       const uint32_t* __restrict__ gtot) {
+                                                       const uint32_t* __restrict__ gtot, size_t cs) {
     constexpr int BINS = 1 << BITS, TILE = RS_T * ITEMS;
     __shared__ uint32_t whist[RS_W][BINS];      // per-wave running digit counts, then exclusive offsets
     __shared__ uint32_t gbase[BINS];
     __shared__ uint32_t dsum[RS_T / kWave];
+    keys_in = seg(keys_in, cs); vals_in = seg(vals_in, cs); keys_out = seg(keys_out, cs); vals_out = seg(vals_out, cs);
+    goffs = seg(goffs, cs); n_dev = seg(n_dev, cs); gtot = seg(gtot, cs);
     if (n_dev) {
         const long m = (long)*n_dev;
         n = m < n ? m : n;
@@ -368,19 +376,19 @@ size_t sort_workspace(long n) {
 template <int BITS, int ITEMS>
 static void radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, long n, int bit,
                        int nbits, uint32_t* ghist, unsigned nb, char* scan_ws, size_t scan_bytes, hipStream_t s, int& rc,
-                       const uint32_t* n_dev) {
+                       const uint32_t* n_dev, Batch b) {
     unsigned mask = (1u << nbits) - 1u;
-    hipLaunchKernelGGL((k_radix_hist<BITS, ITEMS>), dim3(nb), dim3(RS_T), 0, s, kin, n, bit, mask, ghist, nb, n_dev);
+    hipLaunchKernelGGL((k_radix_hist<BITS, ITEMS>), dim3(nb, (unsigned)b.n), dim3(RS_T), 0, s, kin, n, bit, mask, ghist, nb, n_dev, b.cs);
     uint32_t* gtot = (uint32_t*)scan_ws;                       // (mask + 1) row totals
     if (scan_bytes < (size_t)(mask + 1) * sizeof(uint32_t)) { set_error("sort", "workspace too small"); rc = G2PC_ERR_WORKSPACE; return; }
-    hipLaunchKernelGGL(k_radix_rowscan, dim3(mask + 1), dim3(SCAN_T), 0, s, ghist, nb, gtot);
-    hipLaunchKernelGGL((k_radix_scatter<BITS, ITEMS>), dim3(nb), dim3(RS_T), 0, s, kin, vin, kout, vout, n, bit, mask, nbits,
-                       ghist, nb, n_dev, gtot);
+    hipLaunchKernelGGL(k_radix_rowscan, dim3(mask + 1, (unsigned)b.n), dim3(SCAN_T), 0, s, ghist, nb, gtot, b.cs);
+    hipLaunchKernelGGL((k_radix_scatter<BITS, ITEMS>), dim3(nb, (unsigned)b.n), dim3(RS_T), 0, s, kin, vin, kout, vout, n, bit, mask, nbits,
+                       ghist, nb, n_dev, gtot, b.cs);
 }
 
 int sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
                    uint32_t* keys_tmp, uint32_t* vals_tmp, long n, int bit_lo, int bit_hi, void* ws,
-                   size_t ws_bytes, hipStream_t s, const uint32_t* n_dev) {
+                   size_t ws_bytes, hipStream_t s, const uint32_t* n_dev, Batch b) {
     // n_dev (optional, device): the number of keys actually present (<= n).  The launch geometry then depends on n
     // (a capacity) only, so the same sequence of launches -- e.g. a captured hipGraph -- serves any count.
     if (n <= 0) return G2PC_OK;
@@ -393,6 +401,7 @@ int sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* k
     }
     int total_bits = bit_hi - bit_lo;
     if (total_bits <= 0) {
+        if (b.n > 1) { set_error("sort", "batched sort of zero bits"); return G2PC_ERR_UNSUPPORTED; }
         hipMemcpyAsync(keys_out, keys_in, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
         if (!keys_only) hipMemcpyAsync(vals_out, vals_in, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
         return G2PC_OK;
@@ -417,11 +426,11 @@ int sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* k
         uint32_t* kout = to_out ? keys_out : keys_tmp;
         uint32_t* vout = to_out ? vals_out : vals_tmp;
         if (maxbits == 8) {
-            if (items == 4) radix_pass<8, 4>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc, n_dev);
-            else radix_pass<8, 8>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc, n_dev);
+            if (items == 4) radix_pass<8, 4>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc, n_dev, b);
+            else radix_pass<8, 8>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc, n_dev, b);
         } else {
-            if (items == 4) radix_pass<11, 4>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc, n_dev);
-            else radix_pass<11, 8>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc, n_dev);
+            if (items == 4) radix_pass<11, 4>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc, n_dev, b);
+            else radix_pass<11, 8>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc, n_dev, b);
         }
         if (rc) return rc;
         kin = kout; vin = vout;
@@ -496,8 +505,10 @@ __device__ __forceinline__ BucketMap bucket_map_from_partials(const BucketHdr* _
     m.set(lds2[0], lds2[1], h->nbk);
     return m;
 }
-__global__ __launch_bounds__(BK_T) void k_bk_minmax(const uint32_t* __restrict__ keys, long n, BucketHdr* __restrict__ h, BucketPlan plan) {
+__global__ __launch_bounds__(BK_T) void k_bk_minmax(const uint32_t* __restrict__ keys, long n, BucketHdr* __restrict__ h, BucketPlan plan,
+                                                   size_t cs) {
     __shared__ uint32_t red[2];
+    keys = seg(keys, cs); h = seg(h, cs);
     uint32_t a = 0, b = 0;
     for (long i = (long)blockIdx.x * BK_T + threadIdx.x; i < n; i += (long)gridDim.x * BK_T) {
         const uint32_t k = keys[i];
@@ -514,9 +525,10 @@ __global__ __launch_bounds__(BK_T) void k_bk_minmax(const uint32_t* __restrict__
     }
 }
 __global__ __launch_bounds__(BK_T) void k_bk_hist(const uint32_t* __restrict__ keys, long n, const BucketHdr* __restrict__ h,
-                                                 uint32_t* __restrict__ table, BucketPlan plan) {
+                                                 uint32_t* __restrict__ table, BucketPlan plan, size_t cs) {
     __shared__ uint32_t lh[BK_MAX + 1];
     __shared__ uint32_t red[2];
+    keys = seg(keys, cs); h = seg(h, cs); table = seg(table, cs);
     const uint32_t nbk = plan.nbk;
     for (uint32_t i = threadIdx.x; i <= nbk; i += BK_T) lh[i] = 0;
     const BucketMap m = bucket_map_from_partials(h, plan.nminmax, red);   // (its barriers also publish the zeroed histogram)
@@ -529,7 +541,9 @@ __global__ __launch_bounds__(BK_T) void k_bk_hist(const uint32_t* __restrict__ k
     for (uint32_t i = threadIdx.x; i <= nbk; i += BK_T) table[(size_t)i * plan.nchunks + blockIdx.x] = lh[i];
 }
 // one wave per bucket (4 per block): table row -> exclusive prefix over the chunks, row total -> count[bucket]
-__global__ __launch_bounds__(BK_T) void k_bk_colscan(BucketHdr* __restrict__ h, uint32_t* __restrict__ table, BucketPlan plan) {
+__global__ __launch_bounds__(BK_T) void k_bk_colscan(BucketHdr* __restrict__ h, uint32_t* __restrict__ table, BucketPlan plan,
+                                                    size_t cs) {
+    h = seg(h, cs); table = seg(table, cs);
     const uint32_t b = blockIdx.x * (BK_T / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (b > plan.nbk) return;
     uint32_t* row = table + (size_t)b * plan.nchunks;
@@ -543,8 +557,9 @@ __global__ __launch_bounds__(BK_T) void k_bk_colscan(BucketHdr* __restrict__ h, 
     }
     if (lane == 0) h->count[b] = carry;
 }
-__global__ __launch_bounds__(1024) void k_bk_scan(BucketHdr* __restrict__ h) {
+__global__ __launch_bounds__(1024) void k_bk_scan(BucketHdr* __restrict__ h, size_t cs) {
     __shared__ uint32_t wsum[16];
+    h = seg(h, cs);
     const unsigned t = threadIdx.x, lane = t & 63, w = t >> 6;
     const uint32_t nbk = h->nbk, per = nbk >> 10;                     // nbk is a multiple of 1024: `per` buckets per thread
     uint32_t c[BK_MAX / 1024], mine = 0, worst = 0;
@@ -568,9 +583,10 @@ __global__ __launch_bounds__(1024) void k_bk_scan(BucketHdr* __restrict__ h) {
 }
 __global__ __launch_bounds__(BK_T) void k_bk_scatter(const uint32_t* __restrict__ keys, long n, const BucketHdr* __restrict__ h,
                                                     const uint32_t* __restrict__ table, unsigned long long* __restrict__ items,
-                                                    BucketPlan plan) {
+                                                    BucketPlan plan, size_t cs) {
     __shared__ uint32_t cur[BK_MAX + 1];
     __shared__ uint32_t red[2];
+    keys = seg(keys, cs); h = seg(h, cs); table = seg(table, cs); items = seg(items, cs);
     const uint32_t nbk = plan.nbk;
     for (uint32_t i = threadIdx.x; i <= nbk; i += BK_T) cur[i] = h->start[i] + table[(size_t)i * plan.nchunks + blockIdx.x];
     const BucketMap m = bucket_map_from_partials(h, plan.nminmax, red);   // (its barriers also publish the cursors)
@@ -642,8 +658,9 @@ __device__ __forceinline__ void bucket_sort_in_registers(const unsigned long lon
 template <int CAP>
 __global__ __launch_bounds__(64) void k_bk_sort(const BucketHdr* __restrict__ h, const unsigned long long* __restrict__ items,
                                                 const uint32_t* __restrict__ vals, uint32_t* __restrict__ vals_out,
-                                                uint32_t* __restrict__ keys_out) {
+                                                uint32_t* __restrict__ keys_out, size_t cs) {
     __shared__ unsigned long long s_it[CAP > 1024 ? CAP : 1];
+    h = seg(h, cs); items = seg(items, cs); vals = seg(vals, cs); vals_out = seg(vals_out, cs); keys_out = seg(keys_out, cs);
     const unsigned lane = threadIdx.x, nbk = h->nbk;
     // blocks nbk .. nbk + BK_TAILBLOCKS - 1 share the tail bucket (tens of thousands of off-screen keys: one wave copying
     // them alone, two dependent loads per trip, took longer than the rest of the sort)
@@ -702,25 +719,26 @@ size_t bucket_sort_workspace(long n) {
 // keys 0xFFFFFFFF last.  *overflow_flag (device u32, optional) receives the size of the largest bucket when one exceeds
 // the room of a bucket (BucketPlan::cap) -- the output is then a permutation in bucket order only and the caller must sort again with sort_pairs_u32.
 int bucket_sort_u32(const uint32_t* keys, const uint32_t* vals, uint32_t* vals_out, uint32_t* keys_out, long n, void* ws,
-                    size_t ws_bytes, uint32_t** overflow_flag, hipStream_t s) {
+                    size_t ws_bytes, uint32_t** overflow_flag, hipStream_t s, Batch b) {
     if (n <= 0) return G2PC_OK;
     const BucketPlan plan = bucket_plan(n);
+    const unsigned by = (unsigned)b.n;
     Arena ar(ws, ws_bytes);
     BucketHdr* h = ar.get<BucketHdr>(1);
     unsigned long long* items = ar.get<unsigned long long>((size_t)n);
     uint32_t* table = ar.get<uint32_t>((size_t)(plan.nbk + 1) * plan.nchunks);
     if (!ar.ok()) { set_error("bucket_sort", "workspace too small"); return G2PC_ERR_WORKSPACE; }
-    hipLaunchKernelGGL(k_bk_minmax, dim3(plan.nminmax), dim3(BK_T), 0, s, keys, n, h, plan);
-    hipLaunchKernelGGL(k_bk_hist, dim3(plan.nchunks), dim3(BK_T), 0, s, keys, n, (const BucketHdr*)h, table, plan);
-    hipLaunchKernelGGL(k_bk_colscan, dim3(cdiv(plan.nbk + 1, BK_T / 64)), dim3(BK_T), 0, s, h, table, plan);
-    hipLaunchKernelGGL(k_bk_scan, dim3(1), dim3(1024), 0, s, h);
-    hipLaunchKernelGGL(k_bk_scatter, dim3(plan.nchunks), dim3(BK_T), 0, s, keys, n, (const BucketHdr*)h, (const uint32_t*)table, items, plan);
+    hipLaunchKernelGGL(k_bk_minmax, dim3(plan.nminmax, by), dim3(BK_T), 0, s, keys, n, h, plan, b.cs);
+    hipLaunchKernelGGL(k_bk_hist, dim3(plan.nchunks, by), dim3(BK_T), 0, s, keys, n, (const BucketHdr*)h, table, plan, b.cs);
+    hipLaunchKernelGGL(k_bk_colscan, dim3(cdiv(plan.nbk + 1, BK_T / 64), by), dim3(BK_T), 0, s, h, table, plan, b.cs);
+    hipLaunchKernelGGL(k_bk_scan, dim3(1, by), dim3(1024), 0, s, h, b.cs);
+    hipLaunchKernelGGL(k_bk_scatter, dim3(plan.nchunks, by), dim3(BK_T), 0, s, keys, n, (const BucketHdr*)h, (const uint32_t*)table, items, plan, b.cs);
     if (plan.cap == (uint32_t)BK_CAP_SMALL)
-        hipLaunchKernelGGL(k_bk_sort<BK_CAP_SMALL>, dim3(plan.nbk + BK_TAILBLOCKS), dim3(64), 0, s, (const BucketHdr*)h,
-                           (const unsigned long long*)items, vals, vals_out, keys_out);
+        hipLaunchKernelGGL(k_bk_sort<BK_CAP_SMALL>, dim3(plan.nbk + BK_TAILBLOCKS, by), dim3(64), 0, s, (const BucketHdr*)h,
+                           (const unsigned long long*)items, vals, vals_out, keys_out, b.cs);
     else
-        hipLaunchKernelGGL(k_bk_sort<BK_CAP_LARGE>, dim3(plan.nbk + BK_TAILBLOCKS), dim3(64), 0, s, (const BucketHdr*)h,
-                           (const unsigned long long*)items, vals, vals_out, keys_out);
+        hipLaunchKernelGGL(k_bk_sort<BK_CAP_LARGE>, dim3(plan.nbk + BK_TAILBLOCKS, by), dim3(64), 0, s, (const BucketHdr*)h,
+                           (const unsigned long long*)items, vals, vals_out, keys_out, b.cs);
     if (overflow_flag) *overflow_flag = &h->overflow;
     return check_launch("bucket_sort");
 }

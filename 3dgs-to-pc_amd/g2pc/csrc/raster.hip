@@ -20,7 +20,7 @@ namespace g2pc {
 
 constexpr int RA_T = 256;
 __global__ void k_tile_ranges(const uint32_t* __restrict__ tile_sorted, long L, int T, uint32_t* __restrict__ tile_start,
-                              const uint32_t* __restrict__ l_dev, int gshift);
+                              const uint32_t* __restrict__ l_dev, int gshift, size_t cs);
 constexpr float LOG2E = 1.4426950408889634f;
 
 struct Cam {            // device copy of G2pcCamera (passed by value as kernel argument)
@@ -63,11 +63,15 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_py(Cam cam_val, const Cam* 
                                                        uint32_t* __restrict__ index_rev,
                                                        uint32_t* __restrict__ tiles_touched,
                                                        const float* __restrict__ colours,
-                                                       float4* __restrict__ rec, uint32_t* __restrict__ rect) {
+                                                       float4* __restrict__ rec, uint32_t* __restrict__ rect, size_t cs) {
     // device-resident camera: lets ONE captured launch sequence serve every camera.  Staged through LDS once per block
     // (per-thread loads of the 172-byte struct made this kernel 6x slower than the by-value variant).
+    // Batched launch (grid.y cameras): camera c's job is the c-th G2pcCameraJob, its outputs live in the c-th arena.
     __shared__ Cam s_cam;
+    depth_key_rev = seg(depth_key_rev, cs); index_rev = seg(index_rev, cs); tiles_touched = seg(tiles_touched, cs);
+    rec = seg(rec, cs); rect = seg(rect, cs);
     if (CAM_ON_DEVICE) {
+        cam_dev = (const Cam*)((const char*)cam_dev + (size_t)blockIdx.y * sizeof(G2pcCameraJob));
         if (threadIdx.x < sizeof(Cam) / 4) ((uint32_t*)&s_cam)[threadIdx.x] = ((const uint32_t*)cam_dev)[threadIdx.x];
         __syncthreads();
     }
@@ -139,8 +143,10 @@ __global__ __launch_bounds__(RA_T) void k_duplicate(const uint32_t* __restrict__
                                                    const uint32_t* __restrict__ offsets,
                                                    const uint32_t* __restrict__ rect, long n, int nx,
                                                    uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ inst_g,
-                                                   const uint32_t* __restrict__ l_eff, int gshift) {
+                                                   const uint32_t* __restrict__ l_eff, int gshift, size_t cs) {
     // gshift > 0 (inst_g unused): ONE word per instance, tile << gshift | Gaussian -- the tile sort then moves keys only
+    sorted_idx = seg(sorted_idx, cs); offsets = seg(offsets, cs); rect = seg(rect, cs); inst_tile = seg(inst_tile, cs);
+    inst_g = seg(inst_g, cs); l_eff = seg(l_eff, cs);
     long p = (long)blockIdx.x * RA_T + threadIdx.x;
     if (p >= n) return;
     if (l_eff && *l_eff == 0u) return;          // capacity-sized launch: nothing to emit (or more than fits)
@@ -206,9 +212,11 @@ __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __
                                                   unsigned long long* __restrict__ best_key, uint32_t order_base,
                                                   float t_floor, float bg, float* __restrict__ tilebuf,
                                                   uint32_t* __restrict__ chunk_work,
-                                                  const G2pcCameraJob* __restrict__ job) {
+                                                  const G2pcCameraJob* __restrict__ job, size_t cs) {
     // one wave64 per block: the LDS stage is wave-private, no s_barrier anywhere
+    tile_start = seg(tile_start, cs); inst_g = seg(inst_g, cs); rec = seg(rec, cs);      // batched: camera blockIdx.y
     if (job) {
+        job += blockIdx.y;
         order_base = job->camera_slot << 24; t_floor = job->t_floor; bg = job->cam.bg[0];
         const unsigned long long tb = ((unsigned long long)job->tilebuf_hi << 32) | job->tilebuf_lo;
         if (tb) tilebuf = (float*)tb;              // one colour buffer per camera (deferred colour resolve)
@@ -413,8 +421,10 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_pk(Layout lay, const int32_t*
                                                      unsigned long long* __restrict__ best_key, uint32_t order_base,
                                                      float t_floor, float bg, float* __restrict__ tilebuf,
                                                      uint32_t* __restrict__ chunk_work,
-                                                     const G2pcCameraJob* __restrict__ job) {
+                                                     const G2pcCameraJob* __restrict__ job, size_t cs) {
+    tile_start = seg(tile_start, cs); inst_g = seg(inst_g, cs); rec = seg(rec, cs);      // batched: camera blockIdx.y
     if (job) {
+        job += blockIdx.y;
         order_base = job->camera_slot << 24; t_floor = job->t_floor; bg = job->cam.bg[0];
         const unsigned long long tb = ((unsigned long long)job->tilebuf_hi << 32) | job->tilebuf_lo;
         if (tb) tilebuf = (float*)tb;              // one colour buffer per camera (deferred colour resolve)
@@ -598,8 +608,10 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_dl(Layout lay, const int32_t*
                                                      unsigned long long* __restrict__ best_key, uint32_t order_base,
                                                      float t_floor, float bg, float* __restrict__ tilebuf,
                                                      uint32_t* __restrict__ chunk_work,
-                                                     const G2pcCameraJob* __restrict__ job) {
+                                                     const G2pcCameraJob* __restrict__ job, size_t cs) {
+    tile_start = seg(tile_start, cs); inst_g = seg(inst_g, cs); rec = seg(rec, cs);      // batched: camera blockIdx.y
     if (job) {
+        job += blockIdx.y;
         order_base = job->camera_slot << 24; t_floor = job->t_floor; bg = job->cam.bg[0];
         const unsigned long long tb = ((unsigned long long)job->tilebuf_hi << 32) | job->tilebuf_lo;
         if (tb) tilebuf = (float*)tb;              // one colour buffer per camera (deferred colour resolve)
@@ -1236,7 +1248,8 @@ __global__ __launch_bounds__(CU_T) void k_blend_cu(int W, int H, int grid_x, int
 // sorted tile ids (rasterizer_impl.cu:115-137 identifyTileRanges), no histogram, no scan.
 __global__ __launch_bounds__(RA_T) void k_tile_ranges(const uint32_t* __restrict__ tile_sorted, long L, int T,
                                                      uint32_t* __restrict__ tile_start,
-                                                     const uint32_t* __restrict__ l_dev, int gshift) {
+                                                     const uint32_t* __restrict__ l_dev, int gshift, size_t cs) {
+    tile_sorted = seg(tile_sorted, cs); tile_start = seg(tile_start, cs); l_dev = seg(l_dev, cs);
     if (l_dev) L = (long)*l_dev;                 // capacity-sized launch, count on the device
     long l = (long)blockIdx.x * RA_T + threadIdx.x;
     if (l > L) return;
@@ -1249,7 +1262,8 @@ __global__ __launch_bounds__(RA_T) void k_tile_ranges(const uint32_t* __restrict
 // the reference's quad-tree keeps splitting a leaf that holds more than max_gaussians_per_tile Gaussians
 // (gauss_render.py:319); the fixed leaf layout used here cannot follow it there -> raise a flag the host checks
 __global__ __launch_bounds__(RA_T) void k_check_tile_load(const uint32_t* __restrict__ tile_start, int T, uint32_t limit,
-                                                         uint32_t* __restrict__ flag) {
+                                                         uint32_t* __restrict__ flag, size_t cs) {
+    tile_start = seg(tile_start, cs);
     int t = blockIdx.x * RA_T + threadIdx.x;
     if (t < T && tile_start[t + 1] - tile_start[t] > limit) atomicMax(flag, tile_start[t + 1] - tile_start[t]);
 }
@@ -1257,7 +1271,9 @@ __global__ __launch_bounds__(RA_T) void k_check_tile_load(const uint32_t* __rest
 // capacity-sized launches: the instance count stays on the device.  l_eff = L if it fits the buffers, else 0 (the
 // camera is then skipped altogether and the host, which receives L asynchronously, renders it again with more room)
 __global__ void k_resolve_count(const uint32_t* __restrict__ total, uint32_t capacity, uint32_t* __restrict__ l_eff,
-                                uint32_t* __restrict__ count_host, const uint32_t* __restrict__ depth_overflow) {
+                                uint32_t* __restrict__ count_host, const uint32_t* __restrict__ depth_overflow, size_t cs) {
+    total = seg(total, cs); l_eff = seg(l_eff, cs); depth_overflow = seg(depth_overflow, cs);
+    if (count_host) count_host += 2 * blockIdx.y;                                  // [camera][instances, unsorted]
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         const uint32_t unsorted = depth_overflow ? *depth_overflow : 0u;       // the depth bucket sort gave up: skip the camera
         l_eff[0] = (total[0] <= capacity && !unsorted) ? total[0] : 0u;
@@ -1266,7 +1282,8 @@ __global__ void k_resolve_count(const uint32_t* __restrict__ total, uint32_t cap
 }
 // the pinned host job -> device memory, by a kernel rather than a copy node (see g2pc_raster_camera_py)
 __global__ void k_fetch_job(const uint32_t* __restrict__ job_host, uint32_t* __restrict__ job_dev) {
-    if (threadIdx.x < sizeof(G2pcCameraJob) / 4) job_dev[threadIdx.x] = job_host[threadIdx.x];
+    const unsigned o = blockIdx.x * (unsigned)(sizeof(G2pcCameraJob) / 4);          // one block per camera of the batch
+    if (threadIdx.x < sizeof(G2pcCameraJob) / 4) job_dev[o + threadIdx.x] = job_host[o + threadIdx.x];
 }
 
 // binding-side reductions (gaussian_pointcloud_rasterization/__init__.py:128-158): gather the colour of the arg-max
@@ -1369,7 +1386,7 @@ static size_t py_back_ws(long L, int T) {
 // overflow word afterwards (non-zero = NOT sorted: the caller must discard the camera and repeat it with the radix path)
 static int py_front(const Cam& cam_val, const Cam* cam_dev, const G2pcTileLayout* layout, const float* means3D,
                     const float* cov9, const float* opacity, const float* colours, long n, const PyFrontBuffers& fb,
-                    void* ws, size_t ws_bytes, hipStream_t s, uint32_t** depth_overflow = nullptr) {
+                    void* ws, size_t ws_bytes, hipStream_t s, uint32_t** depth_overflow = nullptr, Batch bt = Batch()) {
     Arena ar(ws, ws_bytes);
     uint32_t* key_rev = ar.get<uint32_t>((size_t)n);
     uint32_t* idx_rev = ar.get<uint32_t>((size_t)n);
@@ -1384,16 +1401,16 @@ static int py_front(const Cam& cam_val, const Cam* cam_dev, const G2pcTileLayout
     char* bucket_ws = ar.get<char>(bucket_bytes);
     if (!ar.ok()) { set_error("raster_front_py", "workspace too small"); return G2PC_ERR_WORKSPACE; }
     if (cam_dev)
-        hipLaunchKernelGGL(k_preprocess_py<true>, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, cam_val, cam_dev, to_layout(layout),
-                           means3D, cov9, opacity, n, key_rev, idx_rev, touched, colours, fb.rec, fb.rect);
+        hipLaunchKernelGGL(k_preprocess_py<true>, dim3(cdiv(n, RA_T), (unsigned)bt.n), dim3(RA_T), 0, s, cam_val, cam_dev, to_layout(layout),
+                           means3D, cov9, opacity, n, key_rev, idx_rev, touched, colours, fb.rec, fb.rect, bt.cs);
     else
         hipLaunchKernelGGL(k_preprocess_py<false>, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, cam_val, cam_dev, to_layout(layout),
-                           means3D, cov9, opacity, n, key_rev, idx_rev, touched, colours, fb.rec, fb.rect);
-    int rc = depth_overflow ? bucket_sort_u32(key_rev, idx_rev, fb.sorted_idx, nullptr, n, bucket_ws, bucket_bytes, depth_overflow, s)
-                            : sort_pairs_u32(key_rev, idx_rev, key_sorted, fb.sorted_idx, ktmp, vtmp, n, 0, 32, sort_ws, sort_bytes, s);
+                           means3D, cov9, opacity, n, key_rev, idx_rev, touched, colours, fb.rec, fb.rect, (size_t)0);
+    int rc = depth_overflow ? bucket_sort_u32(key_rev, idx_rev, fb.sorted_idx, nullptr, n, bucket_ws, bucket_bytes, depth_overflow, s, bt)
+                            : sort_pairs_u32(key_rev, idx_rev, key_sorted, fb.sorted_idx, ktmp, vtmp, n, 0, 32, sort_ws, sort_bytes, s, nullptr, bt);
     if (rc) return rc;
     // exclusive scan of the tiles touched, taken in depth order (the gather rides in the scan's first kernel)
-    return scan_exclusive_u32(touched, fb.offsets, n, scan_ws, scan_bytes, s, fb.sorted_idx);
+    return scan_exclusive_u32(touched, fb.offsets, n, scan_ws, scan_bytes, s, fb.sorted_idx, bt);
 }
 
 struct PyBlendArgs {                  // by value ...                      ... or device resident (job != nullptr)
@@ -1404,7 +1421,7 @@ struct PyBlendArgs {                  // by value ...                      ... o
 static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t* l_eff,
                    const PyBlendArgs& ba, int W, int H, const PyFrontBuffers& fb, unsigned long long* best_key,
                    float* colours_out, float* tilebuf, float* image, int phases, uint32_t max_per_tile,
-                   uint32_t* overflow_flag, void* ws, size_t ws_bytes, hipStream_t s) {
+                   uint32_t* overflow_flag, void* ws, size_t ws_bytes, hipStream_t s, Batch bt = Batch()) {
     const int T = layout->nx * layout->ny;
     Arena ar(ws, ws_bytes);
     uint32_t* inst_tile = ar.get<uint32_t>((size_t)L + 1);
@@ -1423,23 +1440,23 @@ static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t*
     const uint32_t* blend_list = gshift ? tile_sorted : g_sorted;
     if (phases & 1) {
         if (L > 0) {
-            hipLaunchKernelGGL(k_duplicate, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, fb.sorted_idx, fb.offsets, fb.rect, n, lay.nx,
-                               inst_tile, inst_g, l_eff, gshift);
+            hipLaunchKernelGGL(k_duplicate, dim3(cdiv(n, RA_T), (unsigned)bt.n), dim3(RA_T), 0, s, fb.sorted_idx, fb.offsets, fb.rect, n, lay.nx,
+                               inst_tile, inst_g, l_eff, gshift, bt.cs);
             int rc = gshift ? sort_pairs_u32(inst_tile, nullptr, tile_sorted, nullptr, tile_tmp, nullptr, L, gshift,
-                                             gshift + bits_for_tiles((unsigned)T), sort_ws, sort_bytes, s, l_eff)
+                                             gshift + bits_for_tiles((unsigned)T), sort_ws, sort_bytes, s, l_eff, bt)
                             : sort_pairs_u32(inst_tile, inst_g, tile_sorted, g_sorted, tile_tmp, g_tmp, L, 0,
-                                             bits_for_tiles((unsigned)T), sort_ws, sort_bytes, s, l_eff);
+                                             bits_for_tiles((unsigned)T), sort_ws, sort_bytes, s, l_eff, bt);
             if (rc) return rc;
         }
-        hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T)), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start, l_eff, gshift);
+        hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T), (unsigned)bt.n), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start, l_eff, gshift, bt.cs);
         if (overflow_flag && max_per_tile)
-            hipLaunchKernelGGL(k_check_tile_load, dim3(cdiv(T, RA_T)), dim3(RA_T), 0, s, tile_start, T, max_per_tile, overflow_flag);
+            hipLaunchKernelGGL(k_check_tile_load, dim3(cdiv(T, RA_T), (unsigned)bt.n), dim3(RA_T), 0, s, tile_start, T, max_per_tile, overflow_flag, bt.cs);
     }
     if (phases & 2) {
 #define G2PC_BLEND(...)                                                                                                 \
-    hipLaunchKernelGGL((__VA_ARGS__), dim3((unsigned)layout->num_chunks), dim3(BL_T), 0, s, lay, layout->chunk_tile,          \
+    hipLaunchKernelGGL((__VA_ARGS__), dim3((unsigned)layout->num_chunks, (unsigned)bt.n), dim3(BL_T), 0, s, lay, layout->chunk_tile, \
                        layout->chunk_pix0, tile_start, blend_list, gmask, (const float4*)fb.rec, best_key,             \
-                       ba.camera_slot << 24, ba.t_floor, ba.bg, tilebuf, g_chunk_work, ba.job)
+                       ba.camera_slot << 24, ba.t_floor, ba.bg, tilebuf, g_chunk_work, ba.job, bt.cs)
         switch (layout->chunk_subblocks) {
             case 1: G2PC_BLEND(k_blend_py<1, 4>); break;
             case 2: {
@@ -1514,29 +1531,37 @@ int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, int
 
 size_t g2pc_raster_camera_workspace(int64_t n, int64_t capacity, int32_t num_tiles) {
     using namespace g2pc;
-    return align_up((size_t)n * 64) + align_up((size_t)n * 4) * 2 + align_up((size_t)(n + 1) * 4) + 256 +
-           py_front_ws((long)n) + py_back_ws((long)capacity, num_tiles) + 4096;
+    // a multiple of 256: batched launches place one such arena per camera back to back (g2pc_raster_cameras_py)
+    return align_up(align_up((size_t)n * 64) + align_up((size_t)n * 4) * 2 + align_up((size_t)(n + 1) * 4) + 256 +
+                    py_front_ws((long)n) + py_back_ws((long)capacity, num_tiles) + 4096);
 }
 
 // One camera up to and including the blend, without any host round trip: the camera, its slot and the transmittance
 // floor are read from device memory (job_dev) and the instance count never leaves the device, so the launch sequence
 // depends on (n, capacity, layout) only and can be captured once into a hipGraph and replayed for every camera.
-int g2pc_raster_camera_py(const G2pcCameraJob* job_dev, const G2pcCameraJob* job_host, const G2pcTileLayout* layout,
-                          const float* means3D, const float* cov9, const float* opacity, const float* colours, int64_t n,
-                          int64_t capacity, unsigned long long* best_key, float* tilebuf, uint32_t* count_host,
-                          uint32_t max_per_tile, uint32_t* overflow_flag, int phases, void* ws, size_t ws_bytes,
-                          void* stream) {
+int g2pc_raster_cameras_py(const G2pcCameraJob* jobs_dev, const G2pcCameraJob* jobs_host, int32_t batch,
+                           const G2pcTileLayout* layout, const float* means3D, const float* cov9, const float* opacity,
+                           const float* colours, int64_t n, int64_t capacity, unsigned long long* best_key, float* tilebuf,
+                           uint32_t* count_host, uint32_t max_per_tile, uint32_t* overflow_flag, int phases, void* ws,
+                           size_t ws_bytes, void* stream) {
     using namespace g2pc;
-    G2PC_REQUIRE(job_dev && layout && means3D && cov9 && opacity && colours && best_key && tilebuf && ws && n > 0 &&
+    G2PC_REQUIRE(jobs_dev && layout && means3D && cov9 && opacity && colours && best_key && tilebuf && ws && n > 0 &&
                      capacity > 0,
                  G2PC_ERR_ARG, "bad arguments");
+    G2PC_REQUIRE(batch >= 1 && batch <= G2PC_MAX_CAMERA_BATCH, G2PC_ERR_ARG, "batch must be in [1, G2PC_MAX_CAMERA_BATCH]");
     G2PC_REQUIRE(layout->nx <= 256 && layout->ny <= 256, G2PC_ERR_UNSUPPORTED, "more than 256 tile intervals per axis");
     G2PC_REQUIRE(layout->nx * layout->ny <= 4096, G2PC_ERR_UNSUPPORTED, "more than 4096 tiles");
     G2PC_REQUIRE(capacity < (1ll << 31), G2PC_ERR_ARG, "capacity must be below 2^31 instances");
     static_assert(sizeof(Cam) == sizeof(G2pcCamera), "Cam mirrors G2pcCamera");
     hipStream_t s = (hipStream_t)stream;
     const int T = layout->nx * layout->ny;
-    Arena ar(ws, ws_bytes);
+    // one arena per camera, all with the same internal layout, `cs` bytes apart: the pointers below are camera 0's and
+    // every kernel moves them by blockIdx.y * cs (g2pc_internal.h: seg)
+    Batch bt;
+    bt.n = batch;
+    bt.cs = g2pc_raster_camera_workspace(n, capacity, T);
+    G2PC_REQUIRE(ws_bytes >= bt.cs * (size_t)batch, G2PC_ERR_WORKSPACE, "workspace too small");
+    Arena ar(ws, bt.cs);
     PyFrontBuffers fb;
     fb.rec = ar.get<float4>((size_t)n * 4);
     fb.rect = ar.get<uint32_t>((size_t)n);
@@ -1552,20 +1577,29 @@ int g2pc_raster_camera_py(const G2pcCameraJob* job_dev, const G2pcCameraJob* job
         // Both hand-overs with the host go through kernels that touch the PINNED buffers via their device mapping, not
         // through copy nodes: a graph whose first node is a host-to-device copy replayed with ~0.1 ms of extra latency
         // per camera for the lifetime of the first buffers a process pinned (25.9 -> 29 ms per 50-camera job).
-        if (job_host)
-            hipLaunchKernelGGL(k_fetch_job, dim3(1), dim3(64), 0, s, (const uint32_t*)job_host, (uint32_t*)job_dev);
+        if (jobs_host)
+            hipLaunchKernelGGL(k_fetch_job, dim3((unsigned)batch), dim3(64), 0, s, (const uint32_t*)jobs_host, (uint32_t*)jobs_dev);
         uint32_t* depth_overflow = nullptr;
-        rc = py_front(Cam{}, (const Cam*)&job_dev->cam, layout, means3D, cov9, opacity, colours, (long)n, fb, front_ws,
-                      front_bytes, s, (g_depth_bucket_sort && bucket_sort_pays((long)n)) ? &depth_overflow : nullptr);
+        rc = py_front(Cam{}, (const Cam*)&jobs_dev->cam, layout, means3D, cov9, opacity, colours, (long)n, fb, front_ws,
+                      front_bytes, s, (g_depth_bucket_sort && bucket_sort_pays((long)n)) ? &depth_overflow : nullptr, bt);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_resolve_count, dim3(1), dim3(64), 0, s, fb.offsets + n, (uint32_t)capacity, l_eff, count_host,
-                           (const uint32_t*)depth_overflow);
+        hipLaunchKernelGGL(k_resolve_count, dim3(1, (unsigned)batch), dim3(64), 0, s, fb.offsets + n, (uint32_t)capacity, l_eff,
+                           count_host, (const uint32_t*)depth_overflow, bt.cs);
     }
-    PyBlendArgs ba{0u, 0.0f, 0.0f, job_dev};
+    PyBlendArgs ba{0u, 0.0f, 0.0f, jobs_dev};
     rc = py_back(layout, (long)n, (long)capacity, l_eff, ba, 0, 0, fb, best_key, nullptr, tilebuf, nullptr,
-                 phases & 3, max_per_tile, overflow_flag, back_ws, back_bytes, s);
+                 phases & (3 | 8), max_per_tile, overflow_flag, back_ws, back_bytes, s, bt);
     if (rc) return rc;
-    return check_launch("g2pc_raster_camera_py");
+    return check_launch("g2pc_raster_cameras_py");
+}
+
+int g2pc_raster_camera_py(const G2pcCameraJob* job_dev, const G2pcCameraJob* job_host, const G2pcTileLayout* layout,
+                          const float* means3D, const float* cov9, const float* opacity, const float* colours, int64_t n,
+                          int64_t capacity, unsigned long long* best_key, float* tilebuf, uint32_t* count_host,
+                          uint32_t max_per_tile, uint32_t* overflow_flag, int phases, void* ws, size_t ws_bytes,
+                          void* stream) {
+    return g2pc_raster_cameras_py(job_dev, job_host, 1, layout, means3D, cov9, opacity, colours, n, capacity, best_key, tilebuf,
+                                  count_host, max_per_tile, overflow_flag, phases, ws, ws_bytes, stream);
 }
 
 /* colour update of a camera rendered with g2pc_raster_camera_py (to be issued in camera order, see g2pc_raster_back_py) */
@@ -1722,7 +1756,7 @@ int g2pc_raster_back_cu_tiles(const G2pcCamera* cam, const int32_t* mask, int64_
     hipLaunchKernelGGL(k_init_camera_state_cu, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, (unsigned long long*)cam_key, (uint32_t*)cam_surf, (long)n);
     if (L > 0) {
         hipLaunchKernelGGL(k_duplicate, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, sorted_idx, offsets, rect, (long)n, gx,
-                           inst_tile, inst_g, (const uint32_t*)nullptr, gshift);
+                           inst_tile, inst_g, (const uint32_t*)nullptr, gshift, (size_t)0);
         int rc = gshift ? sort_pairs_u32(inst_tile, nullptr, tile_sorted, nullptr, tile_tmp, nullptr, L, gshift,
                                          gshift + bits_for_tiles((unsigned)T), sort_ws, sort_bytes, s)
                         : sort_pairs_u32(inst_tile, inst_g, tile_sorted, g_sorted, tile_tmp, g_tmp, L, 0,
@@ -1730,7 +1764,7 @@ int g2pc_raster_back_cu_tiles(const G2pcCamera* cam, const int32_t* mask, int64_
         if (rc) return rc;
     }
     (void)scan_ws; (void)scan_bytes;
-    hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T)), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start, (const uint32_t*)nullptr, gshift);
+    hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T)), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start, (const uint32_t*)nullptr, gshift, (size_t)0);
     }
     if ((phases & 2) && tile_first < T)
     hipLaunchKernelGGL(k_blend_cu, dim3((unsigned)((T - tile_first + tile_step - 1) / tile_step)), dim3(CU_T), 0, s, W, H, gx,
@@ -1776,7 +1810,7 @@ int g2pc_raster_back_cu_dev(const G2pcCamera* cam, const int32_t* mask, int64_t 
     uint32_t* l_eff = ar.get<uint32_t>(1);
     G2PC_REQUIRE(ar.ok(), G2PC_ERR_WORKSPACE, "workspace too small");
     hipLaunchKernelGGL(k_resolve_count, dim3(1), dim3(64), 0, s, offsets + n, (uint32_t)capacity, l_eff, count_host,
-                       (const uint32_t*)nullptr);
+                       (const uint32_t*)nullptr, (size_t)0);
     if (mask || sharded) {                        // without a mask every pixel is written by the blend kernel
         hipMemsetAsync(out_color, 0, (size_t)3 * W * H * 4, s);
         hipMemsetAsync(out_depth, 0, (size_t)W * H * 4, s);
@@ -1786,13 +1820,13 @@ int g2pc_raster_back_cu_dev(const G2pcCamera* cam, const int32_t* mask, int64_t 
     const int gshift = packed_instance_shift((long)n, T);
     const uint32_t gmask = gshift ? ((1u << gshift) - 1u) : 0xFFFFFFFFu;
     hipLaunchKernelGGL(k_duplicate, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, sorted_idx, offsets, rect, (long)n, gx, inst_tile, inst_g,
-                       (const uint32_t*)l_eff, gshift);
+                       (const uint32_t*)l_eff, gshift, (size_t)0);
     int rc = gshift ? sort_pairs_u32(inst_tile, nullptr, tile_sorted, nullptr, tile_tmp, nullptr, L, gshift,
                                      gshift + bits_for_tiles((unsigned)T), sort_ws, sort_bytes, s, l_eff)
                     : sort_pairs_u32(inst_tile, inst_g, tile_sorted, g_sorted, tile_tmp, g_tmp, L, 0, bits_for_tiles((unsigned)T),
                                      sort_ws, sort_bytes, s, l_eff);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T)), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start, (const uint32_t*)l_eff, gshift);
+    hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T)), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start, (const uint32_t*)l_eff, gshift, (size_t)0);
     if (tile_first < T)
         hipLaunchKernelGGL(k_blend_cu, dim3((unsigned)((T - tile_first + tile_step - 1) / tile_step)), dim3(CU_T), 0, s, W, H, gx,
                            (int)tile_first, (int)tile_step, tile_start, gshift ? tile_sorted : g_sorted, gmask, (const float4*)rec, mask,

@@ -49,7 +49,9 @@ def _run(device, semantics):
     from gauss_handler import Gaussians
     from gauss_to_pc import GaussPointCloudSettings, convert_gaussians_to_pc
     from g2pc.synth import make_scene, make_cameras
-    sc = make_scene(512, 7, device=device, scale_lo=0.02, scale_hi=0.1)
+    import os
+    n_mini = int(os.environ.get("G2PC_WARMUP_GAUSSIANS", "512"))
+    sc = make_scene(n_mini, 7, device=device, scale_lo=0.02, scale_hi=0.1)
     for sem in semantics:
         cu = sem == "cuda"
         tr, intr = make_cameras(2 if cu else gauss_render.PIPELINE_STREAMS + 2, width=64, height=48, focal=55.0)

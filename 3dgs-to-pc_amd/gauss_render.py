@@ -72,6 +72,8 @@ nv._RASTER_PROTOS.update({
     "g2pc_raster_camera_workspace": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32]),
     "g2pc_raster_camera_py": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(_Layout)] + [C.c_void_p] * 4 + [C.c_int64, C.c_int64] +
                               [C.c_void_p] * 3 + [C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "g2pc_raster_cameras_py": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(_Layout)] + [C.c_void_p] * 4 + [C.c_int64, C.c_int64] +
+                               [C.c_void_p] * 3 + [C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "g2pc_raster_camera_update_py": (C.c_int, [C.POINTER(_Layout), C.c_int64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "g2pc_graph_capture_begin": (C.c_int, [C.c_void_p]),
     "g2pc_graph_capture_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
@@ -213,7 +215,8 @@ class _Scratch:
 # issues one graph launch plus the (camera-ordered) colour update -- no read-back, no per-kernel launch cost.
 # The packed-key atomicMax makes the blends of different cameras commutative, so camera c+1's small sort / scan
 # kernels (which leave most CUs idle) and even its blend overlap camera c's blend.
-PIPELINE_STREAMS = 4
+PIPELINE_STREAMS = 2              # batches in flight (one HIP stream, one captured graph each)
+CAMERA_BATCH = 4                  # cameras per launch sequence (g2pc_raster_cameras_py): every kernel runs with grid.y = batch
 PIPELINE_IN_EMULATOR = False      # tests: drive the capture / replay path through the CPU emulator too
 CAPACITY_HEADROOM = 1.25          # instance capacity of the captured graphs relative to the largest count seen so far
 MIN_CAPACITY = 1 << 16
@@ -223,21 +226,26 @@ _LAYOUT_CACHE = {}
 class _GraphSlot:
     """One in-flight camera of the capture-and-replay pipeline."""
 
-    def __init__(self, device, on_gpu):
+    def __init__(self, device, on_gpu, batch=1):
         self.on_gpu = on_gpu
+        self.batch = int(batch)
         self.stream = torch.cuda.Stream(device) if on_gpu else None
         self.stream_ptr = C.c_void_p(self.stream.cuda_stream) if on_gpu else C.c_void_p(1)   # the emulator ignores streams
-        nbytes = C.sizeof(_Job)
+        nbytes = C.sizeof(_Job) * self.batch
         self.job_host = torch.zeros((nbytes,), dtype=torch.uint8)
-        self.count_host = torch.zeros((2,), dtype=torch.int32)      # [instances, depth-bucket-sort overflow]
+        self.count_host = torch.zeros((2 * self.batch,), dtype=torch.int32)      # per camera: [instances, depth-bucket-sort overflow]
         if on_gpu:
             self.job_host, self.count_host = self.job_host.pin_memory(), self.count_host.pin_memory()
-        self.job = _Job.from_address(self.job_host.data_ptr())
+        self.jobs = (_Job * self.batch).from_address(self.job_host.data_ptr())
+        self.job = self.jobs[0]
         self.job_dev = torch.zeros((nbytes,), dtype=torch.uint8, device=device)
+        self.fill = 0                          # cameras written into job_host and not launched yet
+        self.fill_lay = None
         self.update_done = torch.cuda.Event() if on_gpu else None
         self.graph, self.graph_key = C.c_void_p(None), None
         self.ws, self.ws_bytes, self.tilebuf = None, 0, None
-        self.inflight = None                   # (camera struct, layout, slot, capacity) of the replay in flight
+        self.inflight = None                   # [(camera struct, layout, slot, capacity)] of the batch replay in flight
+        self.staged = []                       # the same for the cameras staged in job_host
 
     def release(self):
         L = nv.lib()
@@ -284,6 +292,9 @@ DEFERRED_BUDGET_BYTES = 2 << 30
 DEFERRED_MAX = 64
 DEFERRED_MIN = 8
 CONTEXT_POOL_SIZE = 2
+import os as _os
+_EXPERIMENT_SKIP = int(_os.environ.get("G2PC_POOL_SKIP_FIRST_JOBS", "0"))     # experiment knob (tools/experiments/first_context.sh)
+_JOBS_CLOSED = 0
 _CONTEXT_POOL = []            # free contexts, most recently used last
 
 
@@ -375,9 +386,14 @@ class GaussHipRenderer():
             if self.device.type == "cuda" and not nv.emulated():
                 torch.cuda.current_stream(self.device).synchronize()     # nothing of this renderer is still running
             for sl in self.slots:
-                sl.inflight = None
+                sl.inflight, sl.staged, sl.fill, sl.fill_lay = None, [], 0, None
             ctx.slots, ctx.capacity = self.slots, self.capacity
-            _return_context(ctx)
+            global _JOBS_CLOSED
+            _JOBS_CLOSED += 1
+            if _JOBS_CLOSED <= _EXPERIMENT_SKIP:
+                ctx.release()
+            else:
+                _return_context(ctx)
         except Exception:
             ctx.release()
 
@@ -513,11 +529,12 @@ class GaussHipRenderer():
 
     # ---- capture-and-replay pipeline ------------------------------------------------------------------------------
     def _capture(self, sl, lay, key):
-        """(Re)build the slot's hipGraph for (layout, capacity): buffers first, then one recorded camera call."""
+        """(Re)build the slot's hipGraph for (layout, capacity, phases, cameras in the batch): buffers first, then one
+        recorded batch call."""
         L = nv.lib()
         sl.release()
-        capacity = key[1]
-        need = L.g2pc_raster_camera_workspace(self.n, capacity, lay.num_tiles)
+        capacity, batch = key[1], key[3]
+        need = L.g2pc_raster_camera_workspace(self.n, capacity, lay.num_tiles) * sl.batch
         import contextlib
         with (torch.cuda.stream(sl.stream) if sl.on_gpu else contextlib.nullcontext()):   # allocate on the stream using them
             if need > sl.ws_bytes:
@@ -528,43 +545,68 @@ class GaussHipRenderer():
                 sl.tilebuf = torch.empty((lay.total_pixels * 3,), dtype=torch.float32, device=self.device)
         # run the state-free half once outside the capture: kernels that are launched for the first time INSIDE a stream
         # capture (k_preprocess_py<true>, k_resolve_count, ...) leave a graph that replays ~25 % slower for good
-        nv.check(self._camera_call(sl, lay, capacity, 1), "raster_camera_py (warm-up)")
+        nv.check(self._camera_call(sl, lay, capacity, 1, batch), "raster_cameras_py (warm-up)")
         nv.check(L.g2pc_graph_capture_begin(sl.stream_ptr), "graph_capture_begin")
-        rc = self._camera_call(sl, lay, capacity, key[2])
+        rc = self._camera_call(sl, lay, capacity, key[2], batch)
         graph = C.c_void_p(None)
         rc_end = L.g2pc_graph_capture_end(sl.stream_ptr, C.byref(graph))
-        nv.check(rc or rc_end, "raster_camera_py (capture)")
+        nv.check(rc or rc_end, "raster_cameras_py (capture)")
         sl.graph, sl.graph_key = graph, key
 
-    def _camera_call(self, sl, lay, capacity, phases):
-        return nv.lib().g2pc_raster_camera_py(nv.ptr(sl.job_dev), C.c_void_p(sl.job_host.data_ptr()), C.byref(lay.c),
-                                              *self.scene_ptrs, self.colour_ptr, self.n, capacity, self.state_ptrs()[0],
-                                              nv.ptr(sl.tilebuf), C.c_void_p(sl.count_host.data_ptr()),
-                                              self.MAX_GAUSSIANS_PER_TILE, self.overflow_ptr, phases, nv.ptr(sl.ws),
-                                              sl.ws_bytes, sl.stream_ptr)
+    def _camera_call(self, sl, lay, capacity, phases, batch):
+        return nv.lib().g2pc_raster_cameras_py(nv.ptr(sl.job_dev), C.c_void_p(sl.job_host.data_ptr()), int(batch), C.byref(lay.c),
+                                               *self.scene_ptrs, self.colour_ptr, self.n, capacity, self.state_ptrs()[0],
+                                               nv.ptr(sl.tilebuf), C.c_void_p(sl.count_host.data_ptr()),
+                                               self.MAX_GAUSSIANS_PER_TILE, self.overflow_ptr, phases, nv.ptr(sl.ws),
+                                               sl.ws_bytes, sl.stream_ptr)
 
     def _retire(self, sl):
-        """The slot's previous camera: wait for it (normally long done), collect its count / timing, queue a re-render
-        if it did not fit."""
+        """The slot's previous batch: wait for it (normally long done), collect its counts, queue a re-render of every
+        camera that did not fit."""
         if sl.inflight is None:
             return
-        cam, lay, slot, capacity = sl.inflight
-        sl.inflight = None
+        batch, sl.inflight = sl.inflight, None
         if sl.on_gpu:
             sl.update_done.synchronize()
-        num_inst, unsorted = int(sl.count_host[0]), int(sl.count_host[1])
-        if num_inst > capacity or unsorted:
-            # did not fit the graph's buffers, or the depth bucket sort met a pile-up of equal depths: the graph skipped
-            # the camera as a whole; render it again through the two-call path (radix depth sort, exact instance count)
-            if num_inst > capacity:
-                self.capacity = max(self.capacity, int(num_inst * CAPACITY_HEADROOM))
-            self.redo.append((cam, lay, slot))
-            self.rerendered += 1
+        for i, (cam, lay, slot, capacity) in enumerate(batch):
+            num_inst, unsorted = int(sl.count_host[2 * i]), int(sl.count_host[2 * i + 1])
+            if num_inst > capacity or unsorted:
+                # did not fit the graph's buffers, or the depth bucket sort met a pile-up of equal depths: the graph skipped
+                # the camera as a whole; render it again through the two-call path (radix depth sort, exact instance count)
+                if num_inst > capacity:
+                    self.capacity = max(self.capacity, int(num_inst * CAPACITY_HEADROOM))
+                self.redo.append((cam, lay, slot))
+                self.rerendered += 1
+                continue
+            self._note(lay, num_inst, cam.width, cam.height)
+
+    def _launch_batch(self, sl):
+        """Replay the slot's graph for the cameras staged in its job array (a short last batch gets its own graph)."""
+        L = nv.lib()
+        batch, lay = sl.fill, sl.fill_lay
+        if batch == 0:
             return
-        self._note(lay, num_inst, cam.width, cam.height)
+        on_gpu = sl.on_gpu
+        if on_gpu and not any(o.inflight for o in self.slots):
+            for o in self.slots:
+                o.stream.wait_stream(torch.cuda.current_stream(self.device))      # scene tensors / state are ready
+        # profiling: HIP events around the blend alone -> the graph stops before it and the blend is issued directly
+        # (this runtime refuses event-record nodes inside a captured graph)
+        exact = 8 if self.t_floor == 0.0 else 0      # to-the-letter mode: the blend kernel with the reference's operation order
+        key = (id(lay), self.capacity, (1 if nv.PROFILE is not None else 3) | exact, batch)
+        if sl.graph_key != key:
+            self._capture(sl, lay, key)
+        nv.check(L.g2pc_graph_launch(sl.graph, sl.stream_ptr), "graph_launch")
+        if (key[2] & 3) == 1:
+            with nv.region("raster_blend", self.device, sl.stream):
+                nv.check(self._camera_call(sl, lay, key[1], 2 | exact, batch), "raster_cameras_py (blend)")
+        if on_gpu:
+            sl.update_done.record(sl.stream)               # "this batch's blends are done" (the colours are resolved at flush)
+        sl.inflight, sl.staged = [(c, l, s_, key[1]) for (c, l, s_) in sl.staged], []
+        sl.fill, sl.fill_lay = 0, None
+        self.slot_next = (self.slot_next + 1) % len(self.slots)
 
     def _render_pipelined(self, camera, lay, slot):
-        L = nv.lib()
         on_gpu = self.device.type == "cuda" and not nv.emulated()
         if self.redo:
             self.flush()
@@ -573,25 +615,19 @@ class GaussHipRenderer():
             _, num_inst = self._render_sync(self._camera_struct(camera), lay, slot, False)
             self.capacity = max(int(num_inst * CAPACITY_HEADROOM), MIN_CAPACITY)
             return
-        if len(self.slots) != PIPELINE_STREAMS:
+        batch = max(1, min(int(CAMERA_BATCH), 8))
+        if len(self.slots) != PIPELINE_STREAMS or (self.slots and self.slots[0].batch != batch):
+            self.flush()
             for sl in self.slots:
                 sl.release()
-            self.slots[:] = [_GraphSlot(self.device, on_gpu) for _ in range(PIPELINE_STREAMS)]
+            self.slots[:] = [_GraphSlot(self.device, on_gpu, batch) for _ in range(PIPELINE_STREAMS)]
             self.slot_next = 0
         sl = self.slots[self.slot_next]
-        self.slot_next = (self.slot_next + 1) % len(self.slots)
-        self._retire(sl)
-        if on_gpu and not any(o.inflight for o in self.slots):
-            for o in self.slots:
-                o.stream.wait_stream(torch.cuda.current_stream(self.device))      # scene tensors / state are ready
-        # profiling: HIP events around the blend alone -> the graph stops before it and the blend is issued directly
-        # (this runtime refuses event-record nodes inside a captured graph)
-        exact = 8 if self.t_floor == 0.0 else 0      # to-the-letter mode: the blend kernel with the reference's operation order
-        key = (id(lay), self.capacity, (1 if nv.PROFILE is not None else 3) | exact)
-        if sl.graph_key != key:
-            self._capture(sl, lay, key)
-        self._camera_struct(camera, sl.job.cam)                                    # rewrite the pinned job in place
-        sl.job.camera_slot, sl.job.t_floor = slot, self.t_floor
+        if sl.fill and sl.fill_lay is not lay:
+            self._launch_batch(sl)                  # another image size: the staged cameras go as a short batch
+            sl = self.slots[self.slot_next]
+        if sl.fill == 0:
+            self._retire(sl)                        # the job array is rewritten: its previous batch must be through
         # every pipelined camera renders into its OWN per-tile colour buffer (address in the job, not in the graph): the
         # winners' colours are then resolved in one pass at flush() instead of one update per camera chained in camera
         # order across the streams
@@ -600,9 +636,7 @@ class GaussHipRenderer():
         if len(self.deferred) >= limit:
             self.flush()                           # resolve the colours of the cameras so far; their buffers are free again
             del ring[limit:]                       # a smaller image earlier in the job may have grown the ring past this limit
-            if on_gpu:
-                for o in self.slots:
-                    o.stream.wait_stream(torch.cuda.current_stream(self.device))   # ... once the resolve has read them
+            sl = self.slots[self.slot_next]
         idx = len(self.deferred)
         if idx >= len(ring) or ring[idx].numel() < lay.total_pixels * 3:
             import contextlib
@@ -613,21 +647,24 @@ class GaussHipRenderer():
             else:
                 ring[idx] = tb
         tb = ring[idx]
-        sl.job.tilebuf_lo, sl.job.tilebuf_hi = tb.data_ptr() & 0xFFFFFFFF, tb.data_ptr() >> 32
+        job = sl.jobs[sl.fill]
+        self._camera_struct(camera, job.cam)                                        # rewrite the pinned job in place
+        job.camera_slot, job.t_floor = slot, self.t_floor
+        job.tilebuf_lo, job.tilebuf_hi = tb.data_ptr() & 0xFFFFFFFF, tb.data_ptr() >> 32
         self.deferred[slot] = (lay, tb)
-        nv.check(L.g2pc_graph_launch(sl.graph, sl.stream_ptr), "graph_launch")
-        if (key[2] & 3) == 1:
-            with nv.region("raster_blend", self.device, sl.stream):
-                nv.check(self._camera_call(sl, lay, key[1], 2 | exact), "raster_camera_py (blend)")
-        if on_gpu:
-            sl.update_done.record(sl.stream)               # "this camera's blend is done" (its colours are resolved at flush)
-        cam_copy = _Camera.from_buffer_copy(sl.job.cam)
-        sl.inflight = (cam_copy, lay, slot, key[1])
+        sl.staged.append((_Camera.from_buffer_copy(job.cam), lay, slot))
+        sl.fill += 1
+        sl.fill_lay = lay
+        if sl.fill == sl.batch:
+            self._launch_batch(sl)
 
     def flush(self):
-        """Complete every camera in flight and make the running state visible to the current stream."""
+        """Complete every camera staged or in flight and make the running state visible to the current stream."""
         if not self.slots:
             return
+        for sl in self.slots:
+            if sl.fill:
+                self._launch_batch(sl)             # a short last batch
         for sl in self.slots:
             self._retire(sl)
         if self.device.type == "cuda" and not nv.emulated():

@@ -323,6 +323,18 @@ typedef struct G2pcCameraJob {       /* DEVICE (and pinned host staging) struct 
     uint32_t reserved;
 } G2pcCameraJob;
 size_t g2pc_raster_camera_workspace(int64_t n, int64_t capacity, int32_t num_tiles);
+/* BATCHED form: `batch` cameras (1 .. G2PC_MAX_CAMERA_BATCH) through ONE launch sequence -- every kernel of the sequence runs
+ * with grid.y = batch, camera c reading the c-th job of the arrays jobs_dev / jobs_host and working in the c-th of `batch`
+ * consecutive workspaces of g2pc_raster_camera_workspace() bytes each (ws_bytes >= batch times that).  A 50-camera job is
+ * then 13 dependent chains of ~20 launches instead of 50, each kernel four times as wide, and the blends of a batch drain
+ * together.  count_host: u32[batch][2].  The loop over cameras this replaces: gauss_to_pc.py:437-454 (the reference renders
+ * them one at a time).  g2pc_raster_camera_py is batch = 1. */
+#define G2PC_MAX_CAMERA_BATCH 8
+int g2pc_raster_cameras_py(const G2pcCameraJob* jobs_dev, const G2pcCameraJob* jobs_host, int32_t batch,
+                           const G2pcTileLayout* layout, const float* means3D, const float* cov9, const float* opacity,
+                           const float* colours, int64_t n, int64_t capacity, unsigned long long* best_key, float* tilebuf,
+                           uint32_t* count_host, uint32_t max_per_tile, uint32_t* overflow_flag, int phases, void* ws,
+                           size_t ws_bytes, void* stream);
 int g2pc_raster_camera_py(const G2pcCameraJob* job_dev, const G2pcCameraJob* job_host, const G2pcTileLayout* layout,
                           const float* means3D, const float* cov9, const float* opacity, const float* colours, int64_t n,
                           int64_t capacity, unsigned long long* best_key, float* tilebuf, uint32_t* count_host,
