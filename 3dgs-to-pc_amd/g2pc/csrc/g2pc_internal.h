@@ -99,10 +99,28 @@ int sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* k
 
 // bucket sort of (key, input position) pairs for range-spread float-bit keys (see prims.hip); *overflow_flag points into
 // the workspace afterwards (device u32: non-zero = a bucket overflowed, sort again with sort_pairs_u32)
+constexpr int BK_MAX = 8192, BK_PARTIALS = 256;
+struct BucketHdr {
+    uint32_t overflow, nbk, nchunks, cap;
+    uint32_t partial[2 * BK_PARTIALS];              // per minmax slot: max(~key), max(key)
+    uint32_t count[BK_MAX + 2], start[BK_MAX + 2];
+};
+struct BucketPlan { uint32_t nbk, kpb, nchunks, nminmax, cap; };
+BucketPlan bucket_plan(long n);
 size_t bucket_sort_workspace(long n);
 bool bucket_sort_pays(long n);          // measured on MI355X: 90 vs 101 us (radix) at 1 M keys, 533 vs 278 us at 5 M
+// the header bucket_sort_u32 keeps at the start of its workspace: a producer of the keys may fill partial[] itself
+// (zeroed header + atomicMax of (~key, key) into slot block % plan.nminmax, see bucket_hdr_init / bucket_minmax_note) and
+// pass minmax_done = true, which saves the pass over the keys that finds their range
+inline BucketHdr* bucket_sort_header(void* ws) { return (BucketHdr*)ws; }
+__device__ __forceinline__ void bucket_hdr_init(BucketHdr* h, const BucketPlan& plan, unsigned tid, unsigned nthreads) {
+    for (unsigned i = tid; i < 2u * BK_PARTIALS; i += nthreads) h->partial[i] = 0u;
+    if (tid == 0) { h->overflow = 0; h->nbk = plan.nbk; h->nchunks = plan.nchunks; h->cap = plan.cap; }
+}
+// vals == nullptr: the values are the input positions r themselves, or n - 1 - r when `reversed` (keys fed in reversed index order)
 int bucket_sort_u32(const uint32_t* keys, const uint32_t* vals, uint32_t* vals_out, uint32_t* keys_out, long n, void* ws,
-                    size_t ws_bytes, uint32_t** overflow_flag, hipStream_t s, Batch b = Batch());
+                    size_t ws_bytes, uint32_t** overflow_flag, hipStream_t s, Batch b = Batch(), bool minmax_done = false,
+                    bool reversed = false);
 
 // Philox4x32-10 keyed standard normals (see oracle/np_philox.py for the definition)
 struct Normal3 { float x, y, z; };

@@ -458,14 +458,8 @@ int sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* k
 // on 2 K addresses: 0.66 ms per camera, and every co-running kernel slowed 4x) and cleared its header with a
 // hipMemsetAsync, whose graph node this runtime did not order against the kernels around it (replays faulted).
 // ------------------------------------------------------------------------------------------------
-constexpr int BK_MIN = 1024, BK_MAX = 8192, BK_AVG = 256, BK_CAP_SMALL = 1024, BK_CAP_LARGE = 4096, BK_T = 256, BK_MAXCHUNKS = 512, BK_PARTIALS = 256, BK_TAILBLOCKS = 256;
-struct BucketHdr {
-    uint32_t overflow, nbk, nchunks, cap;
-    uint32_t partial[2 * BK_PARTIALS];              // per minmax block: max(~key), max(key)
-    uint32_t count[BK_MAX + 2], start[BK_MAX + 2];
-};
-struct BucketPlan { uint32_t nbk, kpb, nchunks, nminmax, cap; };
-static BucketPlan bucket_plan(long n) {
+constexpr int BK_MIN = 1024, BK_AVG = 256, BK_CAP_SMALL = 1024, BK_CAP_LARGE = 4096, BK_T = 256, BK_MAXCHUNKS = 512, BK_TAILBLOCKS = 256;
+BucketPlan bucket_plan(long n) {
     BucketPlan p;
     p.nbk = BK_MIN;
     while (p.nbk < (uint32_t)BK_MAX && (long)p.nbk * BK_AVG < n) p.nbk <<= 1;
@@ -634,10 +628,15 @@ __device__ __forceinline__ void wave_bitonic_sort(unsigned long long (&v)[R], un
         }
     }
 }
+// value of the item at input position pos: vals[pos], or the position itself (rev = 0), or rev - 1 - pos (keys fed in reversed
+// index order: no index array is read or written at all)
+__device__ __forceinline__ uint32_t bk_value(const uint32_t* __restrict__ vals, uint32_t pos, uint32_t rev) {
+    return vals ? vals[pos] : (rev ? rev - 1u - pos : pos);
+}
 template <int R>
 __device__ __forceinline__ void bucket_sort_in_registers(const unsigned long long* __restrict__ items, uint32_t s0, uint32_t cnt,
                                                          const uint32_t* __restrict__ vals, uint32_t* __restrict__ vals_out,
-                                                         uint32_t* __restrict__ keys_out, unsigned lane) {
+                                                         uint32_t* __restrict__ keys_out, unsigned lane, uint32_t rev) {
     unsigned long long v[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) { const uint32_t e = (uint32_t)r * 64u + lane; v[r] = e < cnt ? items[s0 + e] : ~0ull; }
@@ -646,7 +645,7 @@ __device__ __forceinline__ void bucket_sort_in_registers(const unsigned long lon
     for (int r = 0; r < R; ++r) {
         const uint32_t e = (uint32_t)r * 64u + lane;
         if (e < cnt) {
-            vals_out[s0 + e] = vals[(uint32_t)v[r]];
+            vals_out[s0 + e] = bk_value(vals, (uint32_t)v[r], rev);
             if (keys_out) keys_out[s0 + e] = (uint32_t)(v[r] >> 32);
         }
     }
@@ -658,7 +657,7 @@ __device__ __forceinline__ void bucket_sort_in_registers(const unsigned long lon
 template <int CAP>
 __global__ __launch_bounds__(64) void k_bk_sort(const BucketHdr* __restrict__ h, const unsigned long long* __restrict__ items,
                                                 const uint32_t* __restrict__ vals, uint32_t* __restrict__ vals_out,
-                                                uint32_t* __restrict__ keys_out, size_t cs) {
+                                                uint32_t* __restrict__ keys_out, size_t cs, uint32_t rev) {
     __shared__ unsigned long long s_it[CAP > 1024 ? CAP : 1];
     h = seg(h, cs); items = seg(items, cs); vals = seg(vals, cs); vals_out = seg(vals_out, cs); keys_out = seg(keys_out, cs);
     const unsigned lane = threadIdx.x, nbk = h->nbk;
@@ -671,17 +670,17 @@ __global__ __launch_bounds__(64) void k_bk_sort(const BucketHdr* __restrict__ h,
     if (b == nbk || cnt > (uint32_t)CAP) {                            // tail bucket (or an overflowing one): copy, unsorted
         for (uint32_t j = part * 64 + lane; j < cnt; j += parts * 64) {
             const unsigned long long it = items[s0 + j];
-            vals_out[s0 + j] = vals[(uint32_t)it];
+            vals_out[s0 + j] = bk_value(vals, (uint32_t)it, rev);
             if (keys_out) keys_out[s0 + j] = (uint32_t)(it >> 32);
         }
         return;
     }
     if (CAP <= 1024) {                                                // wave-uniform dispatch on the bucket's size
-        if (cnt <= 64) bucket_sort_in_registers<1>(items, s0, cnt, vals, vals_out, keys_out, lane);
-        else if (cnt <= 128) bucket_sort_in_registers<2>(items, s0, cnt, vals, vals_out, keys_out, lane);
-        else if (cnt <= 256) bucket_sort_in_registers<4>(items, s0, cnt, vals, vals_out, keys_out, lane);
-        else if (cnt <= 512) bucket_sort_in_registers<8>(items, s0, cnt, vals, vals_out, keys_out, lane);
-        else bucket_sort_in_registers<16>(items, s0, cnt, vals, vals_out, keys_out, lane);
+        if (cnt <= 64) bucket_sort_in_registers<1>(items, s0, cnt, vals, vals_out, keys_out, lane, rev);
+        else if (cnt <= 128) bucket_sort_in_registers<2>(items, s0, cnt, vals, vals_out, keys_out, lane, rev);
+        else if (cnt <= 256) bucket_sort_in_registers<4>(items, s0, cnt, vals, vals_out, keys_out, lane, rev);
+        else if (cnt <= 512) bucket_sort_in_registers<8>(items, s0, cnt, vals, vals_out, keys_out, lane, rev);
+        else bucket_sort_in_registers<16>(items, s0, cnt, vals, vals_out, keys_out, lane, rev);
         return;
     }
     uint32_t np = 2;
@@ -702,7 +701,7 @@ __global__ __launch_bounds__(64) void k_bk_sort(const BucketHdr* __restrict__ h,
         }
     for (uint32_t j = lane; j < cnt; j += 64) {
         const unsigned long long it = s_it[j];
-        vals_out[s0 + j] = vals[(uint32_t)it];
+        vals_out[s0 + j] = bk_value(vals, (uint32_t)it, rev);
         if (keys_out) keys_out[s0 + j] = (uint32_t)(it >> 32);
     }
 }
@@ -719,26 +718,27 @@ size_t bucket_sort_workspace(long n) {
 // keys 0xFFFFFFFF last.  *overflow_flag (device u32, optional) receives the size of the largest bucket when one exceeds
 // the room of a bucket (BucketPlan::cap) -- the output is then a permutation in bucket order only and the caller must sort again with sort_pairs_u32.
 int bucket_sort_u32(const uint32_t* keys, const uint32_t* vals, uint32_t* vals_out, uint32_t* keys_out, long n, void* ws,
-                    size_t ws_bytes, uint32_t** overflow_flag, hipStream_t s, Batch b) {
+                    size_t ws_bytes, uint32_t** overflow_flag, hipStream_t s, Batch b, bool minmax_done, bool reversed) {
     if (n <= 0) return G2PC_OK;
     const BucketPlan plan = bucket_plan(n);
     const unsigned by = (unsigned)b.n;
+    const uint32_t rev = (!vals && reversed) ? (uint32_t)n : 0u;
     Arena ar(ws, ws_bytes);
     BucketHdr* h = ar.get<BucketHdr>(1);
     unsigned long long* items = ar.get<unsigned long long>((size_t)n);
     uint32_t* table = ar.get<uint32_t>((size_t)(plan.nbk + 1) * plan.nchunks);
     if (!ar.ok()) { set_error("bucket_sort", "workspace too small"); return G2PC_ERR_WORKSPACE; }
-    hipLaunchKernelGGL(k_bk_minmax, dim3(plan.nminmax, by), dim3(BK_T), 0, s, keys, n, h, plan, b.cs);
+    if (!minmax_done) hipLaunchKernelGGL(k_bk_minmax, dim3(plan.nminmax, by), dim3(BK_T), 0, s, keys, n, h, plan, b.cs);
     hipLaunchKernelGGL(k_bk_hist, dim3(plan.nchunks, by), dim3(BK_T), 0, s, keys, n, (const BucketHdr*)h, table, plan, b.cs);
     hipLaunchKernelGGL(k_bk_colscan, dim3(cdiv(plan.nbk + 1, BK_T / 64), by), dim3(BK_T), 0, s, h, table, plan, b.cs);
     hipLaunchKernelGGL(k_bk_scan, dim3(1, by), dim3(1024), 0, s, h, b.cs);
     hipLaunchKernelGGL(k_bk_scatter, dim3(plan.nchunks, by), dim3(BK_T), 0, s, keys, n, (const BucketHdr*)h, (const uint32_t*)table, items, plan, b.cs);
     if (plan.cap == (uint32_t)BK_CAP_SMALL)
         hipLaunchKernelGGL(k_bk_sort<BK_CAP_SMALL>, dim3(plan.nbk + BK_TAILBLOCKS, by), dim3(64), 0, s, (const BucketHdr*)h,
-                           (const unsigned long long*)items, vals, vals_out, keys_out, b.cs);
+                           (const unsigned long long*)items, vals, vals_out, keys_out, b.cs, rev);
     else
         hipLaunchKernelGGL(k_bk_sort<BK_CAP_LARGE>, dim3(plan.nbk + BK_TAILBLOCKS, by), dim3(64), 0, s, (const BucketHdr*)h,
-                           (const unsigned long long*)items, vals, vals_out, keys_out, b.cs);
+                           (const unsigned long long*)items, vals, vals_out, keys_out, b.cs, rev);
     if (overflow_flag) *overflow_flag = &h->overflow;
     return check_launch("bucket_sort");
 }
@@ -813,7 +813,7 @@ int g2pc_bucket_sort_u32(const uint32_t* keys, const uint32_t* vals, uint32_t* k
     using namespace g2pc;
     G2PC_REQUIRE(n >= 0, G2PC_ERR_ARG, "negative n");
     if (n == 0) return G2PC_OK;
-    G2PC_REQUIRE(keys && vals && vals_out && ws, G2PC_ERR_ARG, "null pointer");
+    G2PC_REQUIRE(keys && vals_out && ws, G2PC_ERR_ARG, "null pointer");      // vals == NULL: the values are the input positions
     uint32_t* flag = nullptr;
     int rc = bucket_sort_u32(keys, vals, vals_out, keys_out, (long)n, ws, ws_bytes, &flag, (hipStream_t)stream);
     if (rc) return rc;

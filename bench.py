@@ -57,7 +57,8 @@ def parse():
     ap.add_argument("--no-context-pool", action="store_true", help="tuning aid: every job captures its camera graphs anew")
     ap.add_argument("--blend-variant", type=int, default=None, choices=[None, 0, 1], help="tuning aid: 1 = dual-list blend kernel, 0 = packed kernel")
     ap.add_argument("--depth-sort", default=None, choices=[None, "bucket", "radix"], help="tuning aid: depth order of the captured camera path")
-    ap.add_argument("--streams", type=int, default=0, help="tuning aid: cameras in flight (HIP streams) of the renderer")
+    ap.add_argument("--streams", type=int, default=0, help="tuning aid: camera batches in flight (HIP streams) of the renderer")
+    ap.add_argument("--camera-batch", type=int, default=0, help="tuning aid: cameras per launch sequence (1 = one camera per graph)")
     ap.add_argument("--camera-subset", type=int, default=0, help="profiling aid: render only the first k cameras of the rig")
     ap.add_argument("--t-floor", type=float, default=None, help="blend transmittance floor (default: gauss_render.DEFAULT_T_FLOOR)")
     return ap.parse_args()
@@ -325,6 +326,8 @@ def main():
         gauss_render.PIPELINE_STREAMS = a.streams
         import gaussian_pointcloud_rasterization as _gpr
         _gpr.PIPELINE_STREAMS = a.streams
+    if a.camera_batch:
+        gauss_render.CAMERA_BATCH = a.camera_batch
     if a.no_context_pool:
         gauss_render.CONTEXT_POOL_SIZE = 0
 
