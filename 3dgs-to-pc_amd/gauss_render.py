@@ -217,6 +217,12 @@ class _Scratch:
 # kernels (which leave most CUs idle) and even its blend overlap camera c's blend.
 PIPELINE_STREAMS = 2              # batches in flight (one HIP stream, one captured graph each)
 CAMERA_BATCH = 4                  # cameras per launch sequence (g2pc_raster_cameras_py): every kernel runs with grid.y = batch
+# How the batches in flight share the device:
+#   "chain": every slot owns a stream and replays head + blend as one graph on it.  Slots started together stay in step --
+#            all heads (which leave most of the device idle), then all blends (which then share its throughput).
+#   "split": ONE head stream (high priority) and ONE blend stream for all slots: the heads of batch i+1 run beside the blends
+#            of batch i, blends run back to back; a slot's arena is handed from one stream to the other with events.
+PIPELINE_MODE = "split"
 PIPELINE_IN_EMULATOR = False      # tests: drive the capture / replay path through the CPU emulator too
 CAPACITY_HEADROOM = 1.25          # instance capacity of the captured graphs relative to the largest count seen so far
 MIN_CAPACITY = 1 << 16
@@ -229,7 +235,7 @@ class _GraphSlot:
     def __init__(self, device, on_gpu, batch=1):
         self.on_gpu = on_gpu
         self.batch = int(batch)
-        self.stream = torch.cuda.Stream(device) if on_gpu else None
+        self.stream = torch.cuda.Stream(device, priority=-1 if PIPELINE_MODE == "split" else 0) if on_gpu else None
         self.stream_ptr = C.c_void_p(self.stream.cuda_stream) if on_gpu else C.c_void_p(1)   # the emulator ignores streams
         nbytes = C.sizeof(_Job) * self.batch
         self.job_host = torch.zeros((nbytes,), dtype=torch.uint8)
@@ -242,6 +248,7 @@ class _GraphSlot:
         self.fill = 0                          # cameras written into job_host and not launched yet
         self.fill_lay = None
         self.update_done = torch.cuda.Event() if on_gpu else None
+        self.head_done = torch.cuda.Event() if on_gpu else None
         self.graph, self.graph_key = C.c_void_p(None), None
         self.ws, self.ws_bytes, self.tilebuf = None, 0, None
         self.inflight = None                   # [(camera struct, layout, slot, capacity)] of the batch replay in flight
@@ -273,9 +280,15 @@ class _RenderContext:
         self.overflow = torch.empty((1,), dtype=torch.int32, device=device)
         self.sync_scratch = _Scratch(n, device)
         self.slots, self.capacity = [], None
+        self._blend_stream = None
         self.cam_tilebufs = []        # ring of per-tile colour buffers, one per pipelined camera whose colours are still to be
                                       # resolved (deferred colour resolve); bounded by DEFERRED_BUDGET_BYTES, reused by the
                                       # next batch / job of this context
+
+    def blend_stream(self, device):
+        if self._blend_stream is None:
+            self._blend_stream = torch.cuda.Stream(device)
+        return self._blend_stream
 
     def release(self):
         for sl in self.slots:
@@ -553,12 +566,12 @@ class GaussHipRenderer():
         nv.check(rc or rc_end, "raster_cameras_py (capture)")
         sl.graph, sl.graph_key = graph, key
 
-    def _camera_call(self, sl, lay, capacity, phases, batch):
+    def _camera_call(self, sl, lay, capacity, phases, batch, stream_ptr=None):
         return nv.lib().g2pc_raster_cameras_py(nv.ptr(sl.job_dev), C.c_void_p(sl.job_host.data_ptr()), int(batch), C.byref(lay.c),
                                                *self.scene_ptrs, self.colour_ptr, self.n, capacity, self.state_ptrs()[0],
                                                nv.ptr(sl.tilebuf), C.c_void_p(sl.count_host.data_ptr()),
                                                self.MAX_GAUSSIANS_PER_TILE, self.overflow_ptr, phases, nv.ptr(sl.ws),
-                                               sl.ws_bytes, sl.stream_ptr)
+                                               sl.ws_bytes, stream_ptr if stream_ptr is not None else sl.stream_ptr)
 
     def _retire(self, sl):
         """The slot's previous batch: wait for it (normally long done), collect its counts, queue a re-render of every
@@ -590,18 +603,33 @@ class GaussHipRenderer():
         if on_gpu and not any(o.inflight for o in self.slots):
             for o in self.slots:
                 o.stream.wait_stream(torch.cuda.current_stream(self.device))      # scene tensors / state are ready
+            if PIPELINE_MODE == "split":
+                self.ctx.blend_stream(self.device).wait_stream(torch.cuda.current_stream(self.device))
         # profiling: HIP events around the blend alone -> the graph stops before it and the blend is issued directly
         # (this runtime refuses event-record nodes inside a captured graph)
         exact = 8 if self.t_floor == 0.0 else 0      # to-the-letter mode: the blend kernel with the reference's operation order
-        key = (id(lay), self.capacity, (1 if nv.PROFILE is not None else 3) | exact, batch)
+        split = on_gpu and PIPELINE_MODE == "split"
+        key = (id(lay), self.capacity, (1 if (nv.PROFILE is not None or split) else 3) | exact, batch)
         if sl.graph_key != key:
             self._capture(sl, lay, key)
-        nv.check(L.g2pc_graph_launch(sl.graph, sl.stream_ptr), "graph_launch")
-        if (key[2] & 3) == 1:
-            with nv.region("raster_blend", self.device, sl.stream):
-                nv.check(self._camera_call(sl, lay, key[1], 2 | exact, batch), "raster_cameras_py (blend)")
-        if on_gpu:
-            sl.update_done.record(sl.stream)               # "this batch's blends are done" (the colours are resolved at flush)
+        if split:
+            # heads of all slots on the slots' common head stream (slot 0's, high priority), blends on the common blend stream
+            head, blend = self.slots[0].stream, self.ctx.blend_stream(self.device)
+            head.wait_stream(sl.stream)                    # (a capture's warm-up run on the slot's own stream)
+            head.wait_event(sl.update_done)                # this slot's arena: its previous blends are through
+            nv.check(L.g2pc_graph_launch(sl.graph, C.c_void_p(head.cuda_stream)), "graph_launch")
+            sl.head_done.record(head)
+            blend.wait_event(sl.head_done)
+            with nv.region("raster_blend", self.device, blend):
+                nv.check(self._camera_call(sl, lay, key[1], 2 | exact, batch, C.c_void_p(blend.cuda_stream)), "raster_cameras_py (blend)")
+            sl.update_done.record(blend)
+        else:
+            nv.check(L.g2pc_graph_launch(sl.graph, sl.stream_ptr), "graph_launch")
+            if (key[2] & 3) == 1:
+                with nv.region("raster_blend", self.device, sl.stream):
+                    nv.check(self._camera_call(sl, lay, key[1], 2 | exact, batch), "raster_cameras_py (blend)")
+            if on_gpu:
+                sl.update_done.record(sl.stream)           # "this batch's blends are done" (the colours are resolved at flush)
         sl.inflight, sl.staged = [(c, l, s_, key[1]) for (c, l, s_) in sl.staged], []
         sl.fill, sl.fill_lay = 0, None
         self.slot_next = (self.slot_next + 1) % len(self.slots)
@@ -671,6 +699,8 @@ class GaussHipRenderer():
             cur = torch.cuda.current_stream(self.device)
             for sl in self.slots:
                 cur.wait_stream(sl.stream)
+            if self.ctx._blend_stream is not None:
+                cur.wait_stream(self.ctx._blend_stream)
         while self.redo:                           # cameras that overflowed their graph: two-call path, original slot
             cam, lay, slot = self.redo.pop(0)
             self.deferred.pop(slot, None)          # ... which updates the colours it wins at once

@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--blend-variant", type=int, default=None, choices=[None, 0, 1], help="tuning aid: 1 = dual-list blend kernel, 0 = packed kernel")
     ap.add_argument("--depth-sort", default=None, choices=[None, "bucket", "radix"], help="tuning aid: depth order of the captured camera path")
     ap.add_argument("--streams", type=int, default=0, help="tuning aid: camera batches in flight (HIP streams) of the renderer")
+    ap.add_argument("--pipeline-mode", default=None, choices=[None, "chain", "split"], help="tuning aid: see gauss_render.PIPELINE_MODE")
     ap.add_argument("--camera-batch", type=int, default=0, help="tuning aid: cameras per launch sequence (1 = one camera per graph)")
     ap.add_argument("--camera-subset", type=int, default=0, help="profiling aid: render only the first k cameras of the rig")
     ap.add_argument("--t-floor", type=float, default=None, help="blend transmittance floor (default: gauss_render.DEFAULT_T_FLOOR)")
@@ -328,6 +329,8 @@ def main():
         _gpr.PIPELINE_STREAMS = a.streams
     if a.camera_batch:
         gauss_render.CAMERA_BATCH = a.camera_batch
+    if a.pipeline_mode:
+        gauss_render.PIPELINE_MODE = a.pipeline_mode
     if a.no_context_pool:
         gauss_render.CONTEXT_POOL_SIZE = 0
 
