@@ -391,11 +391,12 @@ class GaussHipRenderer():
 
     def close(self):
         """Finish the cameras in flight and hand the device-side context back to the pool (idempotent)."""
-        ctx, self.ctx = getattr(self, "ctx", None), None
+        ctx = getattr(self, "ctx", None)
         if ctx is None:
             return
         try:
-            self.flush()
+            self.flush()                           # (needs self.ctx: the ring of colour buffers, the blend stream)
+            self.ctx = None
             if self.device.type == "cuda" and not nv.emulated():
                 torch.cuda.current_stream(self.device).synchronize()     # nothing of this renderer is still running
             for sl in self.slots:
@@ -408,7 +409,9 @@ class GaussHipRenderer():
             else:
                 _return_context(ctx)
         except Exception:
+            self.ctx = None
             ctx.release()
+            raise
 
     def __del__(self):
         try:
