@@ -215,14 +215,14 @@ class _Scratch:
 # issues one graph launch plus the (camera-ordered) colour update -- no read-back, no per-kernel launch cost.
 # The packed-key atomicMax makes the blends of different cameras commutative, so camera c+1's small sort / scan
 # kernels (which leave most CUs idle) and even its blend overlap camera c's blend.
-PIPELINE_STREAMS = 2              # batches in flight (one HIP stream, one captured graph each)
-CAMERA_BATCH = 4                  # cameras per launch sequence (g2pc_raster_cameras_py): every kernel runs with grid.y = batch
+PIPELINE_STREAMS = 4              # batches in flight (one HIP stream, one captured graph each)
+CAMERA_BATCH = 2                  # cameras per launch sequence (g2pc_raster_cameras_py): every kernel runs with grid.y = batch
 # How the batches in flight share the device:
 #   "chain": every slot owns a stream and replays head + blend as one graph on it.  Slots started together stay in step --
 #            all heads (which leave most of the device idle), then all blends (which then share its throughput).
 #   "split": ONE head stream (high priority) and ONE blend stream for all slots: the heads of batch i+1 run beside the blends
 #            of batch i, blends run back to back; a slot's arena is handed from one stream to the other with events.
-PIPELINE_MODE = "split"
+PIPELINE_MODE = "chain"
 PIPELINE_IN_EMULATOR = False      # tests: drive the capture / replay path through the CPU emulator too
 CAPACITY_HEADROOM = 1.25          # instance capacity of the captured graphs relative to the largest count seen so far
 MIN_CAPACITY = 1 << 16

@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--blend-variant", type=int, default=None, choices=[None, 0, 1], help="tuning aid: 1 = dual-list blend kernel, 0 = packed kernel")
     ap.add_argument("--depth-sort", default=None, choices=[None, "bucket", "radix"], help="tuning aid: depth order of the captured camera path")
     ap.add_argument("--streams", type=int, default=0, help="tuning aid: camera batches in flight (HIP streams) of the renderer")
+    ap.add_argument("--no-profile-pass", action="store_true", help="skip the untimed region / kernel profile passes after the timed loop")
     ap.add_argument("--pipeline-mode", default=None, choices=[None, "chain", "split"], help="tuning aid: see gauss_render.PIPELINE_MODE")
     ap.add_argument("--camera-batch", type=int, default=0, help="tuning aid: cameras per launch sequence (1 = one camera per graph)")
     ap.add_argument("--camera-subset", type=int, default=0, help="profiling aid: render only the first k cameras of the rig")
@@ -404,7 +405,7 @@ def main():
         return res
 
     prof, prof_alone = {}, {}
-    if world == 1 and not emulate:
+    if world == 1 and not emulate and not a.no_profile_pass:
         prof = profile_pass(0)                           # production stream count: spans overlap across streams
         prof_alone = profile_pass(1) if workload == "render" else prof
         gauss_render.RENDER_STATS[:] = timed_stats
