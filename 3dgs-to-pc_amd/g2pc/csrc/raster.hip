@@ -63,27 +63,32 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_py(Cam cam_val, const Cam* 
                                                        uint32_t* __restrict__ index_rev,
                                                        uint32_t* __restrict__ tiles_touched,
                                                        const float* __restrict__ colours,
-                                                       float4* __restrict__ rec, uint32_t* __restrict__ rect, size_t cs) {
+                                                       float4* __restrict__ rec, uint32_t* __restrict__ rect, size_t cs,
+                                                       BucketHdr* __restrict__ mm, uint32_t mm_slots) {
     // device-resident camera: lets ONE captured launch sequence serve every camera.  Staged through LDS once per block
     // (per-thread loads of the 172-byte struct made this kernel 6x slower than the by-value variant).
     // Batched launch (grid.y cameras): camera c's job is the c-th G2pcCameraJob, its outputs live in the c-th arena.
+    // mm != nullptr: the depth keys go to the bucket sort (prims.hip), whose first pass -- the range of the keys -- is folded
+    // in here: every block leaves (max ~key, max key) in slot blockIdx.x % mm_slots of the (zeroed) header.
     __shared__ Cam s_cam;
+    __shared__ uint32_t s_mm[2];
     depth_key_rev = seg(depth_key_rev, cs); index_rev = seg(index_rev, cs); tiles_touched = seg(tiles_touched, cs);
-    rec = seg(rec, cs); rect = seg(rect, cs);
+    rec = seg(rec, cs); rect = seg(rect, cs); mm = seg(mm, cs);
+    if (threadIdx.x == 0) { s_mm[0] = 0u; s_mm[1] = 0u; }
     if (CAM_ON_DEVICE) {
         cam_dev = (const Cam*)((const char*)cam_dev + (size_t)blockIdx.y * sizeof(G2pcCameraJob));
         if (threadIdx.x < sizeof(Cam) / 4) ((uint32_t*)&s_cam)[threadIdx.x] = ((const uint32_t*)cam_dev)[threadIdx.x];
-        __syncthreads();
     }
+    if (CAM_ON_DEVICE || mm) __syncthreads();
     long i = (long)blockIdx.x * RA_T + threadIdx.x;
-    if (i >= n) return;
     const Cam& cam = CAM_ON_DEVICE ? s_cam : cam_val;
+    uint32_t key = 0xFFFFFFFFu, touched = 0, rc = 0;
+    if (i < n) {
     const float x = means3D[3 * i], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
     const float* V = cam.V;
     float pv[4];
     py_view(V, x, y, z, pv);                                         // p_view = [x,1] @ V  (gauss_render.py:163)
     const bool in_mask = pv[2] <= -0.000001f;                       // :167
-    uint32_t key = 0xFFFFFFFFu, touched = 0, rc = 0;
     if (in_mask) {
         float cv[4];                                                 // cov2d (:101-148), torch's evaluation order: py_project.inl
         py_cov2d(V, pv, cam.lim_x, cam.lim_y, cam.focal_x, cam.focal_y, cov9 + 9 * i, cv);
@@ -127,9 +132,21 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_py(Cam cam_val, const Cam* 
     }
     const long r = n - 1 - i;
     depth_key_rev[r] = key;
-    index_rev[r] = (uint32_t)i;
+    if (index_rev) index_rev[r] = (uint32_t)i;       // nullptr: the sort returns n - 1 - position itself (bucket sort, reversed)
     tiles_touched[i] = touched;
     rect[i] = rc;
+    }
+    if (mm) {
+        uint32_t a = key != 0xFFFFFFFFu ? ~key : 0u, b = key != 0xFFFFFFFFu ? key : 0u;
+        a = wave_max_u32(a); b = wave_max_u32(b);
+        if ((threadIdx.x & 63) == 0) { atomicMax(&s_mm[0], a); atomicMax(&s_mm[1], b); }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t slot = blockIdx.x % mm_slots;
+            atomicMax(&mm->partial[2 * slot], s_mm[0]);
+            atomicMax(&mm->partial[2 * slot + 1], s_mm[1]);
+        }
+    }
 }
 
 __global__ __launch_bounds__(RA_T) void k_gather_u32(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx,
@@ -1281,9 +1298,12 @@ __global__ void k_resolve_count(const uint32_t* __restrict__ total, uint32_t cap
     }
 }
 // the pinned host job -> device memory, by a kernel rather than a copy node (see g2pc_raster_camera_py)
-__global__ void k_fetch_job(const uint32_t* __restrict__ job_host, uint32_t* __restrict__ job_dev) {
+// ... and, when the depth order comes from the bucket sort, the (zeroed) header its range partials are collected in
+__global__ void k_fetch_job(const uint32_t* __restrict__ job_host, uint32_t* __restrict__ job_dev, BucketHdr* __restrict__ hdr,
+                            size_t cs, BucketPlan plan) {
     const unsigned o = blockIdx.x * (unsigned)(sizeof(G2pcCameraJob) / 4);          // one block per camera of the batch
-    if (threadIdx.x < sizeof(G2pcCameraJob) / 4) job_dev[o + threadIdx.x] = job_host[o + threadIdx.x];
+    if (job_host && threadIdx.x < sizeof(G2pcCameraJob) / 4) job_dev[o + threadIdx.x] = job_host[o + threadIdx.x];
+    if (hdr) bucket_hdr_init((BucketHdr*)((char*)hdr + (size_t)blockIdx.x * cs), plan, threadIdx.x, blockDim.x);
 }
 
 // binding-side reductions (gaussian_pointcloud_rasterization/__init__.py:128-158): gather the colour of the arg-max
@@ -1386,7 +1406,8 @@ static size_t py_back_ws(long L, int T) {
 // overflow word afterwards (non-zero = NOT sorted: the caller must discard the camera and repeat it with the radix path)
 static int py_front(const Cam& cam_val, const Cam* cam_dev, const G2pcTileLayout* layout, const float* means3D,
                     const float* cov9, const float* opacity, const float* colours, long n, const PyFrontBuffers& fb,
-                    void* ws, size_t ws_bytes, hipStream_t s, uint32_t** depth_overflow = nullptr, Batch bt = Batch()) {
+                    void* ws, size_t ws_bytes, hipStream_t s, uint32_t** depth_overflow = nullptr, Batch bt = Batch(),
+                    const G2pcCameraJob* jobs_host = nullptr, G2pcCameraJob* jobs_dev = nullptr) {
     Arena ar(ws, ws_bytes);
     uint32_t* key_rev = ar.get<uint32_t>((size_t)n);
     uint32_t* idx_rev = ar.get<uint32_t>((size_t)n);
@@ -1400,13 +1421,23 @@ static int py_front(const Cam& cam_val, const Cam* cam_dev, const G2pcTileLayout
     const size_t bucket_bytes = depth_overflow ? bucket_sort_workspace(n) : 0;
     char* bucket_ws = ar.get<char>(bucket_bytes);
     if (!ar.ok()) { set_error("raster_front_py", "workspace too small"); return G2PC_ERR_WORKSPACE; }
+    // device-resident cameras whose depth order comes from the bucket sort: the sort's range pass is folded into the
+    // preprocess (header zeroed by the job fetch) and its values are the reversed positions themselves (no index array)
+    const bool fold = cam_dev && depth_overflow;
+    BucketHdr* hdr = fold ? bucket_sort_header(bucket_ws) : nullptr;
+    const BucketPlan plan = bucket_plan(n);
+    if (cam_dev && (jobs_host || hdr))
+        hipLaunchKernelGGL(k_fetch_job, dim3((unsigned)bt.n), dim3(64), 0, s, (const uint32_t*)jobs_host, (uint32_t*)jobs_dev, hdr, bt.cs, plan);
     if (cam_dev)
         hipLaunchKernelGGL(k_preprocess_py<true>, dim3(cdiv(n, RA_T), (unsigned)bt.n), dim3(RA_T), 0, s, cam_val, cam_dev, to_layout(layout),
-                           means3D, cov9, opacity, n, key_rev, idx_rev, touched, colours, fb.rec, fb.rect, bt.cs);
+                           means3D, cov9, opacity, n, key_rev, fold ? (uint32_t*)nullptr : idx_rev, touched, colours, fb.rec, fb.rect,
+                           bt.cs, hdr, plan.nminmax);
     else
         hipLaunchKernelGGL(k_preprocess_py<false>, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, cam_val, cam_dev, to_layout(layout),
-                           means3D, cov9, opacity, n, key_rev, idx_rev, touched, colours, fb.rec, fb.rect, (size_t)0);
-    int rc = depth_overflow ? bucket_sort_u32(key_rev, idx_rev, fb.sorted_idx, nullptr, n, bucket_ws, bucket_bytes, depth_overflow, s, bt)
+                           means3D, cov9, opacity, n, key_rev, idx_rev, touched, colours, fb.rec, fb.rect, (size_t)0,
+                           (BucketHdr*)nullptr, 1u);
+    int rc = depth_overflow ? bucket_sort_u32(key_rev, fold ? nullptr : idx_rev, fb.sorted_idx, nullptr, n, bucket_ws, bucket_bytes,
+                                              depth_overflow, s, bt, fold, fold)
                             : sort_pairs_u32(key_rev, idx_rev, key_sorted, fb.sorted_idx, ktmp, vtmp, n, 0, 32, sort_ws, sort_bytes, s, nullptr, bt);
     if (rc) return rc;
     // exclusive scan of the tiles touched, taken in depth order (the gather rides in the scan's first kernel)
@@ -1577,11 +1608,10 @@ int g2pc_raster_cameras_py(const G2pcCameraJob* jobs_dev, const G2pcCameraJob* j
         // Both hand-overs with the host go through kernels that touch the PINNED buffers via their device mapping, not
         // through copy nodes: a graph whose first node is a host-to-device copy replayed with ~0.1 ms of extra latency
         // per camera for the lifetime of the first buffers a process pinned (25.9 -> 29 ms per 50-camera job).
-        if (jobs_host)
-            hipLaunchKernelGGL(k_fetch_job, dim3((unsigned)batch), dim3(64), 0, s, (const uint32_t*)jobs_host, (uint32_t*)jobs_dev);
         uint32_t* depth_overflow = nullptr;
         rc = py_front(Cam{}, (const Cam*)&jobs_dev->cam, layout, means3D, cov9, opacity, colours, (long)n, fb, front_ws,
-                      front_bytes, s, (g_depth_bucket_sort && bucket_sort_pays((long)n)) ? &depth_overflow : nullptr, bt);
+                      front_bytes, s, (g_depth_bucket_sort && bucket_sort_pays((long)n)) ? &depth_overflow : nullptr, bt, jobs_host,
+                      (G2pcCameraJob*)jobs_dev);
         if (rc) return rc;
         hipLaunchKernelGGL(k_resolve_count, dim3(1, (unsigned)batch), dim3(64), 0, s, fb.offsets + n, (uint32_t)capacity, l_eff,
                            count_host, (const uint32_t*)depth_overflow, bt.cs);

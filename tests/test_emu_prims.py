@@ -90,11 +90,11 @@ def _bucket_sort(nv, keys, vals):
     import ctypes as C
     L = nv.lib()
     n = keys.numel()
-    ko, vo = torch.empty_like(keys), torch.empty_like(vals)
+    ko, vo = torch.empty_like(keys), torch.empty_like(keys)
     flag = torch.zeros(1, dtype=torch.int32, device=keys.device)
     wb = L.g2pc_bucket_sort_workspace(n)
     ws = torch.empty(wb, dtype=torch.uint8, device=keys.device)
-    p = lambda t: C.c_void_p(t.data_ptr())
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
     nv.check(L.g2pc_bucket_sort_u32(p(keys), p(vals), p(ko), p(vo), n, p(flag), p(ws), wb, nv.stream_handle(keys.device)), "bucket_sort")
     return ko, vo, int(flag.item())
 
@@ -117,6 +117,10 @@ def test_bucket_sort_equals_stable_argsort(emu, n, ties):
     assert np.array_equal(ko.numpy().view(np.uint32), keys[order])
     assert np.array_equal(vo.numpy()[:nvalid], vals[order][:nvalid])              # sorted part: exact stable order
     assert sorted(vo.numpy()[nvalid:].tolist()) == sorted(vals[order][nvalid:].tolist())    # tail: any order
+    # values omitted: the sort returns the input positions themselves (no index array is read)
+    ko2, vo2, flag2 = _bucket_sort(emu, torch.from_numpy(keys.view(np.int32)), None)
+    assert flag2 == 0 and np.array_equal(ko2.numpy().view(np.uint32), keys[order])
+    assert np.array_equal(vo2.numpy()[:nvalid], order[:nvalid].astype(np.int32))
 
 
 def test_bucket_sort_flags_a_pile_up(emu):
