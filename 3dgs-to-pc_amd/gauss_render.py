@@ -250,17 +250,23 @@ class _GraphSlot:
         self.update_done = torch.cuda.Event() if on_gpu else None
         self.head_done = torch.cuda.Event() if on_gpu else None
         self.graph, self.graph_key = C.c_void_p(None), None
+        self.graphs = {}                       # key -> executable graph: a short last batch does not evict the full-batch graph
         self.ws, self.ws_bytes, self.tilebuf = None, 0, None
         self.inflight = None                   # [(camera struct, layout, slot, capacity)] of the batch replay in flight
         self.staged = []                       # the same for the cameras staged in job_host
 
     def release(self):
+        """Destroy every executable graph of the slot (the current one and the cached ones of other batch sizes)."""
         L = nv.lib()
-        if self.graph:
-            if self.on_gpu:
-                self.stream.synchronize()          # never destroy an executable graph that may still be in flight
-            L.g2pc_graph_destroy(self.graph)
-            self.graph, self.graph_key = C.c_void_p(None), None
+        graphs = [g for g in getattr(self, "graphs", {}).values() if g]
+        if self.graph and not any(g.value == self.graph.value for g in graphs):
+            graphs.append(self.graph)
+        if graphs and self.on_gpu:
+            self.stream.synchronize()              # never destroy an executable graph that may still be in flight
+        for g in graphs:
+            L.g2pc_graph_destroy(g)
+        self.graphs = {}
+        self.graph, self.graph_key = C.c_void_p(None), None
 
 
 class _RenderContext:
@@ -548,12 +554,16 @@ class GaussHipRenderer():
         """(Re)build the slot's hipGraph for (layout, capacity, phases, cameras in the batch): buffers first, then one
         recorded batch call."""
         L = nv.lib()
-        sl.release()
         capacity, batch = key[1], key[3]
+        # graphs of the same (layout, capacity) but another number of cameras share the slot's buffers and stay cached;
+        # anything else (new capacity, new layout, new buffers) starts the slot afresh
+        if any(k[:2] != key[:2] for k in sl.graphs):
+            sl.release()
         need = L.g2pc_raster_camera_workspace(self.n, capacity, lay.num_tiles) * sl.batch
         import contextlib
         with (torch.cuda.stream(sl.stream) if sl.on_gpu else contextlib.nullcontext()):   # allocate on the stream using them
             if need > sl.ws_bytes:
+                sl.release()                       # the cached graphs hold the old workspace's addresses
                 sl.ws = None
                 sl.ws_bytes = int(need)
                 sl.ws = nv.workspace(sl.ws_bytes, self.device)
@@ -567,6 +577,7 @@ class GaussHipRenderer():
         graph = C.c_void_p(None)
         rc_end = L.g2pc_graph_capture_end(sl.stream_ptr, C.byref(graph))
         nv.check(rc or rc_end, "raster_cameras_py (capture)")
+        sl.graphs[key] = graph
         sl.graph, sl.graph_key = graph, key
 
     def _camera_call(self, sl, lay, capacity, phases, batch, stream_ptr=None):
@@ -614,7 +625,10 @@ class GaussHipRenderer():
         split = on_gpu and PIPELINE_MODE == "split"
         key = (id(lay), self.capacity, (1 if (nv.PROFILE is not None or split) else 3) | exact, batch)
         if sl.graph_key != key:
-            self._capture(sl, lay, key)
+            if key in sl.graphs:
+                sl.graph, sl.graph_key = sl.graphs[key], key
+            else:
+                self._capture(sl, lay, key)
         if split:
             # heads of all slots on the slots' common head stream (slot 0's, high priority), blends on the common blend stream
             head, blend = self.slots[0].stream, self.ctx.blend_stream(self.device)
