@@ -53,18 +53,33 @@ def _host(m):
 
 
 class Camera():
-    """The python-renderer camera (camera_handler.py:35-50)."""
+    """The python-renderer camera (camera_handler.py:35-50).  `view` / `projection`: matrices computed for a whole rig at once
+    (get_cameras): inverse(c2w)^T of this camera and the shared projection of its intrinsics."""
 
-    def __init__(self, width, height, focal_x, focal_y, c2w, znear=_ZNEAR, zfar=_ZFAR):
+    def __init__(self, width, height, focal_x, focal_y, c2w, znear=_ZNEAR, zfar=_ZFAR, view=None, projection=None):
         self.c2w = _host(c2w)
         self.znear, self.zfar = znear, zfar
         self.focal_x, self.focal_y = focal_x, focal_y
         self.image_width, self.image_height = int(width), int(height)
         self.FoVx, self.FoVy = focal2fov(focal_x, width), focal2fov(focal_y, height)
-        self.world_view_transform = _row_vector_view(self.c2w)
-        self.projection_matrix = getProjectionMatrix(znear, zfar, self.FoVx, self.FoVy).transpose(0, 1)
-        self.full_proj_transform = self.world_view_transform @ self.projection_matrix
-        self.camera_center = self.world_view_transform.inverse()[3, :3]
+        self.world_view_transform = _row_vector_view(self.c2w) if view is None else view
+        self.projection_matrix = (getProjectionMatrix(znear, zfar, self.FoVx, self.FoVy).transpose(0, 1)
+                                  if projection is None else projection)
+        self._derived = None
+
+    # full_proj_transform / camera_center (camera_handler.py:47-50) are not read by any renderer: formed on first use
+    def _derive(self):
+        if self._derived is None:
+            self._derived = (self.world_view_transform @ self.projection_matrix, self.world_view_transform.inverse()[3, :3])
+        return self._derived
+
+    @property
+    def full_proj_transform(self):
+        return self._derive()[0]
+
+    @property
+    def camera_center(self):
+        return self._derive()[1]
 
 
 def _render_geometry(cam_intrinsic, colour_resolution, mask):
@@ -98,3 +113,41 @@ def get_camera(renderer_type, transform, cam_intrinsic, colour_resolution=None, 
             campos=view.inverse()[3, :3], mask=mask, prefiltered=False, debug=True, antialiasing=False)
 
     raise Exception(f"Renderer of type {renderer_type} is not supported")
+
+
+def get_cameras(renderer_type, transforms, intrinsics, colour_resolution=None, sh_degree=3, white_bkgd=True):
+    """Camera set-up for a whole rig in one pass (the reference calls get_camera once per image inside its
+    render loop, gauss_to_pc.py:437-454): ONE batched inverse of all camera-to-world matrices -- LAPACK factors every 4x4 of
+    the batch by itself, so each view matrix is bit for bit the one get_camera computes --, one projection matrix per distinct
+    intrinsics.  Returns {name: camera} in the order of `transforms`.  Masked cameras (the mask pins the render size) go
+    through get_camera."""
+    names = list(transforms)
+    if not names:
+        return {}
+    c2w = torch.stack([_host(torch.as_tensor(transforms[k])) for k in names])              # [C, 4, 4]
+    cuda_like = renderer_type in ("cuda", "hip")
+    if not cuda_like and renderer_type != "python":
+        raise Exception(f"Renderer of type {renderer_type} is not supported")
+    if cuda_like:
+        c2w = c2w.clone()
+        c2w[:, :, 1:3].neg_()                                                               # OpenGL -> OpenCV camera axes
+    views = torch.linalg.inv(c2w).transpose(1, 2).contiguous()                              # inverse(c2w)^T per camera
+    proj_of, out = {}, {}
+    for i, k in enumerate(names):
+        width, height, fx, fy = _render_geometry(intrinsics[k], colour_resolution, None)
+        key = (width, height, fx, fy)
+        if key not in proj_of:
+            fov_x, fov_y = focal2fov(fx, width), focal2fov(fy, height)
+            proj_of[key] = (getProjectionMatrix(_ZNEAR, _ZFAR, fov_x, fov_y).transpose(0, 1), fov_x, fov_y)
+        proj, fov_x, fov_y = proj_of[key]
+        if not cuda_like:
+            out[k] = Camera(width, height, fx, fy, c2w[i], view=views[i], projection=proj)
+        else:
+            from gaussian_pointcloud_rasterization import GaussianRasterizationSettings
+            view = views[i]
+            out[k] = GaussianRasterizationSettings(
+                image_height=height, image_width=width, tanfovx=math.tan(0.5 * fov_x), tanfovy=math.tan(0.5 * fov_y),
+                bg=torch.ones(3) if white_bkgd else torch.zeros(3), scale_modifier=1.0, viewmatrix=view,
+                projmatrix=view @ proj, sh_degree=sh_degree, campos=view.inverse()[3, :3], mask=None, prefiltered=False,
+                debug=True, antialiasing=False)
+    return out

@@ -204,6 +204,14 @@ def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, poin
         if transforms is None:
             raise Exception("Transforms are required to render colours")
 
+        # camera set-up for the whole rig at once (one batched inverse) -- except the masked cameras, whose
+        # mask pins the render size and travels with the camera
+        from camera_handler import get_cameras
+        unmasked = {k: v for k, v in transforms.items() if mask_images is None or k not in mask_images}
+        if world > 1 and not split_tiles:
+            unmasked = {k: v for i, (k, v) in enumerate(transforms.items()) if i % world == rank and k in unmasked}
+        rig = get_cameras(s.renderer_type, unmasked, intrinsics, colour_resolution=s.colour_resolution,
+                          sh_degree=s.max_sh_degree, white_bkgd=True)
         for cam_index, (img_name, transform) in enumerate(transforms.items()):
             epochs = getattr(gaussian_renderer, "needs_camera_epochs", False)
             if world > 1:
@@ -212,12 +220,11 @@ def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, poin
                     gaussian_renderer.rebase_keys()
                 if not split_tiles and cam_index % world != rank:
                     continue
-            transform = torch.tensor(list(transform))
-            mask = None
-            if mask_images is not None and img_name in mask_images.keys():
+            camera = rig.get(img_name)
+            if camera is None:
                 mask = mask_images[img_name].to(device)
-            camera = get_camera(s.renderer_type, transform, intrinsics[img_name], colour_resolution=s.colour_resolution,
-                                sh_degree=s.max_sh_degree, white_bkgd=True, mask=mask)
+                camera = get_camera(s.renderer_type, torch.tensor(list(transform)), intrinsics[img_name],
+                                    colour_resolution=s.colour_resolution, sh_degree=s.max_sh_degree, white_bkgd=True, mask=mask)
             # Render new image and Gaussian contributions (the image itself is not used by the pipeline)
             if world > 1:
                 gaussian_renderer(camera, return_image=False, slot=(cam_index % CAMERA_EPOCH if epochs else cam_index) + 1)

@@ -68,6 +68,25 @@ def test_two_rank_pipeline_equals_single_process(tmp_path):
     assert np.array_equal(canon(a), canon(b))          # identical multiset of (xyz, rgb, normal) rows
 
 
+@pytest.mark.parametrize("ncam", [5, 19])
+def test_eight_rank_pipeline_equals_single_process(tmp_path, ncam):
+    """BASELINE configs[3]'s shape on the node it is meant for: 8 ranks.  ncam = 5 < 8 ranks: every rank renders every camera
+    and blends its share of the tiles; ncam = 19 > 8: cameras dealt over the ranks (some ranks get 3, some 2), visibility
+    all-reduced once, sampling sharded by Gaussian index into 8 ranges.  The gathered cloud is the single-process cloud."""
+    from emu_util import build_emu
+    build_emu()
+    _run(0, 1, 0, str(tmp_path), "python", 255, ncam)
+    port = 37500 + (os.getpid() % 2000) + ncam
+    mp.spawn(_run, args=(8, port, str(tmp_path), "python", 255, ncam), nprocs=8, join=True)
+    a, b = np.load(tmp_path / "python_w1_e255.npz"), np.load(tmp_path / "python_w8_e255.npz")
+    assert a["points"].shape == b["points"].shape and a["points"].shape[0] > 10000
+
+    def canon(d):
+        rows = np.concatenate([d["points"], d["colours"], d["normals"]], axis=1)
+        return rows[np.lexsort(rows.T[::-1])]
+    assert np.array_equal(canon(a), canon(b))
+
+
 def test_two_rank_pipeline_cuda_semantics(tmp_path):
     """Native-rasteriser semantics: max / min / winner colour combine exactly (earliest global camera wins ties); the
     total contribution is a float SUM whose order differs across ranks, so the allocation may move by a point."""
