@@ -446,7 +446,8 @@ int sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* k
 // (~BK_AVG keys each) leaves buckets that a bitonic sort of 64-bit (key, position) composites finishes entirely in LDS
 // (32 KB of the CU's 160).  The composite makes the result THE stable ascending order (ties in input order), whatever
 // order the scatter left inside a bucket.  Keys 0xFFFFFFFF ("not on screen") go to a tail bucket that is copied, not
-// sorted.  A bucket with more than its room (1024 keys; 4096 when the mean bucket exceeds 256: depths piled up in 1/nbk of their range) raises
+// sorted: entries with that key come out in UNSPECIFIED (run-dependent) order -- the rasteriser never reads them
+// (tiles touched = 0); a caller that needs them ordered sorts with sort_pairs_u32.  A bucket with more than its room (1024 keys; 4096 when the mean bucket exceeds 256: depths piled up in 1/nbk of their range) raises
 // `overflow`: the caller repeats the sort with the radix path.
 //   k_bk_minmax   per-block (~min, max) partials
 //   k_bk_hist     chunk c of `kpb` keys -> LDS histogram -> column c of table[bucket][chunk]

@@ -279,24 +279,23 @@ __global__ __launch_bounds__(ER_T) void k_emit_rows(
     const float* __restrict__ normals, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ bin_start, int B,
     int A, long gv, int attempt0, unsigned seed_lo, unsigned seed_hi, uint64_t gid_base,
     const uint32_t* __restrict__ dscan, const int64_t* __restrict__ sec_base, float* __restrict__ out_points,
-    float* __restrict__ out_colours, float* __restrict__ out_normals, int32_t* __restrict__ out_gauss) {
+    float* __restrict__ out_colours, float* __restrict__ out_normals, int32_t* __restrict__ out_gauss, long rows_capacity) {
     __shared__ uint32_t s_win[ER_WIN + 1];
     __shared__ float s_rows[ER_T / kWave][192];
-    __shared__ int s_cnt;
     const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int S = B * (1 + A);
-    const long M = (long)sec_base[S];
+    long M = (long)sec_base[S];
+    if (M > rows_capacity) M = rows_capacity;          // never past the caller's arrays (the host compares M with its bound too)
     const long row0 = (long)blockIdx.x * ER_ROWS;
     if (row0 >= M) return;
     const long row1 = row0 + ER_ROWS < M ? row0 + ER_ROWS : M;
-    // first section that ends after row0 (the sections ending at or before row0 form a prefix of the table)
-    int before = 0;
-    for (int i = threadIdx.x; i < S; i += ER_T) before += (sec_base[i + 1] <= (int64_t)row0) ? 1 : 0;
-    if (threadIdx.x == 0) s_cnt = 0;
-    __syncthreads();
-    if (before) atomicAdd(&s_cnt, before);
-    __syncthreads();
-    int si = s_cnt;
+    // first section that ends after row0: sec_base is monotone, so a binary search (every thread finds the same index)
+    int lo = 0, hi = S;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (sec_base[mid + 1] <= (int64_t)row0) lo = mid + 1; else hi = mid;
+    }
+    int si = lo;
     for (; si < S; ++si) {
         const long sb = (long)sec_base[si], se = (long)sec_base[si + 1];
         if (sb >= row1) break;
@@ -536,7 +535,8 @@ int g2pc_sampler_emit_rows(const float* means, const float* cov9, const float* c
     if (rows_capacity <= 0 || num_bins <= 0) return G2PC_OK;
     hipLaunchKernelGGL(k_emit_rows, dim3(cdiv(rows_capacity, ER_ROWS)), dim3(ER_T), 0, (hipStream_t)stream, means, cov9, colours,
                        normals, perm, bin_start, (int)num_bins, (int)attempts, (long)gv, (int)attempt0, (unsigned)seed,
-                       (unsigned)(seed >> 32), gid_base, dscan, sec_base, out_points, out_colours, out_normals, out_gauss);
+                       (unsigned)(seed >> 32), gid_base, dscan, sec_base, out_points, out_colours, out_normals, out_gauss,
+                       (long)rows_capacity);
     return check_launch("g2pc_sampler_emit_rows");
 }
 

@@ -94,9 +94,9 @@ class _CuScratch:
         self.back_bytes, self.back_ws = 0, None
         self.colour = self.depths = self.invdepths = None
         self.stream = stream
-        self.count_host = torch.zeros((2,), dtype=torch.int32)          # [instances, 0], written by the device
-        if stream is not None:
-            self.count_host = self.count_host.pin_memory()
+        # [instances, 0], written by the device through the pinned buffer's mapping -- pipelined scratches only: the
+        # synchronous scratch reads offsets[n] back itself, a pageable buffer here would cost a blocking copy per camera
+        self.count_host = torch.zeros((2,), dtype=torch.int32).pin_memory() if stream is not None else None
         self.front_done = torch.cuda.Event() if stream is not None else None
         self.update_done = torch.cuda.Event() if stream is not None else None
 

@@ -62,7 +62,9 @@ int g2pc_sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32
                         size_t ws_bytes, void* stream);
 /* Stable ascending sort of (key, value) pairs whose keys are bit patterns of positive floats spread over their range (a
  * camera's depths): range-normalised bucket pass (per-chunk histogram table, no global atomics) + one wave per bucket
- * sorting (key, position) composites in LDS -- six launches, every key moved once.  Keys 0xFFFFFFFF go last.
+ * sorting (key, position) composites in LDS -- six launches, every key moved once.  Keys 0xFFFFFFFF go last, in
+ * unspecified order among themselves (everything else is THE stable ascending order).  vals == NULL: the values are the
+ * input positions.
  * *overflow (device u32) != 0 afterwards: a bucket held more keys than its room (1024; 4096 when the mean bucket exceeds
  * 256 keys) and the result is NOT sorted -- repeat with g2pc_sort_pairs_u32.  Pays up to ~2 M keys (MI355X: 90 vs 101 us
  * at 1 M, 533 vs 278 us at 5 M). */
