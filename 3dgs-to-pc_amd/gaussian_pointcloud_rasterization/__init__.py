@@ -82,7 +82,7 @@ def mark_visible(means3D, viewmatrix, projmatrix=None):
 class _CuScratch:
     """Per-stream scratch of one in-flight camera."""
 
-    def __init__(self, n, dev, stream=None):
+    def __init__(self, n, dev, stream=None, pipelined=False):
         f32, i32 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.int32, device=dev)
         self.rec = torch.empty((n, 16), **f32)                    # one 64-byte blend record per Gaussian
         self.rect, self.sorted, self.offsets = torch.empty(n, **i32), torch.empty(n, **i32), torch.empty(n + 1, **i32)
@@ -96,7 +96,9 @@ class _CuScratch:
         self.stream = stream
         # [instances, 0], written by the device through the pinned buffer's mapping -- pipelined scratches only: the
         # synchronous scratch reads offsets[n] back itself, a pageable buffer here would cost a blocking copy per camera
-        self.count_host = torch.zeros((2,), dtype=torch.int32).pin_memory() if stream is not None else None
+        self.count_host = torch.zeros((2,), dtype=torch.int32) if pipelined else None
+        if pipelined and stream is not None:
+            self.count_host = self.count_host.pin_memory()
         self.front_done = torch.cuda.Event() if stream is not None else None
         self.update_done = torch.cuda.Event() if stream is not None else None
 
@@ -324,7 +326,7 @@ class GaussianRasterizer(nn.Module):
         on_gpu = self.device.type == "cuda" and not nv.emulated()
         if discard_images and PIPELINE_STREAMS > 1 and (on_gpu or PIPELINE_IN_EMULATOR):
             if not self._pipe:
-                self._pipe = [_CuScratch(n, self.device, torch.cuda.Stream(self.device) if on_gpu else None)
+                self._pipe = [_CuScratch(n, self.device, torch.cuda.Stream(self.device) if on_gpu else None, pipelined=True)
                               for _ in range(PIPELINE_STREAMS)]
             while len(self._pending) >= PIPELINE_STREAMS:
                 self._finish(self._pending.pop(0))
