@@ -222,6 +222,8 @@ CAMERA_BATCH = 2                  # cameras per launch sequence (g2pc_raster_cam
 #            all heads (which leave most of the device idle), then all blends (which then share its throughput).
 #   "split": ONE head stream (high priority) and ONE blend stream for all slots: the heads of batch i+1 run beside the blends
 #            of batch i, blends run back to back; a slot's arena is handed from one stream to the other with events.
+#   "split_multi": every slot's heads on its OWN high-priority stream (the small head kernels of several batches run side
+#            by side), all blends on ONE shared stream, back to back.
 PIPELINE_MODE = "chain"
 PIPELINE_IN_EMULATOR = False      # tests: drive the capture / replay path through the CPU emulator too
 CAPACITY_HEADROOM = 1.25          # instance capacity of the captured graphs relative to the largest count seen so far
@@ -235,7 +237,7 @@ class _GraphSlot:
     def __init__(self, device, on_gpu, batch=1):
         self.on_gpu = on_gpu
         self.batch = int(batch)
-        self.stream = torch.cuda.Stream(device, priority=-1 if PIPELINE_MODE == "split" else 0) if on_gpu else None
+        self.stream = torch.cuda.Stream(device, priority=-1 if PIPELINE_MODE.startswith("split") else 0) if on_gpu else None
         self.stream_ptr = C.c_void_p(self.stream.cuda_stream) if on_gpu else C.c_void_p(1)   # the emulator ignores streams
         nbytes = C.sizeof(_Job) * self.batch
         self.job_host = torch.zeros((nbytes,), dtype=torch.uint8)
@@ -617,12 +619,12 @@ class GaussHipRenderer():
         if on_gpu and not any(o.inflight for o in self.slots):
             for o in self.slots:
                 o.stream.wait_stream(torch.cuda.current_stream(self.device))      # scene tensors / state are ready
-            if PIPELINE_MODE == "split":
+            if PIPELINE_MODE.startswith("split"):
                 self.ctx.blend_stream(self.device).wait_stream(torch.cuda.current_stream(self.device))
         # profiling: HIP events around the blend alone -> the graph stops before it and the blend is issued directly
         # (this runtime refuses event-record nodes inside a captured graph)
         exact = 8 if self.t_floor == 0.0 else 0      # to-the-letter mode: the blend kernel with the reference's operation order
-        split = on_gpu and PIPELINE_MODE == "split"
+        split = on_gpu and PIPELINE_MODE.startswith("split")
         key = (id(lay), self.capacity, (1 if (nv.PROFILE is not None or split) else 3) | exact, batch)
         if sl.graph_key != key:
             if key in sl.graphs:
@@ -631,7 +633,8 @@ class GaussHipRenderer():
                 self._capture(sl, lay, key)
         if split:
             # heads of all slots on the slots' common head stream (slot 0's, high priority), blends on the common blend stream
-            head, blend = self.slots[0].stream, self.ctx.blend_stream(self.device)
+            head = sl.stream if PIPELINE_MODE == "split_multi" else self.slots[0].stream
+            blend = self.ctx.blend_stream(self.device)
             head.wait_stream(sl.stream)                    # (a capture's warm-up run on the slot's own stream)
             head.wait_event(sl.update_done)                # this slot's arena: its previous blends are through
             nv.check(L.g2pc_graph_launch(sl.graph, C.c_void_p(head.cuda_stream)), "graph_launch")
@@ -660,7 +663,8 @@ class GaussHipRenderer():
             _, num_inst = self._render_sync(self._camera_struct(camera), lay, slot, False)
             self.capacity = max(int(num_inst * CAPACITY_HEADROOM), MIN_CAPACITY)
             return
-        batch = max(1, min(int(CAMERA_BATCH), 8))
+        # (the batched scans take at most 2 M values per camera; larger scenes keep one camera per launch sequence)
+        batch = max(1, min(int(CAMERA_BATCH), 8)) if self.n <= (2 << 20) else 1
         if len(self.slots) != PIPELINE_STREAMS or (self.slots and self.slots[0].batch != batch):
             self.flush()
             for sl in self.slots:

@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--depth-sort", default=None, choices=[None, "bucket", "radix"], help="tuning aid: depth order of the captured camera path")
     ap.add_argument("--streams", type=int, default=0, help="tuning aid: camera batches in flight (HIP streams) of the renderer")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the untimed region / kernel profile passes after the timed loop")
-    ap.add_argument("--pipeline-mode", default=None, choices=[None, "chain", "split"], help="tuning aid: see gauss_render.PIPELINE_MODE")
+    ap.add_argument("--pipeline-mode", default=None, choices=[None, "chain", "split", "split_multi"], help="tuning aid: see gauss_render.PIPELINE_MODE")
     ap.add_argument("--camera-batch", type=int, default=0, help="tuning aid: cameras per launch sequence (1 = one camera per graph)")
     ap.add_argument("--camera-subset", type=int, default=0, help="profiling aid: render only the first k cameras of the rig")
     ap.add_argument("--t-floor", type=float, default=None, help="blend transmittance floor (default: gauss_render.DEFAULT_T_FLOOR)")
@@ -113,7 +113,7 @@ def algorithmic_bytes(workload, n, n_kept, m, cams, stats):
     return b
 
 
-ROCPROF_STATS_FILE = "profiles/r03_render_s1_kernel_stats.csv"   # rocprofv3 --kernel-trace --stats of `bench.py --streams 1 --no-parity --no-extra --no-cpu-baseline`
+ROCPROF_STATS_FILE = "profiles/r03s_render_s1_kernel_stats.csv"   # rocprofv3 --kernel-trace --stats of `bench.py --streams 1 --no-parity --no-extra --no-cpu-baseline`
 
 
 def rocprof_kernel_avg(region):
