@@ -15,6 +15,11 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// diagnostics: where a wave runs.  HW_ID (hwreg 4): wave [3:0], SIMD [5:4], pipe [7:6], CU [11:8], SH [12], SE [15:13];
+// XCC_ID (hwreg 20): the XCD.  s_getreg_b32 immediate = (size - 1) << 11 | offset << 6 | register.
+__device__ __forceinline__ uint32_t g2pc_hw_id() { return __builtin_amdgcn_s_getreg((31 << 11) | 4); }
+__device__ __forceinline__ uint32_t g2pc_xcc_id() { return __builtin_amdgcn_s_getreg((31 << 11) | 20); }
+
 // ---- wave64 reductions on the DPP crossbar (no LDS traffic, unlike ds_bpermute based __shfl) ----------------
 // row_shr:1,2,4,8 give every lane 15 of a 16-lane row the row result; row_bcast:15 / row_bcast:31 fold the four
 // rows into lane 63; v_readlane broadcasts it.  `identity` fills lanes that have no source.

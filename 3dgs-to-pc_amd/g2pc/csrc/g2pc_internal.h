@@ -45,6 +45,11 @@ struct Arena {
 template <typename T> __device__ __forceinline__ T* seg(T* p, size_t cs) {
     return p ? (T*)((char*)p + (size_t)blockIdx.y * cs) : p;
 }
+// The blends put the camera in blockIdx.x instead (workgroups are dispatched x fastest): the chunks of all cameras of the
+// batch start in the layout's long-walks-first order TOGETHER, so the launch has one tail, not one per camera.
+template <typename T> __device__ __forceinline__ T* seg_at(T* p, size_t cs, unsigned cam) {
+    return p ? (T*)((char*)p + (size_t)cam * cs) : p;
+}
 struct Batch { int n = 1; size_t cs = 0; };          // host side: number of cameras, arena stride in bytes
 
 // ---- wave-level helpers -------------------------------------------------------------------------

@@ -33,7 +33,7 @@ struct Cam {            // device copy of G2pcCamera (passed by value as kernel 
 };
 
 struct Layout {         // device pointers of G2pcTileLayout
-    int nx, ny;
+    int nx, ny, num_chunks;
     const int32_t *xs, *ws, *ys, *hs;
     const int32_t *tile_seq, *seq_tile, *tile_pix_off;
 };
@@ -231,9 +231,11 @@ __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __
                                                   uint32_t* __restrict__ chunk_work,
                                                   const G2pcCameraJob* __restrict__ job, size_t cs) {
     // one wave64 per block: the LDS stage is wave-private, no s_barrier anywhere
-    tile_start = seg(tile_start, cs); inst_g = seg(inst_g, cs); rec = seg(rec, cs);      // batched: camera blockIdx.y
+    const unsigned chunk_i = blockIdx.z * gridDim.y + blockIdx.y;       // the blends: camera = blockIdx.x, chunk in (y, z)
+    if ((int)chunk_i >= lay.num_chunks) return;
+    tile_start = seg_at(tile_start, cs, blockIdx.x); inst_g = seg_at(inst_g, cs, blockIdx.x); rec = seg_at(rec, cs, blockIdx.x);
     if (job) {
-        job += blockIdx.y;
+        job += blockIdx.x;
         order_base = job->camera_slot << 24; t_floor = job->t_floor; bg = job->cam.bg[0];
         const unsigned long long tb = ((unsigned long long)job->tilebuf_hi << 32) | job->tilebuf_lo;
         if (tb) tilebuf = (float*)tb;              // one colour buffer per camera (deferred colour resolve)
@@ -242,8 +244,8 @@ __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __
     __shared__ float4 s_p1[BL_BATCH + 4];
     __shared__ float4 s_p2[BL_BATCH + 4];
     __shared__ uint32_t s_g[BL_BATCH];
-    const int tile = chunk_tile[blockIdx.x];
-    const int sb0 = chunk_pix0[blockIdx.x];                 // first 8x8 sub-block of this chunk
+    const int tile = chunk_tile[chunk_i];
+    const int sb0 = chunk_pix0[chunk_i];                 // first 8x8 sub-block of this chunk
     const int ix = tile % lay.nx, iy = tile / lay.nx;
     const int x0 = lay.xs[ix], w = lay.ws[ix], y0 = lay.ys[iy], h = lay.hs[iy];
     const int nsbx = (w + 7) >> 3;
@@ -409,8 +411,8 @@ __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __
         }
     }
     if (chunk_work && lane == 0) {                 // diagnostics: list length and how far this wave walked it
-        chunk_work[2 * blockIdx.x] = end - start;
-        chunk_work[2 * blockIdx.x + 1] = processed;
+        chunk_work[8 * chunk_i] = end - start;
+        chunk_work[8 * chunk_i + 1] = processed;
     }
     float* out = tilebuf + 3 * (size_t)lay.tile_pix_off[tile];
 #pragma unroll
@@ -439,9 +441,11 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_pk(Layout lay, const int32_t*
                                                      float t_floor, float bg, float* __restrict__ tilebuf,
                                                      uint32_t* __restrict__ chunk_work,
                                                      const G2pcCameraJob* __restrict__ job, size_t cs) {
-    tile_start = seg(tile_start, cs); inst_g = seg(inst_g, cs); rec = seg(rec, cs);      // batched: camera blockIdx.y
+    const unsigned chunk_i = blockIdx.z * gridDim.y + blockIdx.y;       // the blends: camera = blockIdx.x, chunk in (y, z)
+    if ((int)chunk_i >= lay.num_chunks) return;
+    tile_start = seg_at(tile_start, cs, blockIdx.x); inst_g = seg_at(inst_g, cs, blockIdx.x); rec = seg_at(rec, cs, blockIdx.x);
     if (job) {
-        job += blockIdx.y;
+        job += blockIdx.x;
         order_base = job->camera_slot << 24; t_floor = job->t_floor; bg = job->cam.bg[0];
         const unsigned long long tb = ((unsigned long long)job->tilebuf_hi << 32) | job->tilebuf_lo;
         if (tb) tilebuf = (float*)tb;              // one colour buffer per camera (deferred colour resolve)
@@ -450,8 +454,8 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_pk(Layout lay, const int32_t*
     __shared__ float4 s_p1[BL_BATCH + 4];
     __shared__ float4 s_p2[BL_BATCH + 4];
     __shared__ uint32_t s_g[BL_BATCH];
-    const int tile = chunk_tile[blockIdx.x];
-    const uint32_t sbpair = (uint32_t)chunk_pix0[blockIdx.x];    // two ADJACENT 8x8 sub-blocks: a | b << 16, b = 0xFFFF: none
+    const int tile = chunk_tile[chunk_i];
+    const uint32_t sbpair = (uint32_t)chunk_pix0[chunk_i];    // two ADJACENT 8x8 sub-blocks: a | b << 16, b = 0xFFFF: none
     const int ix = tile % lay.nx, iy = tile / lay.nx;
     const int x0 = lay.xs[ix], w = lay.ws[ix], y0 = lay.ys[iy], h = lay.hs[iy];
     const int nsbx = (w + 7) >> 3;
@@ -590,8 +594,8 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_pk(Layout lay, const int32_t*
         if (__all((T[0] <= t_floor && T[1] <= t_floor) ? 1 : 0)) break;      // see k_blend_py
     }
     if (chunk_work && lane == 0) {
-        chunk_work[2 * blockIdx.x] = end - start;
-        chunk_work[2 * blockIdx.x + 1] = processed;
+        chunk_work[8 * chunk_i] = end - start;
+        chunk_work[8 * chunk_i + 1] = processed;
     }
     float* out = tilebuf + 3 * (size_t)lay.tile_pix_off[tile];
 #pragma unroll
@@ -626,19 +630,22 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_dl(Layout lay, const int32_t*
                                                      float t_floor, float bg, float* __restrict__ tilebuf,
                                                      uint32_t* __restrict__ chunk_work,
                                                      const G2pcCameraJob* __restrict__ job, size_t cs) {
-    tile_start = seg(tile_start, cs); inst_g = seg(inst_g, cs); rec = seg(rec, cs);      // batched: camera blockIdx.y
+    const unsigned chunk_i = blockIdx.z * gridDim.y + blockIdx.y;       // the blends: camera = blockIdx.x, chunk in (y, z)
+    if ((int)chunk_i >= lay.num_chunks) return;
+    tile_start = seg_at(tile_start, cs, blockIdx.x); inst_g = seg_at(inst_g, cs, blockIdx.x); rec = seg_at(rec, cs, blockIdx.x);
     if (job) {
-        job += blockIdx.y;
+        job += blockIdx.x;
         order_base = job->camera_slot << 24; t_floor = job->t_floor; bg = job->cam.bg[0];
         const unsigned long long tb = ((unsigned long long)job->tilebuf_hi << 32) | job->tilebuf_lo;
         if (tb) tilebuf = (float*)tb;              // one colour buffer per camera (deferred colour resolve)
     }
+    const unsigned long long clk0 = chunk_work ? wall_clock64() : 0ull;     // diagnostics only
     __shared__ float4 s_a[2][BL_BATCH + 4];         // A, B, C, Lu
     __shared__ float4 s_b[2][BL_BATCH + 4];         // Lv, K, red, green
     __shared__ float2 s_c[2][BL_BATCH + 4];         // blue, max(running maximum, FLT_MIN)
     __shared__ uint32_t s_g[2][BL_BATCH];
-    const int tile = chunk_tile[blockIdx.x];
-    const uint32_t sbpair = (uint32_t)chunk_pix0[blockIdx.x];    // a | b << 16, b = 0xFFFF: none
+    const int tile = chunk_tile[chunk_i];
+    const uint32_t sbpair = (uint32_t)chunk_pix0[chunk_i];    // a | b << 16, b = 0xFFFF: none
     const int ix = tile % lay.nx, iy = tile / lay.nx;
     const int x0 = lay.xs[ix], w = lay.ws[ix], y0 = lay.ys[iy], h = lay.hs[iy];
     const int nsbx = (w + 7) >> 3;
@@ -682,7 +689,7 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_dl(Layout lay, const int32_t*
         r2 = rec[4 * (size_t)g_cur + 2];
         gmb = ((const uint32_t*)best_key)[2 * (size_t)g_cur + 1];   // live running maximum
     }
-    uint32_t processed = 0;
+    uint32_t processed = 0, visits = 0;
     for (uint32_t b = start; b < end; b += BL_BATCH) {
         processed = b + BL_BATCH - start;
         if (processed == 16 * BL_BATCH) __builtin_amdgcn_s_setprio(2);
@@ -784,6 +791,7 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_dl(Layout lay, const int32_t*
         constexpr int UF = U / 2;                        // in-step trips: UF entries of each list (same number of exp chains in flight)
         const std::integral_constant<int, UF> nf;
         const std::integral_constant<int, U> nu;
+        visits += (uint32_t)(cnt[0] + cnt[1]);                                       // wave-uniform (diagnostics)
         const int c0 = (cnt[0] + U - 1) / U * U, c1 = (cnt[1] + U - 1) / U * U;      // entries up to the next multiple of U are neutral
         const int cboth = c0 < c1 ? c0 : c1;
         for (int k0 = 0; k0 < cboth; k0 += UF) {
@@ -813,9 +821,15 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_dl(Layout lay, const int32_t*
         }
         if (done[0] && done[1]) break;
     }
-    if (chunk_work && lane == 0) {
-        chunk_work[2 * blockIdx.x] = end - start;
-        chunk_work[2 * blockIdx.x + 1] = processed;
+    if (chunk_work && lane == 0) {                 // diagnostics (+ when and where this wave ran: 100 MHz clock, HW_ID, XCC_ID)
+        uint32_t* cw = chunk_work + 8 * (size_t)chunk_i;
+        cw[0] = end - start;
+        cw[1] = processed;
+        cw[2] = (uint32_t)clk0;
+        cw[3] = (uint32_t)(wall_clock64() - clk0);
+        cw[4] = g2pc_hw_id();
+        cw[5] = g2pc_xcc_id();
+        cw[6] = visits;                              // (Gaussian, sub-block) pairs that survived the cull
     }
     float* out = tilebuf + 3 * (size_t)lay.tile_pix_off[tile];
 #pragma unroll
@@ -1375,7 +1389,7 @@ static Cam to_cam(const G2pcCamera* c) {
 }
 static Layout to_layout(const G2pcTileLayout* l) {
     Layout k;
-    k.nx = l->nx; k.ny = l->ny; k.xs = l->xs; k.ws = l->ws; k.ys = l->ys; k.hs = l->hs;
+    k.nx = l->nx; k.ny = l->ny; k.num_chunks = l->num_chunks; k.xs = l->xs; k.ws = l->ws; k.ys = l->ys; k.hs = l->hs;
     k.tile_seq = l->tile_seq; k.seq_tile = l->seq_tile; k.tile_pix_off = l->tile_pix_off;
     return k;
 }
@@ -1484,8 +1498,9 @@ static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t*
             hipLaunchKernelGGL(k_check_tile_load, dim3(cdiv(T, RA_T), (unsigned)bt.n), dim3(RA_T), 0, s, tile_start, T, max_per_tile, overflow_flag, bt.cs);
     }
     if (phases & 2) {
+        const unsigned chunks_y = layout->num_chunks < 32768 ? (unsigned)layout->num_chunks : 32768u;   // grid.y is 16 bits wide
 #define G2PC_BLEND(...)                                                                                                 \
-    hipLaunchKernelGGL((__VA_ARGS__), dim3((unsigned)layout->num_chunks, (unsigned)bt.n), dim3(BL_T), 0, s, lay, layout->chunk_tile, \
+    hipLaunchKernelGGL((__VA_ARGS__), dim3((unsigned)bt.n, chunks_y, cdiv(layout->num_chunks, chunks_y)), dim3(BL_T), 0, s, lay, layout->chunk_tile, \
                        layout->chunk_pix0, tile_start, blend_list, gmask, (const float4*)fb.rec, best_key,             \
                        ba.camera_slot << 24, ba.t_floor, ba.bg, tilebuf, g_chunk_work, ba.job, bt.cs)
         switch (layout->chunk_subblocks) {
@@ -1652,7 +1667,7 @@ int g2pc_raster_resolve_colours_py(const G2pcTileLayout* layout, int64_t n, cons
     return check_launch("g2pc_raster_resolve_colours_py");
 }
 
-/* diagnostics: when set, the PY blend writes (list length, entries walked) per chunk into u32[2*num_chunks] */
+/* diagnostics: see g2pc.h */
 int g2pc_raster_debug_chunk_work(uint32_t* buf) { g2pc::g_chunk_work = buf; return G2PC_OK; }
 
 /* depth order of the capture-safe camera call: 1 = range-normalised bucket sort + in-LDS bitonic (default), 0 = 4-pass

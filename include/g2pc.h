@@ -358,7 +358,8 @@ int g2pc_set_depth_sort(int bucket);
 /* tuning aid: blend kernel of the python-semantics rasteriser for 2 sub-blocks per wave: 1 = dual-list (default), 0 = packed */
 int g2pc_set_blend_variant(int variant);
 int g2pc_raster_rebase_keys(unsigned long long* best_key, int64_t n, void* stream);
-/* diagnostics: when non-NULL, the PY blend records (tile list length, entries walked) per chunk in u32[2*num_chunks] */
+/* diagnostics: when non-NULL, the PY blend records per chunk, in u32[8*num_chunks] (batch 1): [0] tile list length, [1] entries
+ * walked; the dual-list kernel also [2] start and [3] duration on the 100 MHz wall clock, [4] HW_ID, [5] XCC_ID of its wave, [6] (Gaussian, sub-block) visits after the cull */
 int g2pc_raster_debug_chunk_work(uint32_t* buf);
 /* --- native-rasteriser ("cuda") semantics: _C.rasterize_gaussians (rasterize_points.h:18-41) ----------------------
  * Deterministic spec of SURVEY.md §8(a.5): 16x16 tiles, near cull z_view <= 0.2, radius ceil(3 sqrt(lambda_max)),

@@ -391,3 +391,5 @@ static inline int __builtin_amdgcn_readlane(int v, int lane) {
     return (int)(uint32_t)t[lane & 63];
 }
 static inline void __builtin_amdgcn_s_setprio(int) {}
+static inline unsigned __builtin_amdgcn_s_getreg(int) { return 0u; }
+static inline unsigned long long wall_clock64() { return 0ull; }
