@@ -28,6 +28,7 @@
 #define __shared__ static
 #define __constant__ static const
 #define G2PC_PIN(x) ((void)0)
+#define G2PC_PIN_S(x) ((void)0)
 #define __launch_bounds__(...)
 #define __restrict__ __restrict
 
@@ -340,8 +341,15 @@ static inline unsigned atomicAdd(unsigned* p, int v) { unsigned o = *p; *p = o +
 template <typename T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
 template <typename T> static inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <typename T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
+template <typename T> static inline T atomicSub(T* p, T v) { T o = *p; *p = o - v; return o; }
+template <typename T> static inline T atomicAnd(T* p, T v) { T o = *p; *p = o & v; return o; }
 template <typename T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 template <typename T> static inline T atomicCAS(T* p, T c, T v) { T o = *p; if (o == c) *p = v; return o; }
+
+// scoped atomics (single threaded emulation: plain accesses)
+#define __HIP_MEMORY_SCOPE_AGENT 4
+template <typename T> static inline T __hip_atomic_load(const T* p, int, int) { return *p; }
+template <typename T, typename V> static inline void __hip_atomic_store(T* p, V v, int, int) { *p = (T)v; }
 
 // ---- math ----
 #define __expf(x) expf(x)
@@ -371,7 +379,7 @@ using std::min;
 static inline void __builtin_amdgcn_fence(int, const char*) {}
 static inline void __builtin_amdgcn_wave_barrier() { hipemu::wave_barrier(); }
 
-// DPP / readlane emulation (only the controls g2pc uses: row_shr:n, row_bcast:15, row_bcast:31)
+// DPP / readlane emulation (only the controls g2pc uses: quad_perm, row_shr:n, row_bcast:15, row_bcast:31)
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
     unsigned l = hipemu::S().cur & 63;
     uint64_t act = 0;
@@ -379,7 +387,8 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int ro
     unsigned row = l >> 4, bank = (l & 15) >> 2;
     if (!((row_mask >> row) & 1) || !((bank_mask >> bank) & 1)) return old;
     int j = -1;
-    if (ctrl >= 0x111 && ctrl <= 0x11F) { int n = ctrl - 0x110; if ((int)(l & 15) >= n) j = (int)l - n; }
+    if (ctrl >= 0 && ctrl <= 0xFF) j = (int)((l & ~3u) | ((unsigned)(ctrl >> (2 * (l & 3))) & 3u));      // quad_perm
+    else if (ctrl >= 0x111 && ctrl <= 0x11F) { int n = ctrl - 0x110; if ((int)(l & 15) >= n) j = (int)l - n; }
     else if (ctrl == 0x142) { if (row >= 1) j = (int)(16 * (row - 1) + 15); }
     else if (ctrl == 0x143) { if (row >= 2) j = 31; }
     else { fprintf(stderr, "hipemu: unsupported dpp ctrl 0x%x\n", ctrl); abort(); }

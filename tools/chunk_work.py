@@ -17,7 +17,12 @@ NCAM = int(os.environ.get("CHUNK_WORK_CAMERAS", "6"))
 sc = make_scene(1_000_000, 1237, device=dev)
 G = Gaussians(sc.xyz, sc.scales, sc.rots, sc.colours, sc.opacities)
 tr, intr = make_cameras(50)
-gauss_render.PIPELINE_STREAMS = 1                     # one camera at a time: the clocks of one launch alone on the device
+# one camera at a time: the clocks of one launch alone on the device.  CHUNK_WORK_PIPELINE=1: through the batched camera call
+# (the per-camera blend plan: longest-list-first order, hand-over of long walks), flushed after every camera; otherwise the
+# two-call path (static chunk order, no hand-over)
+PIPE = os.environ.get("CHUNK_WORK_PIPELINE", "0") == "1"
+gauss_render.PIPELINE_STREAMS = 2 if PIPE else 1
+gauss_render.CAMERA_BATCH = 1
 R = gauss_render.get_renderer("python", G.xyz, G.opacities.unsqueeze(1), G.colours, G.covariances, visible_gaussian_threshold=0.05)
 names = sorted(tr)[:NCAM]
 q = lambda a: [int(np.percentile(a, p)) for p in (50, 90, 99, 99.9, 100)]
@@ -32,6 +37,7 @@ for rep in range(2):                                  # the first pass warms the
         torch.cuda.synchronize()
         nv.PROFILE = {}
         R(cam, return_image=False)
+        R.flush()
         torch.cuda.synchronize()
         prof = {k: round(v[1], 3) for k, v in nv.profile_summary().items()}
         nv.PROFILE = None
@@ -39,6 +45,10 @@ for rep in range(2):                                  # the first pass warms the
             continue
         w = buf.cpu().numpy().astype(np.int64).reshape(-1, 8) & 0xFFFFFFFF
         ln, done, t0, dur, hw, xcc, vis = (w[:, i] for i in range(7))
+        life = w[:, 7] >> 16                           # main walk + the exported quarters this wave ran afterwards (10 ns ticks)
+        exported, quarters = int((w[:, 7] & 1).sum()), int(((w[:, 7] >> 8) & 0xFF).sum())
+        own = dur.copy()
+        dur = np.maximum(dur, life)
         full = (done >= ln) & (ln > 0)
         print(name, "chunks", nchunks, "list len p50/90/99/99.9/max", q(ln), "walked", q(done), "sum walked %.3g" % done.sum(),
               "walked-full chunks", int(full.sum()), prof)
@@ -53,6 +63,8 @@ for rep in range(2):                                  # the first pass warms the
         res = [(int(((t0 <= t) & (t1 > t)).sum())) for t in ts]
         order = np.argsort(-dur)
         rec = {"camera": name, "span_us": round(span, 1), "sum_wave_us": round(wave_us, 1), "simds_seen": nsimd,
+               "exported_chunks": exported, "quarters_run": quarters, "sum_own_walk_us": round(float(own.sum()) * 0.01, 1),
+               "own_walk_us p50/90/99/max": [round(float(np.percentile(own, p)) * 0.01, 1) for p in (50, 90, 99, 100)],
                "mean_resident_waves_per_simd": round(wave_us / span / max(nsimd, 1), 2),
                "dur_us p50/90/99/99.9/max": [round(x * 0.01, 1) for x in q(dur)],
                "start_us p50/90/99/max": [round(float(np.percentile(t0, p)) * 0.01, 1) for p in (50, 90, 99, 100)],
