@@ -6,10 +6,6 @@
 #ifndef G2PC_PIN
 #define G2PC_PIN(x) asm volatile("" : "+v"(x))
 #endif
-// the same for a wave-uniform value in a scalar register: what is computed from it afterwards stays behind this point
-#ifndef G2PC_PIN_S
-#define G2PC_PIN_S(x) asm volatile("" : "+s"(x))
-#endif
 
 namespace g2pc {
 
@@ -55,34 +51,6 @@ __device__ __forceinline__ unsigned wave_min_u32_dpp(unsigned v) {
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 #undef G2PC_DPP_STEP
-
-// quad_perm DPP: every lane reads lane SRC (0..3) of its own group of four -- full rate, no LDS
-template <int SRC> __device__ __forceinline__ float quad_bcast_f32(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), SRC * 0x55, 0xF, 0xF, true));
-}
-// sum over the four lanes of a quad (every lane gets it): quad_perm [1,0,3,2] then [2,3,0,1]
-__device__ __forceinline__ float quad_sum_f32(float v) {
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
-    return v;
-}
-
-// ---- words shared between waves of ONE launch (the work hand-over of the PY blend) -------------------------------
-// Relaxed agent-scope atomics: on gfx950 every such access is performed at the device's point of coherence (sc1), so a
-// word written by a wave on one XCD is what a wave on another XCD reads -- without the L2 write-back / invalidate a
-// release / acquire pair would cost.  Ordering is by hand: coh_stores_complete() between the payload and the word that
-// publishes it; the consumer's payload loads depend on the value it read from the publishing word.
-__device__ __forceinline__ uint32_t coh_load(const uint32_t* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void coh_store(uint32_t* p, uint32_t v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void coh_stores_complete() {
-#if defined(__clang__)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-}
 
 // ---- packed f32 pairs: v_pk_add/mul/fma_f32 retire two IEEE f32 operations per lane per issue slot (the 157 TF
 // vector peak of the part is quoted on them); element-wise results are bit-identical to the scalar instructions.

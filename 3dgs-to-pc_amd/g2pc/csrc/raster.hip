@@ -620,327 +620,32 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_pk(Layout lay, const int32_t*
 // -- five FMAs per pixel instead of seven operations, and the opacity multiply rides in K.  Rounding differs from the
 // reference's order of operations by ~eps * (|exponent| + |A| 50): <= 2e-5 relative in alpha for the sharpest Gaussians
 // the 0.3-pixel dilation admits, ~3e-6 typically (the reference's own dx = pixel - mean carries eps * |mean| already).
-//
-// Scheduling (round 3; profiles/r03u_chunk_clocks.txt): the walks of a camera's 8 192 chunks range from 64 to ~7 000 list
-// entries, a wave alone on its SIMD still needs ~150 cycles per entry (the transmittance recurrence is a dependent chain),
-// so a launch lasted as long as its longest walk and half of all wave-time was spent with < 3 waves per SIMD.  Three
-// measures, all inside the launch:
-//  * k_blend_plan orders every camera's chunks by the length of their tile's list, longest first (the list length bounds
-//    the walk), so what is dispatched last -- into the draining machine -- is short;
-//  * a walk raises its wave's priority as it grows (s_setprio), so the long ones run at lone-wave speed inside the crowd;
-//  * a walk that reaches `split_batches` batches stops there and EXPORTS what is left: the (T, r, g, b) of its pixels go to
-//    memory and each 8x8 sub-block becomes four 16-pixel continuations that waves which have finished their own chunk
-//    claim (work stealing over a per-camera queue; no wave ever waits for another: the exporter claims whatever nobody
-//    took) and run in QUAD mode (blend_quarter): lane = 4 * pixel + slot, the four lanes of a quad evaluate the weights
-//    of four consecutive list entries at once and pass the transmittance down the quad with three DPP broadcasts -- the
-//    same multiplications and subtractions in the same order as the one-entry-at-a-time recurrence, on a quarter of the
-//    dependent instructions.  Eight waves then finish a long walk ~5x sooner than its owner would have.
-// A pixel's transmittance sequence and every contribution >= t_floor are bit-identical with and without the hand-over;
-// colours are summed per quad slot and combined at the end (last-bit differences), and a quarter stops when ITS 16
-// pixels are below the floor rather than the sub-block's 64 (differences < t_floor).
-struct BlendSteal {       // per-camera hand-over state in the camera's arena (arenas cs bytes apart), zeroed by k_blend_plan
-    uint32_t* ctl;        // [0] quarter tickets handed out (ticket t = quarter t % 8 of queue entry t / 8), [1] entries in `queue`
-    uint32_t* queue;      // [num_chunks] chunk + 1 of every export in publication order (0: reserved, not written yet)
-    uint32_t* avail;      // [num_chunks] bit 4 j + k: quarter k of sub-block j is exported and not claimed yet
-    uint32_t* resume;     // [num_chunks] list position (from the tile's first entry) an exported walk stopped at
-    float* state;         // [num_chunks][2][64][4]: (T, r, g, b) of the exported pixels, lane-major as the owner holds them
-    int split_batches;    // 0: no hand-over
-    int min_left;         // ... only when at least this many list entries are left
-    int prio_batches;     // wave priority 1 / 2 / 3 at this many / twice / three times as many batches; 0: none
-    int num_chunks;
-};
-__device__ __forceinline__ BlendSteal steal_at(BlendSteal s, size_t cs, unsigned cam) {
-    s.ctl = seg_at(s.ctl, cs, cam); s.queue = seg_at(s.queue, cs, cam); s.avail = seg_at(s.avail, cs, cam);
-    s.resume = seg_at(s.resume, cs, cam); s.state = seg_at(s.state, cs, cam);
-    return s;
-}
-
-// Everything a wave needs to blend (quarters of) chunks of one camera of the batch, written to the camera's arena by
-// k_blend_plan.  In MEMORY, not in kernel arguments: the main walk of k_blend_py_dl is register-bound (5 waves per SIMD at
-// <= 96 VGPRs, and scalar registers spill into vector ones); only the rare hand-over and the epilogue read this.
-struct BlendCam {
-    Layout lay;
-    const uint32_t* tile_start; const uint32_t* inst_g; const float4* rec;
-    const int32_t* chunk_tile; const int32_t* chunk_pix0;
-    unsigned long long* best_key;
-    const G2pcCameraJob* job;      // this camera's job (slot, floor, background, colour buffer), or nullptr: the values below
-    uint32_t gmask, order_base; float t_floor, bg; float* tilebuf;
-    BlendSteal st;
-};
-
-// The plan of one camera's blend: its chunks in the order "longest tile list first" (tiles still taken eight at a time
-// with their chunks interleaved, so that the chunks of a tile land on one XCD, see g2pc/tiles.py), and the zeroed
-// hand-over words.  One block per camera; T <= 4096 tiles.
-constexpr int PLAN_T = 1024, PLAN_MAX_TILES = 4096;
-__global__ __launch_bounds__(PLAN_T) void k_blend_plan(const uint32_t* __restrict__ tile_start, int T, int num_chunks,
-                                                      const int32_t* __restrict__ chunk_tile,
-                                                      const int32_t* __restrict__ chunk_pix0,
-                                                      const int32_t* __restrict__ chunk_cidx,
-                                                      const int32_t* __restrict__ tile_nchunks,
-                                                      int32_t* __restrict__ dyn_tile, int32_t* __restrict__ dyn_pix0,
-                                                      BlendSteal st, BlendCam cam0, BlendCam* __restrict__ cam_dev, int lpt,
-                                                      size_t chunk_cs, size_t cs) {
-    __shared__ uint32_t s_key[PLAN_MAX_TILES];
-    __shared__ uint16_t s_rank[PLAN_MAX_TILES];
-    __shared__ uint32_t s_base[PLAN_MAX_TILES + 1];       // first chunk position of the tile of rank r
-    __shared__ uint32_t s_wsum[PLAN_T / kWave];
-    tile_start = seg(tile_start, cs); dyn_tile = seg(dyn_tile, cs); dyn_pix0 = seg(dyn_pix0, cs);
-    st = steal_at(st, cs, blockIdx.y);
-    cam_dev = seg(cam_dev, cs);
-    const int tid = (int)threadIdx.x;
-    if (tid == 0) {                          // this camera's copy of what the blend's epilogue reads from memory
-        cam0.tile_start = seg(cam0.tile_start, cs); cam0.inst_g = seg(cam0.inst_g, cs); cam0.rec = seg(cam0.rec, cs);
-        cam0.chunk_tile = seg(cam0.chunk_tile, chunk_cs); cam0.chunk_pix0 = seg(cam0.chunk_pix0, chunk_cs);
-        if (cam0.job) cam0.job += blockIdx.y;
-        cam0.st = st;
-        *cam_dev = cam0;
-    }
-    if (st.split_batches) {
-        for (int i = tid; i < num_chunks; i += PLAN_T) { st.queue[i] = 0u; st.avail[i] = 0u; }
-        if (tid < 2) st.ctl[tid] = 0u;
-    }
-    if (!lpt) return;
-    for (int t = tid; t < T; t += PLAN_T) {
-        uint32_t len = tile_start[t + 1] - tile_start[t];
-        if (len > 0xFFFFFu) len = 0xFFFFFu;
-        s_key[t] = (tile_nchunks[t] > 0 ? (len << 12) : 0u) | (uint32_t)(PLAN_MAX_TILES - 1 - t);     // unique; ties: lower tile first
-    }
-    __syncthreads();
-    for (int t = tid; t < T; t += PLAN_T) {
-        const uint32_t k = s_key[t];
-        int r = 0;
-        for (int o = 0; o < T; ++o) r += s_key[o] > k ? 1 : 0;
-        s_rank[t] = (uint16_t)r;
-    }
-    __syncthreads();
-    // chunks of the tile of rank r -> s_base[r + 1] (scattered), then an inclusive scan in place
-    if (tid == 0) s_base[0] = 0u;
-    for (int t = tid; t < T; t += PLAN_T) s_base[(int)s_rank[t] + 1] = (uint32_t)tile_nchunks[t];
-    __syncthreads();
-    {
-        constexpr int PER = PLAN_MAX_TILES / PLAN_T;                   // 4 consecutive ranks per thread
-        uint32_t v[PER], sum = 0;
-#pragma unroll
-        for (int k = 0; k < PER; ++k) { const int r = tid * PER + k; v[k] = r < T ? s_base[r + 1] : 0u; sum += v[k]; }
-        const uint32_t incl = wave_incl_scan_u32(sum);
-        if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
-        __syncthreads();
-        uint32_t off = incl - sum;
-        for (int w = 0; w < (tid >> 6); ++w) off += s_wsum[w];
-#pragma unroll
-        for (int k = 0; k < PER; ++k) { const int r = tid * PER + k; off += v[k]; if (r < T) s_base[r + 1] = off; }
-    }
-    __syncthreads();
-    for (int i = tid; i < num_chunks; i += PLAN_T) {
-        const int t = chunk_tile[i], c = chunk_cidx[i];
-        const int r = (int)s_rank[t], g0 = r & ~7;
-        uint32_t pos = s_base[g0];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int rr = g0 + k;
-            if (rr < T) {
-                const int nk = (int)(s_base[rr + 1] - s_base[rr]);
-                pos += (uint32_t)(nk < c ? nk : c);
-                if (k < (r & 7) && nk > c) ++pos;
-            }
-        }
-        dyn_tile[pos] = t;
-        dyn_pix0[pos] = chunk_pix0[i];
-    }
-}
-
-// One exported quarter of a sub-block (16 pixels: rows 2 kq, 2 kq + 1 of sub-block j of `chunk_i`), from the list position
-// its owner stopped at to the end of the list, in quad mode.  Lane = 4 p + q: p = pixel (p % 8, 2 kq + p / 8), q = slot.
-template <typename LdsA, typename LdsC, typename LdsG>
-__device__ __forceinline__ void blend_quarter(const BlendCam* __restrict__ M, uint32_t chunk_i, int j, int kq,
-                                              LdsA& s_a, LdsA& s_b, LdsC& s_c, LdsG& s_g) {
-    BlendCam C = *M;
-    if (C.job) {
-        C.order_base = C.job->camera_slot << 24; C.t_floor = C.job->t_floor; C.bg = C.job->cam.bg[0];
-        const unsigned long long tb = ((unsigned long long)C.job->tilebuf_hi << 32) | C.job->tilebuf_lo;
-        if (tb) C.tilebuf = (float*)tb;        // one colour buffer per camera (deferred colour resolve)
-    }
-    const Layout& lay = C.lay;
-    const uint32_t gmask = C.gmask;
-    unsigned long long* __restrict__ best_key = C.best_key;
-    const unsigned lane = threadIdx.x;
-    const int q = (int)(lane & 3u), p = (int)(lane >> 2);
-    const int tile = C.chunk_tile[chunk_i];
-    const uint32_t sbpair = (uint32_t)C.chunk_pix0[chunk_i];
-    const int sb = (int)((sbpair >> (16 * j)) & 0xFFFFu);
-    const int ix = tile % lay.nx, iy = tile / lay.nx;
-    const int x0 = lay.xs[ix], w = lay.ws[ix], y0 = lay.ys[iy], h = lay.hs[iy];
-    const int nsbx = (w + 7) >> 3;
-    const int sx = (sb % nsbx) * 8, sy = (sb / nsbx) * 8;
-    const int lx = p & 7, ly = 2 * kq + (p >> 3);
-    if (sy + 2 * kq >= h) return;                          // the whole quarter lies below the tile (wave-uniform)
-    const int x = sx + lx, y = sy + ly;
-    const bool valid = (x < w) && (y < h);
-    const int pix = valid ? y * w + x : -1;
-    const float uu = (float)lx - 3.5f, vv = (float)ly - 3.5f;
-    const float ox = (float)(x0 + sx) + 3.5f, oy = (float)(y0 + sy) + 3.5f;        // the sub-block's centre, as its owner used
-    const float rx0 = (float)(x0 + sx), rx1 = (float)(x0 + (sx + 7 > w - 1 ? w - 1 : sx + 7));
-    const float ry0 = (float)(y0 + sy + 2 * kq);
-    const float ry1 = (float)(y0 + (sy + 2 * kq + 1 > h - 1 ? h - 1 : sy + 2 * kq + 1));
-    const uint32_t order_tile = C.order_base | ((uint32_t)lay.tile_seq[tile] << 12);
-    const uint32_t* sp = (const uint32_t*)(C.st.state + ((size_t)chunk_i * 128 + (size_t)j * 64 + (size_t)kq * 16 + (size_t)p) * 4);
-    float T = __uint_as_float(coh_load(sp));
-    float cr = 0.f, cg = 0.f, cb = 0.f;
-    if (q == 0) { cr = __uint_as_float(coh_load(sp + 1)); cg = __uint_as_float(coh_load(sp + 2)); cb = __uint_as_float(coh_load(sp + 3)); }
-    const uint32_t start = C.tile_start[tile], end = C.tile_start[tile + 1];
-    const uint32_t b0 = start + coh_load(C.st.resume + chunk_i);
-    const float t_floor = C.t_floor;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    __builtin_amdgcn_s_setprio(3);
-    if (!(__all(T <= t_floor ? 1 : 0))) {
-        uint32_t g_cur = 0, g_nxt = 0;
-        bool v_cur = (b0 + lane) < end, v_nxt = (b0 + BL_BATCH + lane) < end;
-        if (v_cur) g_cur = C.inst_g[b0 + lane] & gmask;
-        if (v_nxt) g_nxt = C.inst_g[b0 + BL_BATCH + lane] & gmask;
-        float4 r0 = zero4, r1 = zero4, r2 = zero4;
-        uint32_t gmb = 0x7F000000u;
-        if (v_cur) {
-            r0 = C.rec[4 * (size_t)g_cur]; r1 = C.rec[4 * (size_t)g_cur + 1]; r2 = C.rec[4 * (size_t)g_cur + 2];
-            gmb = ((const uint32_t*)best_key)[2 * (size_t)g_cur + 1];
-        }
-        for (uint32_t b = b0; b < end; b += BL_BATCH) {
-            wave_sync();
-            const bool keep = v_cur && rect_may_touch(r0.x, r0.y, r0.z, r0.w, r1.x, r1.z, r1.w, r2.w, rx0, rx1, ry0, ry1);
-            const unsigned long long kept = __ballot(keep ? 1 : 0);
-            const int cnt = __popcll(kept);
-            if (keep) {
-                const int pos = __popcll(kept & ((1ull << lane) - 1ull));
-                const float mx = r0.x - ox, my = r0.y - oy;
-                const float A = r0.z, B = r0.w, Cc = r1.x;
-                const float h1 = fmaf(A, mx, B * my);
-                const float Lu = -(fmaf(A, mx, h1)), Lv = -(fmaf(2.0f * Cc, my, B * mx));
-                const float K = fmaf(h1, mx, fmaf(Cc * my, my, -25.5f - r2.w));
-                s_a[0][pos] = make_float4(A, B, Cc, Lu);
-                s_b[0][pos] = make_float4(Lv, K, r2.x, r2.y);
-                s_c[0][pos] = make_float2(r2.z, fmaxf(__uint_as_float(gmb), 1.17549435e-38f));
-                s_g[0][pos] = g_cur;
-            }
-            if (lane < 4u) {                                 // a trip reads up to 3 entries past cnt: alpha = 0 ones
-                s_a[0][cnt + lane] = zero4;
-                s_b[0][cnt + lane] = make_float4(0.f, -INFINITY, 0.f, 0.f);
-                s_c[0][cnt + lane] = make_float2(0.f, 1.17549435e-38f);
-            }
-            g_cur = g_nxt;
-            v_cur = v_nxt;
-            v_nxt = (b + 2 * BL_BATCH + lane) < end;
-            g_nxt = 0;
-            if (v_nxt) g_nxt = C.inst_g[b + 2 * BL_BATCH + lane] & gmask;
-            r0 = zero4; r1 = zero4; r2 = zero4; gmb = 0x7F000000u;
-            if (v_cur) {
-                r0 = C.rec[4 * (size_t)g_cur]; r1 = C.rec[4 * (size_t)g_cur + 1]; r2 = C.rec[4 * (size_t)g_cur + 2];
-                gmb = ((const uint32_t*)best_key)[2 * (size_t)g_cur + 1];
-            }
-            wave_sync();
-            for (int k0 = 0; k0 < cnt; k0 += 4) {
-                const float4 a = s_a[0][k0 + q];
-                const float4 qb = s_b[0][k0 + q];
-                const float2 qc = s_c[0][k0 + q];
-                float t1 = fmaf(a.x, uu, a.w);
-                t1 = fmaf(a.y, vv, t1);
-                const float t2 = fmaf(a.z, vv, qb.x);
-                float pw = fmaf(uu, t1, qb.y);
-                pw = fmaf(vv, t2, pw);
-                const float alpha = fminf(__builtin_amdgcn_exp2f(pw), 0.99f);
-                // the recurrence of the four entries, passed down the quad: slot s is final after step s
-                float c = T * alpha, Tn = T - c, tb;
-                tb = quad_bcast_f32<0>(Tn); if (q >= 1) { c = tb * alpha; Tn = tb - c; }
-                tb = quad_bcast_f32<1>(Tn); if (q >= 2) { c = tb * alpha; Tn = tb - c; }
-                tb = quad_bcast_f32<2>(Tn); if (q >= 3) { c = tb * alpha; Tn = tb - c; }
-                T = quad_bcast_f32<3>(Tn);
-                cr = fmaf(c, qb.z, cr);
-                cg = fmaf(c, qb.w, cg);
-                cb = fmaf(c, qc.x, cb);
-                if (__any(c >= qc.y ? 1 : 0)) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const bool mine = q == u;
-                        if (__any((mine && c >= qc.y) ? 1 : 0)) {
-                            const uint32_t bits = mine ? __float_as_uint(c) : 0u;
-                            const uint32_t m = wave_max_u32_dpp(bits);
-                            // p grows with the pixel index inside the quarter: the lowest lane at the maximum owns it
-                            const unsigned long long at_max = __ballot((mine && bits == m) ? 1 : 0);
-                            const uint32_t pm = (uint32_t)__builtin_amdgcn_readlane(pix, __ffsll(at_max) - 1);
-                            if (lane == 0) {
-                                unsigned long long key = ((unsigned long long)m << 32) | (unsigned long long)(uint32_t)(~(order_tile | pm));
-                                atomicMax(&best_key[s_g[0][k0 + u]], key);
-                            }
-                        }
-                    }
-                }
-            }
-            if (__all(T <= t_floor ? 1 : 0)) break;
-        }
-    }
-    __builtin_amdgcn_s_setprio(0);
-    cr = quad_sum_f32(cr); cg = quad_sum_f32(cg); cb = quad_sum_f32(cb);
-    if (q == 0 && pix >= 0) {
-        float* out = C.tilebuf + 3 * (size_t)lay.tile_pix_off[tile];
-        out[3 * (size_t)pix + 0] = fmaf(T, C.bg, cr);
-        out[3 * (size_t)pix + 1] = fmaf(T, C.bg, cg);
-        out[3 * (size_t)pix + 2] = fmaf(T, C.bg, cb);
-    }
-}
-
-// pref == 8: claims and runs exported quarters of `chunk` until none is left unclaimed (the exporter itself).  pref < 8 (a
-// ticket): claims ONE quarter of the chunk -- the ticket's own if it is still there, else any other -- and runs it.
-template <typename LdsA, typename LdsC, typename LdsG>
-__device__ __forceinline__ void blend_drain_chunk(const BlendCam* __restrict__ M, uint32_t chunk, uint32_t pref,
-                                                  LdsA& s_a, LdsA& s_b, LdsC& s_c, LdsG& s_g, uint32_t& ran) {
-    uint32_t* avail = M->st.avail + chunk;
-    for (;;) {
-        uint32_t bit = 0xFFFFFFFFu;
-        if (threadIdx.x == 0) {
-            uint32_t a = coh_load(avail);
-            while (a) {                                         // (a failed claim returns the fresh mask: no re-load)
-                const uint32_t k = (pref < 8u && ((a >> pref) & 1u)) ? pref : (uint32_t)__ffs(a) - 1u;
-                const uint32_t old = atomicAnd(avail, ~(1u << k));
-                if ((old >> k) & 1u) { bit = k; break; }
-                a = old & ~(1u << k);
-            }
-        }
-        bit = (uint32_t)__builtin_amdgcn_readfirstlane((int)bit);
-        if (bit == 0xFFFFFFFFu) return;
-        blend_quarter(M, chunk, (int)(bit >> 2), (int)(bit & 3u), s_a, s_b, s_c, s_g);
-        ++ran;
-        if (pref < 8u) return;
-    }
-}
-
 template <int U>
-__global__ __launch_bounds__(BL_T) __attribute__((amdgpu_waves_per_eu(5))) void k_blend_py_dl(Layout lay, const int32_t* __restrict__ chunk_tile,
-                                                     const int32_t* __restrict__ chunk_pix0, size_t chunk_cs,
+__global__ __launch_bounds__(BL_T) void k_blend_py_dl(Layout lay, const int32_t* __restrict__ chunk_tile,
+                                                     const int32_t* __restrict__ chunk_pix0,
                                                      const uint32_t* __restrict__ tile_start,
                                                      const uint32_t* __restrict__ inst_g, uint32_t gmask,
                                                      const float4* __restrict__ rec,
                                                      unsigned long long* __restrict__ best_key, uint32_t order_base,
                                                      float t_floor, float bg, float* __restrict__ tilebuf,
                                                      uint32_t* __restrict__ chunk_work,
-                                                     const G2pcCameraJob* __restrict__ job, size_t cs,
-                                                     const BlendCam* __restrict__ plan_dev, int prio_b) {
-    // plan_dev: camera 0's BlendCam in its arena (written by k_blend_plan; nullptr = no hand-over)
+                                                     const G2pcCameraJob* __restrict__ job, size_t cs) {
     const unsigned chunk_i = blockIdx.z * gridDim.y + blockIdx.y;       // the blends: camera = blockIdx.x, chunk in (y, z)
     if ((int)chunk_i >= lay.num_chunks) return;
-    {   // this wave's camera (plain locals: the main walk must not carry the hand-over pointers in registers)
-        const unsigned cam = blockIdx.x;
-        tile_start = seg_at(tile_start, cs, cam); inst_g = seg_at(inst_g, cs, cam); rec = seg_at(rec, cs, cam);
-        if (job) {
-            const G2pcCameraJob* jb = job + cam;
-            order_base = jb->camera_slot << 24; t_floor = jb->t_floor; bg = jb->cam.bg[0];
-        }
+    tile_start = seg_at(tile_start, cs, blockIdx.x); inst_g = seg_at(inst_g, cs, blockIdx.x); rec = seg_at(rec, cs, blockIdx.x);
+    if (job) {
+        job += blockIdx.x;
+        order_base = job->camera_slot << 24; t_floor = job->t_floor; bg = job->cam.bg[0];
+        const unsigned long long tb = ((unsigned long long)job->tilebuf_hi << 32) | job->tilebuf_lo;
+        if (tb) tilebuf = (float*)tb;              // one colour buffer per camera (deferred colour resolve)
     }
     const unsigned long long clk0 = chunk_work ? wall_clock64() : 0ull;     // diagnostics only
     __shared__ float4 s_a[2][BL_BATCH + 4];         // A, B, C, Lu
     __shared__ float4 s_b[2][BL_BATCH + 4];         // Lv, K, red, green
     __shared__ float2 s_c[2][BL_BATCH + 4];         // blue, max(running maximum, FLT_MIN)
     __shared__ uint32_t s_g[2][BL_BATCH];
-    // (readfirstlane: wave-uniform by construction -- everything derived from them then lives in scalar registers)
-    const int tile = __builtin_amdgcn_readfirstlane(seg_at(chunk_tile, chunk_cs, blockIdx.x)[chunk_i]);
-    const uint32_t sbpair = (uint32_t)__builtin_amdgcn_readfirstlane(seg_at(chunk_pix0, chunk_cs, blockIdx.x)[chunk_i]);    // a | b << 16, b = 0xFFFF: none
+    const int tile = chunk_tile[chunk_i];
+    const uint32_t sbpair = (uint32_t)chunk_pix0[chunk_i];    // a | b << 16, b = 0xFFFF: none
     const int ix = tile % lay.nx, iy = tile / lay.nx;
     const int x0 = lay.xs[ix], w = lay.ws[ix], y0 = lay.ys[iy], h = lay.hs[iy];
     const int nsbx = (w + 7) >> 3;
@@ -949,10 +654,8 @@ __global__ __launch_bounds__(BL_T) __attribute__((amdgpu_waves_per_eu(5))) void 
     const int lx = lane & 7, ly = lane >> 3;
     const float uu = (float)lx - 3.5f, vv = (float)ly - 3.5f;
 
-    // the sub-blocks' geometry is wave-uniform: kept as integers (scalar registers) and turned into floats where a batch is
-    // staged -- as floats they would sit in eight vector registers for the whole walk (no scalar float unit on gfx950)
-    int pix[2], gx0[2], gy0[2], gx1[2], gy1[2];
-    float T[2], cr[2], cg[2], cb[2];
+    int pix[2];
+    float T[2], cr[2], cg[2], cb[2], ox[2], oy[2], rx1[2], ry1[2];
     bool done[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -964,10 +667,10 @@ __global__ __launch_bounds__(BL_T) __attribute__((amdgpu_waves_per_eu(5))) void 
         pix[j] = valid ? y * w + x : -1;
         T[j] = valid ? 1.0f : 0.0f;
         cr[j] = cg[j] = cb[j] = 0.0f;
-        gx0[j] = __builtin_amdgcn_readfirstlane(x0 + sx);
-        gy0[j] = __builtin_amdgcn_readfirstlane(y0 + sy);
-        gx1[j] = __builtin_amdgcn_readfirstlane(x0 + (sx + 7 > w - 1 ? w - 1 : sx + 7));     // the cull rectangle stops at the tile's edge
-        gy1[j] = __builtin_amdgcn_readfirstlane(y0 + (sy + 7 > h - 1 ? h - 1 : sy + 7));
+        ox[j] = (float)(x0 + sx) + 3.5f;
+        oy[j] = (float)(y0 + sy) + 3.5f;
+        rx1[j] = (float)(x0 + (sx + 7 > w - 1 ? w - 1 : sx + 7));   // the cull rectangle stops at the tile's edge
+        ry1[j] = (float)(y0 + (sy + 7 > h - 1 ? h - 1 : sy + 7));
         done[j] = !present;
     }
     const bool cull = t_floor > 0.0f;        // t_floor = 0 is the to-the-letter mode: nothing is skipped
@@ -986,39 +689,26 @@ __global__ __launch_bounds__(BL_T) __attribute__((amdgpu_waves_per_eu(5))) void 
         r2 = rec[4 * (size_t)g_cur + 2];
         gmb = ((const uint32_t*)best_key)[2 * (size_t)g_cur + 1];   // live running maximum
     }
-    uint32_t processed = 0, visits = 0, exported = 0, ran = 0, resume_at = 0xFFFFFFFFu;
-    const BlendCam* own_plan = plan_dev ? seg_at(plan_dev, cs, blockIdx.x) : nullptr;
-    const int split_b = (own_plan && cull) ? own_plan->st.split_batches : 0;
-    const uint32_t min_left = own_plan ? (uint32_t)own_plan->st.min_left : 0u;
-    int nb = 0;
+    uint32_t processed = 0, visits = 0;
     for (uint32_t b = start; b < end; b += BL_BATCH) {
-        if (split_b && nb == split_b && end - b >= min_left) { resume_at = b - start; break; }    // hand-over, below
-        ++nb;
         processed = b + BL_BATCH - start;
-        if (prio_b) {
-            if (nb == prio_b) __builtin_amdgcn_s_setprio(1);
-            else if (nb == 2 * prio_b) __builtin_amdgcn_s_setprio(2);
-            else if (nb == 3 * prio_b) __builtin_amdgcn_s_setprio(3);
-        } else if (processed == 16 * BL_BATCH) __builtin_amdgcn_s_setprio(2);
+        if (processed == 16 * BL_BATCH) __builtin_amdgcn_s_setprio(2);
         wave_sync();
         int cnt[2] = {0, 0};
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             if (done[j]) continue;                          // wave-uniform
-            int ax0 = gx0[j], ay0 = gy0[j], ax1 = gx1[j], ay1 = gy1[j];
-            G2PC_PIN_S(ax0); G2PC_PIN_S(ay0); G2PC_PIN_S(ax1); G2PC_PIN_S(ay1);     // (converted here, every batch: not hoisted)
-            const float fx0 = (float)ax0, fy0 = (float)ay0, oxj = fx0 + 3.5f, oyj = fy0 + 3.5f;
-            const bool keep = v_cur && (!cull || chunk_may_touch(r0, r1, r2.w, fx0, (float)ax1, fy0, (float)ay1));
+            const bool keep = v_cur && (!cull || chunk_may_touch(r0, r1, r2.w, ox[j] - 3.5f, rx1[j], oy[j] - 3.5f, ry1[j]));
             const unsigned long long kept = __ballot(keep ? 1 : 0);
             cnt[j] = __popcll(kept);
             if (keep) {
                 const int pos = __popcll(kept & ((1ull << lane) - 1ull));
-                const float mx = r0.x - oxj, my = r0.y - oyj;
-                const float A = r0.z, B = r0.w, Cc = r1.x;
+                const float mx = r0.x - ox[j], my = r0.y - oy[j];
+                const float A = r0.z, B = r0.w, C = r1.x;
                 const float h1 = fmaf(A, mx, B * my);                                     // A mx + B my
-                const float Lu = -(fmaf(A, mx, h1)), Lv = -(fmaf(2.0f * Cc, my, B * mx));
-                const float K = fmaf(h1, mx, fmaf(Cc * my, my, -25.5f - r2.w));           // ... + log2(opacity)
-                s_a[j][pos] = make_float4(A, B, Cc, Lu);
+                const float Lu = -(fmaf(A, mx, h1)), Lv = -(fmaf(2.0f * C, my, B * mx));
+                const float K = fmaf(h1, mx, fmaf(C * my, my, -25.5f - r2.w));            // ... + log2(opacity)
+                s_a[j][pos] = make_float4(A, B, C, Lu);
                 s_b[j][pos] = make_float4(Lv, K, r2.x, r2.y);
                 s_c[j][pos] = make_float2(r2.z, fmaxf(__uint_as_float(gmb), 1.17549435e-38f));
                 s_g[j][pos] = g_cur;
@@ -1131,31 +821,15 @@ __global__ __launch_bounds__(BL_T) __attribute__((amdgpu_waves_per_eu(5))) void 
         }
         if (done[0] && done[1]) break;
     }
-    if (resume_at != 0xFFFFFFFFu) {
-        // hand the rest of the walk over: the pixels' state, where the walk stands, then the word that publishes both
-        const BlendSteal st = own_plan->st;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (done[j]) continue;                          // wave-uniform
-            uint32_t* sp = (uint32_t*)(st.state + ((size_t)chunk_i * 128 + (size_t)j * 64 + lane) * 4);
-            coh_store(sp + 0, __float_as_uint(T[j])); coh_store(sp + 1, __float_as_uint(cr[j]));
-            coh_store(sp + 2, __float_as_uint(cg[j])); coh_store(sp + 3, __float_as_uint(cb[j]));
-            exported |= 0xFu << (4 * j);
-            pix[j] = -1;                                    // written by the continuations
-        }
-        if (lane == 0) coh_store(st.resume + chunk_i, resume_at);
-        coh_stores_complete();
-        if (lane == 0) {
-            atomicOr(st.avail + chunk_i, exported);
-            coh_stores_complete();
-            const uint32_t t = atomicAdd(st.ctl + 1, 1u);
-            if (t < (uint32_t)st.num_chunks) coh_store(st.queue + t, chunk_i + 1u);
-        }
-    }
-    if (job) {
-        const G2pcCameraJob* jb = job + blockIdx.x;
-        const unsigned long long tb = ((unsigned long long)jb->tilebuf_hi << 32) | jb->tilebuf_lo;
-        if (tb) tilebuf = (float*)tb;              // one colour buffer per camera (deferred colour resolve)
+    if (chunk_work && lane == 0) {                 // diagnostics (+ when and where this wave ran: 100 MHz clock, HW_ID, XCC_ID)
+        uint32_t* cw = chunk_work + 8 * (size_t)chunk_i;
+        cw[0] = end - start;
+        cw[1] = processed;
+        cw[2] = (uint32_t)clk0;
+        cw[3] = (uint32_t)(wall_clock64() - clk0);
+        cw[4] = g2pc_hw_id();
+        cw[5] = g2pc_xcc_id();
+        cw[6] = visits;                              // (Gaussian, sub-block) pairs that survived the cull
     }
     float* out = tilebuf + 3 * (size_t)lay.tile_pix_off[tile];
 #pragma unroll
@@ -1165,59 +839,6 @@ __global__ __launch_bounds__(BL_T) __attribute__((amdgpu_waves_per_eu(5))) void 
             out[3 * (size_t)pix[j] + 1] = fmaf(T[j], bg, cg[j]);
             out[3 * (size_t)pix[j] + 2] = fmaf(T[j], bg, cb[j]);
         }
-    }
-    const uint32_t own_us = chunk_work ? (uint32_t)(wall_clock64() - clk0) : 0u;
-    if (split_b) {
-        // A wave that is through with its own chunk looks for exported quarters: its own first (nobody may have taken them),
-        // then what the queues of the batch's cameras offer.  Nothing here waits for another wave.
-        __builtin_amdgcn_s_setprio(0);
-        wave_sync();                                            // the lists in LDS are free
-        for (unsigned dc = 0; dc < gridDim.x; ++dc) {
-            const unsigned cam = (blockIdx.x + dc) % gridDim.x;
-            const BlendCam* S = seg_at(plan_dev, cs, cam);
-            if (dc == 0 && exported) blend_drain_chunk(S, chunk_i, 8u, s_a, s_b, s_c, s_g, ran);
-            uint32_t* ctl = S->st.ctl;
-            const uint32_t* queue = S->st.queue;
-            const uint32_t qcap = (uint32_t)S->st.num_chunks;
-            // Tickets: ctl[0] counts the quarter tickets handed out, ctl[1] the queue entries published; ticket t stands for
-            // quarter t % 8 of entry t / 8.  ONE atomic add per steal and no shared cursor to fight over: every wave that
-            // asks gets another quarter.  A ticket beyond the published entries is handed back (the counter may then skip
-            // or repeat a ticket: harmless, a quarter nobody stole is run by its exporter).
-            for (;;) {
-                uint32_t e = 0, pref = 0;
-                if (lane == 0) {
-                    const unsigned long long ht = __hip_atomic_load((const unsigned long long*)ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    uint32_t tl = (uint32_t)(ht >> 32);
-                    if (tl > qcap) tl = qcap;
-                    if ((uint32_t)ht < 8u * tl) {
-                        const uint32_t t = atomicAdd(ctl, 1u);
-                        if (t < 8u * tl) {
-                            e = coh_load(queue + (t >> 3));      // 0: reserved, not written yet -- its exporter looks after it
-                            pref = t & 7u;
-                            if (e == 0) e = 0xFFFFFFFFu;         // ... on to the next ticket
-                        } else {
-                            atomicSub(ctl, 1u);
-                        }
-                    }
-                }
-                e = (uint32_t)__builtin_amdgcn_readfirstlane((int)e);
-                if (e == 0) break;
-                if (e == 0xFFFFFFFFu) continue;
-                pref = (uint32_t)__builtin_amdgcn_readfirstlane((int)pref);
-                blend_drain_chunk(S, e - 1u, pref, s_a, s_b, s_c, s_g, ran);
-            }
-        }
-    }
-    if (chunk_work && lane == 0) {                 // diagnostics (+ when and where this wave ran: 100 MHz clock, HW_ID, XCC_ID)
-        uint32_t* cw = chunk_work + 8 * (size_t)chunk_i;
-        cw[0] = end - start;
-        cw[1] = processed;
-        cw[2] = (uint32_t)clk0;
-        cw[3] = own_us;
-        cw[4] = g2pc_hw_id();
-        cw[5] = g2pc_xcc_id();
-        cw[6] = visits;                              // (Gaussian, sub-block) pairs that survived the cull
-        cw[7] = (exported ? 1u : 0u) | (ran << 8) | ((uint32_t)(wall_clock64() - clk0) << 16);   // exported, quarters run, total life
     }
 }
 
@@ -1783,13 +1404,6 @@ static size_t py_front_ws(long n) {
 }
 static int g_blend_variant = 1;               // 2 sub-blocks per wave: 1 = dual-list kernel (k_blend_py_dl), 0 = packed kernel (k_blend_py_pk)
 static int g_depth_bucket_sort = 1;           // captured camera path: 1 = bucket sort of the depth keys, 0 = radix (g2pc_set_depth_sort)
-// scheduling of the dual-list blend inside g2pc_raster_cameras_py (g2pc_set_blend_tuning; see k_blend_py_dl)
-static int g_blend_lpt = 1, g_blend_split_batches = 12, g_blend_split_min_left = 128, g_blend_prio_batches = 6;
-// per camera: the dynamic chunk order (2 tables) and the hand-over state of BlendSteal
-static size_t blend_plan_ws(int num_chunks) {
-    const size_t nc = (size_t)(num_chunks > 0 ? num_chunks : 0);
-    return align_up(nc * 4) * 5 + align_up(nc * 128 * 4 * sizeof(float)) + 256 + 256;
-}
 // Packed tile-sort instances: when the tile id and the Gaussian index share one 32-bit word (tile << gshift | index) the
 // stable sort by tile moves keys only -- half the traffic of the two passes -- and the blend masks the index out.
 // Returns gshift (0: they do not fit, separate arrays as before).
@@ -1852,8 +1466,7 @@ struct PyBlendArgs {                  // by value ...                      ... o
 static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t* l_eff,
                    const PyBlendArgs& ba, int W, int H, const PyFrontBuffers& fb, unsigned long long* best_key,
                    float* colours_out, float* tilebuf, float* image, int phases, uint32_t max_per_tile,
-                   uint32_t* overflow_flag, void* ws, size_t ws_bytes, hipStream_t s, Batch bt = Batch(),
-                   void* plan_ws = nullptr, size_t plan_bytes = 0) {
+                   uint32_t* overflow_flag, void* ws, size_t ws_bytes, hipStream_t s, Batch bt = Batch()) {
     const int T = layout->nx * layout->ny;
     Arena ar(ws, ws_bytes);
     uint32_t* inst_tile = ar.get<uint32_t>((size_t)L + 1);
@@ -1870,34 +1483,6 @@ static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t*
     const int gshift = packed_instance_shift(n, T);
     const uint32_t gmask = gshift ? ((1u << gshift) - 1u) : 0xFFFFFFFFu;
     const uint32_t* blend_list = gshift ? tile_sorted : g_sorted;
-    // the per-camera blend plan (dual-list kernel inside the batched camera call only): chunk order + hand-over state
-    const int32_t *blend_chunk_tile = layout->chunk_tile, *blend_chunk_pix0 = layout->chunk_pix0;
-    size_t blend_chunk_cs = 0;
-    BlendSteal steal{};
-    BlendCam* plan_dev = nullptr;
-    const bool exact_mode = ba.job ? ((phases & 8) != 0) : (ba.t_floor == 0.0f);
-    const bool planned = plan_ws && layout->chunk_subblocks == 2 && g_blend_variant == 1 && !exact_mode && T <= PLAN_MAX_TILES &&
-                         layout->num_chunks > 0;
-    const bool lpt = planned && g_blend_lpt && layout->chunk_cidx && layout->tile_nchunks;
-    if (planned) {
-        Arena pa(plan_ws, plan_bytes);
-        const size_t nc = (size_t)layout->num_chunks;
-        int32_t* dyn_tile = pa.get<int32_t>(nc);
-        int32_t* dyn_pix0 = pa.get<int32_t>(nc);
-        steal.ctl = pa.get<uint32_t>(2);
-        steal.queue = pa.get<uint32_t>(nc);
-        steal.avail = pa.get<uint32_t>(nc);
-        steal.resume = pa.get<uint32_t>(nc);
-        steal.state = pa.get<float>(nc * 128 * 4);
-        if (!pa.ok()) { set_error("raster_back_py", "plan workspace too small"); return G2PC_ERR_WORKSPACE; }
-        plan_dev = pa.get<BlendCam>(1);
-        if (!pa.ok()) { set_error("raster_back_py", "plan workspace too small"); return G2PC_ERR_WORKSPACE; }
-        steal.split_batches = g_blend_split_batches; steal.min_left = g_blend_split_min_left;
-        steal.num_chunks = layout->num_chunks;
-        if (lpt) { blend_chunk_tile = dyn_tile; blend_chunk_pix0 = dyn_pix0; blend_chunk_cs = bt.cs; }
-    }
-    steal.prio_batches = g_blend_prio_batches;
-    if (!(planned && (lpt || steal.split_batches))) plan_dev = nullptr;      // no plan kernel, nothing to read
     if (phases & 1) {
         if (L > 0) {
             hipLaunchKernelGGL(k_duplicate, dim3(cdiv(n, RA_T), (unsigned)bt.n), dim3(RA_T), 0, s, fb.sorted_idx, fb.offsets, fb.rect, n, lay.nx,
@@ -1911,16 +1496,6 @@ static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t*
         hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T), (unsigned)bt.n), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start, l_eff, gshift, bt.cs);
         if (overflow_flag && max_per_tile)
             hipLaunchKernelGGL(k_check_tile_load, dim3(cdiv(T, RA_T), (unsigned)bt.n), dim3(RA_T), 0, s, tile_start, T, max_per_tile, overflow_flag, bt.cs);
-        if (planned && (lpt || steal.split_batches)) {
-            BlendCam cam0{};
-            cam0.lay = lay; cam0.tile_start = tile_start; cam0.inst_g = blend_list; cam0.rec = (const float4*)fb.rec;
-            cam0.chunk_tile = blend_chunk_tile; cam0.chunk_pix0 = blend_chunk_pix0; cam0.best_key = best_key; cam0.job = ba.job;
-            cam0.gmask = gmask; cam0.order_base = ba.camera_slot << 24; cam0.t_floor = ba.t_floor; cam0.bg = ba.bg; cam0.tilebuf = tilebuf;
-            hipLaunchKernelGGL(k_blend_plan, dim3(1, (unsigned)bt.n), dim3(PLAN_T), 0, s, (const uint32_t*)tile_start, T, layout->num_chunks,
-                               layout->chunk_tile, layout->chunk_pix0, layout->chunk_cidx, layout->tile_nchunks,
-                               (int32_t*)blend_chunk_tile, (int32_t*)blend_chunk_pix0, steal, cam0, plan_dev, lpt ? 1 : 0, blend_chunk_cs,
-                               bt.cs);
-        }
     }
     if (phases & 2) {
         const unsigned chunks_y = layout->num_chunks < 32768 ? (unsigned)layout->num_chunks : 32768u;   // grid.y is 16 bits wide
@@ -1928,19 +1503,14 @@ static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t*
     hipLaunchKernelGGL((__VA_ARGS__), dim3((unsigned)bt.n, chunks_y, cdiv(layout->num_chunks, chunks_y)), dim3(BL_T), 0, s, lay, layout->chunk_tile, \
                        layout->chunk_pix0, tile_start, blend_list, gmask, (const float4*)fb.rec, best_key,             \
                        ba.camera_slot << 24, ba.t_floor, ba.bg, tilebuf, g_chunk_work, ba.job, bt.cs)
-#define G2PC_BLEND_DL(...)                                                                                              \
-    hipLaunchKernelGGL((__VA_ARGS__), dim3((unsigned)bt.n, chunks_y, cdiv(layout->num_chunks, chunks_y)), dim3(BL_T), 0, s, lay, blend_chunk_tile, \
-                       blend_chunk_pix0, blend_chunk_cs, tile_start, blend_list, gmask, (const float4*)fb.rec, best_key,  \
-                       ba.camera_slot << 24, ba.t_floor, ba.bg, tilebuf, g_chunk_work, ba.job, bt.cs,               \
-                       (const BlendCam*)plan_dev, g_blend_prio_batches)
         switch (layout->chunk_subblocks) {
             case 1: G2PC_BLEND(k_blend_py<1, 4>); break;
             case 2: {
                 // t_floor == 0 is the to-the-letter mode: it takes the kernel that evaluates the exponent in the reference's
                 // operation order (k_blend_py_pk); the dual-list kernel's expanded exponent differs by up to ~2e-5 relative
                 // in alpha.  A captured camera reads t_floor from its device job: the caller says so with phase bit 8.
-                const bool exact = exact_mode;
-                if (g_blend_variant == 1 && !exact) G2PC_BLEND_DL(k_blend_py_dl<4>);
+                const bool exact = ba.job ? ((phases & 8) != 0) : (ba.t_floor == 0.0f);
+                if (g_blend_variant == 1 && !exact) G2PC_BLEND(k_blend_py_dl<4>);
                 else G2PC_BLEND(k_blend_py_pk<4>);
                 break;
             }
@@ -1948,7 +1518,6 @@ static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t*
             default: set_error("raster_back_py", "chunk_subblocks must be 1, 2 or 4"); return G2PC_ERR_ARG;
         }
 #undef G2PC_BLEND
-#undef G2PC_BLEND_DL
     }
     if (phases & 4) {
         hipLaunchKernelGGL(k_update_colours_py, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, lay, best_key, n, ba.camera_slot,
@@ -2006,11 +1575,11 @@ int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, int
     return check_launch("g2pc_raster_back_py");
 }
 
-size_t g2pc_raster_camera_workspace(int64_t n, int64_t capacity, int32_t num_tiles, int32_t num_chunks) {
+size_t g2pc_raster_camera_workspace(int64_t n, int64_t capacity, int32_t num_tiles) {
     using namespace g2pc;
     // a multiple of 256: batched launches place one such arena per camera back to back (g2pc_raster_cameras_py)
     return align_up(align_up((size_t)n * 64) + align_up((size_t)n * 4) * 2 + align_up((size_t)(n + 1) * 4) + 256 +
-                    py_front_ws((long)n) + py_back_ws((long)capacity, num_tiles) + blend_plan_ws(num_chunks) + 4096);
+                    py_front_ws((long)n) + py_back_ws((long)capacity, num_tiles) + 4096);
 }
 
 // One camera up to and including the blend, without any host round trip: the camera, its slot and the transmittance
@@ -2036,7 +1605,7 @@ int g2pc_raster_cameras_py(const G2pcCameraJob* jobs_dev, const G2pcCameraJob* j
     // every kernel moves them by blockIdx.y * cs (g2pc_internal.h: seg)
     Batch bt;
     bt.n = batch;
-    bt.cs = g2pc_raster_camera_workspace(n, capacity, T, layout->num_chunks);
+    bt.cs = g2pc_raster_camera_workspace(n, capacity, T);
     G2PC_REQUIRE(ws_bytes >= bt.cs * (size_t)batch, G2PC_ERR_WORKSPACE, "workspace too small");
     Arena ar(ws, bt.cs);
     PyFrontBuffers fb;
@@ -2048,8 +1617,6 @@ int g2pc_raster_cameras_py(const G2pcCameraJob* jobs_dev, const G2pcCameraJob* j
     const size_t front_bytes = py_front_ws((long)n), back_bytes = py_back_ws((long)capacity, T);
     char* front_ws = ar.get<char>(front_bytes);
     char* back_ws = ar.get<char>(back_bytes);
-    const size_t plan_bytes = blend_plan_ws(layout->num_chunks);
-    char* plan_ws = ar.get<char>(plan_bytes);
     G2PC_REQUIRE(ar.ok(), G2PC_ERR_WORKSPACE, "workspace too small");
     int rc;
     if (phases & 1) {
@@ -2066,7 +1633,7 @@ int g2pc_raster_cameras_py(const G2pcCameraJob* jobs_dev, const G2pcCameraJob* j
     }
     PyBlendArgs ba{0u, 0.0f, 0.0f, jobs_dev};
     rc = py_back(layout, (long)n, (long)capacity, l_eff, ba, 0, 0, fb, best_key, nullptr, tilebuf, nullptr,
-                 phases & (3 | 8), max_per_tile, overflow_flag, back_ws, back_bytes, s, bt, plan_ws, plan_bytes);
+                 phases & (3 | 8), max_per_tile, overflow_flag, back_ws, back_bytes, s, bt);
     if (rc) return rc;
     return check_launch("g2pc_raster_cameras_py");
 }
@@ -2107,18 +1674,6 @@ int g2pc_raster_debug_chunk_work(uint32_t* buf) { g2pc::g_chunk_work = buf; retu
  * radix.  Identical results; a camera whose depths pile up (bucket overflow) is skipped and reported through
  * count_host[1] -- the caller repeats it with g2pc_raster_front_py / _back_py, which always use the radix sort. */
 int g2pc_set_blend_variant(int variant) { g2pc::g_blend_variant = variant; return G2PC_OK; }
-int g2pc_set_blend_tuning(int what, int value) {
-    using namespace g2pc;
-    G2PC_REQUIRE(value >= 0, G2PC_ERR_ARG, "negative value");
-    switch (what) {
-        case G2PC_BLEND_LPT: g_blend_lpt = value ? 1 : 0; break;
-        case G2PC_BLEND_SPLIT_BATCHES: g_blend_split_batches = value; break;
-        case G2PC_BLEND_SPLIT_MIN_LEFT: g_blend_split_min_left = value; break;
-        case G2PC_BLEND_PRIO_BATCHES: g_blend_prio_batches = value; break;
-        default: set_error("g2pc_set_blend_tuning", "unknown parameter"); return G2PC_ERR_ARG;
-    }
-    return G2PC_OK;
-}
 int g2pc_set_depth_sort(int bucket) { g2pc::g_depth_bucket_sort = bucket ? 1 : 0; return G2PC_OK; }
 
 int g2pc_raster_rebase_keys(unsigned long long* best_key, int64_t n, void* stream) {

@@ -76,8 +76,7 @@ def _finish(xs, ws, ys, hs, seq_of, subblocks=None, tile_shard=None) -> Dict[str
         # binning are replicated, the visibility exchange is the usual one (g2pc/dist.py)
         r, w = tile_shard
         order_t = order_t[r::w]
-    chunk_tile, chunk_pix0, chunk_cidx = [], [], []
-    tile_nchunks = np.zeros((T,), dtype=np.int32)
+    chunk_tile, chunk_pix0 = [], []
     for g0 in range(0, len(order_t), 8):
         group = order_t[g0:g0 + 8]
         per_tile = [_chunks_of_tile((ws[t % nx] + 7) // 8, (hs[t // nx] + 7) // 8, subblocks) for t in group]
@@ -86,13 +85,9 @@ def _finish(xs, ws, ys, hs, seq_of, subblocks=None, tile_shard=None) -> Dict[str
                 if c < len(per_tile[k]):
                     chunk_tile.append(t)
                     chunk_pix0.append(per_tile[k][c])
-                    chunk_cidx.append(c)              # (the per-camera blend plan re-orders the tiles by list length,
-        for k, t in enumerate(group):                 #  k_blend_plan: it needs each chunk's index inside its tile and
-            tile_nchunks[t] = len(per_tile[k])        #  the number of chunks per tile)
     return dict(nx=nx, ny=ny, xs=np.asarray(xs, np.int32), ws=np.asarray(ws, np.int32),
                 ys=np.asarray(ys, np.int32), hs=np.asarray(hs, np.int32), tile_seq=rank, seq_tile=seq_tile,
                 tile_pix_off=off.astype(np.int32), chunk_tile=np.asarray(chunk_tile, np.int32),
-                chunk_cidx=np.asarray(chunk_cidx, np.int32), tile_nchunks=tile_nchunks,
                 chunk_pix0=np.asarray(chunk_pix0, np.int64).astype(np.uint32).view(np.int32), total_pixels=int(off[-1]), chunk_subblocks=int(subblocks))
 
 

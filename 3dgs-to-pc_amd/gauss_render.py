@@ -59,7 +59,7 @@ class _Layout(C.Structure):
     _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("xs", C.c_void_p), ("ws", C.c_void_p), ("ys", C.c_void_p),
                 ("hs", C.c_void_p), ("tile_seq", C.c_void_p), ("seq_tile", C.c_void_p), ("tile_pix_off", C.c_void_p),
                 ("num_chunks", C.c_int32), ("chunk_tile", C.c_void_p), ("chunk_pix0", C.c_void_p),
-                ("chunk_subblocks", C.c_int32), ("chunk_cidx", C.c_void_p), ("tile_nchunks", C.c_void_p)]
+                ("chunk_subblocks", C.c_int32)]
 
 
 nv._RASTER_PROTOS.update({
@@ -69,7 +69,7 @@ nv._RASTER_PROTOS.update({
     "g2pc_raster_back_workspace": (C.c_size_t, [C.c_int64, C.c_int32]),
     "g2pc_raster_back_py": (C.c_int, [C.POINTER(_Camera), C.POINTER(_Layout), C.c_int64, C.c_int64] +
                             [C.c_void_p] * 4 + [C.c_uint32, C.c_float] + [C.c_void_p] * 4 + [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
-    "g2pc_raster_camera_workspace": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
+    "g2pc_raster_camera_workspace": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32]),
     "g2pc_raster_camera_py": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(_Layout)] + [C.c_void_p] * 4 + [C.c_int64, C.c_int64] +
                               [C.c_void_p] * 3 + [C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "g2pc_raster_cameras_py": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(_Layout)] + [C.c_void_p] * 4 + [C.c_int64, C.c_int64] +
@@ -84,7 +84,6 @@ nv._RASTER_PROTOS.update({
     "g2pc_raster_resolve_colours_py": (C.c_int, [C.POINTER(_Layout), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "g2pc_set_depth_sort": (C.c_int, [C.c_int]),
     "g2pc_set_blend_variant": (C.c_int, [C.c_int]),
-    "g2pc_set_blend_tuning": (C.c_int, [C.c_int, C.c_int]),
     "g2pc_raster_key_owner": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "g2pc_raster_keep_winner_colours": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "g2pc_raster_contributions": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
@@ -186,8 +185,7 @@ class _DeviceLayout:
     def __init__(self, lay, device):
         self.host = lay
         self.t = {k: torch.from_numpy(lay[k]).to(device) for k in
-                  ("xs", "ws", "ys", "hs", "tile_seq", "seq_tile", "tile_pix_off", "chunk_tile", "chunk_pix0", "chunk_cidx",
-                   "tile_nchunks")}
+                  ("xs", "ws", "ys", "hs", "tile_seq", "seq_tile", "tile_pix_off", "chunk_tile", "chunk_pix0")}
         self.c = _Layout(nx=lay["nx"], ny=lay["ny"], num_chunks=len(lay["chunk_tile"]),
                          chunk_subblocks=lay["chunk_subblocks"],
                          **{k: v.data_ptr() for k, v in self.t.items()})
@@ -231,22 +229,6 @@ PIPELINE_IN_EMULATOR = False      # tests: drive the capture / replay path throu
 CAPACITY_HEADROOM = 1.25          # instance capacity of the captured graphs relative to the largest count seen so far
 MIN_CAPACITY = 1 << 16
 _LAYOUT_CACHE = {}
-# Scheduling of the dual-list blend (include/g2pc.h, g2pc_set_blend_tuning): None = the library's defaults.  Experiments
-# set these through the environment (G2PC_BLEND_LPT / _SPLIT / _MINLEFT / _PRIO), one process per configuration.
-BLEND_TUNING = {"lpt": None, "split_batches": None, "split_min_left": None, "prio_batches": None}
-_BLEND_TUNING_IDS = {"lpt": 0, "split_batches": 1, "split_min_left": 2, "prio_batches": 3}
-_BLEND_TUNING_ENV = {"lpt": "G2PC_BLEND_LPT", "split_batches": "G2PC_BLEND_SPLIT", "split_min_left": "G2PC_BLEND_MINLEFT",
-                     "prio_batches": "G2PC_BLEND_PRIO"}
-
-
-def _apply_blend_tuning():
-    import os
-    for name, ident in _BLEND_TUNING_IDS.items():
-        v = BLEND_TUNING[name]
-        if v is None and os.environ.get(_BLEND_TUNING_ENV[name], "") != "":
-            v = int(os.environ[_BLEND_TUNING_ENV[name]])
-        if v is not None:
-            nv.check(nv.lib().g2pc_set_blend_tuning(ident, int(v)), "set_blend_tuning")
 
 
 class _GraphSlot:
@@ -373,7 +355,6 @@ class GaussHipRenderer():
         if semantics != "python":
             raise NotImplementedError("use gaussian_pointcloud_rasterization.GaussianRasterizer for 'cuda' semantics")
         nv.lib()
-        _apply_blend_tuning()
         self.white_bkgd = white_bkgd
         self.device = means3D.device
         self.semantics = semantics
@@ -580,7 +561,7 @@ class GaussHipRenderer():
         # anything else (new capacity, new layout, new buffers) starts the slot afresh
         if any(k[:2] != key[:2] for k in sl.graphs):
             sl.release()
-        need = L.g2pc_raster_camera_workspace(self.n, capacity, lay.num_tiles, lay.c.num_chunks) * sl.batch
+        need = L.g2pc_raster_camera_workspace(self.n, capacity, lay.num_tiles) * sl.batch
         import contextlib
         with (torch.cuda.stream(sl.stream) if sl.on_gpu else contextlib.nullcontext()):   # allocate on the stream using them
             if need > sl.ws_bytes:

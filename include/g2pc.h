@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define G2PC_ABI_VERSION 3
+#define G2PC_ABI_VERSION 2
 
 #define G2PC_OK 0
 #define G2PC_ERR_ARG (-1)
@@ -264,10 +264,6 @@ typedef struct G2pcTileLayout {      /* HOST struct of DEVICE pointers: tiles = 
     const int32_t* chunk_tile;       /* [num_chunks]    sub-blocks of a tile (sub-blocks row-major inside the tile)   */
     const int32_t* chunk_pix0;       /* [num_chunks] first sub-block of the chunk; chunk_subblocks = 2: a | b << 16, two adjacent sub-blocks (b = 0xFFFF: none) */
     int32_t chunk_subblocks;         /* 1, 2 or 4 (pixels per lane) */
-    /* ABI 3 -- the two tables the per-camera blend plan (longest tile lists first) is built from; may be NULL: the blends
-     * then keep the static order of chunk_tile / chunk_pix0 */
-    const int32_t* chunk_cidx;       /* [num_chunks] index of the chunk among the chunks of its tile (0 .. tile_nchunks-1) */
-    const int32_t* tile_nchunks;     /* [ny*nx] chunks of tile iy*nx+ix in this list (0: none, e.g. another rank's tile) */
 } G2pcTileLayout;
 
 size_t g2pc_raster_front_workspace(int64_t n);
@@ -328,7 +324,7 @@ typedef struct G2pcCameraJob {       /* DEVICE (and pinned host staging) struct 
                                       * resolve the winners' colours once, g2pc_raster_resolve_colours_py */
     uint32_t reserved;
 } G2pcCameraJob;
-size_t g2pc_raster_camera_workspace(int64_t n, int64_t capacity, int32_t num_tiles, int32_t num_chunks);
+size_t g2pc_raster_camera_workspace(int64_t n, int64_t capacity, int32_t num_tiles);
 /* BATCHED form: `batch` cameras (1 .. G2PC_MAX_CAMERA_BATCH) through ONE launch sequence -- every kernel of the sequence runs
  * with grid.y = batch, camera c reading the c-th job of the arrays jobs_dev / jobs_host and working in the c-th of `batch`
  * consecutive workspaces of g2pc_raster_camera_workspace() bytes each (ws_bytes >= batch times that).  A 50-camera job is
@@ -361,17 +357,6 @@ int g2pc_raster_resolve_colours_py(const G2pcTileLayout* layout, int64_t n, cons
 int g2pc_set_depth_sort(int bucket);
 /* tuning aid: blend kernel of the python-semantics rasteriser for 2 sub-blocks per wave: 1 = dual-list (default), 0 = packed */
 int g2pc_set_blend_variant(int variant);
-/* Scheduling of the dual-list blend inside g2pc_raster_cameras_py (results do not depend on it beyond the last bits of a
- * pixel colour and contributions below the transmittance floor):
- *   G2PC_BLEND_LPT (0)           1 = every camera's chunks are dispatched longest tile list first (k_blend_plan), 0 = the
- *                                layout's static centre-out order
- *   G2PC_BLEND_SPLIT_BATCHES (1) a wave whose walk reaches this many 64-entry batches hands the rest of it over as eight
- *                                16-pixel continuations that idle waves of the launch pick up and blend four list entries
- *                                at a time; 0 = never
- *   G2PC_BLEND_SPLIT_MIN_LEFT (2) ... only if at least this many list entries are left
- *   G2PC_BLEND_PRIO_BATCHES (3)  a walk gets wave priority 1 / 2 / 3 once it is v / 2v / 3v batches long; 0 = no priorities */
-enum { G2PC_BLEND_LPT = 0, G2PC_BLEND_SPLIT_BATCHES = 1, G2PC_BLEND_SPLIT_MIN_LEFT = 2, G2PC_BLEND_PRIO_BATCHES = 3 };
-int g2pc_set_blend_tuning(int what, int value);
 int g2pc_raster_rebase_keys(unsigned long long* best_key, int64_t n, void* stream);
 /* diagnostics: when non-NULL, the PY blend records per chunk, in u32[8*num_chunks] (batch 1): [0] tile list length, [1] entries
  * walked; the dual-list kernel also [2] start and [3] duration on the 100 MHz wall clock, [4] HW_ID, [5] XCC_ID of its wave, [6] (Gaussian, sub-block) visits after the cull */

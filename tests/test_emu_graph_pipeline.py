@@ -135,41 +135,3 @@ def test_deferred_colour_buffers_are_bounded(emu, monkeypatch):
     k1, c1, _, R = _render_all(True, monkeypatch, ncam=7)
     assert np.array_equal(k0, k1) and np.array_equal(c0, c1)
     assert len(R.ctx.cam_tilebufs) <= 2 and not R.deferred
-
-
-def _tune(emu, **kw):
-    names = {"lpt": 0, "split_batches": 1, "split_min_left": 2, "prio_batches": 3}
-    for k, v in kw.items():
-        emu.check(emu.lib().g2pc_set_blend_tuning(names[k], int(v)), "set_blend_tuning")
-
-
-@pytest.mark.parametrize("batch,lpt", [(1, 1), (2, 1), (2, 0)])
-def test_blend_hand_over_equals_unsplit_walk(emu, monkeypatch, batch, lpt):
-    """The dual-list blend with the work hand-over forced after ONE batch of every walk (exported 16-pixel quarters run in quad
-    mode: four list entries per trip, transmittance passed down the quad) against the two-call path, which never
-    hands over: every contribution >= the transmittance floor and its arg-max pixel bit for bit, colours to the last bits
-    (a quad sums a pixel's colour in four partial sums).  Also the longest-list-first chunk order on / off."""
-    import gauss_render                                         # noqa: F401  (registers the rasteriser prototypes)
-    try:
-        _tune(emu, lpt=lpt, split_batches=0)
-        k0, c0, st0, _ = _render_all(False, monkeypatch, subblocks=2, ncam=5)
-        _tune(emu, lpt=lpt, split_batches=1, split_min_left=1)
-        import ctypes as C
-        work = torch.zeros((8 * 4096,), dtype=torch.int32)      # per-chunk diagnostics of the last blend launch (camera 0 of it)
-        emu.lib().g2pc_raster_debug_chunk_work(C.c_void_p(work.data_ptr()))
-        k1, c1, st1, R = _render_all(True, monkeypatch, subblocks=2, ncam=5, batch=batch)
-    finally:
-        emu.lib().g2pc_raster_debug_chunk_work(None)
-        _tune(emu, lpt=1, split_batches=12, split_min_left=128)
-    cw = work.numpy().view(np.uint32).reshape(-1, 8)
-    exported, quarters = int((cw[:, 7] & 1).sum()), int(((cw[:, 7] >> 8) & 0xFF).sum())
-    assert exported > 20 and quarters >= 4 * exported          # walks really were handed over and their quarters run
-    assert sorted(st0) == sorted(st1)
-    contrib0 = (k0.view(np.uint64) >> np.uint64(32)).astype(np.uint32).view(np.float32)
-    contrib1 = (k1.view(np.uint64) >> np.uint64(32)).astype(np.uint32).view(np.float32)
-    big = (contrib0 >= 1e-6) | (contrib1 >= 1e-6)
-    assert big.sum() > 100
-    assert np.array_equal(k0[big], k1[big])
-    assert np.abs(contrib0 - contrib1).max() < 1e-6
-    assert np.abs(c0 - c1).max() < 2e-3                        # colours are on the 0..255 scale here
-    assert any(len(s) > 0 for s in [st1])
