@@ -140,7 +140,9 @@ def check_validate_covariances_cull_branch(golden_dir, device="cpu"):
     """validate_covariances with rows that really are culled (gauss_handler.py:142-166).  A row can only be culled when
     three clamp-and-rebuild rounds in fp32 still leave an eigenvalue <= 1e-8, i.e. when lambda_max * 6e-8 exceeds the
     1e-7 clamp: the verdict is then decided by the rounding of LAPACK's eigh / eigvals, which no other implementation
-    reproduces bit for bit.  Pinned here: (1) spectra within fp32's range agree EXACTLY with the reference (nothing is
+    reproduces bit for bit -- not even the reference itself once the nine multiply-adds of its recomposition product are
+    evaluated in another order (tools/validate_cov_noise.py, profiles/r03z_validate_cov_noise.txt: 91 % agreement with its
+    own stored verdicts; numpy's float32 LAPACK 81 %).  Pinned here: (1) spectra within fp32's range agree EXACTLY with the reference (nothing is
     culled), (2) beyond it the verdicts agree for most rows and ours never keeps a matrix whose smallest eigenvalue is
     below the threshold, (3) the cull mechanics (keep mask -> filter -> every per-Gaussian array compacted)."""
     from g2pc import ops
