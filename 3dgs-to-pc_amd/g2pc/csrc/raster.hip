@@ -33,7 +33,7 @@ struct Cam {            // device copy of G2pcCamera (passed by value as kernel 
 };
 
 struct Layout {         // device pointers of G2pcTileLayout
-    int nx, ny, num_chunks;
+    int nx, ny, num_chunks, seq_bits;
     const int32_t *xs, *ws, *ys, *hs;
     const int32_t *tile_seq, *seq_tile, *tile_pix_off;
 };
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __
     tile_start = seg_at(tile_start, cs, blockIdx.x); inst_g = seg_at(inst_g, cs, blockIdx.x); rec = seg_at(rec, cs, blockIdx.x);
     if (job) {
         job += blockIdx.x;
-        order_base = job->camera_slot << 24; t_floor = job->t_floor; bg = job->cam.bg[0];
+        order_base = job->camera_slot << (12 + lay.seq_bits); t_floor = job->t_floor; bg = job->cam.bg[0];
         const unsigned long long tb = ((unsigned long long)job->tilebuf_hi << 32) | job->tilebuf_lo;
         if (tb) tilebuf = (float*)tb;              // one colour buffer per camera (deferred colour resolve)
     }   // see k_preprocess_py
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_pk(Layout lay, const int32_t*
     tile_start = seg_at(tile_start, cs, blockIdx.x); inst_g = seg_at(inst_g, cs, blockIdx.x); rec = seg_at(rec, cs, blockIdx.x);
     if (job) {
         job += blockIdx.x;
-        order_base = job->camera_slot << 24; t_floor = job->t_floor; bg = job->cam.bg[0];
+        order_base = job->camera_slot << (12 + lay.seq_bits); t_floor = job->t_floor; bg = job->cam.bg[0];
         const unsigned long long tb = ((unsigned long long)job->tilebuf_hi << 32) | job->tilebuf_lo;
         if (tb) tilebuf = (float*)tb;              // one colour buffer per camera (deferred colour resolve)
     }
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_dl(Layout lay, const int32_t*
     tile_start = seg_at(tile_start, cs, blockIdx.x); inst_g = seg_at(inst_g, cs, blockIdx.x); rec = seg_at(rec, cs, blockIdx.x);
     if (job) {
         job += blockIdx.x;
-        order_base = job->camera_slot << 24; t_floor = job->t_floor; bg = job->cam.bg[0];
+        order_base = job->camera_slot << (12 + lay.seq_bits); t_floor = job->t_floor; bg = job->cam.bg[0];
         const unsigned long long tb = ((unsigned long long)job->tilebuf_hi << 32) | job->tilebuf_lo;
         if (tb) tilebuf = (float*)tb;              // one colour buffer per camera (deferred colour resolve)
     }
@@ -852,8 +852,8 @@ __global__ __launch_bounds__(RA_T) void k_update_colours_py(Layout lay, const un
     unsigned long long key = best_key[i];
     if ((key >> 32) == 0ull) return;
     uint32_t order = ~(uint32_t)key;
-    if ((order >> 24) != slot) return;
-    int seq = (order >> 12) & 0xFFF, pix = order & 0xFFF;
+    if ((order >> (12 + lay.seq_bits)) != slot) return;
+    int seq = (order >> 12) & ((1 << lay.seq_bits) - 1), pix = order & 0xFFF;
     int tile = lay.seq_tile[seq];
     const float* src = tilebuf + 3 * ((size_t)lay.tile_pix_off[tile] + pix);
     colours_out[3 * i + 0] = src[0];
@@ -871,9 +871,9 @@ __global__ __launch_bounds__(RA_T) void k_resolve_colours_py(Layout lay, const u
     unsigned long long key = best_key[i];
     if ((key >> 32) == 0ull) return;
     uint32_t order = ~(uint32_t)key;
-    const float* tb = (const float*)tilebufs[order >> 24];
+    const float* tb = (const float*)tilebufs[order >> (12 + lay.seq_bits)];
     if (!tb) return;
-    int seq = (order >> 12) & 0xFFF, pix = order & 0xFFF;
+    int seq = (order >> 12) & ((1 << lay.seq_bits) - 1), pix = order & 0xFFF;
     int tile = lay.seq_tile[seq];
     const float* src = tb + 3 * ((size_t)lay.tile_pix_off[tile] + pix);
     colours_out[3 * i + 0] = src[0];
@@ -1389,11 +1389,17 @@ static Cam to_cam(const G2pcCamera* c) {
 }
 static Layout to_layout(const G2pcTileLayout* l) {
     Layout k;
-    k.nx = l->nx; k.ny = l->ny; k.num_chunks = l->num_chunks; k.xs = l->xs; k.ws = l->ws; k.ys = l->ys; k.hs = l->hs;
+    k.nx = l->nx; k.ny = l->ny; k.num_chunks = l->num_chunks; k.seq_bits = l->seq_bits ? l->seq_bits : 12; k.xs = l->xs; k.ws = l->ws; k.ys = l->ys; k.hs = l->hs;
     k.tile_seq = l->tile_seq; k.seq_tile = l->seq_tile; k.tile_pix_off = l->tile_pix_off;
     return k;
 }
 static int bits_for_tiles(unsigned t) { int b = 1; while ((1u << b) < t && b < 31) ++b; return b; }
+// packed visibility keys: the tile-sequence field is seq_bits wide (12 .. 14), the camera slot gets the 20 - seq_bits above it
+static bool layout_keys_ok(const G2pcTileLayout* l) {
+    const int sb = l->seq_bits ? l->seq_bits : 12;
+    return sb >= 12 && sb <= 14 && (long)l->nx * l->ny <= (1l << sb);
+}
+static uint32_t max_camera_slot(const G2pcTileLayout* l) { return (1u << (20 - (l->seq_bits ? l->seq_bits : 12))) - 1u; }
 
 // ---- host side of the PY path, shared by the two-call API (count read back by the host) and the single-call,
 // capture-safe API (count stays on the device, launch geometry fixed by a capacity) -------------------------------
@@ -1502,7 +1508,7 @@ static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t*
 #define G2PC_BLEND(...)                                                                                                 \
     hipLaunchKernelGGL((__VA_ARGS__), dim3((unsigned)bt.n, chunks_y, cdiv(layout->num_chunks, chunks_y)), dim3(BL_T), 0, s, lay, layout->chunk_tile, \
                        layout->chunk_pix0, tile_start, blend_list, gmask, (const float4*)fb.rec, best_key,             \
-                       ba.camera_slot << 24, ba.t_floor, ba.bg, tilebuf, g_chunk_work, ba.job, bt.cs)
+                       ba.camera_slot << (12 + lay.seq_bits), ba.t_floor, ba.bg, tilebuf, g_chunk_work, ba.job, bt.cs)
         switch (layout->chunk_subblocks) {
             case 1: G2PC_BLEND(k_blend_py<1, 4>); break;
             case 2: {
@@ -1565,8 +1571,8 @@ int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, int
     using namespace g2pc;
     G2PC_REQUIRE(cam && layout && rec && rect && sorted_idx && offsets && best_key && colours_out && tilebuf && ws && n > 0,
                  G2PC_ERR_ARG, "bad arguments");
-    G2PC_REQUIRE(camera_slot >= 1 && camera_slot <= 255, G2PC_ERR_ARG, "camera_slot must be in [1,255]");
-    G2PC_REQUIRE(layout->nx * layout->ny <= 4096, G2PC_ERR_UNSUPPORTED, "more than 4096 tiles");
+    G2PC_REQUIRE(layout_keys_ok(layout), G2PC_ERR_UNSUPPORTED, "seq_bits must be 12 .. 14 and hold every tile (at most 16384 tiles)");
+    G2PC_REQUIRE(camera_slot >= 1 && camera_slot <= max_camera_slot(layout), G2PC_ERR_ARG, "camera_slot must be in [1, (1 << (20 - seq_bits)) - 1]");
     PyFrontBuffers fb{(float4*)rec, (uint32_t*)rect, (uint32_t*)sorted_idx, (uint32_t*)offsets};
     PyBlendArgs ba{camera_slot, t_floor, cam->bg[0], nullptr};
     int rc = py_back(layout, (long)n, (long)num_instances, nullptr, ba, cam->width, cam->height, fb, best_key,
@@ -1596,7 +1602,7 @@ int g2pc_raster_cameras_py(const G2pcCameraJob* jobs_dev, const G2pcCameraJob* j
                  G2PC_ERR_ARG, "bad arguments");
     G2PC_REQUIRE(batch >= 1 && batch <= G2PC_MAX_CAMERA_BATCH, G2PC_ERR_ARG, "batch must be in [1, G2PC_MAX_CAMERA_BATCH]");
     G2PC_REQUIRE(layout->nx <= 256 && layout->ny <= 256, G2PC_ERR_UNSUPPORTED, "more than 256 tile intervals per axis");
-    G2PC_REQUIRE(layout->nx * layout->ny <= 4096, G2PC_ERR_UNSUPPORTED, "more than 4096 tiles");
+    G2PC_REQUIRE(layout_keys_ok(layout), G2PC_ERR_UNSUPPORTED, "seq_bits must be 12 .. 14 and hold every tile (at most 16384 tiles)");
     G2PC_REQUIRE(capacity < (1ll << 31), G2PC_ERR_ARG, "capacity must be below 2^31 instances");
     static_assert(sizeof(Cam) == sizeof(G2pcCamera), "Cam mirrors G2pcCamera");
     hipStream_t s = (hipStream_t)stream;
@@ -1652,7 +1658,8 @@ int g2pc_raster_camera_update_py(const G2pcTileLayout* layout, int64_t n, uint32
                                  const unsigned long long* best_key, const float* tilebuf, float* colours_out, void* stream) {
     using namespace g2pc;
     G2PC_REQUIRE(layout && best_key && tilebuf && colours_out && n > 0, G2PC_ERR_ARG, "bad arguments");
-    G2PC_REQUIRE(camera_slot >= 1 && camera_slot <= 255, G2PC_ERR_ARG, "camera_slot must be in [1,255]");
+    G2PC_REQUIRE(layout_keys_ok(layout), G2PC_ERR_UNSUPPORTED, "seq_bits must be 12 .. 14 and hold every tile");
+    G2PC_REQUIRE(camera_slot >= 1 && camera_slot <= max_camera_slot(layout), G2PC_ERR_ARG, "camera_slot must be in [1, (1 << (20 - seq_bits)) - 1]");
     hipLaunchKernelGGL(k_update_colours_py, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, (hipStream_t)stream, to_layout(layout),
                        best_key, (long)n, camera_slot, tilebuf, colours_out);
     return check_launch("g2pc_raster_camera_update_py");

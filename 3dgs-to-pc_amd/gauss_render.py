@@ -59,7 +59,7 @@ class _Layout(C.Structure):
     _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("xs", C.c_void_p), ("ws", C.c_void_p), ("ys", C.c_void_p),
                 ("hs", C.c_void_p), ("tile_seq", C.c_void_p), ("seq_tile", C.c_void_p), ("tile_pix_off", C.c_void_p),
                 ("num_chunks", C.c_int32), ("chunk_tile", C.c_void_p), ("chunk_pix0", C.c_void_p),
-                ("chunk_subblocks", C.c_int32)]
+                ("chunk_subblocks", C.c_int32), ("seq_bits", C.c_int32)]
 
 
 nv._RASTER_PROTOS.update({
@@ -186,8 +186,9 @@ class _DeviceLayout:
         self.host = lay
         self.t = {k: torch.from_numpy(lay[k]).to(device) for k in
                   ("xs", "ws", "ys", "hs", "tile_seq", "seq_tile", "tile_pix_off", "chunk_tile", "chunk_pix0")}
+        self.seq_bits = max(12, int(np.ceil(np.log2(max(lay["nx"] * lay["ny"], 2)))))   # tile-sequence bits its keys need
         self.c = _Layout(nx=lay["nx"], ny=lay["ny"], num_chunks=len(lay["chunk_tile"]),
-                         chunk_subblocks=lay["chunk_subblocks"],
+                         chunk_subblocks=lay["chunk_subblocks"], seq_bits=self.seq_bits,
                          **{k: v.data_ptr() for k, v in self.t.items()})
         self.num_tiles = lay["nx"] * lay["ny"]
         self.total_pixels = lay["total_pixels"]
@@ -379,6 +380,10 @@ class GaussHipRenderer():
         self.gaussian_colours.zero_()
         self.overflow.zero_()
         self.camera_slot = 0
+        # Width of the tile-sequence field of the packed keys (include/g2pc.h, G2pcTileLayout.seq_bits): 12 bits (4096 leaf
+        # tiles, 255 cameras per key epoch) until a camera needs more (up to 14: 16384 leaves = 7680 x 4320 at 60-pixel
+        # leaves, 63 cameras per epoch).  All keys of the running state share one width: widening rebases them first.
+        self.seq_bits = 12
 
         self.sync_scratch = ctx.sync_scratch
         self.overflow_ptr = nv.ptr(self.overflow)
@@ -461,10 +466,10 @@ class GaussHipRenderer():
         key = (width, height, self.MAX_TILE_SIZE, BLEND_SUBBLOCKS, self.tile_shard, str(self.device))
         if key not in _LAYOUT_CACHE:
             host = tiles.python_quadtree_layout(width, height, self.MAX_TILE_SIZE, BLEND_SUBBLOCKS, self.tile_shard)
-            if host["nx"] * host["ny"] > 4096 or host["nx"] > 256 or host["ny"] > 256:
-                # 12-bit tile field of the packed visibility keys / 8-bit tile-interval ranges of the per-Gaussian rects
+            if host["nx"] * host["ny"] > 16384 or host["nx"] > 256 or host["ny"] > 256:
+                # 14-bit tile field of the packed visibility keys / 8-bit tile-interval ranges of the per-Gaussian rects
                 raise NotImplementedError("%dx%d at max_tile_size=%d needs %d quad-tree leaves; the python-semantics rasteriser "
-                                          "supports at most 4096 (images up to 3840 px wide): lower --colour_quality"
+                                          "supports at most 16384 (images up to 7680 x 4320): lower --colour_quality"
                                           % (width, height, self.MAX_TILE_SIZE, host["nx"] * host["ny"]))
             _LAYOUT_CACHE[key] = _DeviceLayout(host, self.device)
         return _LAYOUT_CACHE[key]
@@ -490,6 +495,11 @@ class GaussHipRenderer():
                  "keep_winner_colours")
         dist.all_reduce(self.gaussian_colours, op=dist.ReduceOp.SUM, group=group)
         self.best_key.copy_(global_key)            # in place: the captured graphs hold this tensor's address
+
+    @property
+    def camera_epoch(self):
+        """Cameras per key epoch: the camera-order field holds slots 1 .. camera_epoch."""
+        return (1 << (20 - self.seq_bits)) - 1
 
     def rebase_keys(self):
         """Forget the camera order of the current keys (they become "earliest"), freeing the 8-bit order field."""
@@ -625,7 +635,7 @@ class GaussHipRenderer():
         # (this runtime refuses event-record nodes inside a captured graph)
         exact = 8 if self.t_floor == 0.0 else 0      # to-the-letter mode: the blend kernel with the reference's operation order
         split = on_gpu and PIPELINE_MODE.startswith("split")
-        key = (id(lay), self.capacity, (1 if (nv.PROFILE is not None or split) else 3) | exact, batch)
+        key = (id(lay), self.capacity, (1 if (nv.PROFILE is not None or split) else 3) | exact, batch, self.seq_bits)
         if sl.graph_key != key:
             if key in sl.graphs:
                 sl.graph, sl.graph_key = sl.graphs[key], key
@@ -762,12 +772,17 @@ class GaussHipRenderer():
         W, H = int(camera.image_width), int(camera.image_height)
         lay = self._layout(W, H)
         self._dirty = True
+        if lay.seq_bits > self.seq_bits:           # more leaf tiles than the keys' tile field holds: widen it (keys rebased)
+            if self.camera_slot:
+                self.rebase_keys()
+            self.seq_bits = lay.seq_bits
+        lay.c.seq_bits = self.seq_bits             # (layouts are shared between renderers: every call states its width)
         if slot is not None:                       # caller-assigned global camera order (multi-GPU camera sharding)
-            if not (1 <= slot <= 255):
-                raise ValueError("camera slot must be in [1, 255]")
+            if not (1 <= slot <= self.camera_epoch):
+                raise ValueError("camera slot must be in [1, %d]" % self.camera_epoch)
             self.camera_slot = int(slot)
         else:
-            if self.camera_slot >= 255:
+            if self.camera_slot >= self.camera_epoch:
                 self.rebase_keys()
             self.camera_slot += 1
         slot = self.camera_slot

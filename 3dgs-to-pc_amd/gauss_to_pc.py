@@ -32,7 +32,7 @@ from camera_handler import get_camera
 COLOR_QUALITY_OPTIONS = {"tiny": 180, "low": 360, "medium": 720, "high": 1280, "ultra": 1920, "original": None}
 
 SAMPLER_SEED = 0
-CAMERA_EPOCH = 255          # cameras per epoch of the renderer's 8-bit camera-order field (multi-GPU camera sharding)
+CAMERA_EPOCH = 255          # at most this many cameras per epoch of the renderer's camera-order field (multi-GPU camera sharding)
 REFERENCE_DTYPES = False
 
 
@@ -212,10 +212,16 @@ def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, poin
             unmasked = {k: v for i, (k, v) in enumerate(transforms.items()) if i % world == rank and k in unmasked}
         rig = get_cameras(s.renderer_type, unmasked, intrinsics, colour_resolution=s.colour_resolution,
                           sh_degree=s.max_sh_degree, white_bkgd=True)
+        epoch = CAMERA_EPOCH
+        if world > 1 and hasattr(gaussian_renderer, "seq_bits"):
+            # every rank's keys must share one layout whatever cameras it renders: the widest tile field from the start
+            # (16384 leaf tiles; 63 cameras per epoch instead of 255)
+            gaussian_renderer.seq_bits = 14
+            epoch = min(CAMERA_EPOCH, gaussian_renderer.camera_epoch)
         for cam_index, (img_name, transform) in enumerate(transforms.items()):
             epochs = getattr(gaussian_renderer, "needs_camera_epochs", False)
             if world > 1:
-                if epochs and cam_index > 0 and cam_index % CAMERA_EPOCH == 0:   # 8-bit camera-order field of the keys
+                if epochs and cam_index > 0 and cam_index % epoch == 0:   # camera-order field of the keys
                     gaussian_renderer.all_reduce_visibility(group)
                     gaussian_renderer.rebase_keys()
                 if not split_tiles and cam_index % world != rank:
@@ -227,7 +233,7 @@ def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, poin
                                     colour_resolution=s.colour_resolution, sh_degree=s.max_sh_degree, white_bkgd=True, mask=mask)
             # Render new image and Gaussian contributions (the image itself is not used by the pipeline)
             if world > 1:
-                gaussian_renderer(camera, return_image=False, slot=(cam_index % CAMERA_EPOCH if epochs else cam_index) + 1)
+                gaussian_renderer(camera, return_image=False, slot=(cam_index % epoch if epochs else cam_index) + 1)
             else:
                 gaussian_renderer(camera, return_image=False)
         if world > 1:

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define G2PC_ABI_VERSION 2
+#define G2PC_ABI_VERSION 3
 
 #define G2PC_OK 0
 #define G2PC_ERR_ARG (-1)
@@ -264,6 +264,11 @@ typedef struct G2pcTileLayout {      /* HOST struct of DEVICE pointers: tiles = 
     const int32_t* chunk_tile;       /* [num_chunks]    sub-blocks of a tile (sub-blocks row-major inside the tile)   */
     const int32_t* chunk_pix0;       /* [num_chunks] first sub-block of the chunk; chunk_subblocks = 2: a | b << 16, two adjacent sub-blocks (b = 0xFFFF: none) */
     int32_t chunk_subblocks;         /* 1, 2 or 4 (pixels per lane) */
+    int32_t seq_bits;                /* ABI 3: width of the tile-sequence field of the packed visibility keys, 12 .. 14 (0 = 12):
+                                      * key = contribution bits << 32 | ~(camera_slot << (12 + seq_bits) | tile_seq << 12 | pixel).
+                                      * ny*nx <= 1 << seq_bits tiles, camera slots 1 .. (1 << (20 - seq_bits)) - 1 (255 / 127 / 63).
+                                      * Every camera whose keys meet in one best_key array must use the same width (a renderer
+                                      * that needs a wider field later rebases its keys first, g2pc_raster_rebase_keys). */
 } G2pcTileLayout;
 
 size_t g2pc_raster_front_workspace(int64_t n);
@@ -282,7 +287,7 @@ size_t g2pc_raster_back_workspace(int64_t num_instances, int32_t num_tiles);
  * max-contribution / arg-max pixel, colour update, optional image (f32[H,W,3], already flipped as the reference
  * returns it).  rec / rect / sorted_idx / offsets from the front half; best_key u64[n] and colours_out f32[n,3] are the renderer's
  * running state (zero-initialised by the caller); tilebuf f32[tile_pix_off[T],3] scratch.  camera_slot in
- * [1,255] must increase from camera to camera (call g2pc_raster_rebase_keys before wrapping around).
+ * [1, 255] (seq_bits 12; see G2pcTileLayout) must increase from camera to camera (call g2pc_raster_rebase_keys before wrapping around).
  * t_floor: 0 = exact python semantics; > 0 stops a pixel chunk once every pixel's transmittance is below it
  * (all later contributions and colour terms are then < t_floor).
  * phases: bit 0 = binning (duplicate, tile sort, ranges), bit 1 = blend, bit 2 = colour update + image; 7 = all

@@ -56,7 +56,7 @@ def assert_render_matches(g, R, images, contribs, tol=1e-4, allow_mask_flips=0, 
 
 
 def run_vs_oracle(n, seed, width, height, focal, ncam, device="cpu", scale=(0.004, 0.04), colour_resolution=None,
-                  t_floor=0.0):
+                  t_floor=0.0, max_tile_size=None):
     """HIP renderer vs oracle/ref_render.py (itself bit-pinned to the reference) on a seeded synthetic scene."""
     import gauss_render
     import camera_handler
@@ -74,7 +74,10 @@ def run_vs_oracle(n, seed, width, height, focal, ncam, device="cpu", scale=(0.00
     R = gauss_render.get_renderer("python", G.xyz, G.opacities.unsqueeze(1), G.colours, cov.to(dev),
                                   visible_gaussian_threshold=0.05)
     R.t_floor = t_floor
-    O = RR.PythonRendererOracle(sc.xyz, sc.opacities.unsqueeze(1), sc.colours.double(), cov, threshold=0.05)
+    if max_tile_size is not None:                  # render()'s max_tile_size argument (gauss_render.py:266), both sides
+        R.MAX_TILE_SIZE = max_tile_size
+    O = RR.PythonRendererOracle(sc.xyz, sc.opacities.unsqueeze(1), sc.colours.double(), cov, threshold=0.05,
+                                **({} if max_tile_size is None else {"max_tile_size": max_tile_size}))
     worst = dict(image=0.0, contribution=0.0, colour=0.0, flips=0, near_threshold=0, image_frac_off=0.0)
     for name in transforms:
         cam = camera_handler.get_camera("python", torch.tensor(transforms[name]), intr[name], colour_resolution=colour_resolution)
@@ -101,6 +104,7 @@ def run_vs_oracle(n, seed, width, height, focal, ncam, device="cpu", scale=(0.00
     worst["seen_gaussians"] = int(seen.sum())
     flips = (R.get_visible_gaussians().cpu() != O.get_visible_gaussians())
     worst["flips"] = int(flips.sum())
+    worst["seq_bits"] = R.seq_bits
     worst["near_threshold"] = int(((O.max_contribution - 0.05).abs() < 1e-5).sum())
     worst["flip_margins"] = (O.max_contribution[flips] - 0.05).abs().tolist()
     return worst
