@@ -54,6 +54,8 @@ _PROTOS = {
 }
 _PROTOS["g2pc_scatter_ones_u8"] = (C.c_int, [_vp, _i64, _vp, _i64, _vp])
 _PROTOS["g2pc_sampler_partition"] = (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _sz, _vp])
+_PROTOS["g2pc_sampler_bin_table_workspace"] = (_sz, [_i64])
+_PROTOS["g2pc_sampler_bin_table"] = (C.c_int, [_vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp])
 _PROTOS["g2pc_sampler_scan_workspace"] = (_sz, [_i64, _i32])
 _PROTOS["g2pc_sampler_scan_counts"] = (C.c_int, [_vp, _vp, _i64, _i32, _vp, _sz, _vp])
 _PROTOS["g2pc_sampler_sections"] = (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i64, C.c_int, _vp, _vp, _vp, _vp])

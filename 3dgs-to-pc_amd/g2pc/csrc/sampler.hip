@@ -114,11 +114,13 @@ __global__ __launch_bounds__(SM_T) void k_count_thread(const float* __restrict__
         unsigned d = 0;
         if (have < (unsigned)n) {
             unsigned acc = 0;
-            for (int k = 0; k < n; ++k) {
+            const unsigned room = (unsigned)n - have;
+            // d = min(accepted, room): once `room` draws are accepted the rest of the attempt cannot change d (every attempt
+            // after the first has room for a quarter of the quota only)
+            for (int k = 0; k < n && acc < room; ++k) {
                 float x, y, z;
                 acc += draw(s, seed_lo, seed_hi, gid_lo, gid_hi, (unsigned)(attempt0 + a), (unsigned)k, std_limit, x, y, z) ? 1u : 0u;
             }
-            unsigned room = (unsigned)n - have;
             d = acc < room ? acc : room;
             have += d;
         }
@@ -173,6 +175,170 @@ __global__ __launch_bounds__(SM_T) void k_count_wave(const float* __restrict__ m
         added[p] = have;
         if (have < (unsigned)n) atomicAdd(remaining, 1u);
     }
+}
+
+// ---- device-side bin table ----------------------------------------------------------------------------------------
+// The bin heuristics of generate_pointcloud / calculate_bin_sizes (gauss_to_pc.py:105-138, :308-337) on the histogram of
+// points per Gaussian, in ONE block: until round 3 the histogram went to the host, numpy built the table and the look-up
+// table came back (a round trip plus ~0.2 ms of host work in the middle of a 1 ms job).  The arithmetic is numpy's, value
+// for value: np.gradient twice in float64 (the second differences of integer counts are multiples of 1/4, so every sum
+// below is exact whatever its order), bin_size = max(D // 100, 1), the group sums, cut = max // 50 (floor division),
+// start_bin = first group at or after the peak below the cut -- counted FROM the peak, as the reference does --, the
+// tail rounded up to multiples of bin_size, quota = floor(s + (e - s) / 2).  Work arrays live in the caller's workspace.
+constexpr int BT_T = 1024, BT_PER = 8, BT_MAX = BT_T * BT_PER;      // histograms of up to 8 192 entries
+struct BinPlan {            // what the host needs back (pinned memory), all int64
+    int64_t num_bins, gv, p_wave, any_sampling, means_rows, rows_ub, error, start_bin, bin_size, distinct;
+};
+// exclusive scan of one value per (thread, k) in thread-major order; returns the total.  s_w: BT_T / 64 + 1 words
+__device__ __forceinline__ uint32_t block_excl_scan8(const uint32_t v[BT_PER], uint32_t out[BT_PER], uint32_t* s_w) {
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < BT_PER; ++k) sum += v[k];
+    const uint32_t incl = wave_incl_scan_u32(sum);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t off = incl - sum, total = 0;
+    for (int w = 0; w < BT_T / kWave; ++w) { const uint32_t t = s_w[w]; if (w < (int)(threadIdx.x >> 6)) off += t; total += t; }
+#pragma unroll
+    for (int k = 0; k < BT_PER; ++k) { out[k] = off; off += v[k]; }
+    return total;
+}
+
+__global__ __launch_bounds__(BT_T) void k_bin_table(const uint32_t* __restrict__ hist, int hist_len,
+                                                   const int64_t* __restrict__ stats /* [3] = max points per Gaussian */,
+                                                   int exact, int emit_means, int wave_min_draws,
+                                                   int32_t* __restrict__ lut, int32_t* __restrict__ quota,
+                                                   uint32_t* __restrict__ bin_start, int32_t* __restrict__ bin_lo,
+                                                   int32_t* __restrict__ val, uint32_t* __restrict__ cnt,
+                                                   double* __restrict__ g1, double* __restrict__ g2,
+                                                   int32_t* __restrict__ pd, uint32_t* __restrict__ members,
+                                                   BinPlan* __restrict__ plan_host) {
+    __shared__ uint32_t s_w[BT_T / kWave + 1];
+    __shared__ int s_i[8];
+    __shared__ unsigned long long s_rows[2];
+    const int tid = (int)threadIdx.x;
+    const long max_ppg = stats ? (long)stats[3] : (long)hist_len - 1;
+    if (max_ppg >= hist_len || hist_len > BT_MAX) {                 // histogram too short for this job: the host takes over
+        if (tid == 0) { BinPlan p{}; p.error = 1; *plan_host = p; }
+        return;
+    }
+    const int HL = (int)max_ppg + 1;
+    // (1) the distinct values (ascending) and their counts
+    uint32_t f[BT_PER], o[BT_PER];
+#pragma unroll
+    for (int k = 0; k < BT_PER; ++k) { const int v = tid * BT_PER + k; f[k] = (v < HL && hist[v] != 0u) ? 1u : 0u; lut[v < hist_len ? v : 0] = -1; }
+    // (the line above also clears the look-up table: every v < hist_len is visited by exactly one (thread, k))
+    const int D = (int)block_excl_scan8(f, o, s_w);
+#pragma unroll
+    for (int k = 0; k < BT_PER; ++k) { const int v = tid * BT_PER + k; if (f[k]) { val[o[k]] = v; cnt[o[k]] = hist[v]; } }
+    __syncthreads();
+    int start_bin = D, bin_size = 1;                               // exact mode: every distinct value is a bin
+    if (!exact) {
+        if (D < 2) {                                               // np.gradient needs two samples: the reference raises here
+            if (tid == 0) { BinPlan p{}; p.error = 2; p.distinct = D; *plan_host = p; }
+            return;
+        }
+        for (int i = tid; i < D; i += BT_T) {
+            const double a = (double)cnt[i > 0 ? i - 1 : 0], b = (double)cnt[i], c = (double)cnt[i < D - 1 ? i + 1 : D - 1];
+            g1[i] = i == 0 ? c - b : (i == D - 1 ? b - a : (c - a) / 2.0);
+        }
+        __syncthreads();
+        for (int i = tid; i < D; i += BT_T) {
+            const double a = g1[i > 0 ? i - 1 : 0], b = g1[i], c = g1[i < D - 1 ? i + 1 : D - 1];
+            g2[i] = fabs(i == 0 ? c - b : (i == D - 1 ? b - a : (c - a) / 2.0));
+        }
+        __syncthreads();
+        bin_size = D / 100 > 1 ? D / 100 : 1;
+        const int K = D / bin_size;                                // groups (the remainder of g2 is dropped)
+        for (int k = tid; k < K; k += BT_T) {
+            double acc = 0.0;
+            for (int j = 0; j < bin_size; ++j) acc += g2[k * bin_size + j];
+            g1[k] = acc;                                           // (g1 is free again: the group sums)
+        }
+        __syncthreads();
+        if (tid == 0) {                                            // K <= 199: peak, cut, first group below the cut
+            int peak = 0;
+            double mx = g1[0];
+            for (int k = 1; k < K; ++k) if (g1[k] > mx) { mx = g1[k]; peak = k; }
+            const double cut = (mx - fmod(mx, 50.0)) / 50.0;       // np.max(sums) // 50 (non-negative operands)
+            int sb = 1;
+            for (int k = peak; k < K; ++k) if (g1[k] < cut) { sb = k - peak; break; }
+            s_i[0] = sb;
+        }
+        __syncthreads();
+        start_bin = s_i[0] < D ? s_i[0] : D;
+    }
+    // (2) pd = val[:start_bin] ++ unique(ceil(val[start_bin:] / bin_size)) * bin_size
+#pragma unroll
+    for (int k = 0; k < BT_PER; ++k) {
+        const int i = tid * BT_PER + k;
+        uint32_t keep = 0;
+        if (i < D) {
+            if (i < start_bin) keep = 1;
+            else {
+                const int t = (val[i] + bin_size - 1) / bin_size;
+                keep = (i == start_bin || (val[i - 1] + bin_size - 1) / bin_size != t) ? 1u : 0u;
+            }
+        }
+        f[k] = keep;
+    }
+    const int B = (int)block_excl_scan8(f, o, s_w);
+#pragma unroll
+    for (int k = 0; k < BT_PER; ++k) {
+        const int i = tid * BT_PER + k;
+        if (f[k]) pd[o[k]] = i < start_bin ? val[i] : (val[i] + bin_size - 1) / bin_size * bin_size;
+    }
+    if (tid == 0) { s_i[1] = 0x7FFFFFFF; s_i[2] = 0; s_rows[0] = 0ull; s_rows[1] = 0ull; }
+    __syncthreads();
+    // (3) bins (start, end, quota), their members, the look-up table
+    for (int b = tid; b < B; b += BT_T) {
+        const int sv = pd[b], ev = b != B - 1 ? pd[b + 1] : sv + 1;
+        const int q = sv + (ev - sv) / 2;                          // floor(s + (e - s) / 2), integers with e > s
+        int lo = sv, hi = ev < HL ? ev : HL;
+        uint32_t m = 0;
+        if (q > 0 && hi > lo) for (int v = lo; v < hi; ++v) { lut[v] = b; m += hist[v]; }
+        quota[b] = q;
+        members[b] = m;
+        bin_lo[b] = sv;
+    }
+    __syncthreads();
+    // (4) bin_start = exclusive scan of the members; totals
+    uint32_t mv[BT_PER], mo[BT_PER];
+#pragma unroll
+    for (int k = 0; k < BT_PER; ++k) { const int b = tid * BT_PER + k; mv[k] = b < B ? members[b] : 0u; }
+    const uint32_t gv = block_excl_scan8(mv, mo, s_w);
+    unsigned long long means = 0ull, rows = 0ull;
+    int any_sampling = 0, first_wave = 0x7FFFFFFF;
+#pragma unroll
+    for (int k = 0; k < BT_PER; ++k) {
+        const int b = tid * BT_PER + k;
+        if (b < B) {
+            bin_start[b] = mo[k];
+            const int q = quota[b];
+            if (mv[k]) {
+                if (q > 0) means += mv[k];
+                if (q > 1) { rows += (unsigned long long)mv[k] * (unsigned long long)(q - 1); any_sampling = 1; }
+                if (q - 1 >= wave_min_draws && b < first_wave) first_wave = b;
+            }
+        }
+    }
+    if (means) atomicAdd(&s_rows[0], means);
+    if (rows) atomicAdd(&s_rows[1], rows);
+    if (any_sampling) atomicOr(&s_i[2], 1);
+    if (first_wave != 0x7FFFFFFF) atomicMin(&s_i[1], first_wave);
+    __syncthreads();
+    if (tid == 0) {
+        bin_start[B] = gv; bin_start[B + 1] = gv;
+        BinPlan p{};
+        p.num_bins = B; p.gv = gv; p.any_sampling = s_i[2];
+        p.means_rows = emit_means ? (int64_t)s_rows[0] : 0;
+        p.rows_ub = p.means_rows + (int64_t)s_rows[1];
+        p.start_bin = start_bin; p.bin_size = bin_size; p.distinct = D;
+        *plan_host = p;                                            // p_wave below needs bin_start of another thread's bin
+    }
+    __syncthreads();
+    if (tid == 0) plan_host->p_wave = s_i[1] != 0x7FFFFFFF ? (int64_t)bin_start[s_i[1]] : (int64_t)gv;
 }
 
 // ---- device-side section table ------------------------------------------------------------------------------------
@@ -437,6 +603,41 @@ int g2pc_sampler_plan(const int32_t* ppg, int64_t g, const int32_t* bin_of_ppg, 
     rc = scan_exclusive_u32(bin_start, bin_start, num_bins + 1, scan_ws, scan_bytes, s);
     if (rc) return rc;
     return check_launch("g2pc_sampler_plan");
+}
+
+size_t g2pc_sampler_bin_table_workspace(int64_t hist_len) {
+    using namespace g2pc;
+    const size_t n = (size_t)(hist_len > 0 ? hist_len : 0) + 2;
+    return align_up(n * 4) * 4 + align_up(n * 8) * 2 + 1024;
+}
+
+/* The bin table on the device (see k_bin_table): hist u32[hist_len] = bincount of the points per Gaussian, stats = the
+ * device-side result of g2pc_distribute_points ([3] = max points per Gaussian; NULL: hist_len - 1).  Out: lut i32[hist_len]
+ * (bin of every point count, -1: none), quota i32[hist_len], bin_start u32[hist_len + 2], bin_lo i32[hist_len] (first
+ * point count of every bin), plan_host (PINNED host memory, i64[10]: bins, Gaussians in bins, first wave-mode position,
+ * any sampling, mean rows, row bound, error, start_bin, bin_size, distinct counts) written through its device mapping.
+ * error 1: some Gaussian has hist_len or more points (build a longer histogram); 2: fewer than two distinct point counts in
+ * binned mode (the reference's np.gradient raises). */
+int g2pc_sampler_bin_table(const uint32_t* hist, int64_t hist_len, const int64_t* stats, int32_t exact, int32_t emit_means,
+                           int32_t wave_min_draws, int32_t* lut, int32_t* quota, uint32_t* bin_start, int32_t* bin_lo,
+                           int64_t* plan_host, void* ws, size_t ws_bytes, void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(hist && hist_len > 0 && lut && quota && bin_start && bin_lo && plan_host && ws, G2PC_ERR_ARG, "bad arguments");
+    G2PC_REQUIRE(hist_len <= BT_MAX, G2PC_ERR_UNSUPPORTED, "histograms of more than 8192 entries go through the host");
+    static_assert(sizeof(BinPlan) == 10 * sizeof(int64_t), "BinPlan is ten int64");
+    Arena ar(ws, ws_bytes);
+    const size_t n = (size_t)hist_len + 2;
+    int32_t* val = ar.get<int32_t>(n);
+    uint32_t* cnt = ar.get<uint32_t>(n);
+    int32_t* pd = ar.get<int32_t>(n);
+    uint32_t* members = ar.get<uint32_t>(n);
+    double* g1 = ar.get<double>(n);
+    double* g2 = ar.get<double>(n);
+    G2PC_REQUIRE(ar.ok(), G2PC_ERR_WORKSPACE, "workspace too small");
+    hipLaunchKernelGGL(k_bin_table, dim3(1), dim3(BT_T), 0, (hipStream_t)stream, hist, (int)hist_len, stats, (int)exact,
+                       (int)emit_means, (int)wave_min_draws, lut, quota, bin_start, bin_lo, val, cnt, g1, g2, pd, members,
+                       (BinPlan*)plan_host);
+    return check_launch("g2pc_sampler_bin_table");
 }
 
 /* The partition alone (bin keys + stable radix sort): perm / pbin as g2pc_sampler_plan, for callers that know the bin

@@ -270,52 +270,82 @@ def sample_pointcloud(xyz: torch.Tensor, cov: torch.Tensor, colours: torch.Tenso
     normals = _f32c(normals) if normals is not None else None
     G = xyz.shape[0]
 
-    if max_ppg is None:
-        # the caller hands over distribute_points' device-side stats instead of reading max(ppg) back first: histogram
-        # with a generous fixed length, ONE read-back for both (falls back to the exact length if some Gaussian got more
-        # than HIST_GUESS points)
+    plan = None
+    if bins is None and max_ppg is None and stats is not None:
+        # The bin table is built ON THE DEVICE from the histogram (g2pc_sampler_bin_table: numpy's arithmetic value for
+        # value); the host reads back ten numbers -- how many bins, how many Gaussians they hold, the bound of the output
+        # rows -- through pinned memory after one stream synchronisation.  No histogram download, no numpy in the middle
+        # of the job, no look-up-table upload.
         hist_dev = bincount(ppg_i32, HIST_GUESS)
-        both = torch.cat([stats.to(torch.int64), hist_dev.to(torch.int64)]).cpu().numpy()            # round trip #1
-        max_ppg = int(both[3])
-        hist = both[4:4 + max_ppg + 1] if max_ppg < HIST_GUESS else None
+        lut_d = torch.empty((HIST_GUESS,), dtype=torch.int32, device=dev)
+        quota_d = torch.empty((HIST_GUESS,), dtype=torch.int32, device=dev)
+        bin_start = torch.empty((HIST_GUESS + 2,), dtype=torch.int32, device=dev)
+        bin_lo = torch.empty((HIST_GUESS,), dtype=torch.int32, device=dev)
+        plan_host = _pinned_i64(dev, 10)
+        tb = L.g2pc_sampler_bin_table_workspace(HIST_GUESS)
+        tws = nv.workspace(tb, dev)
+        nv.check(L.g2pc_sampler_bin_table(nv.ptr(hist_dev), HIST_GUESS, nv.ptr(stats.to(torch.int64)), int(exact),
+                                          1 if emit_means else 0, WAVE_MODE_MIN_DRAWS, nv.ptr(lut_d), nv.ptr(quota_d),
+                                          nv.ptr(bin_start), nv.ptr(bin_lo), C_void(plan_host), nv.ptr(tws), tb, st),
+                 "sampler_bin_table")
+        if dev.type == "cuda" and not nv.emulated():
+            torch.cuda.current_stream(dev).synchronize()                                   # round trip #1: ten numbers
+        plan = [int(v) for v in plan_host.tolist()]
+        if plan[6] == 2:
+            raise ValueError("fewer than two distinct points-per-Gaussian values: the reference's calculate_bin_sizes "
+                             "(np.gradient) cannot bin such a distribution")
+        if plan[6] != 0:
+            plan = None                                      # some Gaussian got >= HIST_GUESS points: the host path below
+    if plan is not None:
+        B, gv, p_wave, any_sampling, means_rows, rows_ub = plan[0], plan[1], plan[2], bool(plan[3]), plan[4], plan[5]
+        lut_len = HIST_GUESS
+        bins = _LazyBins(bin_lo, quota_d, B)
     else:
-        hist = None
-    if hist is None:
-        hist = bincount(ppg_i32, int(max_ppg) + 1).cpu().numpy().astype(np.int64)      # round trip #1
-    if bins is None:
-        bins = bin_table_from_hist(hist, exact)
-    B = len(bins)
-    lut = np.full((int(max_ppg) + 1,), -1, dtype=np.int32)
-    quota = np.zeros((max(B, 1),), dtype=np.int32)
-    members = np.zeros((max(B, 1),), dtype=np.int64)
-    for b, (s, e, n) in enumerate(bins):
-        quota[b] = n
-        lo, hi = int(np.ceil(s)), int(np.ceil(e))
-        hi = min(hi, int(max_ppg) + 1)
-        if n > 0 and hi > lo:
-            lut[lo:hi] = b
-            members[b] = hist[lo:hi].sum()
-    # bin sizes are known on the host from the histogram: bin_start is uploaded with the other small tables (one copy)
-    bs_host = np.zeros((B + 2,), dtype=np.int64)
-    bs_host[1:B + 1] = np.cumsum(members[:B])
-    bs_host[B + 1] = bs_host[B]
-    gv = int(bs_host[B])
-    packed = torch.from_numpy(np.concatenate([lut, quota, bs_host.astype(np.int32)])).to(dev)
-    lut_d, quota_d = packed[:lut.shape[0]], packed[lut.shape[0]:lut.shape[0] + quota.shape[0]]
-    bin_start = packed[lut.shape[0] + quota.shape[0]:]
+        if max_ppg is None:
+            # histogram with a generous fixed length, ONE read-back for it and distribute_points' stats (falls back to the
+            # exact length if some Gaussian got more than HIST_GUESS points)
+            hist_dev = bincount(ppg_i32, HIST_GUESS)
+            both = torch.cat([stats.to(torch.int64), hist_dev.to(torch.int64)]).cpu().numpy()            # round trip #1
+            max_ppg = int(both[3])
+            hist = both[4:4 + max_ppg + 1] if max_ppg < HIST_GUESS else None
+        else:
+            hist = None
+        if hist is None:
+            hist = bincount(ppg_i32, int(max_ppg) + 1).cpu().numpy().astype(np.int64)      # round trip #1
+        if bins is None:
+            bins = bin_table_from_hist(hist, exact)
+        B = len(bins)
+        lut = np.full((int(max_ppg) + 1,), -1, dtype=np.int32)
+        quota = np.zeros((max(B, 1),), dtype=np.int32)
+        members = np.zeros((max(B, 1),), dtype=np.int64)
+        for b, (s, e, n) in enumerate(bins):
+            quota[b] = n
+            lo, hi = int(np.ceil(s)), int(np.ceil(e))
+            hi = min(hi, int(max_ppg) + 1)
+            if n > 0 and hi > lo:
+                lut[lo:hi] = b
+                members[b] = hist[lo:hi].sum()
+        # bin sizes are known on the host from the histogram: bin_start is uploaded with the other small tables (one copy)
+        bs_host = np.zeros((B + 2,), dtype=np.int64)
+        bs_host[1:B + 1] = np.cumsum(members[:B])
+        bs_host[B + 1] = bs_host[B]
+        gv = int(bs_host[B])
+        packed = torch.from_numpy(np.concatenate([lut, quota, bs_host.astype(np.int32)])).to(dev)
+        lut_d, quota_d = packed[:lut.shape[0]], packed[lut.shape[0]:lut.shape[0] + quota.shape[0]]
+        bin_start = packed[lut.shape[0] + quota.shape[0]:]
+        lut_len = lut.shape[0]
+        wave_bins = [b for b in range(B) if quota[b] - 1 >= WAVE_MODE_MIN_DRAWS and members[b] > 0]
+        p_wave = int(bs_host[wave_bins[0]]) if wave_bins else gv
+        any_sampling = bool(np.any((quota[:B] > 1) & (members[:B] > 0))) if B else False
+        means_rows = int(sum(members[b] for b in range(B) if quota[b] > 0)) if emit_means else 0
+        rows_ub = means_rows + int(sum(members[b] * max(int(quota[b]) - 1, 0) for b in range(B)))
 
     perm = torch.empty((G,), dtype=torch.int32, device=dev)
     pbin = torch.empty((G,), dtype=torch.int32, device=dev)
     ws_bytes = L.g2pc_sampler_plan_workspace(G)
     ws = nv.workspace(ws_bytes, dev)
-    nv.check(L.g2pc_sampler_partition(nv.ptr(ppg_i32), G, nv.ptr(lut_d), lut.shape[0], B, nv.ptr(perm), nv.ptr(pbin),
+    nv.check(L.g2pc_sampler_partition(nv.ptr(ppg_i32), G, nv.ptr(lut_d), lut_len, B, nv.ptr(perm), nv.ptr(pbin),
                                       nv.ptr(ws), ws_bytes, st), "sampler_partition")
-    wave_bins = [b for b in range(B) if quota[b] - 1 >= WAVE_MODE_MIN_DRAWS and members[b] > 0]
-    p_wave = int(bs_host[wave_bins[0]]) if wave_bins else gv
-
-    any_sampling = bool(np.any((quota[:B] > 1) & (members[:B] > 0))) if B else False
-    means_rows = int(sum(members[b] for b in range(B) if quota[b] > 0)) if emit_means else 0
-    rows_ub = means_rows + int(sum(members[b] * max(int(quota[b]) - 1, 0) for b in range(B)))
     added = torch.zeros((max(gv, 1) + 1,), dtype=torch.int32, device=dev)        # [gv] = unfinished Gaussians ("remaining")
     remaining = added[max(gv, 1):]
     info = _pinned_i64(dev)
@@ -377,6 +407,33 @@ def sample_pointcloud(xyz: torch.Tensor, cov: torch.Tensor, colours: torch.Tenso
 def C_void(t: torch.Tensor):
     import ctypes as C
     return C.c_void_p(t.data_ptr())
+
+
+class _LazyBins:
+    """The bin table ((start, end, quota) triples in loop order, gauss_to_pc.py:308-337) of a device-built plan: read from
+    the device on first use (diagnostics and tests; the pipeline never looks at it)."""
+
+    def __init__(self, bin_lo, quota, B):
+        self._lo, self._q, self._B, self._v = bin_lo, quota, B, None
+
+    def _get(self):
+        if self._v is None:
+            lo = self._lo[:self._B].cpu().numpy().astype(np.float64)
+            q = self._q[:self._B].cpu().numpy()
+            self._v = [(float(lo[i]), float(lo[i + 1] if i != self._B - 1 else lo[i] + 1), int(q[i])) for i in range(self._B)]
+        return self._v
+
+    def __getitem__(self, i):
+        return self._get()[i]
+
+    def __len__(self):
+        return self._B
+
+    def __iter__(self):
+        return iter(self._get())
+
+    def __eq__(self, other):
+        return list(self._get()) == list(other)
 
 
 class _LazyPerAttempt:

@@ -183,6 +183,21 @@ int g2pc_sampler_count(const float* means, const float* cov9, const uint32_t* pe
 
 /* Stage 3 (emission in the reference's order) is g2pc_sampler_scan_counts / _sections / _emit_rows below. */
 
+/* The bin table of generate_pointcloud / calculate_bin_sizes (gauss_to_pc.py:105-138, :308-337) built ON THE DEVICE from the
+ * histogram of points per Gaussian (g2pc_bincount_i32), numpy's arithmetic value for value (float64 second differences,
+ * group sums, cut = max // 50, start_bin counted from the peak as the reference does, tail rounded up to multiples of
+ * bin_size, quota = floor(s + (e - s) / 2)).  Replaces the mid-pipeline round trip histogram -> host numpy -> look-up table.
+ * hist u32[hist_len <= 8192]; stats = g2pc_distribute_points' device result ([3] = max points per Gaussian; NULL: hist_len-1).
+ * Out (device): lut i32[hist_len] (bin of a point count, -1 none), quota i32[hist_len], bin_start u32[hist_len + 2]
+ * (exclusive scan of the bins' member counts), bin_lo i32[hist_len] (first point count of each bin).  plan_host: PINNED
+ * host memory, i64[10], written through its device mapping: {bins, Gaussians in bins, first wave-mode position, any
+ * sampling, mean rows, upper bound of output rows, error, start_bin, bin_size, distinct point counts}; error 1 = some
+ * Gaussian has >= hist_len points (use a longer histogram on the host path), 2 = fewer than two distinct point counts in
+ * binned mode (the reference's np.gradient raises there). */
+size_t g2pc_sampler_bin_table_workspace(int64_t hist_len);
+int g2pc_sampler_bin_table(const uint32_t* hist, int64_t hist_len, const int64_t* stats, int32_t exact, int32_t emit_means,
+                           int32_t wave_min_draws, int32_t* lut, int32_t* quota, uint32_t* bin_start, int32_t* bin_lo,
+                           int64_t* plan_host, void* ws, size_t ws_bytes, void* stream);
 /* --- sampler, device-resident bookkeeping (no host round trip between the count and the emission) ---------------
  * g2pc_sampler_scan_counts: dscan[a] (u32[gv+1] per attempt) = exclusive scan of dcount[a] (u32[gv] per attempt).
  * g2pc_sampler_sections:    sec_base i64[num_bins * (1 + attempts) + 1] = first output row of every (bin, means |

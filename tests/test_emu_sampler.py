@@ -26,3 +26,54 @@ def test_sampler_wave_mode_equals_thread_mode(emu, golden_dir, monkeypatch):
     monkeypatch.setattr(ops, "WAVE_MODE_MIN_DRAWS", 10 ** 9)      # and none
     g3, sc3, ppg3, out3 = run_sampler_case(golden_dir, "sampler_binned_n3000.npz")
     assert torch.equal(out.points, out3.points)
+
+
+@pytest.mark.parametrize("seed,g,scale,exact", [(1, 5000, 30.0, False), (2, 20000, 300.0, False), (3, 3000, 3.0, False),
+                                                (4, 4000, 50.0, True), (5, 150, 800.0, False), (6, 9000, 1500.0, False)])
+def test_device_bin_table_equals_the_host_table(emu, seed, g, scale, exact):
+    """g2pc_sampler_bin_table (the bin heuristics of gauss_to_pc.py:105-138 / :308-337 in one block on the device) against
+    the numpy restatement the host path uses (pinned to the reference by the sampler fixtures): the same bins, quotas,
+    look-up table, member offsets and plan numbers for point-count distributions of several shapes, binned and exact."""
+    import numpy as np
+    import torch
+    from g2pc import ops
+    rng = np.random.default_rng(seed)
+    ppg = np.minimum(np.floor(rng.lognormal(np.log(scale), 0.9, g)), ops.HIST_GUESS - 1).astype(np.int32)
+    ppg[rng.random(g) < 0.1] = 0
+    t = torch.from_numpy(ppg)
+    L = emu.lib()
+    HL = ops.HIST_GUESS
+    hist_dev = ops.bincount(t, HL)
+    stats = torch.tensor([int(ppg.sum()), int((ppg == 0).sum()), 0, int(ppg.max())], dtype=torch.int64)
+    lut, quota, bin_lo = (torch.empty((HL,), dtype=torch.int32) for _ in range(3))
+    bin_start = torch.empty((HL + 2,), dtype=torch.int32)
+    plan = torch.zeros((10,), dtype=torch.int64)
+    wb = L.g2pc_sampler_bin_table_workspace(HL)
+    ws = emu.workspace(wb, "cpu")
+    emu.check(L.g2pc_sampler_bin_table(emu.ptr(hist_dev), HL, emu.ptr(stats), int(exact), 1, ops.WAVE_MODE_MIN_DRAWS, emu.ptr(lut),
+                                       emu.ptr(quota), emu.ptr(bin_start), emu.ptr(bin_lo), ops.C_void(plan), emu.ptr(ws), wb,
+                                       None), "bin_table")
+    B, gv, p_wave, any_s, means_rows, rows_ub, err = [int(v) for v in plan[:7]]
+    assert err == 0
+    hist = np.bincount(ppg, minlength=int(ppg.max()) + 1).astype(np.int64)
+    ref = ops.bin_table_from_hist(hist, exact)
+    assert B == len(ref)
+    got = list(ops._LazyBins(bin_lo, quota, B))
+    assert got == [(float(s), float(e), int(n)) for s, e, n in ref]
+    # look-up table, members, offsets: the host path's construction
+    rl = np.full((int(ppg.max()) + 1,), -1, dtype=np.int32)
+    members = np.zeros((B,), dtype=np.int64)
+    for b, (s, e, n) in enumerate(ref):
+        lo, hi = int(np.ceil(s)), min(int(np.ceil(e)), int(ppg.max()) + 1)
+        if n > 0 and hi > lo:
+            rl[lo:hi] = b
+            members[b] = hist[lo:hi].sum()
+    assert np.array_equal(lut.numpy()[:rl.shape[0]], rl) and (lut.numpy()[rl.shape[0]:] == -1).all()
+    bs = np.concatenate([[0], np.cumsum(members)])
+    assert np.array_equal(bin_start.numpy()[:B + 1].astype(np.int64), bs) and gv == int(bs[-1])
+    q = np.array([n for _, _, n in ref])
+    wave = [b for b in range(B) if q[b] - 1 >= ops.WAVE_MODE_MIN_DRAWS and members[b] > 0]
+    assert p_wave == (int(bs[wave[0]]) if wave else gv)
+    assert bool(any_s) == bool(np.any((q > 1) & (members > 0)))
+    assert means_rows == int(members[q > 0].sum())
+    assert rows_ub == means_rows + int((members * np.maximum(q - 1, 0)).sum())
