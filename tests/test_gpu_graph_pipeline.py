@@ -67,18 +67,19 @@ def test_resolution_change_and_more_cameras_than_order_slots():
 
 
 def test_wide_tile_field_and_its_shorter_camera_epoch():
-    """8 192 quad-tree leaves (320 x 180 at max_tile_size 4): the keys' tile field widens to 13 bits, which leaves 127 cameras
-    per key epoch -- 140 cameras wrap it (keys rebased).  Replayed graphs against the two-call path."""
+    """16 384 quad-tree leaves (512 x 288 at max_tile_size 4 -- what 7680 x 4320 is at the default 60): the keys' tile field
+    widens to 14 bits, which leaves 63 cameras per key epoch -- 70 cameras wrap it (keys rebased).  Replayed graphs against
+    the two-call path."""
     import gauss_render
     old = gauss_render.GaussHipRenderer.MAX_TILE_SIZE
     gauss_render.GaussHipRenderer.MAX_TILE_SIZE = 4
     try:
         G = _scene(20_000, 9)
-        cams = _cams(140, width=320, height=180)
+        cams = _cams(70, width=512, height=288)
         k0, c0, R0 = _render(G, cams, False)
         k1, c1, R = _render(G, cams, True)
     finally:
         gauss_render.GaussHipRenderer.MAX_TILE_SIZE = old
         gauss_render.clear_context_pool()
-    assert R.seq_bits == 13 and R.camera_epoch == 127 and R0.seq_bits == 13
+    assert R.seq_bits == 14 and R.camera_epoch == 63 and R0.seq_bits == 14
     assert np.array_equal(k0 >> 32, k1 >> 32) and np.array_equal(c0, c1)
