@@ -226,6 +226,8 @@ CAMERA_BATCH = 2                  # cameras per launch sequence (g2pc_raster_cam
 #   "split_multi": every slot's heads on its OWN high-priority stream (the small head kernels of several batches run side
 #            by side), all blends on ONE shared stream, back to back.
 PIPELINE_MODE = "chain"
+PIPELINE_BLEND_STREAMS = 1        # split modes: blend streams the batches alternate over (2: two blends in flight -- the
+                                  # throughput phase of one beside the draining tail of the other)
 PIPELINE_IN_EMULATOR = False      # tests: drive the capture / replay path through the CPU emulator too
 CAPACITY_HEADROOM = 1.25          # instance capacity of the captured graphs relative to the largest count seen so far
 MIN_CAPACITY = 1 << 16
@@ -289,15 +291,15 @@ class _RenderContext:
         self.overflow = torch.empty((1,), dtype=torch.int32, device=device)
         self.sync_scratch = _Scratch(n, device)
         self.slots, self.capacity = [], None
-        self._blend_stream = None
+        self._blend_streams = []
         self.cam_tilebufs = []        # ring of per-tile colour buffers, one per pipelined camera whose colours are still to be
                                       # resolved (deferred colour resolve); bounded by DEFERRED_BUDGET_BYTES, reused by the
                                       # next batch / job of this context
 
-    def blend_stream(self, device):
-        if self._blend_stream is None:
-            self._blend_stream = torch.cuda.Stream(device)
-        return self._blend_stream
+    def blend_stream(self, device, index=0):
+        while len(self._blend_streams) <= index:
+            self._blend_streams.append(torch.cuda.Stream(device))
+        return self._blend_streams[index]
 
     def release(self):
         for sl in self.slots:
@@ -630,7 +632,8 @@ class GaussHipRenderer():
             for o in self.slots:
                 o.stream.wait_stream(torch.cuda.current_stream(self.device))      # scene tensors / state are ready
             if PIPELINE_MODE.startswith("split"):
-                self.ctx.blend_stream(self.device).wait_stream(torch.cuda.current_stream(self.device))
+                for b in range(max(1, int(PIPELINE_BLEND_STREAMS))):
+                    self.ctx.blend_stream(self.device, b).wait_stream(torch.cuda.current_stream(self.device))
         # profiling: HIP events around the blend alone -> the graph stops before it and the blend is issued directly
         # (this runtime refuses event-record nodes inside a captured graph)
         exact = 8 if self.t_floor == 0.0 else 0      # to-the-letter mode: the blend kernel with the reference's operation order
@@ -644,7 +647,7 @@ class GaussHipRenderer():
         if split:
             # heads of all slots on the slots' common head stream (slot 0's, high priority), blends on the common blend stream
             head = sl.stream if PIPELINE_MODE == "split_multi" else self.slots[0].stream
-            blend = self.ctx.blend_stream(self.device)
+            blend = self.ctx.blend_stream(self.device, self.slots.index(sl) % max(1, int(PIPELINE_BLEND_STREAMS)))
             head.wait_stream(sl.stream)                    # (a capture's warm-up run on the slot's own stream)
             head.wait_event(sl.update_done)                # this slot's arena: its previous blends are through
             nv.check(L.g2pc_graph_launch(sl.graph, C.c_void_p(head.cuda_stream)), "graph_launch")
@@ -730,8 +733,8 @@ class GaussHipRenderer():
             cur = torch.cuda.current_stream(self.device)
             for sl in self.slots:
                 cur.wait_stream(sl.stream)
-            if self.ctx._blend_stream is not None:
-                cur.wait_stream(self.ctx._blend_stream)
+            for b in self.ctx._blend_streams:
+                cur.wait_stream(b)
         while self.redo:                           # cameras that overflowed their graph: two-call path, original slot
             cam, lay, slot = self.redo.pop(0)
             self.deferred.pop(slot, None)          # ... which updates the colours it wins at once
