@@ -238,8 +238,10 @@ inline const uint64_t* exchange(uint64_t v, uint64_t* active_mask = nullptr) {
     unsigned w = s.cur >> 6, l = s.cur & 63;
     wave_barrier();              // previous readers are done
     s.slot[w][l] = v;
-    wave_barrier();
+    // the participants, taken while all of them are still inside the collective: a lane released early from the second
+    // barrier may run to the end of the kernel before the others look (readfirstlane then picked the wrong lane)
     if (active_mask) *active_mask = alive_mask();
+    wave_barrier();
     return s.slot[w];
 }
 inline int block_reduce(int v, int op) {   // op 0: or, 1: sum
