@@ -18,8 +18,7 @@ namespace g2pc {
 
 constexpr int CL_T = 256;
 __global__ void k_tile_ranges(const uint32_t* __restrict__ tile_sorted, long L, int T, uint32_t* __restrict__ tile_start,
-                              const uint32_t* __restrict__ l_dev, int gshift, size_t cs,
-                              uint32_t* __restrict__ zero_word);                            // raster.hip: boundaries of sorted ids
+                              const uint32_t* __restrict__ l_dev, int gshift, size_t cs);   // raster.hip: boundaries of sorted ids
 
 struct Grid {
     float ox, oy, oz, h, inv_h;
@@ -282,7 +281,7 @@ int g2pc_outlier_grid_build(const float* points, int64_t m, const float* origin,
     int rc = sort_pairs_u32(key, idx, key_s, idx_s, ktmp, vtmp, (long)m, 0, bits_for((unsigned)cells), sort_ws, sort_bytes, s);
     if (rc) return rc;
     hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(m + 1, CL_T)), dim3(CL_T), 0, s, key_s, (long)m, (int)cells, cell_start,
-                       (const uint32_t*)nullptr, 0, (size_t)0, (uint32_t*)nullptr);
+                       (const uint32_t*)nullptr, 0, (size_t)0);
     hipLaunchKernelGGL(k_gather_sorted, dim3(cdiv(m, CL_T)), dim3(CL_T), 0, s, points, idx_s, (long)m, (float4*)sorted_pos);
     if (occupied) {
         hipMemsetAsync(occupied, 0, sizeof(uint32_t), s);

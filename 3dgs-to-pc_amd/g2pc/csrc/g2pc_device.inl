@@ -52,17 +52,6 @@ __device__ __forceinline__ unsigned wave_min_u32_dpp(unsigned v) {
 }
 #undef G2PC_DPP_STEP
 
-// quad_perm DPP: every lane reads lane SRC (0..3) of its own group of four -- full rate, no LDS
-template <int SRC> __device__ __forceinline__ float quad_bcast_f32(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), SRC * 0x55, 0xF, 0xF, true));
-}
-// sum over the four lanes of a quad (every lane gets it): quad_perm [1,0,3,2] then [2,3,0,1]
-__device__ __forceinline__ float quad_sum_f32(float v) {
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
-    return v;
-}
-
 // ---- packed f32 pairs: v_pk_add/mul/fma_f32 retire two IEEE f32 operations per lane per issue slot (the 157 TF
 // vector peak of the part is quoted on them); element-wise results are bit-identical to the scalar instructions.
 #if defined(__clang__)

@@ -20,7 +20,7 @@ namespace g2pc {
 
 constexpr int RA_T = 256;
 __global__ void k_tile_ranges(const uint32_t* __restrict__ tile_sorted, long L, int T, uint32_t* __restrict__ tile_start,
-                              const uint32_t* __restrict__ l_dev, int gshift, size_t cs, uint32_t* __restrict__ zero_word);
+                              const uint32_t* __restrict__ l_dev, int gshift, size_t cs);
 constexpr float LOG2E = 1.4426950408889634f;
 
 struct Cam {            // device copy of G2pcCamera (passed by value as kernel argument)
@@ -620,28 +620,6 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_pk(Layout lay, const int32_t*
 // -- five FMAs per pixel instead of seven operations, and the opacity multiply rides in K.  Rounding differs from the
 // reference's order of operations by ~eps * (|exponent| + |A| 50): <= 2e-5 relative in alpha for the sharpest Gaussians
 // the 0.3-pixel dilation admits, ~3e-6 typically (the reference's own dx = pixel - mean carries eps * |mean| already).
-// ---- the tail of the dual-list blend ---------------------------------------------------------------------------------
-// A launch of k_blend_py_dl lasts as long as its longest walk: one wave works through a 5 000-entry tile list at ~155 cycles
-// per entry while most of the machine has drained.  A walk that reaches `cap_batches` 64-entry batches with
-// at least `min_left` entries to go therefore STOPS there: the wave writes the (T, r, g, b) of its pixels and where the walk
-// stands into the camera's tail list, and k_blend_tail -- the next launch on the stream -- finishes it with a 512-thread
-// workgroup per chunk: the eight waves stage the rest of the list TOGETHER (512 entries per round, one cull and one
-// compacted list per 8x8 sub-block in LDS) and each blends one 16-pixel quarter of a sub-block in QUAD mode: lane = 4 *
-// pixel + slot, the four lanes of a quad evaluate the weights of four consecutive list entries at once and pass the
-// transmittance down the quad with three DPP broadcasts -- the same multiplications and subtractions in the same order as
-// the one-entry-at-a-time recurrence, on a quarter of the dependent instructions.  A pixel's transmittance sequence and
-// every contribution >= t_floor are bit-identical with and without the hand-over; a pixel's colour is summed per quad slot
-// and combined at the end (last bits), and a quarter stops when ITS 16 pixels are below the floor (differences < t_floor).
-struct BlendTail {
-    uint32_t* count;      // [1] per camera: chunks handed over (may exceed capacity: the excess was not handed over)
-    uint4* list;          // [capacity][2] (chunk, list position the walk stopped at, sub-blocks handed over (bit j), tile),
-                          //               (tile list start, end, the chunk's sub-block pair, -): what the tail would otherwise chase
-    float4* state;        // [capacity][2][64] (T, r, g, b) of the handed-over pixels, lane-major as the owner held them
-    int cap_batches;      // 0: no hand-over
-    int min_left, capacity;
-};
-constexpr int TL_GRID = 1024;               // tail workgroups per camera (each takes every TL_GRID-th handed-over chunk)
-
 template <int U>
 __global__ __launch_bounds__(BL_T) void k_blend_py_dl(Layout lay, const int32_t* __restrict__ chunk_tile,
                                                      const int32_t* __restrict__ chunk_pix0,
@@ -651,7 +629,7 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_dl(Layout lay, const int32_t*
                                                      unsigned long long* __restrict__ best_key, uint32_t order_base,
                                                      float t_floor, float bg, float* __restrict__ tilebuf,
                                                      uint32_t* __restrict__ chunk_work,
-                                                     const G2pcCameraJob* __restrict__ job, size_t cs, BlendTail tail) {
+                                                     const G2pcCameraJob* __restrict__ job, size_t cs) {
     const unsigned chunk_i = blockIdx.z * gridDim.y + blockIdx.y;       // the blends: camera = blockIdx.x, chunk in (y, z)
     if ((int)chunk_i >= lay.num_chunks) return;
     tile_start = seg_at(tile_start, cs, blockIdx.x); inst_g = seg_at(inst_g, cs, blockIdx.x); rec = seg_at(rec, cs, blockIdx.x);
@@ -712,14 +690,7 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_dl(Layout lay, const int32_t*
         gmb = ((const uint32_t*)best_key)[2 * (size_t)g_cur + 1];   // live running maximum
     }
     uint32_t processed = 0, visits = 0;
-    // a long walk stops after cap_batches batches and hands the rest over to k_blend_tail (see BlendTail): the loop simply
-    // ends there -- one exit, as without the hand-over
-    uint32_t walk_end = end;
-    if (cull && tail.cap_batches > 0) {
-        const uint32_t cap = start + (uint32_t)tail.cap_batches * BL_BATCH;
-        if (end > cap && end - cap >= (uint32_t)tail.min_left) walk_end = cap;
-    }
-    for (uint32_t b = start; b < walk_end; b += BL_BATCH) {
+    for (uint32_t b = start; b < end; b += BL_BATCH) {
         processed = b + BL_BATCH - start;
         if (processed == 16 * BL_BATCH) __builtin_amdgcn_s_setprio(2);
         wave_sync();
@@ -860,26 +831,6 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_dl(Layout lay, const int32_t*
         cw[5] = g2pc_xcc_id();
         cw[6] = visits;                              // (Gaussian, sub-block) pairs that survived the cull
     }
-    if (walk_end != end && !(done[0] && done[1])) {
-        uint32_t tail_slot = 0;
-        if (lane == 0) tail_slot = atomicAdd(seg_at(tail.count, cs, blockIdx.x), 1u);      // < capacity = the number of chunks
-        tail_slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)tail_slot);
-        const uint32_t resume_at = walk_end - start;
-        float4* st = seg_at(tail.state, cs, blockIdx.x) + (size_t)tail_slot * 128;
-        uint32_t handed = 0;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (done[j]) continue;                          // wave-uniform
-            st[j * 64 + lane] = make_float4(T[j], cr[j], cg[j], cb[j]);
-            handed |= 1u << j;
-            pix[j] = -1;                                    // written by k_blend_tail
-        }
-        if (lane == 0) {
-            uint4* le = seg_at(tail.list, cs, blockIdx.x) + 2 * (size_t)tail_slot;
-            le[0] = make_uint4(chunk_i, start + resume_at, handed, (uint32_t)tile);
-            le[1] = make_uint4(start, end, sbpair, 0u);
-        }
-    }
     float* out = tilebuf + 3 * (size_t)lay.tile_pix_off[tile];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -888,190 +839,6 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_dl(Layout lay, const int32_t*
             out[3 * (size_t)pix[j] + 1] = fmaf(T[j], bg, cg[j]);
             out[3 * (size_t)pix[j] + 2] = fmaf(T[j], bg, cb[j]);
         }
-    }
-}
-
-// The tail kernel (see BlendTail): one 512-thread workgroup per handed-over chunk, wave w = quarter w % 4 of sub-block w / 4.
-constexpr int TL_T = 512, TL_WAVES = TL_T / 64, TL_ROUND = TL_T;
-__global__ __launch_bounds__(TL_T) void k_blend_tail(Layout lay, const int32_t* __restrict__ chunk_tile,
-                                                    const int32_t* __restrict__ chunk_pix0,
-                                                    const uint32_t* __restrict__ tile_start,
-                                                    const uint32_t* __restrict__ inst_g, uint32_t gmask,
-                                                    const float4* __restrict__ rec,
-                                                    unsigned long long* __restrict__ best_key, uint32_t order_base,
-                                                    float t_floor, float bg, float* __restrict__ tilebuf,
-                                                    const G2pcCameraJob* __restrict__ job, size_t cs, BlendTail tail) {
-    const unsigned cam = blockIdx.x;
-    uint32_t n_tail = *seg_at(tail.count, cs, cam);
-    if (n_tail > (uint32_t)tail.capacity) n_tail = (uint32_t)tail.capacity;
-    if (blockIdx.y >= n_tail) return;                           // (whole block)
-    tile_start = seg_at(tile_start, cs, cam); inst_g = seg_at(inst_g, cs, cam); rec = seg_at(rec, cs, cam);
-    if (job) {
-        job += cam;
-        order_base = job->camera_slot << (12 + lay.seq_bits); t_floor = job->t_floor; bg = job->cam.bg[0];
-        const unsigned long long tb = ((unsigned long long)job->tilebuf_hi << 32) | job->tilebuf_lo;
-        if (tb) tilebuf = (float*)tb;
-    }
-    __shared__ float4 s_a[2][TL_ROUND + 4];         // A, B, C, Lu          (one compacted list per sub-block)
-    __shared__ float4 s_b[2][TL_ROUND + 4];         // Lv, K, red, green
-    __shared__ float2 s_c[2][TL_ROUND + 4];         // blue, max(running maximum, FLT_MIN)
-    __shared__ uint32_t s_g[2][TL_ROUND];
-    __shared__ int s_cnt[2][TL_WAVES];              // survivors of wave w's 64 entries, per sub-block
-    __shared__ int s_live[TL_WAVES];                // quarter w still takes entries
-    for (uint32_t slot = blockIdx.y; slot < n_tail; slot += gridDim.y) {      // (block-uniform trip count)
-    const uint4 ent = seg_at(tail.list, cs, cam)[2 * (size_t)slot], ent2 = seg_at(tail.list, cs, cam)[2 * (size_t)slot + 1];
-    const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    const int j = (int)(w >> 2), kq = (int)(w & 3u);
-    const int q = (int)(lane & 3u), p = (int)(lane >> 2);
-    const int tile = (int)ent.w;
-    const uint32_t sbpair = ent2.z;
-    const int ix = tile % lay.nx, iy = tile / lay.nx;
-    const int x0 = lay.xs[ix], wd = lay.ws[ix], y0 = lay.ys[iy], h = lay.hs[iy];
-    const int nsbx = (wd + 7) >> 3;
-    // the two sub-blocks' squares (for the cull, clipped to the tile) and this wave's own pixels
-    float cx0[2], cx1[2], cy0[2], cy1[2], ocx[2], ocy[2];
-    int sxj = 0, syj = 0;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int sb = (int)((sbpair >> (16 * t)) & 0xFFFFu);
-        const bool present = sb != 0xFFFF;
-        const int sx = present ? (sb % nsbx) * 8 : 0, sy = present ? (sb / nsbx) * 8 : 0;
-        cx0[t] = (float)(x0 + sx); cy0[t] = (float)(y0 + sy);
-        cx1[t] = (float)(x0 + (sx + 7 > wd - 1 ? wd - 1 : sx + 7));
-        cy1[t] = (float)(y0 + (sy + 7 > h - 1 ? h - 1 : sy + 7));
-        ocx[t] = (float)(x0 + sx) + 3.5f; ocy[t] = (float)(y0 + sy) + 3.5f;
-        if (t == j) { sxj = sx; syj = sy; }
-    }
-    const int lx = p & 7, ly = 2 * kq + (p >> 3);
-    const int x = sxj + lx, y = syj + ly;
-    const bool handed = ((ent.z >> j) & 1u) != 0u;
-    const bool valid = handed && (x < wd) && (y < h);
-    const int pix = valid ? y * wd + x : -1;
-    const float uu = (float)lx - 3.5f, vv = (float)ly - 3.5f;
-    const uint32_t order_tile = order_base | ((uint32_t)lay.tile_seq[tile] << 12);
-    float T = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
-    if (handed) {
-        const float4 st = (seg_at(tail.state, cs, cam) + (size_t)slot * 128)[j * 64 + kq * 16 + p];
-        T = st.x;
-        if (q == 0) { cr = st.y; cg = st.z; cb = st.w; }
-    }
-    bool live = handed && (syj + 2 * kq < h) && !(__all(T <= t_floor ? 1 : 0));
-    if (lane == 0) s_live[w] = live ? 1 : 0;
-    const uint32_t end = ent2.y;
-    const uint32_t b0 = ent.y;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    // every wave stages 64 entries of a round; the records of the next round are requested before this one is blended
-    const unsigned e_off = w * 64u + lane;
-    bool v_cur = (b0 + e_off) < end, v_nxt = (b0 + TL_ROUND + e_off) < end;
-    uint32_t g_cur = v_cur ? (inst_g[b0 + e_off] & gmask) : 0u;
-    uint32_t g_nxt = v_nxt ? (inst_g[b0 + TL_ROUND + e_off] & gmask) : 0u;       // the list is read two rounds ahead, the records one
-    float4 r0 = zero4, r1 = zero4, r2 = zero4;
-    uint32_t gmb = 0x7F000000u;
-    if (v_cur) {
-        r0 = rec[4 * (size_t)g_cur]; r1 = rec[4 * (size_t)g_cur + 1]; r2 = rec[4 * (size_t)g_cur + 2];
-        gmb = ((const uint32_t*)best_key)[2 * (size_t)g_cur + 1];
-    }
-    __syncthreads();
-    for (uint32_t b = b0; b < end; b += TL_ROUND) {
-        const bool sb_live[2] = {(s_live[0] | s_live[1] | s_live[2] | s_live[3]) != 0, (s_live[4] | s_live[5] | s_live[6] | s_live[7]) != 0};
-        if (!sb_live[0] && !sb_live[1]) break;                  // (block-uniform: read after a barrier)
-        unsigned long long kept[2];
-        int pos[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const bool keep = sb_live[t] && v_cur && chunk_may_touch(r0, r1, r2.w, cx0[t], cx1[t], cy0[t], cy1[t]);
-            kept[t] = __ballot(keep ? 1 : 0);
-            pos[t] = keep ? __popcll(kept[t] & ((1ull << lane) - 1ull)) : -1;
-            if (lane == 0) s_cnt[t][w] = __popcll(kept[t]);
-        }
-        __syncthreads();                                        // counts of all waves; the previous round's readers are through
-        int total[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            int off = 0, tot = 0;
-#pragma unroll
-            for (int v = 0; v < TL_WAVES; ++v) { const int c = s_cnt[t][v]; if (v < (int)w) off += c; tot += c; }
-            total[t] = tot;
-            if (pos[t] >= 0) {
-                const int at = off + pos[t];
-                const float mx = r0.x - ocx[t], my = r0.y - ocy[t];
-                const float A = r0.z, B = r0.w, Cc = r1.x;
-                const float h1 = fmaf(A, mx, B * my);
-                const float Lu = -(fmaf(A, mx, h1)), Lv = -(fmaf(2.0f * Cc, my, B * mx));
-                const float K = fmaf(h1, mx, fmaf(Cc * my, my, -25.5f - r2.w));
-                s_a[t][at] = make_float4(A, B, Cc, Lu);
-                s_b[t][at] = make_float4(Lv, K, r2.x, r2.y);
-                s_c[t][at] = make_float2(r2.z, fmaxf(__uint_as_float(gmb), 1.17549435e-38f));
-                s_g[t][at] = g_cur;
-            }
-            if (w == (unsigned)t && lane < 4u) {                 // a trip reads up to 3 entries past the end: alpha = 0 ones
-                s_a[t][tot + lane] = zero4;
-                s_b[t][tot + lane] = make_float4(0.f, -INFINITY, 0.f, 0.f);
-                s_c[t][tot + lane] = make_float2(0.f, 1.17549435e-38f);
-            }
-        }
-        // next round's records (their indices arrived a round ago), the indices of the round after
-        g_cur = g_nxt; v_cur = v_nxt;
-        v_nxt = (b + 2 * TL_ROUND + e_off) < end;
-        g_nxt = v_nxt ? (inst_g[b + 2 * TL_ROUND + e_off] & gmask) : 0u;
-        r0 = zero4; r1 = zero4; r2 = zero4; gmb = 0x7F000000u;
-        if (v_cur) {
-            r0 = rec[4 * (size_t)g_cur]; r1 = rec[4 * (size_t)g_cur + 1]; r2 = rec[4 * (size_t)g_cur + 2];
-            gmb = ((const uint32_t*)best_key)[2 * (size_t)g_cur + 1];
-        }
-        __syncthreads();                                        // the lists are complete
-        if (live) {
-            const int cnt = total[j];
-            for (int k0 = 0; k0 < cnt; k0 += 4) {
-                const float4 a = s_a[j][k0 + q];
-                const float4 qb = s_b[j][k0 + q];
-                const float2 qc = s_c[j][k0 + q];
-                float t1 = fmaf(a.x, uu, a.w);
-                t1 = fmaf(a.y, vv, t1);
-                const float t2 = fmaf(a.z, vv, qb.x);
-                float pw = fmaf(uu, t1, qb.y);
-                pw = fmaf(vv, t2, pw);
-                const float alpha = fminf(__builtin_amdgcn_exp2f(pw), 0.99f);
-                // the recurrence of the four entries, passed down the quad: slot s is final after step s
-                float c = T * alpha, Tn = T - c, tb;
-                tb = quad_bcast_f32<0>(Tn); if (q >= 1) { c = tb * alpha; Tn = tb - c; }
-                tb = quad_bcast_f32<1>(Tn); if (q >= 2) { c = tb * alpha; Tn = tb - c; }
-                tb = quad_bcast_f32<2>(Tn); if (q >= 3) { c = tb * alpha; Tn = tb - c; }
-                T = quad_bcast_f32<3>(Tn);
-                cr = fmaf(c, qb.z, cr);
-                cg = fmaf(c, qb.w, cg);
-                cb = fmaf(c, qc.x, cb);
-                if (__any(c >= qc.y ? 1 : 0)) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const bool mine = q == u;
-                        if (__any((mine && c >= qc.y) ? 1 : 0)) {
-                            const uint32_t bits = mine ? __float_as_uint(c) : 0u;
-                            const uint32_t m = wave_max_u32_dpp(bits);
-                            // p grows with the pixel index inside the quarter: the lowest lane at the maximum owns it
-                            const unsigned long long at_max = __ballot((mine && bits == m) ? 1 : 0);
-                            const uint32_t pm = (uint32_t)__builtin_amdgcn_readlane(pix, __ffsll(at_max) - 1);
-                            if (lane == 0) {
-                                unsigned long long key = ((unsigned long long)m << 32) | (unsigned long long)(uint32_t)(~(order_tile | pm));
-                                atomicMax(&best_key[s_g[j][k0 + u]], key);
-                            }
-                        }
-                    }
-                }
-            }
-            live = !(__all(T <= t_floor ? 1 : 0));
-            if (lane == 0 && !live) s_live[w] = 0;
-        }
-        __syncthreads();                                        // s_live of this round; the lists may be overwritten
-    }
-    cr = quad_sum_f32(cr); cg = quad_sum_f32(cg); cb = quad_sum_f32(cb);
-    if (q == 0 && pix >= 0) {
-        float* out = tilebuf + 3 * (size_t)lay.tile_pix_off[tile];
-        out[3 * (size_t)pix + 0] = fmaf(T, bg, cr);
-        out[3 * (size_t)pix + 1] = fmaf(T, bg, cg);
-        out[3 * (size_t)pix + 2] = fmaf(T, bg, cb);
-    }
-    __syncthreads();                                            // s_live / the lists belong to the next chunk
     }
 }
 
@@ -1512,11 +1279,8 @@ __global__ __launch_bounds__(CU_T) void k_blend_cu(int W, int H, int grid_x, int
 // sorted tile ids (rasterizer_impl.cu:115-137 identifyTileRanges), no histogram, no scan.
 __global__ __launch_bounds__(RA_T) void k_tile_ranges(const uint32_t* __restrict__ tile_sorted, long L, int T,
                                                      uint32_t* __restrict__ tile_start,
-                                                     const uint32_t* __restrict__ l_dev, int gshift, size_t cs,
-                                                     uint32_t* __restrict__ zero_word) {
-    // zero_word (optional): one per-camera word this launch clears -- the blend's tail count (k_blend_py_dl / k_blend_tail)
-    tile_sorted = seg(tile_sorted, cs); tile_start = seg(tile_start, cs); l_dev = seg(l_dev, cs); zero_word = seg(zero_word, cs);
-    if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0u;
+                                                     const uint32_t* __restrict__ l_dev, int gshift, size_t cs) {
+    tile_sorted = seg(tile_sorted, cs); tile_start = seg(tile_start, cs); l_dev = seg(l_dev, cs);
     if (l_dev) L = (long)*l_dev;                 // capacity-sized launch, count on the device
     long l = (long)blockIdx.x * RA_T + threadIdx.x;
     if (l > L) return;
@@ -1646,7 +1410,6 @@ static size_t py_front_ws(long n) {
 }
 static int g_blend_variant = 1;               // 2 sub-blocks per wave: 1 = dual-list kernel (k_blend_py_dl), 0 = packed kernel (k_blend_py_pk)
 static int g_depth_bucket_sort = 1;           // captured camera path: 1 = bucket sort of the depth keys, 0 = radix (g2pc_set_depth_sort)
-static int g_blend_tail_batches = 16, g_blend_tail_min_left = 256;   // see BlendTail / g2pc_set_blend_tail (0 batches = off)
 // Packed tile-sort instances: when the tile id and the Gaussian index share one 32-bit word (tile << gshift | index) the
 // stable sort by tile moves keys only -- half the traffic of the two passes -- and the blend masks the index out.
 // Returns gshift (0: they do not fit, separate arrays as before).
@@ -1654,11 +1417,6 @@ static int packed_instance_shift(long n, int T) {
     int gbits = 1;
     while (((long)1 << gbits) < n) ++gbits;
     return (gbits + bits_for_tiles((unsigned)T) <= 32) ? gbits : 0;
-}
-// the tail list of one camera: every chunk may hand over (2 KB of pixel state each)
-static size_t blend_tail_ws(int num_chunks) {
-    const size_t nc = (size_t)(num_chunks > 0 ? num_chunks : 0);
-    return align_up(nc * 32) + align_up(nc * 128 * 16) + 512;
 }
 static size_t py_back_ws(long L, int T) {
     return align_up((size_t)(L + 1) * 4) * 6 + sort_workspace(L) + scan_workspace(T + 1) + align_up((size_t)(T + 2) * 4) + 4096 + 256;
@@ -1714,8 +1472,7 @@ struct PyBlendArgs {                  // by value ...                      ... o
 static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t* l_eff,
                    const PyBlendArgs& ba, int W, int H, const PyFrontBuffers& fb, unsigned long long* best_key,
                    float* colours_out, float* tilebuf, float* image, int phases, uint32_t max_per_tile,
-                   uint32_t* overflow_flag, void* ws, size_t ws_bytes, hipStream_t s, Batch bt = Batch(),
-                   void* tail_ws = nullptr, size_t tail_bytes = 0) {
+                   uint32_t* overflow_flag, void* ws, size_t ws_bytes, hipStream_t s, Batch bt = Batch()) {
     const int T = layout->nx * layout->ny;
     Arena ar(ws, ws_bytes);
     uint32_t* inst_tile = ar.get<uint32_t>((size_t)L + 1);
@@ -1728,15 +1485,6 @@ static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t*
     size_t sort_bytes = sort_workspace(L);
     char* sort_ws = ar.get<char>(sort_bytes);
     if (!ar.ok()) { set_error("raster_back_py", "workspace too small"); return G2PC_ERR_WORKSPACE; }
-    BlendTail tail{};                              // (the batched camera call only: the two-call path finishes every walk in place)
-    if (tail_ws && g_blend_tail_batches > 0 && layout->num_chunks > 0) {
-        Arena ta(tail_ws, tail_bytes);
-        tail.count = ta.get<uint32_t>(1);
-        tail.list = ta.get<uint4>(2 * (size_t)layout->num_chunks);
-        tail.state = ta.get<float4>((size_t)layout->num_chunks * 128);
-        if (!ta.ok()) { set_error("raster_back_py", "tail workspace too small"); return G2PC_ERR_WORKSPACE; }
-        tail.cap_batches = g_blend_tail_batches; tail.min_left = g_blend_tail_min_left; tail.capacity = layout->num_chunks;
-    }
     Layout lay = to_layout(layout);
     const int gshift = packed_instance_shift(n, T);
     const uint32_t gmask = gshift ? ((1u << gshift) - 1u) : 0xFFFFFFFFu;
@@ -1751,7 +1499,7 @@ static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t*
                                              bits_for_tiles((unsigned)T), sort_ws, sort_bytes, s, l_eff, bt);
             if (rc) return rc;
         }
-        hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T), (unsigned)bt.n), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start, l_eff, gshift, bt.cs, tail.count);
+        hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T), (unsigned)bt.n), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start, l_eff, gshift, bt.cs);
         if (overflow_flag && max_per_tile)
             hipLaunchKernelGGL(k_check_tile_load, dim3(cdiv(T, RA_T), (unsigned)bt.n), dim3(RA_T), 0, s, tile_start, T, max_per_tile, overflow_flag, bt.cs);
     }
@@ -1768,15 +1516,7 @@ static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t*
                 // operation order (k_blend_py_pk); the dual-list kernel's expanded exponent differs by up to ~2e-5 relative
                 // in alpha.  A captured camera reads t_floor from its device job: the caller says so with phase bit 8.
                 const bool exact = ba.job ? ((phases & 8) != 0) : (ba.t_floor == 0.0f);
-                if (g_blend_variant == 1 && !exact) {
-                    hipLaunchKernelGGL((k_blend_py_dl<4>), dim3((unsigned)bt.n, chunks_y, cdiv(layout->num_chunks, chunks_y)), dim3(BL_T), 0, s, lay,
-                                       layout->chunk_tile, layout->chunk_pix0, tile_start, blend_list, gmask, (const float4*)fb.rec, best_key,
-                                       ba.camera_slot << (12 + lay.seq_bits), ba.t_floor, ba.bg, tilebuf, g_chunk_work, ba.job, bt.cs, tail);
-                    if (tail.cap_batches > 0)
-                        hipLaunchKernelGGL(k_blend_tail, dim3((unsigned)bt.n, (unsigned)(layout->num_chunks < TL_GRID ? layout->num_chunks : TL_GRID)), dim3(TL_T), 0, s, lay, layout->chunk_tile,
-                                           layout->chunk_pix0, tile_start, blend_list, gmask, (const float4*)fb.rec, best_key,
-                                           ba.camera_slot << (12 + lay.seq_bits), ba.t_floor, ba.bg, tilebuf, ba.job, bt.cs, tail);
-                }
+                if (g_blend_variant == 1 && !exact) G2PC_BLEND(k_blend_py_dl<4>);
                 else G2PC_BLEND(k_blend_py_pk<4>);
                 break;
             }
@@ -1841,11 +1581,11 @@ int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, int
     return check_launch("g2pc_raster_back_py");
 }
 
-size_t g2pc_raster_camera_workspace(int64_t n, int64_t capacity, int32_t num_tiles, int32_t num_chunks) {
+size_t g2pc_raster_camera_workspace(int64_t n, int64_t capacity, int32_t num_tiles) {
     using namespace g2pc;
     // a multiple of 256: batched launches place one such arena per camera back to back (g2pc_raster_cameras_py)
     return align_up(align_up((size_t)n * 64) + align_up((size_t)n * 4) * 2 + align_up((size_t)(n + 1) * 4) + 256 +
-                    py_front_ws((long)n) + py_back_ws((long)capacity, num_tiles) + blend_tail_ws(num_chunks) + 4096);
+                    py_front_ws((long)n) + py_back_ws((long)capacity, num_tiles) + 4096);
 }
 
 // One camera up to and including the blend, without any host round trip: the camera, its slot and the transmittance
@@ -1871,7 +1611,7 @@ int g2pc_raster_cameras_py(const G2pcCameraJob* jobs_dev, const G2pcCameraJob* j
     // every kernel moves them by blockIdx.y * cs (g2pc_internal.h: seg)
     Batch bt;
     bt.n = batch;
-    bt.cs = g2pc_raster_camera_workspace(n, capacity, T, layout->num_chunks);
+    bt.cs = g2pc_raster_camera_workspace(n, capacity, T);
     G2PC_REQUIRE(ws_bytes >= bt.cs * (size_t)batch, G2PC_ERR_WORKSPACE, "workspace too small");
     Arena ar(ws, bt.cs);
     PyFrontBuffers fb;
@@ -1883,8 +1623,6 @@ int g2pc_raster_cameras_py(const G2pcCameraJob* jobs_dev, const G2pcCameraJob* j
     const size_t front_bytes = py_front_ws((long)n), back_bytes = py_back_ws((long)capacity, T);
     char* front_ws = ar.get<char>(front_bytes);
     char* back_ws = ar.get<char>(back_bytes);
-    const size_t tail_bytes = blend_tail_ws(layout->num_chunks);
-    char* tail_ws = ar.get<char>(tail_bytes);
     G2PC_REQUIRE(ar.ok(), G2PC_ERR_WORKSPACE, "workspace too small");
     int rc;
     if (phases & 1) {
@@ -1901,7 +1639,7 @@ int g2pc_raster_cameras_py(const G2pcCameraJob* jobs_dev, const G2pcCameraJob* j
     }
     PyBlendArgs ba{0u, 0.0f, 0.0f, jobs_dev};
     rc = py_back(layout, (long)n, (long)capacity, l_eff, ba, 0, 0, fb, best_key, nullptr, tilebuf, nullptr,
-                 phases & (3 | 8), max_per_tile, overflow_flag, back_ws, back_bytes, s, bt, tail_ws, tail_bytes);
+                 phases & (3 | 8), max_per_tile, overflow_flag, back_ws, back_bytes, s, bt);
     if (rc) return rc;
     return check_launch("g2pc_raster_cameras_py");
 }
@@ -1943,12 +1681,6 @@ int g2pc_raster_debug_chunk_work(uint32_t* buf) { g2pc::g_chunk_work = buf; retu
  * radix.  Identical results; a camera whose depths pile up (bucket overflow) is skipped and reported through
  * count_host[1] -- the caller repeats it with g2pc_raster_front_py / _back_py, which always use the radix sort. */
 int g2pc_set_blend_variant(int variant) { g2pc::g_blend_variant = variant; return G2PC_OK; }
-int g2pc_set_blend_tail(int cap_batches, int min_left) {
-    using namespace g2pc;
-    G2PC_REQUIRE(cap_batches >= 0 && min_left >= 0, G2PC_ERR_ARG, "negative value");
-    g_blend_tail_batches = cap_batches; g_blend_tail_min_left = min_left;
-    return G2PC_OK;
-}
 int g2pc_set_depth_sort(int bucket) { g2pc::g_depth_bucket_sort = bucket ? 1 : 0; return G2PC_OK; }
 
 int g2pc_raster_rebase_keys(unsigned long long* best_key, int64_t n, void* stream) {
@@ -2084,7 +1816,7 @@ int g2pc_raster_back_cu_tiles(const G2pcCamera* cam, const int32_t* mask, int64_
         if (rc) return rc;
     }
     (void)scan_ws; (void)scan_bytes;
-    hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T)), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start, (const uint32_t*)nullptr, gshift, (size_t)0, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T)), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start, (const uint32_t*)nullptr, gshift, (size_t)0);
     }
     if ((phases & 2) && tile_first < T)
     hipLaunchKernelGGL(k_blend_cu, dim3((unsigned)((T - tile_first + tile_step - 1) / tile_step)), dim3(CU_T), 0, s, W, H, gx,
@@ -2146,7 +1878,7 @@ int g2pc_raster_back_cu_dev(const G2pcCamera* cam, const int32_t* mask, int64_t 
                     : sort_pairs_u32(inst_tile, inst_g, tile_sorted, g_sorted, tile_tmp, g_tmp, L, 0, bits_for_tiles((unsigned)T),
                                      sort_ws, sort_bytes, s, l_eff);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T)), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start, (const uint32_t*)l_eff, gshift, (size_t)0, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T)), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start, (const uint32_t*)l_eff, gshift, (size_t)0);
     if (tile_first < T)
         hipLaunchKernelGGL(k_blend_cu, dim3((unsigned)((T - tile_first + tile_step - 1) / tile_step)), dim3(CU_T), 0, s, W, H, gx,
                            (int)tile_first, (int)tile_step, tile_start, gshift ? tile_sorted : g_sorted, gmask, (const float4*)rec, mask,

@@ -69,7 +69,7 @@ nv._RASTER_PROTOS.update({
     "g2pc_raster_back_workspace": (C.c_size_t, [C.c_int64, C.c_int32]),
     "g2pc_raster_back_py": (C.c_int, [C.POINTER(_Camera), C.POINTER(_Layout), C.c_int64, C.c_int64] +
                             [C.c_void_p] * 4 + [C.c_uint32, C.c_float] + [C.c_void_p] * 4 + [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
-    "g2pc_raster_camera_workspace": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
+    "g2pc_raster_camera_workspace": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32]),
     "g2pc_raster_camera_py": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(_Layout)] + [C.c_void_p] * 4 + [C.c_int64, C.c_int64] +
                               [C.c_void_p] * 3 + [C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "g2pc_raster_cameras_py": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(_Layout)] + [C.c_void_p] * 4 + [C.c_int64, C.c_int64] +
@@ -84,7 +84,6 @@ nv._RASTER_PROTOS.update({
     "g2pc_raster_resolve_colours_py": (C.c_int, [C.POINTER(_Layout), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "g2pc_set_depth_sort": (C.c_int, [C.c_int]),
     "g2pc_set_blend_variant": (C.c_int, [C.c_int]),
-    "g2pc_set_blend_tail": (C.c_int, [C.c_int, C.c_int]),
     "g2pc_raster_key_owner": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "g2pc_raster_keep_winner_colours": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "g2pc_raster_contributions": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
@@ -233,17 +232,6 @@ PIPELINE_IN_EMULATOR = False      # tests: drive the capture / replay path throu
 CAPACITY_HEADROOM = 1.25          # instance capacity of the captured graphs relative to the largest count seen so far
 MIN_CAPACITY = 1 << 16
 _LAYOUT_CACHE = {}
-BLEND_TAIL = None                 # (cap_batches, min_left) of the blend's tail hand-over (include/g2pc.h, g2pc_set_blend_tail);
-                                  # None = the library's default; experiments also set G2PC_BLEND_TAIL="cap,min_left"
-
-
-def _apply_blend_tail():
-    import os
-    v = BLEND_TAIL
-    if v is None and os.environ.get("G2PC_BLEND_TAIL", "") != "":
-        v = tuple(int(x) for x in os.environ["G2PC_BLEND_TAIL"].split(","))
-    if v is not None:
-        nv.check(nv.lib().g2pc_set_blend_tail(int(v[0]), int(v[1])), "set_blend_tail")
 
 
 class _GraphSlot:
@@ -370,7 +358,6 @@ class GaussHipRenderer():
         if semantics != "python":
             raise NotImplementedError("use gaussian_pointcloud_rasterization.GaussianRasterizer for 'cuda' semantics")
         nv.lib()
-        _apply_blend_tail()
         self.white_bkgd = white_bkgd
         self.device = means3D.device
         self.semantics = semantics
@@ -586,7 +573,7 @@ class GaussHipRenderer():
         # anything else (new capacity, new layout, new buffers) starts the slot afresh
         if any(k[:2] != key[:2] for k in sl.graphs):
             sl.release()
-        need = L.g2pc_raster_camera_workspace(self.n, capacity, lay.num_tiles, lay.c.num_chunks) * sl.batch
+        need = L.g2pc_raster_camera_workspace(self.n, capacity, lay.num_tiles) * sl.batch
         import contextlib
         with (torch.cuda.stream(sl.stream) if sl.on_gpu else contextlib.nullcontext()):   # allocate on the stream using them
             if need > sl.ws_bytes:

@@ -344,7 +344,7 @@ typedef struct G2pcCameraJob {       /* DEVICE (and pinned host staging) struct 
                                       * resolve the winners' colours once, g2pc_raster_resolve_colours_py */
     uint32_t reserved;
 } G2pcCameraJob;
-size_t g2pc_raster_camera_workspace(int64_t n, int64_t capacity, int32_t num_tiles, int32_t num_chunks);
+size_t g2pc_raster_camera_workspace(int64_t n, int64_t capacity, int32_t num_tiles);
 /* BATCHED form: `batch` cameras (1 .. G2PC_MAX_CAMERA_BATCH) through ONE launch sequence -- every kernel of the sequence runs
  * with grid.y = batch, camera c reading the c-th job of the arrays jobs_dev / jobs_host and working in the c-th of `batch`
  * consecutive workspaces of g2pc_raster_camera_workspace() bytes each (ws_bytes >= batch times that).  A 50-camera job is
@@ -377,12 +377,6 @@ int g2pc_raster_resolve_colours_py(const G2pcTileLayout* layout, int64_t n, cons
 int g2pc_set_depth_sort(int bucket);
 /* tuning aid: blend kernel of the python-semantics rasteriser for 2 sub-blocks per wave: 1 = dual-list (default), 0 = packed */
 int g2pc_set_blend_variant(int variant);
-/* The tail of the dual-list blend: a wave whose walk through its tile list reaches cap_batches 64-entry batches with at least
- * min_left entries to go hands the rest over to a second kernel (k_blend_tail: one 512-thread workgroup per such chunk, the
- * list staged once for its eight waves, four list entries blended per trip).  cap_batches = 0 switches the hand-over off.
- * Every contribution >= the transmittance floor and its arg-max pixel are bit-identical either way; pixel colours agree to
- * the last bits.  Captured graphs keep the values they were captured with. */
-int g2pc_set_blend_tail(int cap_batches, int min_left);
 int g2pc_raster_rebase_keys(unsigned long long* best_key, int64_t n, void* stream);
 /* diagnostics: when non-NULL, the PY blend records per chunk, in u32[8*num_chunks] (batch 1): [0] tile list length, [1] entries
  * walked; the dual-list kernel also [2] start and [3] duration on the 100 MHz wall clock, [4] HW_ID, [5] XCC_ID of its wave, [6] (Gaussian, sub-block) visits after the cull */

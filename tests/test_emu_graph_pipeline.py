@@ -135,29 +135,3 @@ def test_deferred_colour_buffers_are_bounded(emu, monkeypatch):
     k1, c1, _, R = _render_all(True, monkeypatch, ncam=7)
     assert np.array_equal(k0, k1) and np.array_equal(c0, c1)
     assert len(R.ctx.cam_tilebufs) <= 2 and not R.deferred
-
-
-@pytest.mark.parametrize("batch,cap", [(1, 1), (2, 1), (2, 2)])
-def test_blend_tail_kernel_equals_unsplit_walk(emu, monkeypatch, batch, cap):
-    """The blend's tail (k_blend_tail: walks cut after `cap` batches, the rest finished by a 512-thread workgroup per chunk
-    that stages the list once and blends four entries per trip in quad mode) against the same pipeline with the hand-over
-    switched off: every contribution >= the transmittance floor and its arg-max pixel bit for bit, colours to the last bits
-    (a quad sums a pixel's colour in four partial sums)."""
-    import gauss_render                                         # noqa: F401  (registers the rasteriser prototypes)
-    L = emu.lib()
-    try:
-        emu.check(L.g2pc_set_blend_tail(0, 0), "set_blend_tail")
-        k0, c0, st0, _ = _render_all(True, monkeypatch, subblocks=2, ncam=5, batch=batch)
-        emu.check(L.g2pc_set_blend_tail(cap, 1), "set_blend_tail")
-        k1, c1, st1, R = _render_all(True, monkeypatch, subblocks=2, ncam=5, batch=batch)
-    finally:
-        L.g2pc_set_blend_tail(16, 256)
-    assert sorted(st0) == sorted(st1)
-    contrib0 = (k0.view(np.uint64) >> np.uint64(32)).astype(np.uint32).view(np.float32)
-    contrib1 = (k1.view(np.uint64) >> np.uint64(32)).astype(np.uint32).view(np.float32)
-    big = (contrib0 >= 1e-6) | (contrib1 >= 1e-6)
-    assert big.sum() > 100
-    assert np.array_equal(k0[big], k1[big])
-    assert np.abs(contrib0 - contrib1).max() < 1e-6
-    assert np.abs(c0 - c1)[big].max() < 2e-3                   # colours are on the 0..255 scale here
-    assert not np.array_equal(c0, c1)                          # the tail really ran (its colour sums differ in the last bits)
