@@ -77,3 +77,23 @@ def test_device_bin_table_equals_the_host_table(emu, seed, g, scale, exact):
     assert bool(any_s) == bool(np.any((q > 1) & (members > 0)))
     assert means_rows == int(members[q > 0].sum())
     assert rows_ub == means_rows + int((members * np.maximum(q - 1, 0)).sum())
+
+
+def test_point_counts_beyond_the_device_histogram_fall_back_to_the_host_table(emu, monkeypatch):
+    """A Gaussian with more points than the device-side bin table's histogram holds (HIST_GUESS, shrunk here): the plan kernel
+    reports it and sample_pointcloud builds the table on the host as before -- same cloud as with the count known up front."""
+    import numpy as np
+    import torch
+    from g2pc import ops
+    from g2pc.synth import make_scene
+    monkeypatch.setattr(ops, "HIST_GUESS", 64)
+    sc = make_scene(300, 21)
+    cov, _, nrm = ops.build_covariances(sc.scales, sc.rots, 1.0, want_normals=True)
+    ppg = torch.full((300,), 5, dtype=torch.int32)
+    ppg[:40] = torch.arange(60, 100, dtype=torch.int32)         # 60 .. 99 points: beyond the 64-entry histogram
+    stats = torch.tensor([int(ppg.sum()), 0, 0, int(ppg.max())], dtype=torch.int64)
+    kw = dict(exact=False, std=2.0, attempts=5, seed=7)
+    a = ops.sample_pointcloud(sc.xyz, cov, sc.colours * 255, nrm, ppg, None, stats=stats, **kw)
+    b = ops.sample_pointcloud(sc.xyz, cov, sc.colours * 255, nrm, ppg, int(ppg.max()), **kw)
+    assert a.points.shape == b.points.shape and torch.equal(a.points, b.points) and torch.equal(a.colours, b.colours)
+    assert list(a.bins) == list(b.bins)
