@@ -40,6 +40,7 @@ _PROTOS = {
     "g2pc_compact_workspace": (_sz, [_i64]),
     "g2pc_compact_index": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "g2pc_gather_rows": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
+    "g2pc_gather_rows_multi": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i64, _vp]),
     "g2pc_pack_ply_vertices": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "g2pc_validate_covariances": (C.c_int, [_vp, _i64, C.c_int, _f32, _f32, _f32, C.c_int, _vp, _vp]),
     "g2pc_validate_covariances_counted": (C.c_int, [_vp, _i64, C.c_int, _f32, _f32, _f32, C.c_int, _vp, _vp, _vp]),

@@ -265,6 +265,21 @@ __global__ __launch_bounds__(GEO_T) void k_gather_rows(const uint32_t* __restric
     dst[t] = src[(size_t)index[j] * row_words + w];
 }
 
+// the same for up to eight arrays that share the index (filter_gaussians compacts xyz, scales, rotations, colours,
+// opacities, covariances, normals with ONE index): one launch instead of one per array -- the job's tail is launch-bound
+struct GatherSet { const uint32_t* src[8]; uint32_t* dst[8]; int words[8]; int first[9]; int count; };
+__global__ __launch_bounds__(GEO_T) void k_gather_rows_multi(GatherSet g, const uint32_t* __restrict__ index, long m) {
+    const int total_words = g.first[g.count];
+    long t = (long)blockIdx.x * GEO_T + threadIdx.x;
+    if (t >= m * total_words) return;
+    const long j = t / total_words;
+    const int w = (int)(t - j * total_words);
+    int a = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) if (k < g.count && w >= g.first[k]) a = k;
+    const int ww = w - g.first[a];
+    g.dst[a][(size_t)j * g.words[a] + ww] = g.src[a][(size_t)index[j] * g.words[a] + ww];
+}
 
 // save_xyz_to_ply (gauss_dataloader.py:172-202): pack one binary-little-endian PLY vertex record per point,
 // x y z [nx ny nz] r g b = 3 (or 6) float32 + 3 uchar (colours truncated like numpy's astype(np.uint8)).
@@ -383,6 +398,27 @@ int g2pc_gather_rows(const void* src, const uint32_t* index, int64_t m, int32_t 
     hipLaunchKernelGGL(k_gather_rows, dim3(cdiv(total, GEO_T)), dim3(GEO_T), 0, (hipStream_t)stream,
                        (const uint32_t*)src, index, (long)m, (int)(row_bytes / 4), (uint32_t*)dst);
     return check_launch("g2pc_gather_rows");
+}
+}
+
+extern "C" {
+int g2pc_gather_rows_multi(const void* const* srcs, void* const* dsts, const int32_t* row_bytes, int32_t count,
+                           const uint32_t* index, int64_t m, void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(count >= 1 && count <= 8 && m >= 0 && srcs && dsts && row_bytes, G2PC_ERR_ARG, "1 .. 8 arrays");
+    if (m == 0) return G2PC_OK;
+    G2PC_REQUIRE(index, G2PC_ERR_ARG, "null index");
+    GatherSet g{};
+    g.count = count;
+    g.first[0] = 0;
+    for (int k = 0; k < count; ++k) {
+        G2PC_REQUIRE(srcs[k] && dsts[k] && row_bytes[k] > 0 && row_bytes[k] % 4 == 0, G2PC_ERR_ARG, "rows must be whole 4-byte words");
+        g.src[k] = (const uint32_t*)srcs[k]; g.dst[k] = (uint32_t*)dsts[k]; g.words[k] = row_bytes[k] / 4;
+        g.first[k + 1] = g.first[k] + g.words[k];
+    }
+    const long total = (long)m * g.first[count];
+    hipLaunchKernelGGL(k_gather_rows_multi, dim3(cdiv(total, GEO_T)), dim3(GEO_T), 0, (hipStream_t)stream, g, index, (long)m);
+    return check_launch("g2pc_gather_rows_multi");
 }
 }
 

@@ -126,6 +126,36 @@ def gather_rows(src: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def gather_rows_multi(srcs, index: torch.Tensor):
+    """[src[index] for src in srcs] (None entries pass through) in ONE launch per eight arrays; rows must be whole 4-byte
+    words (others take gather_rows)."""
+    import ctypes as C
+    out = [None] * len(srcs)
+    todo = []
+    m = index.numel()
+    for i, t in enumerate(srcs):
+        if t is None:
+            continue
+        t = t.contiguous()
+        rb = (t.numel() // max(t.shape[0], 1)) * t.element_size() if t.shape[0] else 0
+        if m == 0 or rb == 0 or rb % 4 != 0:
+            out[i] = gather_rows(t, index)
+        else:
+            out[i] = torch.empty((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            todo.append((t, out[i], rb))
+    idx = index.contiguous()
+    for k in range(0, len(todo), 8):
+        part = todo[k:k + 8]
+        n = len(part)
+        S = (C.c_void_p * n)(*[p[0].data_ptr() for p in part])
+        D = (C.c_void_p * n)(*[p[1].data_ptr() for p in part])
+        R = (C.c_int32 * n)(*[p[2] for p in part])
+        nv.ptr(part[0][0])                                      # (device check: raises for host tensors outside the emulator)
+        nv.check(nv.lib().g2pc_gather_rows_multi(C.cast(S, C.c_void_p), C.cast(D, C.c_void_p), C.cast(R, C.c_void_p), n, nv.ptr(idx), m,
+                                                 nv.stream_handle(idx.device)), "gather_rows_multi")
+    return out
+
+
 def validate_covariances_(cov: torch.Tensor, regularise: bool = True, reg_eps: float = 5e-7, eps: float = 1e-7,
                           min_eps: float = 1e-8, iters: int = 3, want_count: bool = False):
     """In-place gauss_handler.py:142-166; returns the keep mask (bool[n]); want_count=True also returns the number of

@@ -132,18 +132,10 @@ class Gaussians():
         index = ops.compact_index(filter_indices)
         self.last_filter_index = index        # int32 positions of the survivors: select(per_gaussian_tensor) reuses it
 
-        self.xyz = ops.gather_rows(self.xyz, index)
-        self.scales = ops.gather_rows(self.scales, index)
-        self.rots = ops.gather_rows(self.rots, index)
-        self.colours = ops.gather_rows(self.colours, index)
-        self.opacities = ops.gather_rows(self.opacities, index)
-        self.covariances = ops.gather_rows(self.covariances, index)
-
-        if self.shs is not None:
-            self.shs = ops.gather_rows(self.shs, index)
-
-        if self.normals is not None:
-            self.normals = ops.gather_rows(self.normals, index)
+        # every per-Gaussian array through ONE gather launch (they share the index)
+        (self.xyz, self.scales, self.rots, self.colours, self.opacities, self.covariances, self.shs, self.normals) = \
+            ops.gather_rows_multi([self.xyz, self.scales, self.rots, self.colours, self.opacities, self.covariances, self.shs,
+                                   self.normals], index)
         self._normals_from_build = self.normals
 
         self.set_default_filter()

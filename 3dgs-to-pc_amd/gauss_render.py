@@ -400,6 +400,7 @@ class GaussHipRenderer():
         self.layouts = {}
         self.last_stats = []          # (instances L, tile-sort passes, W*H) per rendered camera
         self._dirty = False           # rendered since the last all_reduce_visibility
+        self._contrib = None          # contributions unpacked from best_key since the last render / exchange
 
     def state_ptrs(self):
         return nv.ptr(self.best_key), nv.ptr(self.gaussian_colours)
@@ -438,10 +439,13 @@ class GaussHipRenderer():
     @property
     def gaussian_max_contribution(self):
         self.flush()
-        out = torch.empty((self.n,), dtype=torch.float32, device=self.device)
-        nv.check(nv.lib().g2pc_raster_contributions(nv.ptr(self.best_key), self.n, nv.ptr(out),
-                                                    nv.stream_handle(self.device)), "contributions")
-        return out
+        # (the getters of one job -- visible mask, total contributions -- read the same state: unpacked once per render)
+        if self._contrib is None:
+            out = torch.empty((self.n,), dtype=torch.float32, device=self.device)
+            nv.check(nv.lib().g2pc_raster_contributions(nv.ptr(self.best_key), self.n, nv.ptr(out),
+                                                        nv.stream_handle(self.device)), "contributions")
+            self._contrib = out
+        return self._contrib
 
     def get_gaussian_colours(self):
         self.flush()
@@ -497,6 +501,7 @@ class GaussHipRenderer():
                  "keep_winner_colours")
         dist.all_reduce(self.gaussian_colours, op=dist.ReduceOp.SUM, group=group)
         self.best_key.copy_(global_key)            # in place: the captured graphs hold this tensor's address
+        self._contrib = None
 
     @property
     def camera_epoch(self):
@@ -775,6 +780,7 @@ class GaussHipRenderer():
         W, H = int(camera.image_width), int(camera.image_height)
         lay = self._layout(W, H)
         self._dirty = True
+        self._contrib = None
         if lay.seq_bits > self.seq_bits:           # more leaf tiles than the keys' tile field holds: widen it (keys rebased)
             if self.camera_slot:
                 self.rebase_keys()

@@ -107,6 +107,11 @@ size_t g2pc_compact_workspace(int64_t n);
 int g2pc_compact_index(const uint8_t* mask, int64_t n, uint32_t* index, uint32_t* count, void* ws, size_t ws_bytes,
                        void* stream);
 int g2pc_gather_rows(const void* src, const uint32_t* index, int64_t m, int32_t row_bytes, void* dst, void* stream);
+/* The same for `count` (1 .. 8) arrays that share the index, in ONE launch: dsts[k][j, :] = srcs[k][index[j], :], rows of
+ * row_bytes[k] bytes (multiples of 4).  srcs / dsts / row_bytes are HOST arrays of device pointers / sizes.
+ * filter_gaussians (gauss_handler.py:171-193) compacts every per-Gaussian array with one index. */
+int g2pc_gather_rows_multi(const void* const* srcs, void* const* dsts, const int32_t* row_bytes, int32_t count,
+                           const uint32_t* index, int64_t m, void* stream);
 /* dst[index[i]] = 1 for i < m (uint8 mask of n entries): the keep mask of cull_large_gaussians (gauss_handler.py:235-250) */
 int g2pc_scatter_ones_u8(const uint32_t* index, int64_t m, uint8_t* dst, int64_t n, void* stream);
 
