@@ -227,8 +227,11 @@ __global__ __launch_bounds__(BT_T) void k_bin_table(const uint32_t* __restrict__
     // (1) the distinct values (ascending) and their counts
     uint32_t f[BT_PER], o[BT_PER];
 #pragma unroll
-    for (int k = 0; k < BT_PER; ++k) { const int v = tid * BT_PER + k; f[k] = (v < HL && hist[v] != 0u) ? 1u : 0u; lut[v < hist_len ? v : 0] = -1; }
-    // (the line above also clears the look-up table: every v < hist_len is visited by exactly one (thread, k))
+    for (int k = 0; k < BT_PER; ++k) {
+        const int v = tid * BT_PER + k;
+        f[k] = (v < HL && hist[v] != 0u) ? 1u : 0u;
+        if (v < hist_len) lut[v] = -1;             // (clears the look-up table: every v is visited by exactly one (thread, k))
+    }
     const int D = (int)block_excl_scan8(f, o, s_w);
 #pragma unroll
     for (int k = 0; k < BT_PER; ++k) { const int v = tid * BT_PER + k; if (f[k]) { val[o[k]] = v; cnt[o[k]] = hist[v]; } }

@@ -314,7 +314,8 @@ def sample_pointcloud(xyz: torch.Tensor, cov: torch.Tensor, colours: torch.Tenso
         plan_host = _pinned_i64(dev, 10)
         tb = L.g2pc_sampler_bin_table_workspace(HIST_GUESS)
         tws = nv.workspace(tb, dev)
-        nv.check(L.g2pc_sampler_bin_table(nv.ptr(hist_dev), HIST_GUESS, nv.ptr(stats.to(torch.int64)), int(exact),
+        stats64 = stats.to(torch.int64).contiguous()
+        nv.check(L.g2pc_sampler_bin_table(nv.ptr(hist_dev), HIST_GUESS, nv.ptr(stats64), int(exact),
                                           1 if emit_means else 0, WAVE_MODE_MIN_DRAWS, nv.ptr(lut_d), nv.ptr(quota_d),
                                           nv.ptr(bin_start), nv.ptr(bin_lo), C_void(plan_host), nv.ptr(tws), tb, st),
                  "sampler_bin_table")
