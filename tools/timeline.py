@@ -42,3 +42,41 @@ for name, s, e, q, st in rows:
     busy[k][0] += 1; busy[k][1] += e - s
 for k, (n, d) in sorted(busy.items(), key=lambda kv: -kv[1][1])[:12]:
     print("%-42s n=%5d  mean %8.1f us  total %8.2f ms (%.0f%% of window)" % (k, n, d / n / 1e3, d / 1e6, 100.0 * d / tot))
+
+# ---- per stream: when was each blend READY (its predecessor on the stream ended) and when did it start? -------------------
+# A long ready->start delay means the hardware held a runnable blend back (behind another queue's blend); a short one means
+# the blend could not have started earlier: its own head chain ended just before.
+by_stream = collections.defaultdict(list)
+for name, s, e, q, st in rows:
+    by_stream[(q, st)].append((s, e, name))
+delays, head_spans, blend_spans = [], [], []
+for key, ks in by_stream.items():
+    ks.sort()
+    head_start = None
+    for i, (s, e, name) in enumerate(ks):
+        if "blend" in name:
+            if i > 0:
+                delays.append((s - ks[i - 1][1]) / 1e3)
+                if head_start is not None:
+                    head_spans.append((ks[i - 1][1] - head_start) / 1e3)
+            blend_spans.append((e - s) / 1e3)
+            head_start = None
+        elif head_start is None:
+            head_start = s
+if delays:
+    import statistics as st_
+    q = lambda a, p: sorted(a)[min(len(a) - 1, int(p * len(a)))]
+    print("blend ready->start delay us: n=%d mean %.1f p50 %.1f p90 %.1f max %.1f" % (len(delays), st_.mean(delays), q(delays, .5), q(delays, .9), max(delays)))
+    if head_spans:
+        print("head chain span us (first head kernel start -> last head kernel end): mean %.1f p50 %.1f p90 %.1f" % (st_.mean(head_spans), q(head_spans, .5), q(head_spans, .9)))
+    print("blend span us: mean %.1f p50 %.1f p90 %.1f" % (st_.mean(blend_spans), q(blend_spans, .5), q(blend_spans, .9)))
+    # for every blend: was another blend running when it became ready?
+    bl2 = sorted((s, e) for name, s, e, q_, st in rows if "blend" in name)
+    held = 0
+    for key, ks in by_stream.items():
+        for i, (s, e, name) in enumerate(ks):
+            if "blend" in name and i > 0:
+                ready = ks[i - 1][1]
+                if any(bs < ready < be and (bs, be) != (s, e) for bs, be in bl2):
+                    held += 1
+    print("blends that became ready while another blend was running: %d of %d" % (held, len(delays)))
