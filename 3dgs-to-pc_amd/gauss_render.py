@@ -226,6 +226,10 @@ CAMERA_BATCH = 2                  # cameras per launch sequence (g2pc_raster_cam
 #   "split_multi": every slot's heads on its OWN high-priority stream (the small head kernels of several batches run side
 #            by side), all blends on ONE shared stream, back to back.
 PIPELINE_MODE = "chain"
+PIPELINE_SLOTS_PER_STREAM = 1     # batch slots (pinned jobs, arena, captured graphs) per stream: with 2 the next batch of a stream is
+                                  # queued while its previous one still runs, so the stream never waits ~0.5 ms for the host to
+                                  # notice that a batch is through, stage the next cameras and launch.  Measured (r03zv): no gain
+                                  # (17.3-17.6 against 16.9-17.6 ms) -- the kernels of the filled gaps slow the others down
 PIPELINE_BLEND_STREAMS = 1        # split modes: blend streams the batches alternate over (2: two blends in flight -- the
                                   # throughput phase of one beside the draining tail of the other)
 PIPELINE_IN_EMULATOR = False      # tests: drive the capture / replay path through the CPU emulator too
@@ -237,10 +241,12 @@ _LAYOUT_CACHE = {}
 class _GraphSlot:
     """One in-flight camera of the capture-and-replay pipeline."""
 
-    def __init__(self, device, on_gpu, batch=1):
+    def __init__(self, device, on_gpu, batch=1, stream=None):
         self.on_gpu = on_gpu
         self.batch = int(batch)
-        self.stream = torch.cuda.Stream(device, priority=-1 if PIPELINE_MODE.startswith("split") else 0) if on_gpu else None
+        # (slots may share a stream: PIPELINE_SLOTS_PER_STREAM)
+        self.stream = stream if stream is not None else (
+            torch.cuda.Stream(device, priority=-1 if PIPELINE_MODE.startswith("split") else 0) if on_gpu else None)
         self.stream_ptr = C.c_void_p(self.stream.cuda_stream) if on_gpu else C.c_void_p(1)   # the emulator ignores streams
         nbytes = C.sizeof(_Job) * self.batch
         self.job_host = torch.zeros((nbytes,), dtype=torch.uint8)
@@ -683,11 +689,16 @@ class GaussHipRenderer():
             return
         # (the batched scans take at most 2 M values per camera; larger scenes keep one camera per launch sequence)
         batch = max(1, min(int(CAMERA_BATCH), 8)) if self.n <= (2 << 20) else 1
-        if len(self.slots) != PIPELINE_STREAMS or (self.slots and self.slots[0].batch != batch):
+        per_stream = max(1, int(PIPELINE_SLOTS_PER_STREAM)) if PIPELINE_MODE == "chain" else 1
+        if len(self.slots) != PIPELINE_STREAMS * per_stream or (self.slots and self.slots[0].batch != batch):
             self.flush()
             for sl in self.slots:
                 sl.release()
-            self.slots[:] = [_GraphSlot(self.device, on_gpu, batch) for _ in range(PIPELINE_STREAMS)]
+            # slot i and slot i + PIPELINE_STREAMS share stream i: the cameras go A1 B1 C1 D1 A2 B2 ..., so a stream's second
+            # slot is staged and launched while its first is still running
+            first = [_GraphSlot(self.device, on_gpu, batch) for _ in range(PIPELINE_STREAMS)]
+            self.slots[:] = first + [_GraphSlot(self.device, on_gpu, batch, stream=first[i % PIPELINE_STREAMS].stream)
+                                     for i in range(PIPELINE_STREAMS * (per_stream - 1))]
             self.slot_next = 0
         sl = self.slots[self.slot_next]
         if sl.fill and sl.fill_lay is not lay:

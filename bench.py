@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=0, help="tuning aid: camera batches in flight (HIP streams) of the renderer")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the untimed region / kernel profile passes after the timed loop")
     ap.add_argument("--pipeline-mode", default=None, choices=[None, "chain", "split", "split_multi"], help="tuning aid: see gauss_render.PIPELINE_MODE")
+    ap.add_argument("--slots-per-stream", type=int, default=0, help="tuning aid: batch slots per stream (gauss_render.PIPELINE_SLOTS_PER_STREAM)")
     ap.add_argument("--blend-streams", type=int, default=0, help="tuning aid (split modes): blend streams the batches alternate over")
     ap.add_argument("--camera-batch", type=int, default=0, help="tuning aid: cameras per launch sequence (1 = one camera per graph)")
     ap.add_argument("--camera-subset", type=int, default=0, help="profiling aid: render only the first k cameras of the rig")
@@ -335,6 +336,8 @@ def main():
         gauss_render.PIPELINE_MODE = a.pipeline_mode
     if a.blend_streams:
         gauss_render.PIPELINE_BLEND_STREAMS = a.blend_streams
+    if a.slots_per_stream:
+        gauss_render.PIPELINE_SLOTS_PER_STREAM = a.slots_per_stream
     if a.no_context_pool:
         gauss_render.CONTEXT_POOL_SIZE = 0
 
