@@ -45,13 +45,26 @@ struct Layout {         // device pointers of G2pcTileLayout
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void interval_range(const int32_t* __restrict__ start, const int32_t* __restrict__ size,
                                                int n, float rmin, float rmax, int& i0, int& i1) {
-    i0 = n; i1 = -1;
-    for (int i = 0; i < n; ++i) {
-        float lo = (float)start[i], hi = (float)(start[i] + size[i] - 1);
-        float tl = rmin > lo ? rmin : lo;        // rect_min.clip(min = tile start)
-        float br = rmax < hi ? rmax : hi;        // rect_max.clip(max = tile end)
-        if (br > tl) { if (i < i0) i0 = i; i1 = i; }
-    }
+    // Interval i overlaps iff  min(rmax, hi_i) > max(rmin, lo_i)  (rect_max.clip(max = tile end) > rect_min.clip(min = tile
+    // start), gauss_render.py:306-309), lo_i = start, hi_i = start + size - 1.  lo and hi grow with i, so the overlapped
+    // intervals are those between the first with hi_i > rmin and the last with lo_i < rmax: two binary searches instead of
+    // a pass over all n (the pass was two thirds of this kernel's instructions), the reference's predicate itself deciding
+    // the two ends.  NaNs compare false everywhere: nothing overlaps, as before.
+    auto overlaps = [&](int i) {
+        const float lo = (float)start[i], hi = (float)(start[i] + size[i] - 1);
+        const float tl = rmin > lo ? rmin : lo;        // rect_min.clip(min = tile start)
+        const float br = rmax < hi ? rmax : hi;        // rect_max.clip(max = tile end)
+        return br > tl;
+    };
+    int a = 0, b = n;                                  // first i with hi_i > rmin
+    while (a < b) { const int m = (a + b) >> 1; if ((float)(start[m] + size[m] - 1) > rmin) b = m; else a = m + 1; }
+    int first = a;
+    a = -1; b = n - 1;                                 // last i with lo_i < rmax
+    while (a < b) { const int m = (a + b + 1) >> 1; if ((float)start[m] < rmax) a = m; else b = m - 1; }
+    int last = a;
+    while (first <= last && !overlaps(first)) ++first;
+    while (last >= first && !overlaps(last)) --last;
+    if (first <= last) { i0 = first; i1 = last; } else { i0 = n; i1 = -1; }
 }
 
 template <bool CAM_ON_DEVICE>
