@@ -754,6 +754,7 @@ class GaussHipRenderer():
         while self.redo:                           # cameras that overflowed their graph: two-call path, original slot
             cam, lay, slot = self.redo.pop(0)
             self.deferred.pop(slot, None)          # ... which updates the colours it wins at once
+            lay.c.seq_bits = self.seq_bits         # (layouts are shared between renderers)
             self._render_sync(cam, lay, slot, False)
         if self.deferred:
             # deferred colour resolve: one pass per layout over the Gaussians, colour = the winner camera's tile buffer
@@ -761,6 +762,7 @@ class GaussHipRenderer():
             for slot, (lay, tb) in self.deferred.items():
                 by_layout.setdefault(id(lay), (lay, []))[1].append((slot, tb))
             for lay, slots in by_layout.values():
+                lay.c.seq_bits = self.seq_bits
                 table = np.zeros((256,), dtype=np.uint64)
                 for slot, tb in slots:
                     table[slot] = tb.data_ptr()
