@@ -131,8 +131,8 @@ def rocprof_kernel_avg(region):
     return None
 
 
-PMC_TRAFFIC_FILE = "profiles/r03t_pmc_traffic.json"      # tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE passes of THIS command
-PMC_SQ_FILE = "profiles/r03t_pmc_sq.json"               # tools/pmc_kernel.py: SQ counter pass of THIS command
+PMC_TRAFFIC_FILE = "profiles/r03zs_pmc_traffic.json"      # tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE passes of THIS command
+PMC_SQ_FILE = "profiles/r03zs_pmc_sq.json"               # tools/pmc_kernel.py: SQ counter pass of THIS command
 BLEND_KERNEL = "void g2pc::k_blend_py_dl<4>"
 
 
