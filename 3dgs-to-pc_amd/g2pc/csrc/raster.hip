@@ -36,6 +36,11 @@ struct Layout {         // device pointers of G2pcTileLayout
     int nx, ny, num_chunks, seq_bits;
     const int32_t *xs, *ws, *ys, *hs;
     const int32_t *tile_seq, *seq_tile, *tile_pix_off;
+    int seq_base, seq_count;          // the keys of this layout carry sequence numbers [seq_base, seq_base + seq_count)
+    const uint8_t* tile_mask;         // image assembly: compose only these tiles (nullptr = all, whole image written)
+    int depth;                        // quad-tree info (python semantics): nx == ny == 1 << depth, 0 = none
+    const int32_t *inner_x, *inner_y; // [(1 << depth) - 1][2] inclusive pixel extents of the interior nodes per axis
+    const int32_t* tile_stick;        // [ny*nx] bit k: the leaf reaches beyond its level-k ancestor (nullptr = none does)
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -236,7 +241,7 @@ __device__ __forceinline__ bool chunk_may_touch(const float4& r0, const float4& 
 template <int PPT, int U>
 __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __restrict__ chunk_tile,
                                                   const int32_t* __restrict__ chunk_pix0,
-                                                  const uint32_t* __restrict__ tile_start,
+                                                  const uint2* __restrict__ tile_range,
                                                   const uint32_t* __restrict__ inst_g, uint32_t gmask,
                                                   const float4* __restrict__ rec,
                                                   unsigned long long* __restrict__ best_key, uint32_t order_base,
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __
     // one wave64 per block: the LDS stage is wave-private, no s_barrier anywhere
     const unsigned chunk_i = blockIdx.z * gridDim.y + blockIdx.y;       // the blends: camera = blockIdx.x, chunk in (y, z)
     if ((int)chunk_i >= lay.num_chunks) return;
-    tile_start = seg_at(tile_start, cs, blockIdx.x); inst_g = seg_at(inst_g, cs, blockIdx.x); rec = seg_at(rec, cs, blockIdx.x);
+    tile_range = seg_at(tile_range, cs, blockIdx.x); inst_g = seg_at(inst_g, cs, blockIdx.x); rec = seg_at(rec, cs, blockIdx.x);
     if (job) {
         job += blockIdx.x;
         order_base = job->camera_slot << (12 + lay.seq_bits); t_floor = job->t_floor; bg = job->cam.bg[0];
@@ -288,7 +293,8 @@ __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __
     bx1 = bx1 > w - 1 ? w - 1 : bx1; by1 = by1 > h - 1 ? h - 1 : by1;
     const float rx0 = (float)(x0 + bx0), rx1 = (float)(x0 + bx1), ry0 = (float)(y0 + by0), ry1 = (float)(y0 + by1);
     const bool cull = t_floor > 0.0f;        // t_floor = 0 is the to-the-letter mode: nothing is skipped
-    const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
+    const uint2 se = tile_range[tile];        // k_tile_gate: [first, end) of the tile's instances, empty for a gated tile
+    const uint32_t start = se.x, end = se.y;
     // Software pipeline of the list staging (the gathers are two dependent HBM/L2 round trips and sit on the
     // critical path of the waves that never saturate): ids run two batches ahead, parameters one batch ahead.
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -447,7 +453,7 @@ __global__ __launch_bounds__(BL_T) void k_blend_py(Layout lay, const int32_t* __
 template <int U>
 __global__ __launch_bounds__(BL_T) void k_blend_py_pk(Layout lay, const int32_t* __restrict__ chunk_tile,
                                                      const int32_t* __restrict__ chunk_pix0,
-                                                     const uint32_t* __restrict__ tile_start,
+                                                     const uint2* __restrict__ tile_range,
                                                      const uint32_t* __restrict__ inst_g, uint32_t gmask,
                                                      const float4* __restrict__ rec,
                                                      unsigned long long* __restrict__ best_key, uint32_t order_base,
@@ -456,7 +462,7 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_pk(Layout lay, const int32_t*
                                                      const G2pcCameraJob* __restrict__ job, size_t cs) {
     const unsigned chunk_i = blockIdx.z * gridDim.y + blockIdx.y;       // the blends: camera = blockIdx.x, chunk in (y, z)
     if ((int)chunk_i >= lay.num_chunks) return;
-    tile_start = seg_at(tile_start, cs, blockIdx.x); inst_g = seg_at(inst_g, cs, blockIdx.x); rec = seg_at(rec, cs, blockIdx.x);
+    tile_range = seg_at(tile_range, cs, blockIdx.x); inst_g = seg_at(inst_g, cs, blockIdx.x); rec = seg_at(rec, cs, blockIdx.x);
     if (job) {
         job += blockIdx.x;
         order_base = job->camera_slot << (12 + lay.seq_bits); t_floor = job->t_floor; bg = job->cam.bg[0];
@@ -502,7 +508,8 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_pk(Layout lay, const int32_t*
     pk2 T = pk_make(Ts[0], Ts[1]);
     pk2 cr = pk_splat(0.f), cg = pk_splat(0.f), cb = pk_splat(0.f);
 
-    const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
+    const uint2 se = tile_range[tile];        // k_tile_gate: [first, end) of the tile's instances, empty for a gated tile
+    const uint32_t start = se.x, end = se.y;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t g_cur = 0, g_nxt = 0;
     bool v_cur = (start + lane) < end, v_nxt = (start + BL_BATCH + lane) < end;
@@ -636,7 +643,7 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_pk(Layout lay, const int32_t*
 template <int U>
 __global__ __launch_bounds__(BL_T) void k_blend_py_dl(Layout lay, const int32_t* __restrict__ chunk_tile,
                                                      const int32_t* __restrict__ chunk_pix0,
-                                                     const uint32_t* __restrict__ tile_start,
+                                                     const uint2* __restrict__ tile_range,
                                                      const uint32_t* __restrict__ inst_g, uint32_t gmask,
                                                      const float4* __restrict__ rec,
                                                      unsigned long long* __restrict__ best_key, uint32_t order_base,
@@ -645,7 +652,7 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_dl(Layout lay, const int32_t*
                                                      const G2pcCameraJob* __restrict__ job, size_t cs) {
     const unsigned chunk_i = blockIdx.z * gridDim.y + blockIdx.y;       // the blends: camera = blockIdx.x, chunk in (y, z)
     if ((int)chunk_i >= lay.num_chunks) return;
-    tile_start = seg_at(tile_start, cs, blockIdx.x); inst_g = seg_at(inst_g, cs, blockIdx.x); rec = seg_at(rec, cs, blockIdx.x);
+    tile_range = seg_at(tile_range, cs, blockIdx.x); inst_g = seg_at(inst_g, cs, blockIdx.x); rec = seg_at(rec, cs, blockIdx.x);
     if (job) {
         job += blockIdx.x;
         order_base = job->camera_slot << (12 + lay.seq_bits); t_floor = job->t_floor; bg = job->cam.bg[0];
@@ -688,7 +695,8 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_dl(Layout lay, const int32_t*
     }
     const bool cull = t_floor > 0.0f;        // t_floor = 0 is the to-the-letter mode: nothing is skipped
 
-    const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
+    const uint2 se = tile_range[tile];        // k_tile_gate: [first, end) of the tile's instances, empty for a gated tile
+    const uint32_t start = se.x, end = se.y;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t g_cur = 0, g_nxt = 0;
     bool v_cur = (start + lane) < end, v_nxt = (start + BL_BATCH + lane) < end;
@@ -866,7 +874,8 @@ __global__ __launch_bounds__(RA_T) void k_update_colours_py(Layout lay, const un
     if ((key >> 32) == 0ull) return;
     uint32_t order = ~(uint32_t)key;
     if ((order >> (12 + lay.seq_bits)) != slot) return;
-    int seq = (order >> 12) & ((1 << lay.seq_bits) - 1), pix = order & 0xFFF;
+    int seq = (int)((order >> 12) & ((1u << lay.seq_bits) - 1u)) - lay.seq_base, pix = order & 0xFFF;
+    if ((unsigned)seq >= (unsigned)lay.seq_count) return;      // a key of another pass of this camera (quad-tree passes)
     int tile = lay.seq_tile[seq];
     const float* src = tilebuf + 3 * ((size_t)lay.tile_pix_off[tile] + pix);
     colours_out[3 * i + 0] = src[0];
@@ -886,7 +895,8 @@ __global__ __launch_bounds__(RA_T) void k_resolve_colours_py(Layout lay, const u
     uint32_t order = ~(uint32_t)key;
     const float* tb = (const float*)tilebufs[order >> (12 + lay.seq_bits)];
     if (!tb) return;
-    int seq = (order >> 12) & ((1 << lay.seq_bits) - 1), pix = order & 0xFFF;
+    int seq = (int)((order >> 12) & ((1u << lay.seq_bits) - 1u)) - lay.seq_base, pix = order & 0xFFF;
+    if ((unsigned)seq >= (unsigned)lay.seq_count) return;      // set by a quad-tree pass of that camera, which updated on its own
     int tile = lay.seq_tile[seq];
     const float* src = tb + 3 * ((size_t)lay.tile_pix_off[tile] + pix);
     colours_out[3 * i + 0] = src[0];
@@ -941,9 +951,11 @@ __global__ __launch_bounds__(RA_T) void k_assemble_image_py(Layout lay, int W, i
     for (int a = 0; a < nby; ++a)
         for (int b = 0; b < nbx; ++b) {
             int tile = by[a] * lay.nx + bx[b];
+            if (lay.tile_mask && !lay.tile_mask[tile]) continue;    // not painted by this pass
             int s = lay.tile_seq[tile];
             if (s > best_seq) { best_seq = s; best_tile = tile; }
         }
+    if (lay.tile_mask && best_tile < 0) return;   // compose mode: the pixel keeps what earlier passes / fills left there
     float r = 1.0f, g = 1.0f, bl = 1.0f;          // torch.ones init (gauss_render.py:287)
     if (best_tile >= 0) {
         int ix = best_tile % lay.nx, iy = best_tile / lay.nx;
@@ -1303,13 +1315,119 @@ __global__ __launch_bounds__(RA_T) void k_tile_ranges(const uint32_t* __restrict
     if (l == L) tile_start[T + 1] = (uint32_t)L;                              // no memset of tile_start is needed
 }
 
-// the reference's quad-tree keeps splitting a leaf that holds more than max_gaussians_per_tile Gaussians
-// (gauss_render.py:319); the fixed leaf layout used here cannot follow it there -> raise a flag the host checks
-__global__ __launch_bounds__(RA_T) void k_check_tile_load(const uint32_t* __restrict__ tile_start, int T, uint32_t limit,
-                                                         uint32_t* __restrict__ flag, size_t cs) {
-    tile_start = seg(tile_start, cs);
-    int t = blockIdx.x * RA_T + threadIdx.x;
-    if (t < T && tile_start[t + 1] - tile_start[t] > limit) atomicMax(flag, tile_start[t + 1] - tile_start[t]);
+// The pixel rectangle of Gaussian i as k_preprocess_py forms it (gauss_render.py:151-193, 435-436): the same device
+// functions in the same order, so the floats are the preprocess's own.  false: outside projection_ndc's in_mask.
+__device__ __forceinline__ bool py_rect(const Cam& cam, const float* __restrict__ means3D, const float* __restrict__ cov9,
+                                        long i, float r[4]) {
+    float pv[4];
+    py_view(cam.V, means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2], pv);
+    if (!(pv[2] <= -0.000001f)) return false;
+    float cv[4], ph[4], det;
+    py_cov2d(cam.V, pv, cam.lim_x, cam.lim_y, cam.focal_x, cam.focal_y, cov9 + 9 * i, cv);
+    py_hom(cam.P, pv, ph);
+    const float pw = 1.0f / (ph[3] + 0.000001f);
+    const float ndx = ph[0] * pw, ndy = ph[1] * pw;
+    const float mx = ((ndx + 1.0f) * (float)cam.W - 1.0f) * 0.5f;
+    const float my = ((ndy + 1.0f) * (float)cam.H - 1.0f) * 0.5f;
+    const float radius = py_radius(cv, det);
+    const float wmax = (float)cam.W - 1.0f, hmax = (float)cam.H - 1.0f;
+    r[0] = fminf(fmaxf(mx - radius, 0.0f), wmax); r[1] = fminf(fmaxf(mx + radius, 0.0f), wmax);
+    r[2] = fminf(fmaxf(my - radius, 0.0f), hmax); r[3] = fminf(fmaxf(my + radius, 0.0f), hmax);
+    return (mx == mx) && (my == my) && (det == det);      // NaNs belong to no tile (k_preprocess_py's `ok`)
+}
+// membership of a rectangle in the node [x0, x1] x [y0, y1] (inclusive pixels): gauss_render.py:306-309
+__device__ __forceinline__ bool rect_in_node(const float r[4], int x0, int x1, int y0, int y1) {
+    const float tlx = fmaxf(r[0], (float)x0), brx = fminf(r[1], (float)x1);
+    const float tly = fmaxf(r[2], (float)y0), bry = fminf(r[3], (float)y1);
+    return (brx > tlx) && (bry > tly);
+}
+
+// The reference's quad-tree is data dependent in two ways the fixed leaf grid does not show (gauss_render.py:311-335):
+//  * a leaf holding more than max_gaussians_per_tile Gaussians is split further (:319) -- state 1: the leaf is NOT blended
+//    here, the host renders its children in further passes (GaussHipRenderer._quadtree_passes);
+//  * a node without any Gaussian is painted with the background and its children are never visited (:311-314), while a
+//    child reaches up to one pixel per odd split beyond its parent (:321-334): a leaf whose members all live in that
+//    strip of an otherwise empty ancestor is never blended by the reference -- state 2 | level << 8.  A leaf that lies
+//    inside an ancestor proves that ancestor non-empty by having a member, so only the levels a leaf sticks out of
+//    (tile_stick, a handful of border leaves) are examined: first the other leaves of the ancestor's block, and only if all
+//    of those inside it are empty the members of the sticking-out ones, with the reference's own predicate.
+// tile_range[t] = the instances the blend walks: [first, end), empty for a gated leaf.  One thread per leaf.
+__global__ __launch_bounds__(RA_T) void k_tile_gate(Layout lay, Cam cam_val, const Cam* __restrict__ cam_dev,
+                                                   const float* __restrict__ means3D, const float* __restrict__ cov9,
+                                                   const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ inst_g,
+                                                   uint32_t gmask, int T, uint32_t limit, uint2* __restrict__ tile_range,
+                                                   uint32_t* __restrict__ tile_state, uint32_t* __restrict__ flag,
+                                                   uint32_t* __restrict__ count_host, size_t cs) {
+    tile_start = seg(tile_start, cs); inst_g = seg(inst_g, cs); tile_range = seg(tile_range, cs); tile_state = seg(tile_state, cs);
+    const int t = blockIdx.x * RA_T + threadIdx.x;
+    if (t >= T) return;
+    const uint32_t first = tile_start[t], end = tile_start[t + 1], cnt = end - first;
+    uint32_t state = 0u;
+    if (limit && cnt > limit) {
+        state = 1u;
+        if (flag) atomicMax(flag, cnt);
+        if (count_host) count_host[4 * blockIdx.y + 2] = cnt;          // pinned, through its device mapping: "some leaf of this camera"
+    } else if (cnt && lay.tile_stick && lay.tile_stick[t]) {
+        const uint32_t sticks = (uint32_t)lay.tile_stick[t];
+        const Cam& cam = cam_dev ? *(const Cam*)((const char*)cam_dev + (size_t)blockIdx.y * sizeof(G2pcCameraJob)) : cam_val;
+        const int ix = t % lay.nx, iy = t / lay.nx;
+        for (int k = 0; k < lay.depth && !state; ++k) {
+            if (!((sticks >> k) & 1u)) continue;
+            const int sh = lay.depth - k, ax = ix >> sh, ay = iy >> sh, node = (1 << k) - 1;
+            const int x0 = lay.inner_x[2 * (node + ax)], x1 = lay.inner_x[2 * (node + ax) + 1];
+            const int y0 = lay.inner_y[2 * (node + ay)], y1 = lay.inner_y[2 * (node + ay) + 1];
+            bool occupied = false;
+            for (int pass = 0; pass < 2 && !occupied; ++pass)          // 0: leaves inside the node, 1: members of the others
+                for (int by = ay << sh; by < ((ay + 1) << sh) && !occupied; ++by)
+                    for (int bx = ax << sh; bx < ((ax + 1) << sh) && !occupied; ++bx) {
+                        const int u = by * lay.nx + bx;
+                        const uint32_t u0 = tile_start[u], u1 = tile_start[u + 1];
+                        if (u1 == u0) continue;
+                        const bool inside = !((((uint32_t)lay.tile_stick[u]) >> k) & 1u);
+                        if (pass == 0) { occupied = inside; continue; }
+                        if (inside) continue;
+                        for (uint32_t m = u0; m < u1 && !occupied; ++m) {
+                            float r[4];
+                            occupied = py_rect(cam, means3D, cov9, (long)(inst_g[m] & gmask), r) && rect_in_node(r, x0, x1, y0, y1);
+                        }
+                    }
+            if (!occupied) state = 2u | ((uint32_t)k << 8);
+        }
+    }
+    tile_range[t] = make_uint2(first, state ? first : end);
+    tile_state[t] = state;
+}
+
+// Gaussians per node for a list of pixel rectangles (x0, y0, w, h) -- the reference's `tile_mask.sum()` of gauss_render.py:309
+// for nodes that are not tiles of a layout (interior nodes of the quad-tree).  One block = 256 Gaussians x all nodes.
+__global__ __launch_bounds__(RA_T) void k_node_counts(Cam cam, const float* __restrict__ means3D, const float* __restrict__ cov9,
+                                                     long n, const int32_t* __restrict__ nodes, int m,
+                                                     uint32_t* __restrict__ counts) {
+    const long i = (long)blockIdx.x * RA_T + threadIdx.x;
+    float r[4];
+    const bool live = i < n && py_rect(cam, means3D, cov9, i, r);
+    for (int j = 0; j < m; ++j) {
+        const int x0 = nodes[4 * j], y0 = nodes[4 * j + 1], w = nodes[4 * j + 2], h = nodes[4 * j + 3];
+        const bool in = live && rect_in_node(r, x0, x0 + w - 1, y0, y0 + h - 1);
+        const unsigned long long b = __ballot(in ? 1 : 0);
+        if ((threadIdx.x & 63) == 0 && b) atomicAdd(&counts[j], (uint32_t)__popcll(b));
+    }
+}
+
+__global__ __launch_bounds__(RA_T) void k_adjacent_diff(const uint32_t* __restrict__ start, int T, uint32_t* __restrict__ out) {
+    const int t = blockIdx.x * RA_T + threadIdx.x;
+    if (t < T) out[t] = start[t + 1] - start[t];
+}
+
+// keys packed with an `ob`-bit tile field -> an `nb`-bit one (same camera slot, tile sequence and pixel)
+__global__ __launch_bounds__(RA_T) void k_repack_keys(unsigned long long* __restrict__ best_key, long n, int ob, int nb) {
+    long i = (long)blockIdx.x * RA_T + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long key = best_key[i];
+    if ((key >> 32) == 0ull) return;
+    const uint32_t order = ~(uint32_t)key;
+    const uint32_t slot = order >> (12 + ob), seq = (order >> 12) & ((1u << ob) - 1u), pix = order & 0xFFFu;
+    best_key[i] = (key & 0xFFFFFFFF00000000ull) | (uint32_t)~((slot << (12 + nb)) | (seq << 12) | pix);
 }
 
 // capacity-sized launches: the instance count stays on the device.  l_eff = L if it fits the buffers, else 0 (the
@@ -1317,11 +1435,12 @@ __global__ __launch_bounds__(RA_T) void k_check_tile_load(const uint32_t* __rest
 __global__ void k_resolve_count(const uint32_t* __restrict__ total, uint32_t capacity, uint32_t* __restrict__ l_eff,
                                 uint32_t* __restrict__ count_host, const uint32_t* __restrict__ depth_overflow, size_t cs) {
     total = seg(total, cs); l_eff = seg(l_eff, cs); depth_overflow = seg(depth_overflow, cs);
-    if (count_host) count_host += 2 * blockIdx.y;                                  // [camera][instances, unsorted]
+    if (count_host) count_host += 4 * blockIdx.y;                                  // [camera][instances, unsorted, overloaded leaf, -]
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         const uint32_t unsorted = depth_overflow ? *depth_overflow : 0u;       // the depth bucket sort gave up: skip the camera
         l_eff[0] = (total[0] <= capacity && !unsorted) ? total[0] : 0u;
-        if (count_host) { count_host[0] = total[0]; count_host[1] = unsorted; }   // pinned host memory, through its device mapping
+        // pinned host memory, through its device mapping ([2] is raised by k_tile_gate later in the sequence)
+        if (count_host) { count_host[0] = total[0]; count_host[1] = unsorted; count_host[2] = 0u; }
     }
 }
 // the pinned host job -> device memory, by a kernel rather than a copy node (see g2pc_raster_camera_py)
@@ -1404,13 +1523,18 @@ static Layout to_layout(const G2pcTileLayout* l) {
     Layout k;
     k.nx = l->nx; k.ny = l->ny; k.num_chunks = l->num_chunks; k.seq_bits = l->seq_bits ? l->seq_bits : 12; k.xs = l->xs; k.ws = l->ws; k.ys = l->ys; k.hs = l->hs;
     k.tile_seq = l->tile_seq; k.seq_tile = l->seq_tile; k.tile_pix_off = l->tile_pix_off;
+    k.seq_base = l->seq_count ? l->seq_base : 0; k.seq_count = l->seq_count ? l->seq_count : l->nx * l->ny;
+    k.tile_mask = l->tile_mask;
+    const bool tree = l->depth > 0 && l->inner_x && l->inner_y && l->tile_stick && l->nx == (1 << l->depth) && l->ny == (1 << l->depth);
+    k.depth = tree ? l->depth : 0; k.inner_x = l->inner_x; k.inner_y = l->inner_y; k.tile_stick = tree ? l->tile_stick : nullptr;
     return k;
 }
 static int bits_for_tiles(unsigned t) { int b = 1; while ((1u << b) < t && b < 31) ++b; return b; }
 // packed visibility keys: the tile-sequence field is seq_bits wide (12 .. 14), the camera slot gets the 20 - seq_bits above it
 static bool layout_keys_ok(const G2pcTileLayout* l) {
     const int sb = l->seq_bits ? l->seq_bits : 12;
-    return sb >= 12 && sb <= 14 && (long)l->nx * l->ny <= (1l << sb);
+    const long top = l->seq_count ? (long)l->seq_base + l->seq_count : (long)l->nx * l->ny;     // largest sequence number + 1
+    return sb >= 12 && sb <= 14 && l->seq_base >= 0 && l->seq_count >= 0 && top <= (1l << sb);
 }
 static uint32_t max_camera_slot(const G2pcTileLayout* l) { return (1u << (20 - (l->seq_bits ? l->seq_bits : 12))) - 1u; }
 
@@ -1432,8 +1556,32 @@ static int packed_instance_shift(long n, int T) {
     return (gbits + bits_for_tiles((unsigned)T) <= 32) ? gbits : 0;
 }
 static size_t py_back_ws(long L, int T) {
-    return align_up((size_t)(L + 1) * 4) * 6 + sort_workspace(L) + scan_workspace(T + 1) + align_up((size_t)(T + 2) * 4) + 4096 + 256;
+    return align_up((size_t)(L + 1) * 4) * 6 + sort_workspace(L) + scan_workspace(T + 1) + align_up((size_t)(T + 2) * 4) +
+           align_up((size_t)(T + 1) * 8) + align_up((size_t)(T + 1) * 4) + 4096 + 256;
 }
+// the arena of the back half (shared by py_back and g2pc_raster_tile_states)
+struct PyBackArena {
+    uint32_t *inst_tile, *inst_g, *tile_sorted, *g_sorted, *tile_tmp, *g_tmp, *tile_start, *tile_state;
+    uint2* tile_range;
+    char* sort_ws;
+    size_t sort_bytes;
+    bool ok;
+    PyBackArena(void* ws, size_t ws_bytes, long L, int T) {
+        Arena ar(ws, ws_bytes);
+        inst_tile = ar.get<uint32_t>((size_t)L + 1);
+        inst_g = ar.get<uint32_t>((size_t)L + 1);
+        tile_sorted = ar.get<uint32_t>((size_t)L + 1);
+        g_sorted = ar.get<uint32_t>((size_t)L + 1);
+        tile_tmp = ar.get<uint32_t>((size_t)L + 1);       // ping-pong scratch of the multi-pass sort: must NOT
+        g_tmp = ar.get<uint32_t>((size_t)L + 1);          // alias its input (pass 0 writes here when #passes is even)
+        tile_start = ar.get<uint32_t>((size_t)T + 2);
+        tile_range = ar.get<uint2>((size_t)T + 1);        // k_tile_gate: what the blend walks per tile
+        tile_state = ar.get<uint32_t>((size_t)T + 1);     // k_tile_gate: 0 blended, 1 overloaded, 2 | level << 8 under an empty node
+        sort_bytes = sort_workspace(L);
+        sort_ws = ar.get<char>(sort_bytes);
+        ok = ar.ok();
+    }
+};
 
 // depth_overflow != nullptr: the depth order comes from the bucket sort (prims.hip) and *depth_overflow points at its
 // overflow word afterwards (non-zero = NOT sorted: the caller must discard the camera and repeat it with the radix path)
@@ -1480,24 +1628,23 @@ static int py_front(const Cam& cam_val, const Cam* cam_dev, const G2pcTileLayout
 struct PyBlendArgs {                  // by value ...                      ... or device resident (job != nullptr)
     uint32_t camera_slot; float t_floor; float bg; const G2pcCameraJob* job;
 };
+struct PyScene {                      // what k_tile_gate re-derives a member's rectangle from (means3D == nullptr: it does not look)
+    Cam cam_val; const Cam* cam_dev; const float* means3D; const float* cov9; uint32_t* count_host;
+};
 
 // L: the instance count, or (l_eff != nullptr) the capacity of the buffers with the count in device memory
 static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t* l_eff,
                    const PyBlendArgs& ba, int W, int H, const PyFrontBuffers& fb, unsigned long long* best_key,
                    float* colours_out, float* tilebuf, float* image, int phases, uint32_t max_per_tile,
-                   uint32_t* overflow_flag, void* ws, size_t ws_bytes, hipStream_t s, Batch bt = Batch()) {
+                   uint32_t* overflow_flag, void* ws, size_t ws_bytes, hipStream_t s, Batch bt = Batch(),
+                   const PyScene& sc = PyScene{}) {
     const int T = layout->nx * layout->ny;
-    Arena ar(ws, ws_bytes);
-    uint32_t* inst_tile = ar.get<uint32_t>((size_t)L + 1);
-    uint32_t* inst_g = ar.get<uint32_t>((size_t)L + 1);
-    uint32_t* tile_sorted = ar.get<uint32_t>((size_t)L + 1);
-    uint32_t* g_sorted = ar.get<uint32_t>((size_t)L + 1);
-    uint32_t* tile_tmp = ar.get<uint32_t>((size_t)L + 1);       // ping-pong scratch of the multi-pass sort: must NOT
-    uint32_t* g_tmp = ar.get<uint32_t>((size_t)L + 1);          // alias its input (pass 0 writes here when #passes is even)
-    uint32_t* tile_start = ar.get<uint32_t>((size_t)T + 2);
-    size_t sort_bytes = sort_workspace(L);
-    char* sort_ws = ar.get<char>(sort_bytes);
-    if (!ar.ok()) { set_error("raster_back_py", "workspace too small"); return G2PC_ERR_WORKSPACE; }
+    PyBackArena A(ws, ws_bytes, L, T);
+    if (!A.ok) { set_error("raster_back_py", "workspace too small"); return G2PC_ERR_WORKSPACE; }
+    uint32_t *inst_tile = A.inst_tile, *inst_g = A.inst_g, *tile_sorted = A.tile_sorted, *g_sorted = A.g_sorted;
+    uint32_t *tile_tmp = A.tile_tmp, *g_tmp = A.g_tmp, *tile_start = A.tile_start;
+    char* sort_ws = A.sort_ws;
+    const size_t sort_bytes = A.sort_bytes;
     Layout lay = to_layout(layout);
     const int gshift = packed_instance_shift(n, T);
     const uint32_t gmask = gshift ? ((1u << gshift) - 1u) : 0xFFFFFFFFu;
@@ -1513,14 +1660,17 @@ static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t*
             if (rc) return rc;
         }
         hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T), (unsigned)bt.n), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start, l_eff, gshift, bt.cs);
-        if (overflow_flag && max_per_tile)
-            hipLaunchKernelGGL(k_check_tile_load, dim3(cdiv(T, RA_T), (unsigned)bt.n), dim3(RA_T), 0, s, tile_start, T, max_per_tile, overflow_flag, bt.cs);
+        Layout glay = lay;
+        if (!sc.means3D) glay.tile_stick = nullptr;       // no scene: leaves under empty nodes are not looked for
+        hipLaunchKernelGGL(k_tile_gate, dim3(cdiv(T, RA_T), (unsigned)bt.n), dim3(RA_T), 0, s, glay, sc.cam_val, sc.cam_dev, sc.means3D,
+                           sc.cov9, tile_start, blend_list, gmask, T, max_per_tile, A.tile_range, A.tile_state, overflow_flag,
+                           sc.count_host, bt.cs);
     }
-    if (phases & 2) {
+    if ((phases & 2) && layout->num_chunks > 0) {
         const unsigned chunks_y = layout->num_chunks < 32768 ? (unsigned)layout->num_chunks : 32768u;   // grid.y is 16 bits wide
 #define G2PC_BLEND(...)                                                                                                 \
     hipLaunchKernelGGL((__VA_ARGS__), dim3((unsigned)bt.n, chunks_y, cdiv(layout->num_chunks, chunks_y)), dim3(BL_T), 0, s, lay, layout->chunk_tile, \
-                       layout->chunk_pix0, tile_start, blend_list, gmask, (const float4*)fb.rec, best_key,             \
+                       layout->chunk_pix0, A.tile_range, blend_list, gmask, (const float4*)fb.rec, best_key,           \
                        ba.camera_slot << (12 + lay.seq_bits), ba.t_floor, ba.bg, tilebuf, g_chunk_work, ba.job, bt.cs)
         switch (layout->chunk_subblocks) {
             case 1: G2PC_BLEND(k_blend_py<1, 4>); break;
@@ -1578,7 +1728,7 @@ size_t g2pc_raster_back_workspace(int64_t num_instances, int32_t num_tiles) {
 // Back half: duplicate -> stable sort by tile id -> tile ranges -> blend + visibility -> colour update.
 int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, int64_t n, int64_t num_instances,
                         const float* rec, const uint32_t* rect, const uint32_t* sorted_idx, const uint32_t* offsets,
-                        uint32_t camera_slot, float t_floor,
+                        const float* means3D, const float* cov9, uint32_t camera_slot, float t_floor,
                         unsigned long long* best_key, float* colours_out, float* tilebuf, float* image, int phases,
                         uint32_t max_per_tile, uint32_t* overflow_flag, void* ws, size_t ws_bytes, void* stream) {
     using namespace g2pc;
@@ -1588,8 +1738,10 @@ int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, int
     G2PC_REQUIRE(camera_slot >= 1 && camera_slot <= max_camera_slot(layout), G2PC_ERR_ARG, "camera_slot must be in [1, (1 << (20 - seq_bits)) - 1]");
     PyFrontBuffers fb{(float4*)rec, (uint32_t*)rect, (uint32_t*)sorted_idx, (uint32_t*)offsets};
     PyBlendArgs ba{camera_slot, t_floor, cam->bg[0], nullptr};
+    PyScene scene{to_cam(cam), nullptr, cov9 ? means3D : nullptr, cov9, nullptr};
     int rc = py_back(layout, (long)n, (long)num_instances, nullptr, ba, cam->width, cam->height, fb, best_key,
-                     colours_out, tilebuf, image, phases, max_per_tile, overflow_flag, ws, ws_bytes, (hipStream_t)stream);
+                     colours_out, tilebuf, image, phases, max_per_tile, overflow_flag, ws, ws_bytes, (hipStream_t)stream,
+                     Batch(), scene);
     if (rc) return rc;
     return check_launch("g2pc_raster_back_py");
 }
@@ -1651,8 +1803,9 @@ int g2pc_raster_cameras_py(const G2pcCameraJob* jobs_dev, const G2pcCameraJob* j
                            count_host, (const uint32_t*)depth_overflow, bt.cs);
     }
     PyBlendArgs ba{0u, 0.0f, 0.0f, jobs_dev};
+    PyScene scene{Cam{}, (const Cam*)&jobs_dev->cam, means3D, cov9, count_host};
     rc = py_back(layout, (long)n, (long)capacity, l_eff, ba, 0, 0, fb, best_key, nullptr, tilebuf, nullptr,
-                 phases & (3 | 8), max_per_tile, overflow_flag, back_ws, back_bytes, s, bt);
+                 phases & (3 | 8), max_per_tile, overflow_flag, back_ws, back_bytes, s, bt, scene);
     if (rc) return rc;
     return check_launch("g2pc_raster_cameras_py");
 }
@@ -1685,6 +1838,39 @@ int g2pc_raster_resolve_colours_py(const G2pcTileLayout* layout, int64_t n, cons
     hipLaunchKernelGGL(k_resolve_colours_py, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, (hipStream_t)stream, to_layout(layout),
                        best_key, (long)n, tilebufs, colours_out);
     return check_launch("g2pc_raster_resolve_colours_py");
+}
+
+/* what k_tile_gate decided for the tiles of the camera last binned in `ws` (g2pc_raster_back_py phase 1) */
+int g2pc_raster_tile_states(const void* ws, size_t ws_bytes, int64_t num_instances, int32_t num_tiles, uint32_t* counts,
+                            uint32_t* states, void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(ws && num_tiles > 0 && num_instances >= 0 && (counts || states), G2PC_ERR_ARG, "bad arguments");
+    PyBackArena A(const_cast<void*>(ws), ws_bytes, (long)num_instances, num_tiles);
+    G2PC_REQUIRE(A.ok, G2PC_ERR_WORKSPACE, "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    if (counts)
+        hipLaunchKernelGGL(k_adjacent_diff, dim3(cdiv(num_tiles, RA_T)), dim3(RA_T), 0, s, (const uint32_t*)A.tile_start, num_tiles, counts);
+    if (states) hipMemcpyAsync(states, A.tile_state, (size_t)num_tiles * 4, hipMemcpyDeviceToDevice, s);
+    return check_launch("g2pc_raster_tile_states");
+}
+
+int g2pc_raster_node_counts(const G2pcCamera* cam, const float* means3D, const float* cov9, int64_t n, const int32_t* nodes,
+                            int32_t num_nodes, uint32_t* counts, void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(cam && means3D && cov9 && nodes && counts && n > 0 && num_nodes > 0, G2PC_ERR_ARG, "bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    hipMemsetAsync(counts, 0, (size_t)num_nodes * 4, s);
+    hipLaunchKernelGGL(k_node_counts, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, to_cam(cam), means3D, cov9, (long)n, nodes, num_nodes, counts);
+    return check_launch("g2pc_raster_node_counts");
+}
+
+int g2pc_raster_repack_keys(unsigned long long* best_key, int64_t n, int32_t old_seq_bits, int32_t new_seq_bits, void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(best_key && n > 0, G2PC_ERR_ARG, "bad arguments");
+    G2PC_REQUIRE(old_seq_bits >= 12 && new_seq_bits >= old_seq_bits && new_seq_bits <= 14, G2PC_ERR_ARG, "seq_bits must grow within 12 .. 14");
+    if (new_seq_bits != old_seq_bits)
+        hipLaunchKernelGGL(k_repack_keys, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, (hipStream_t)stream, best_key, (long)n, old_seq_bits, new_seq_bits);
+    return check_launch("g2pc_raster_repack_keys");
 }
 
 /* diagnostics: see g2pc.h */

@@ -123,8 +123,87 @@ def python_quadtree_layout(width: int, height: int, max_tile_size: int = 60, sub
         if wof[x0] != w or hof[y0] != h:
             raise NotImplementedError("non-uniform quad-tree leaves")
         seq_of[(x0, y0)] = s
-    return _finish([x for x, _ in xs], [w for _, w in xs], [y for y, _ in ys], [h for _, h in ys], seq_of, subblocks,
-                   tile_shard)
+    lay = _finish([x for x, _ in xs], [w for _, w in xs], [y for y, _ in ys], [h for _, h in ys], seq_of, subblocks,
+                  tile_shard)
+    lay.update(_tree_tables(width, height, lay))
+    return lay
+
+
+def split_interval(x0: int, w: int, limit: int):
+    """The two children of a node's interval along one axis (gauss_render.py:321-334 and :304-305): both ceil(w/2) wide, the
+    second starting right after the first and clipped to the IMAGE -- it reaches one pixel beyond an odd-sized parent."""
+    c = ceil(w / 2)
+    return (x0, c), (x0 + c, min(c, limit - (x0 + c)))
+
+
+def _axis_levels(length: int, depth: int):
+    """Intervals (start, size) of every level 0 .. depth of the uniform tree along one axis."""
+    levels = [[(0, length)]]
+    for _ in range(depth):
+        levels.append([c for iv in levels[-1] for c in split_interval(iv[0], iv[1], length)])
+    return levels
+
+
+def _tree_tables(width: int, height: int, lay) -> Dict[str, np.ndarray]:
+    """Quad-tree information of a leaf layout for the rasteriser's gate (G2pcTileLayout.depth / inner_x / inner_y / tile_stick):
+    the pixel extents of the interior nodes per axis and, per leaf, the levels whose ancestor it reaches beyond."""
+    nx, ny = lay["nx"], lay["ny"]
+    depth = int(round(np.log2(nx))) if nx > 1 else 0
+    none = dict(depth=0, inner_x=np.zeros((1, 2), np.int32), inner_y=np.zeros((1, 2), np.int32), tile_stick=np.zeros((nx * ny,), np.int32))
+    if nx != ny or (1 << depth) != nx or depth == 0:
+        return none
+    lx, ly = _axis_levels(width, depth), _axis_levels(height, depth)
+    if [tuple(v) for v in lx[depth]] != list(zip(lay["xs"].tolist(), lay["ws"].tolist())) or \
+            [tuple(v) for v in ly[depth]] != list(zip(lay["ys"].tolist(), lay["hs"].tolist())):
+        return none
+    inner_x = np.array([(x0, x0 + w - 1) for k in range(depth) for (x0, w) in lx[k]], np.int32)
+    inner_y = np.array([(y0, y0 + h - 1) for k in range(depth) for (y0, h) in ly[k]], np.int32)
+    x1 = lay["xs"] + lay["ws"] - 1
+    y1 = lay["ys"] + lay["hs"] - 1
+    sx = np.zeros((nx,), np.int32)
+    sy = np.zeros((ny,), np.int32)
+    for k in range(depth):
+        base, sh = (1 << k) - 1, depth - k
+        sx |= ((x1 > inner_x[base + (np.arange(nx) >> sh), 1]).astype(np.int32) << k)
+        sy |= ((y1 > inner_y[base + (np.arange(ny) >> sh), 1]).astype(np.int32) << k)
+    stick = (sy[:, None] | sx[None, :]).reshape(-1).astype(np.int32)
+    return dict(depth=depth, inner_x=inner_x, inner_y=inner_y, tile_stick=stick)
+
+
+def child_layout(width: int, height: int, parents, subblocks=None, tile_shard=None):
+    """The next quad-tree level below a set of split nodes, as a tile layout.
+
+    parents: list of (x0, y0, w, h, order) -- the nodes the reference splits (gauss_render.py:319-335), `order` any sortable
+    key that reproduces their FIFO order.  Returns (layout, children): the layout is the product of the distinct child column
+    intervals with the distinct child row intervals (children narrower or lower than 2 pixels are dropped, :301), and
+    children[i] = (tile index, x0, y0, w, h, order + (c,)) lists the tiles that ARE children of a parent, in FIFO order
+    (c = 0 top-left, 1 bottom-left, 2 top-right, 3 bottom-right, :325-333).  The other tiles of the product are not part of
+    the tree: the caller masks them out (tile_mask, chunk list)."""
+    xi, yi, kids = {}, {}, []
+    for (x0, y0, w, h, order) in parents:
+        cx = split_interval(x0, w, width)
+        cy = split_interval(y0, h, height)
+        for c, (a, b) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+            (kx, kw), (ky, kh) = cx[a], cy[b]
+            if kw <= 1 or kh <= 1:
+                continue
+            if xi.setdefault(kx, kw) != kw or yi.setdefault(ky, kh) != kh:
+                raise NotImplementedError("children of different widths share a first column")
+            kids.append((kx, ky, kw, kh, tuple(order) + (c,)))
+    if not kids:
+        return None, []
+    xs, ys = sorted(xi), sorted(yi)
+    kids.sort(key=lambda k: k[4])
+    seq_of = {(x, y): len(kids) for x in xs for y in ys}            # tiles outside the tree: after every child (never blended)
+    for s, (kx, ky, _, _, _) in enumerate(kids):
+        seq_of[(kx, ky)] = s
+    lay = _finish(xs, [xi[x] for x in xs], ys, [yi[y] for y in ys], seq_of, subblocks, None)
+    colx, rowy = {x: i for i, x in enumerate(xs)}, {y: i for i, y in enumerate(ys)}
+    children = [(rowy[ky] * len(xs) + colx[kx], kx, ky, kw, kh, order) for (kx, ky, kw, kh, order) in kids]
+    if tile_shard is not None:
+        r, w_ = tile_shard
+        children = children[r::w_]
+    return lay, children
 
 
 def grid_layout(width: int, height: int, block: int = 16) -> Dict[str, np.ndarray]:

@@ -39,7 +39,6 @@ C3 = [-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.37317633259
 # `>` against the initial 0 marks it as rendered with a contribution < 3e-8; it is far below any usable threshold.
 DEFAULT_T_FLOOR = 1e-6
 BLEND_SUBBLOCKS = None     # 8x8 sub-blocks per blend wave (None -> g2pc.tiles.SUBBLOCKS_PER_CHUNK)
-STRICT_TILE_LOAD = False   # raise (instead of warn) when a leaf tile exceeds max_gaussians_per_tile, see check_tile_load
 RENDER_STATS = []          # (instances L, tile-sort passes, W*H) of every camera rendered (bench.py reads this)
 
 
@@ -59,7 +58,9 @@ class _Layout(C.Structure):
     _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("xs", C.c_void_p), ("ws", C.c_void_p), ("ys", C.c_void_p),
                 ("hs", C.c_void_p), ("tile_seq", C.c_void_p), ("seq_tile", C.c_void_p), ("tile_pix_off", C.c_void_p),
                 ("num_chunks", C.c_int32), ("chunk_tile", C.c_void_p), ("chunk_pix0", C.c_void_p),
-                ("chunk_subblocks", C.c_int32), ("seq_bits", C.c_int32)]
+                ("chunk_subblocks", C.c_int32), ("seq_bits", C.c_int32),
+                ("seq_base", C.c_int32), ("seq_count", C.c_int32), ("tile_mask", C.c_void_p), ("depth", C.c_int32),
+                ("inner_x", C.c_void_p), ("inner_y", C.c_void_p), ("tile_stick", C.c_void_p)]
 
 
 nv._RASTER_PROTOS.update({
@@ -68,7 +69,10 @@ nv._RASTER_PROTOS.update({
                              [C.c_void_p] * 6 + [C.c_size_t, C.c_void_p]),
     "g2pc_raster_back_workspace": (C.c_size_t, [C.c_int64, C.c_int32]),
     "g2pc_raster_back_py": (C.c_int, [C.POINTER(_Camera), C.POINTER(_Layout), C.c_int64, C.c_int64] +
-                            [C.c_void_p] * 4 + [C.c_uint32, C.c_float] + [C.c_void_p] * 4 + [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+                            [C.c_void_p] * 6 + [C.c_uint32, C.c_float] + [C.c_void_p] * 4 + [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "g2pc_raster_tile_states": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "g2pc_raster_node_counts": (C.c_int, [C.POINTER(_Camera), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "g2pc_raster_repack_keys": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "g2pc_raster_camera_workspace": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32]),
     "g2pc_raster_camera_py": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(_Layout)] + [C.c_void_p] * 4 + [C.c_int64, C.c_int64] +
                               [C.c_void_p] * 3 + [C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -180,18 +184,49 @@ def strip_symmetric(sym):
 
 
 class _DeviceLayout:
-    """A tile layout uploaded once per (image size, tiling) and kept alive with its ctypes mirror."""
+    """A tile layout uploaded once per (image size, tiling) and kept alive with its ctypes mirror.  seq_count != 0: a level of a
+    camera's data-dependent quad-tree -- its keys carry the sequence numbers seq_base + tile_seq (G2pcTileLayout.seq_base)."""
 
-    def __init__(self, lay, device):
+    def __init__(self, lay, device, seq_base=0, seq_count=0):
         self.host = lay
-        self.t = {k: torch.from_numpy(lay[k]).to(device) for k in
-                  ("xs", "ws", "ys", "hs", "tile_seq", "seq_tile", "tile_pix_off", "chunk_tile", "chunk_pix0")}
+        self.device = device
+        names = ["xs", "ws", "ys", "hs", "tile_seq", "seq_tile", "tile_pix_off", "chunk_tile", "chunk_pix0"]
+        self.has_tree = int(lay.get("depth", 0)) > 0
+        if self.has_tree:
+            names += ["inner_x", "inner_y", "tile_stick"]
+        self.t = {k: torch.from_numpy(np.ascontiguousarray(lay[k])).to(device) for k in names}
+        if seq_count:
+            self.t["tile_seq"] = self.t["tile_seq"] + int(seq_base)
         self.seq_bits = max(12, int(np.ceil(np.log2(max(lay["nx"] * lay["ny"], 2)))))   # tile-sequence bits its keys need
         self.c = _Layout(nx=lay["nx"], ny=lay["ny"], num_chunks=len(lay["chunk_tile"]),
-                         chunk_subblocks=lay["chunk_subblocks"], seq_bits=self.seq_bits,
+                         chunk_subblocks=lay["chunk_subblocks"], seq_bits=self.seq_bits, seq_base=int(seq_base),
+                         seq_count=int(seq_count), depth=int(lay.get("depth", 0)) if self.has_tree else 0,
                          **{k: v.data_ptr() for k, v in self.t.items()})
         self.num_tiles = lay["nx"] * lay["ny"]
         self.total_pixels = lay["total_pixels"]
+        self.sticks_out = self.has_tree and bool(np.any(lay["tile_stick"]))
+
+    def only(self, enabled):
+        """The same layout restricted to the tiles with enabled[t]: the blend walks only their chunks and the image
+        assembly paints only their pixels (G2pcTileLayout.tile_mask)."""
+        return _PassLayout(self, np.asarray(enabled, dtype=bool))
+
+
+class _PassLayout:
+    """One pass of a camera whose quad-tree departs from the leaf grid: a layout with some of its tiles switched off."""
+
+    def __init__(self, base, enabled):
+        keep = enabled[base.host["chunk_tile"]]
+        dev = base.device
+        self.base = base                      # (keeps the shared tables alive)
+        self.t = dict(chunk_tile=torch.from_numpy(np.ascontiguousarray(base.host["chunk_tile"][keep])).to(dev),
+                      chunk_pix0=torch.from_numpy(np.ascontiguousarray(base.host["chunk_pix0"][keep])).to(dev),
+                      tile_mask=torch.from_numpy(enabled.astype(np.uint8)).to(dev))
+        self.c = _Layout.from_buffer_copy(base.c)
+        self.c.num_chunks = int(keep.sum())
+        for k, v in self.t.items():
+            setattr(self.c, k, v.data_ptr())
+        self.num_tiles, self.total_pixels = base.num_tiles, base.total_pixels
 
 
 class _Scratch:
@@ -250,7 +285,7 @@ class _GraphSlot:
         self.stream_ptr = C.c_void_p(self.stream.cuda_stream) if on_gpu else C.c_void_p(1)   # the emulator ignores streams
         nbytes = C.sizeof(_Job) * self.batch
         self.job_host = torch.zeros((nbytes,), dtype=torch.uint8)
-        self.count_host = torch.zeros((2 * self.batch,), dtype=torch.int32)      # per camera: [instances, depth-bucket-sort overflow]
+        self.count_host = torch.zeros((4 * self.batch,), dtype=torch.int32)      # per camera: [instances, depth-bucket-sort overflow, load of an overloaded leaf, -]
         if on_gpu:
             self.job_host, self.count_host = self.job_host.pin_memory(), self.count_host.pin_memory()
         self.jobs = (_Job * self.batch).from_address(self.job_host.data_ptr())
@@ -402,6 +437,8 @@ class GaussHipRenderer():
         self.capacity = ctx.capacity  # instance capacity of the captured graphs (learned from the first camera rendered)
         self.deferred = {}            # camera slot -> layout of the pipelined cameras whose colours are resolved at flush()
         self.redo = []                # cameras that did not fit their graph's capacity: (camera struct, layout, slot)
+        self.fixups = []              # cameras whose overloaded leaves still need their children rendered: (camera struct, layout, slot)
+        self.split_leaves = 0         # children of overloaded leaves rendered so far (the reference's count-driven split)
         self.rerendered = 0           # cameras that overflowed their graph's capacity and went through the two-call path
         self.layouts = {}
         self.last_stats = []          # (instances L, tile-sort passes, W*H) per rendered camera
@@ -455,7 +492,6 @@ class GaussHipRenderer():
 
     def get_gaussian_colours(self):
         self.flush()
-        self.check_tile_load()
         return self.gaussian_colours * 255
 
     def get_gaussians_above_contribution_threshold(self, contribution_threshold):
@@ -552,7 +588,7 @@ class GaussHipRenderer():
             sc.tilebuf_ptr = nv.ptr(sc.tilebuf)
         with nv.region(name, self.device):
             nv.check(L.g2pc_raster_back_py(C.byref(cam), C.byref(lay.c), self.n, num_inst, *sc.ptrs,
-                                           slot, self.t_floor, self.state_ptrs()[0], self.state_ptrs()[1], sc.tilebuf_ptr,
+                                           self.scene_ptrs[0], self.scene_ptrs[1], slot, self.t_floor, self.state_ptrs()[0], self.state_ptrs()[1], sc.tilebuf_ptr,
                                            nv.ptr(image), phases, self.MAX_GAUSSIANS_PER_TILE, self.overflow_ptr, sc.back_ws_ptr,
                                            sc.back_ws_bytes, nv.stream_handle(self.device)),
                      "raster_back_py")
@@ -562,17 +598,153 @@ class GaussHipRenderer():
         self.last_stats.append((num_inst, (bits + 7) // 8, W * H))
         RENDER_STATS.append((num_inst, (bits + 7) // 8, W * H))
 
-    def _render_sync(self, cam, lay, slot, return_image):
-        """Two-call path on the current stream: the host reads the instance count between the halves."""
+    def _render_sync(self, cam, lay, slot, return_image, static_done=False):
+        """Two-call path on the current stream: the host reads the instance count between the halves -- and what the gate
+        decided for the leaves (g2pc_raster_tile_states): a camera whose quad-tree departs from the leaf grid continues in
+        _render_tree.  static_done: the pipeline already blended this camera's leaves (minus the gated ones)."""
         sc = self.sync_scratch
         self._front(sc, cam, lay)
         num_inst = int(sc.offsets[self.n].item())                       # the one read-back per camera
         image = torch.empty((cam.height, cam.width, 3), dtype=torch.float32, device=self.device) if return_image else None
         self._back(sc, cam, lay, slot, num_inst, image, 1, "raster_bin")
-        self._back(sc, cam, lay, slot, num_inst, image, 2, "raster_blend")
-        self._back(sc, cam, lay, slot, num_inst, image, 4, "raster_update")
+        counts, states = self._tile_states(sc, lay, num_inst)
+        plan = None
+        if states.any() or (return_image and lay.has_tree and not counts.all()):
+            plan = self._static_plan(cam, lay, counts, states)
+        if plan is not None and (plan["overloaded"].any() or plan["dead"].any()):
+            self._render_tree(sc, cam, lay, slot, num_inst, image, plan, static_done)
+        elif not static_done:
+            self._back(sc, cam, lay, slot, num_inst, image, 2, "raster_blend")
+            self._back(sc, cam, lay, slot, num_inst, image, 4, "raster_update")
         self._note(lay, num_inst, cam.width, cam.height)
         return image, num_inst
+
+    # ---- the reference's data-dependent quad-tree (gauss_render.py:290-335) beyond the fixed leaf grid ---------------------
+    def _tile_states(self, sc, lay, num_inst):
+        """(Gaussians per tile, gate state per tile) of the camera just binned in the scratch, as numpy arrays."""
+        T = lay.num_tiles
+        out = torch.empty((2, T), dtype=torch.int32, device=self.device)
+        nv.check(nv.lib().g2pc_raster_tile_states(sc.back_ws_ptr, sc.back_ws_bytes, num_inst, T, nv.ptr(out[0]), nv.ptr(out[1]),
+                                                  nv.stream_handle(self.device)), "raster_tile_states")
+        host = out.cpu().numpy().astype(np.int64)
+        return host[0], host[1]
+
+    def _node_counts(self, cam, nodes):
+        """Gaussians per pixel rectangle (x0, y0, w, h) by the reference's membership test (gauss_render.py:306-309)."""
+        nodes = np.ascontiguousarray(nodes, dtype=np.int32).reshape(-1, 4)
+        dev_nodes = torch.from_numpy(nodes).to(self.device)
+        out = torch.empty((len(nodes),), dtype=torch.int32, device=self.device)
+        nv.check(nv.lib().g2pc_raster_node_counts(C.byref(cam), self.scene_ptrs[0], self.scene_ptrs[1], self.n, nv.ptr(dev_nodes),
+                                                  len(nodes), nv.ptr(out), nv.stream_handle(self.device)), "raster_node_counts")
+        return out.cpu().numpy().astype(np.int64)
+
+    def _static_plan(self, cam, lay, counts, states):
+        """Which leaves of the fixed grid the reference's queue really reaches for this camera: a leaf over
+        max_gaussians_per_tile is split (:319), a node without any Gaussian is painted with the background and its subtree
+        never visited (:311-314) -- `dead` leaves, `fills` = the painted rectangles.  A node is occupied if a leaf inside it
+        has a member, empty if no leaf below it has one; in between (only leaves reaching beyond it have members, odd splits)
+        the device counts its members with the reference's test."""
+        h = lay.host
+        nx, ny, T = h["nx"], h["ny"], lay.num_tiles
+        over = (counts > self.MAX_GAUSSIANS_PER_TILE) if self.MAX_GAUSSIANS_PER_TILE else np.zeros((T,), bool)
+        dead, fills = np.zeros((T,), bool), []
+        d = int(h.get("depth", 0)) if lay.has_tree else 0
+        if d > 0:
+            Cn = counts.reshape(ny, nx)
+            stick = h["tile_stick"].reshape(ny, nx)
+            occupied, unsure = [], []
+            for k in range(d):
+                m, b = 1 << k, 1 << (d - k)
+                blk = Cn.reshape(m, b, m, b)
+                inside = (((stick >> k) & 1) == 0).reshape(m, b, m, b)
+                occ = (blk * inside).sum(axis=(1, 3)) > 0
+                for ay, ax in zip(*np.nonzero(~occ & (blk.sum(axis=(1, 3)) > 0))):
+                    unsure.append((k, ay, ax))
+                occupied.append(occ)
+            if unsure:
+                ix, iy = h["inner_x"], h["inner_y"]
+                nodes = [(ix[(1 << k) - 1 + ax, 0], iy[(1 << k) - 1 + ay, 0], ix[(1 << k) - 1 + ax, 1] - ix[(1 << k) - 1 + ax, 0] + 1,
+                          iy[(1 << k) - 1 + ay, 1] - iy[(1 << k) - 1 + ay, 0] + 1) for (k, ay, ax) in unsure]
+                for (k, ay, ax), c in zip(unsure, self._node_counts(cam, nodes)):
+                    occupied[k][ay, ax] = c > 0
+            alive = np.ones((1, 1), bool)
+            for k in range(d):
+                ix, iy = h["inner_x"], h["inner_y"]
+                for ay, ax in zip(*np.nonzero(alive & ~occupied[k])):
+                    fills.append((ix[(1 << k) - 1 + ax, 0], iy[(1 << k) - 1 + ay, 0], ix[(1 << k) - 1 + ax, 1], iy[(1 << k) - 1 + ay, 1]))
+                alive = (alive & occupied[k]).repeat(2, axis=0).repeat(2, axis=1)
+            dead = ~alive.reshape(-1)
+            over = over & ~dead
+        # the gate (k_tile_gate) took the same decisions for every leaf with members, by other means
+        has = counts > 0
+        if not (np.array_equal(states == 1, over) and np.array_equal(((states & 0xFF) == 2) & has, dead & has)):
+            raise RuntimeError("quad-tree plan: the device gate and the host disagree on %d leaves"
+                               % int(((states == 1) != over).sum() + ((((states & 0xFF) == 2) & has) != (dead & has)).sum()))
+        return dict(overloaded=over, dead=dead, fills=fills)
+
+    def _ensure_seq_room(self, top):
+        """The packed keys' tile field must hold sequence numbers below `top` (leaves + the children of split leaves)."""
+        need = max(12, int(np.ceil(np.log2(max(top, 2)))))
+        if need <= self.seq_bits:
+            return
+        if need > 14 or self.camera_slot > (1 << (20 - need)) - 1:
+            raise NotImplementedError("a camera's quad-tree needs %d leaf sequence numbers: beyond the %s of the packed "
+                                      "visibility keys (set renderer.seq_bits = 14 before the first camera)"
+                                      % (top, "14-bit tile field" if need > 14 else "camera slots left at that width"))
+        nv.check(nv.lib().g2pc_raster_repack_keys(self.state_ptrs()[0], self.n, self.seq_bits, need,
+                                                  nv.stream_handle(self.device)), "raster_repack_keys")
+        self.seq_bits = need
+
+    def _render_tree(self, sc, cam, lay, slot, num_inst, image, plan, static_done):
+        """A camera whose quad-tree departs from the leaf grid, pass by pass in the reference's FIFO order: the background of
+        the empty nodes, the leaves the queue reaches (minus the overloaded ones), then level by level the children of the
+        split nodes -- each level one layout (tiles.child_layout) whose keys continue the camera's sequence numbers."""
+        W, H = cam.width, cam.height
+        h = lay.host
+        if image is not None:
+            image.fill_(1.0)                                            # torch.ones (:287); the image is returned flipped (:402)
+            for (x0, y0, x1, y1) in plan["fills"]:
+                image[y0:y1 + 1, W - 1 - x1:W - x0, :] = float(cam.bg[0])
+        if not static_done:
+            leaves = lay.only(~plan["overloaded"] & ~plan["dead"])
+            leaves.c.seq_bits = self.seq_bits
+            self._back(sc, cam, leaves, slot, num_inst, image, 2, "raster_blend")
+            self._back(sc, cam, leaves, slot, num_inst, image, 4, "raster_update")
+        nx = h["nx"]
+        parents = [(int(h["xs"][t % nx]), int(h["ys"][t // nx]), int(h["ws"][t % nx]), int(h["hs"][t // nx]), (int(h["tile_seq"][t]),))
+                   for t in np.nonzero(plan["overloaded"])[0]]
+        seq_next = lay.num_tiles
+        while parents:
+            host, children = tiles.child_layout(W, H, parents, BLEND_SUBBLOCKS)
+            if host is None:
+                break                                                   # every child is narrower than 2 pixels (:301)
+            if host["nx"] > 256 or host["ny"] > 256:
+                raise NotImplementedError("a quad-tree level with more than 256 tile intervals per axis")
+            self._ensure_seq_room(seq_next + len(children))
+            level = _DeviceLayout(host, self.device, seq_base=seq_next, seq_count=len(children))
+            level.c.seq_bits = self.seq_bits
+            self._front(sc, cam, level)
+            n_inst = int(sc.offsets[self.n].item())
+            self._back(sc, cam, level, slot, n_inst, image, 1, "raster_bin")
+            counts, states = self._tile_states(sc, level, n_inst)
+            enabled = np.zeros((level.num_tiles,), bool)
+            parents = []
+            for (t, x0, y0, w, h_, order) in children:
+                if self.MAX_GAUSSIANS_PER_TILE and counts[t] > self.MAX_GAUSSIANS_PER_TILE:
+                    parents.append((x0, y0, w, h_, order))              # split again at the next level
+                else:
+                    enabled[t] = True                                   # blended (an empty child paints the background, :311-314)
+            if self.tile_shard is not None:                             # this rank's share of the children
+                mine = np.zeros_like(enabled)
+                mine[[c[0] for c in children][self.tile_shard[0]::self.tile_shard[1]]] = True
+                enabled &= mine
+            if enabled.any():
+                part = level.only(enabled)
+                part.c.seq_bits = self.seq_bits
+                self._back(sc, cam, part, slot, n_inst, image, 2, "raster_blend")
+                self._back(sc, cam, part, slot, n_inst, image, 4, "raster_update")
+            seq_next += len(children)
+            self.split_leaves += len(children)
 
     # ---- capture-and-replay pipeline ------------------------------------------------------------------------------
     def _capture(self, sl, lay, key):
@@ -621,7 +793,7 @@ class GaussHipRenderer():
         if sl.on_gpu:
             sl.update_done.synchronize()
         for i, (cam, lay, slot, capacity) in enumerate(batch):
-            num_inst, unsorted = int(sl.count_host[2 * i]), int(sl.count_host[2 * i + 1])
+            num_inst, unsorted, overloaded = (int(sl.count_host[4 * i + j]) for j in range(3))
             if num_inst > capacity or unsorted:
                 # did not fit the graph's buffers, or the depth bucket sort met a pile-up of equal depths: the graph skipped
                 # the camera as a whole; render it again through the two-call path (radix depth sort, exact instance count)
@@ -630,6 +802,10 @@ class GaussHipRenderer():
                 self.redo.append((cam, lay, slot))
                 self.rerendered += 1
                 continue
+            if overloaded:
+                # some leaf held more than max_gaussians_per_tile Gaussians: the graph left it out (k_tile_gate); its children
+                # are rendered at flush() -- the packed keys make the order of the passes irrelevant
+                self.fixups.append((cam, lay, slot))
             self._note(lay, num_inst, cam.width, cam.height)
 
     def _launch_batch(self, sl):
@@ -756,6 +932,12 @@ class GaussHipRenderer():
             self.deferred.pop(slot, None)          # ... which updates the colours it wins at once
             lay.c.seq_bits = self.seq_bits         # (layouts are shared between renderers)
             self._render_sync(cam, lay, slot, False)
+        while self.fixups:                         # cameras with overloaded leaves: the children of those leaves, original slot
+            cam, lay, slot = self.fixups.pop(0)
+            lay.c.seq_bits = self.seq_bits
+            self._render_sync(cam, lay, slot, False, static_done=True)
+            self.last_stats.pop()                  # (noted when its batch retired)
+            RENDER_STATS.pop()
         if self.deferred:
             # deferred colour resolve: one pass per layout over the Gaussians, colour = the winner camera's tile buffer
             by_layout = {}
@@ -773,21 +955,10 @@ class GaussHipRenderer():
             self.deferred = {}
 
     def check_tile_load(self):
-        """Some leaf tile held more Gaussians than `render()`'s default max_gaussians_per_tile: the reference, run with
-        that default, would have split the leaf further (gauss_render.py:319), which this fixed leaf layout cannot
-        follow.  The reference's own __call__ derives the limit from the free device memory (gauss_render.py:440-463;
-        1.6 M per tile on a 288 GB part), so the unsplit result is one the reference produces too: warn, or raise when
-        STRICT_TILE_LOAD is set (parity runs against the pinned oracle)."""
+        """Largest number of Gaussians met in one leaf tile above max_gaussians_per_tile (0: no leaf was ever split).  Such
+        leaves are split as the reference's queue splits them (gauss_render.py:319-335; _render_tree)."""
         worst = int(self.overflow.item())
-        if worst:
-            msg = ("a %dx%d-limited leaf tile holds %d Gaussians (> max_gaussians_per_tile = %d): the reference's "
-                   "quad-tree, pinned to that limit, would subdivide it further"
-                   % (self.MAX_TILE_SIZE, self.MAX_TILE_SIZE, worst, self.MAX_GAUSSIANS_PER_TILE))
-            if STRICT_TILE_LOAD:
-                raise NotImplementedError(msg + "; not supported")
-            import warnings
-            warnings.warn(msg + "; rendering it unsplit (what the reference does with a larger memory-derived limit)")
-            self.overflow.zero_()
+        return worst
 
     def __call__(self, camera, return_image=True, slot=None, **kwargs):
         W, H = int(camera.image_width), int(camera.image_height)

@@ -96,7 +96,7 @@ class _CuScratch:
         self.stream = stream
         # [instances, 0], written by the device through the pinned buffer's mapping -- pipelined scratches only: the
         # synchronous scratch reads offsets[n] back itself, a pageable buffer here would cost a blocking copy per camera
-        self.count_host = torch.zeros((2,), dtype=torch.int32) if pipelined else None
+        self.count_host = torch.zeros((4,), dtype=torch.int32) if pipelined else None   # (instances, unsorted, -, -)
         if pipelined and stream is not None:
             self.count_host = self.count_host.pin_memory()
         self.front_done = torch.cuda.Event() if stream is not None else None

@@ -288,7 +288,21 @@ typedef struct G2pcTileLayout {      /* HOST struct of DEVICE pointers: tiles = 
                                       * key = contribution bits << 32 | ~(camera_slot << (12 + seq_bits) | tile_seq << 12 | pixel).
                                       * ny*nx <= 1 << seq_bits tiles, camera slots 1 .. (1 << (20 - seq_bits)) - 1 (255 / 127 / 63).
                                       * Every camera whose keys meet in one best_key array must use the same width (a renderer
-                                      * that needs a wider field later rebases its keys first, g2pc_raster_rebase_keys). */
+                                      * that needs a wider field later rebases its keys first, g2pc_raster_rebase_keys, or widens
+                                      * them in place, g2pc_raster_repack_keys). */
+    /* --- the reference's DATA-DEPENDENT quad-tree (gauss_render.py:311-335); all optional, zero = a plain tile grid ---
+     * A camera whose tree departs from the fixed leaf grid is rendered in several passes over different layouts (the leaf
+     * grid, then the children of overloaded leaves level by level) that share the camera's slot: */
+    int32_t seq_base, seq_count;     /* seq_count != 0: tile_seq holds the sequence numbers as they go into the keys, all in
+                                      * [seq_base, seq_base + seq_count); seq_tile is indexed by (number - seq_base); the colour
+                                      * update / resolve of this layout leaves keys outside the range alone */
+    const uint8_t* tile_mask;        /* [ny*nx], optional: image assembly paints only the pixels of tiles with a non-zero entry and
+                                      * leaves every other pixel of `image` as it is (NULL: every pixel is written) */
+    int32_t depth;                   /* splits above the leaves (nx == ny == 1 << depth), with the three tables below: */
+    const int32_t* inner_x;          /* [(1 << depth) - 1][2]: first and last pixel column of the interior nodes' column intervals,
+                                      * level k (0 = root) interval i at row (1 << k) - 1 + i */
+    const int32_t* inner_y;          /* the same for rows */
+    const int32_t* tile_stick;       /* [ny*nx]: bit k set = the leaf reaches beyond its level-k ancestor (odd splits) */
 } G2pcTileLayout;
 
 size_t g2pc_raster_front_workspace(int64_t n);
@@ -313,11 +327,15 @@ size_t g2pc_raster_back_workspace(int64_t num_instances, int32_t num_tiles);
  * phases: bit 0 = binning (duplicate, tile sort, ranges), bit 1 = blend, bit 2 = colour update + image; 7 = all
  * (the phases share `ws`).  The packed-key atomicMax is commutative, so the blends of different cameras may run
  * concurrently on different streams; only the colour updates must be issued in camera order.
- * overflow_flag (optional, device u32, zeroed by the caller): receives max(tile load) if any tile holds more than
- * max_per_tile Gaussians -- the reference would subdivide such a leaf further (gauss_render.py:319), this layout cannot. */
+ * max_per_tile (0 = no limit) / overflow_flag (optional, device u32, zeroed by the caller): a tile holding more than
+ * max_per_tile Gaussians is NOT blended -- the reference subdivides such a leaf (gauss_render.py:319): the caller renders
+ * its children in further passes (layouts with seq_base / seq_count / tile_mask) -- and overflow_flag receives max(tile load).
+ * means3D / cov9 (optional, the front half's inputs): with them and the layout's quad-tree tables, a leaf whose members all
+ * live in the strip it reaches beyond an EMPTY ancestor is not blended either (the reference paints that ancestor with the
+ * background and never visits its children, gauss_render.py:311-314).  g2pc_raster_tile_states reports both decisions. */
 int g2pc_raster_back_py(const G2pcCamera* cam, const G2pcTileLayout* layout, int64_t n, int64_t num_instances,
                         const float* rec, const uint32_t* rect, const uint32_t* sorted_idx, const uint32_t* offsets,
-                        uint32_t camera_slot, float t_floor,
+                        const float* means3D, const float* cov9, uint32_t camera_slot, float t_floor,
                         unsigned long long* best_key, float* colours_out, float* tilebuf, float* image, int phases,
                         uint32_t max_per_tile, uint32_t* overflow_flag, void* ws, size_t ws_bytes, void* stream);
 /* --- the same camera without a host round trip (capture-safe) -----------------------------------------------------
@@ -350,11 +368,24 @@ typedef struct G2pcCameraJob {       /* DEVICE (and pinned host staging) struct 
     uint32_t reserved;
 } G2pcCameraJob;
 size_t g2pc_raster_camera_workspace(int64_t n, int64_t capacity, int32_t num_tiles);
+/* After phase 1 of g2pc_raster_back_py (same ws, num_instances, num_tiles): Gaussians per tile (counts u32[T], optional) and
+ * what the gate decided (states u32[T], optional): 0 = blended, 1 = more than max_per_tile members (not blended: to be split,
+ * gauss_render.py:319), 2 | level << 8 = lies under the empty level-`level` node (not blended, gauss_render.py:311-314). */
+int g2pc_raster_tile_states(const void* ws, size_t ws_bytes, int64_t num_instances, int32_t num_tiles, uint32_t* counts,
+                            uint32_t* states, void* stream);
+/* Gaussians per node for arbitrary pixel rectangles nodes i32[num_nodes][4] = (x0, y0, w, h) (device): the reference's
+ * `tile_mask.sum()` (gauss_render.py:306-309) for the interior nodes of its quad-tree.  counts u32[num_nodes] (device). */
+int g2pc_raster_node_counts(const G2pcCamera* cam, const float* means3D, const float* cov9, int64_t n, const int32_t* nodes,
+                            int32_t num_nodes, uint32_t* counts, void* stream);
+/* Widen the tile field of every key in place (old_seq_bits -> new_seq_bits, 12 <= old <= new <= 14), keeping camera slot, tile
+ * sequence and pixel: legal while no key carries a camera slot above (1 << (20 - new_seq_bits)) - 1. */
+int g2pc_raster_repack_keys(unsigned long long* best_key, int64_t n, int32_t old_seq_bits, int32_t new_seq_bits, void* stream);
 /* BATCHED form: `batch` cameras (1 .. G2PC_MAX_CAMERA_BATCH) through ONE launch sequence -- every kernel of the sequence runs
  * with grid.y = batch, camera c reading the c-th job of the arrays jobs_dev / jobs_host and working in the c-th of `batch`
  * consecutive workspaces of g2pc_raster_camera_workspace() bytes each (ws_bytes >= batch times that).  A 50-camera job is
  * then 13 dependent chains of ~20 launches instead of 50, each kernel four times as wide, and the blends of a batch drain
- * together.  count_host: u32[batch][2].  The loop over cameras this replaces: gauss_to_pc.py:437-454 (the reference renders
+ * together.  count_host: u32[batch][4] = (instances, depth sort gave up, load of an overloaded leaf or 0, reserved): a camera
+ * with [2] != 0 had leaves over max_per_tile that were left out (g2pc_raster_back_py) and needs their children rendered.  The loop over cameras this replaces: gauss_to_pc.py:437-454 (the reference renders
  * them one at a time).  g2pc_raster_camera_py is batch = 1. */
 #define G2PC_MAX_CAMERA_BATCH 8
 int g2pc_raster_cameras_py(const G2pcCameraJob* jobs_dev, const G2pcCameraJob* jobs_host, int32_t batch,
@@ -376,7 +407,7 @@ int g2pc_raster_camera_update_py(const G2pcTileLayout* layout, int64_t n, uint32
 int g2pc_raster_resolve_colours_py(const G2pcTileLayout* layout, int64_t n, const unsigned long long* best_key,
                                    const unsigned long long* tilebufs, float* colours_out, void* stream);
 /* depth order inside g2pc_raster_camera_py: 1 = range-normalised bucket sort + in-LDS bitonic sort (default; five
- * launches), 0 = four-pass radix sort.  Same order bit for bit.  count_host must hold TWO words: [0] = instance count,
+ * launches), 0 = four-pass radix sort.  Same order bit for bit.  count_host holds FOUR words per camera: [0] = instance count,
  * [1] != 0 = the bucket sort overflowed (depths piled up in 1/1024 of their range), the camera was skipped as a whole
  * and has to be rendered again through the two-call path (which always sorts by radix). */
 int g2pc_set_depth_sort(int bucket);

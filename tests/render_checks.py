@@ -56,7 +56,7 @@ def assert_render_matches(g, R, images, contribs, tol=1e-4, allow_mask_flips=0, 
 
 
 def run_vs_oracle(n, seed, width, height, focal, ncam, device="cpu", scale=(0.004, 0.04), colour_resolution=None,
-                  t_floor=0.0, max_tile_size=None):
+                  t_floor=0.0, max_tile_size=None, max_gaussians_per_tile=None, xyz_scale=1.0, pipelined=False):
     """HIP renderer vs oracle/ref_render.py (itself bit-pinned to the reference) on a seeded synthetic scene."""
     import gauss_render
     import camera_handler
@@ -65,6 +65,8 @@ def run_vs_oracle(n, seed, width, height, focal, ncam, device="cpu", scale=(0.00
     from gauss_handler import Gaussians
     dev = torch.device(device)
     sc = make_scene(n, seed, scale_lo=scale[0], scale_hi=scale[1])
+    if xyz_scale != 1.0:                           # crowd the scene towards its centre (leaves over max_gaussians_per_tile)
+        sc = sc._replace(xyz=sc.xyz * xyz_scale)
     transforms, intr = make_cameras(ncam, width=width, height=height, focal=focal)
     G = Gaussians(sc.xyz.to(dev), sc.scales.to(dev), sc.rots.to(dev), sc.colours.to(dev), sc.opacities.to(dev))
     # both renderers get the SAME host-arithmetic inputs: the oracle's covariances (torch.exp on the CPU is MKL's, within an
@@ -76,8 +78,11 @@ def run_vs_oracle(n, seed, width, height, focal, ncam, device="cpu", scale=(0.00
     R.t_floor = t_floor
     if max_tile_size is not None:                  # render()'s max_tile_size argument (gauss_render.py:266), both sides
         R.MAX_TILE_SIZE = max_tile_size
-    O = RR.PythonRendererOracle(sc.xyz, sc.opacities.unsqueeze(1), sc.colours.double(), cov, threshold=0.05,
-                                **({} if max_tile_size is None else {"max_tile_size": max_tile_size}))
+    okw = {} if max_tile_size is None else {"max_tile_size": max_tile_size}
+    if max_gaussians_per_tile is not None:         # ... and its max_gaussians_per_tile (the count-driven split, :319)
+        R.MAX_GAUSSIANS_PER_TILE = max_gaussians_per_tile
+        okw["max_gaussians_per_tile"] = max_gaussians_per_tile
+    O = RR.PythonRendererOracle(sc.xyz, sc.opacities.unsqueeze(1), sc.colours.double(), cov, threshold=0.05, **okw)
     worst = dict(image=0.0, contribution=0.0, colour=0.0, flips=0, near_threshold=0, image_frac_off=0.0)
     for name in transforms:
         cam = camera_handler.get_camera("python", torch.tensor(transforms[name]), intr[name], colour_resolution=colour_resolution)
@@ -85,8 +90,11 @@ def run_vs_oracle(n, seed, width, height, focal, ncam, device="cpu", scale=(0.00
         assert torch.allclose(cam.world_view_transform, ocam.world_view_transform, rtol=1e-5, atol=1e-6)
         cam.world_view_transform, cam.projection_matrix = ocam.world_view_transform, ocam.projection_matrix
         cam.FoVx, cam.FoVy, cam.focal_x, cam.focal_y = ocam.FoVx, ocam.FoVy, ocam.focal_x, ocam.focal_y
-        img = R(cam)[0].cpu()
         ref = O(ocam)
+        if pipelined:                              # the capture / replay path returns no image
+            R(cam, return_image=False)
+            continue
+        img = R(cam)[0].cpu()
         d = (img - ref).abs()
         worst["image"] = max(worst["image"], float(d.max()))
         worst["image_frac_off"] = max(worst["image_frac_off"], float((d > 1e-4).float().mean()))
@@ -105,6 +113,7 @@ def run_vs_oracle(n, seed, width, height, focal, ncam, device="cpu", scale=(0.00
     flips = (R.get_visible_gaussians().cpu() != O.get_visible_gaussians())
     worst["flips"] = int(flips.sum())
     worst["seq_bits"] = R.seq_bits
+    worst["split_leaves"] = R.split_leaves
     worst["near_threshold"] = int(((O.max_contribution - 0.05).abs() < 1e-5).sum())
     worst["flip_margins"] = (O.max_contribution[flips] - 0.05).abs().tolist()
     return worst

@@ -51,7 +51,7 @@ def test_raster_argument_checks(emu):
     rec, rect, sidx, offs = f(n, 16), i(n), i(n), i(n + 1)
     key, cols, tilebuf = torch.zeros(n, dtype=torch.int64), f(n, 3), f(lay.total_pixels * 3)
     ws = torch.empty(1 << 20, dtype=torch.uint8)
-    args = lambda slot: (C.byref(cam), C.byref(lay.c), n, 0, _p(rec), _p(rect), _p(sidx), _p(offs), slot, 0.0, _p(key),
+    args = lambda slot: (C.byref(cam), C.byref(lay.c), n, 0, _p(rec), _p(rect), _p(sidx), _p(offs), None, None, slot, 0.0, _p(key),
                          _p(cols), _p(tilebuf), None, 7, 0, None, _p(ws), ws.numel(), None)
     assert L.g2pc_raster_back_py(*args(0)) == -1 and b"camera_slot" in L.g2pc_last_error()       # slots are 1..255
     assert L.g2pc_raster_back_py(*args(256)) == -1

@@ -1,0 +1,89 @@
+"""The reference's DATA-DEPENDENT quad-tree (gauss_render.py:290-335) through the emulator: leaves holding more than
+max_gaussians_per_tile Gaussians are split level by level (children in the reference's FIFO order, children narrower than
+two pixels dropped), nodes without any Gaussian are painted with the background and never descended into.  Checked against
+oracle/ref_render.py (itself pinned to the untouched reference, tests/test_oracle_render.py), whose queue is the reference's."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from emu_util import emu  # noqa: F401
+from render_checks import run_vs_oracle
+
+
+def _tight(res, split=True):
+    assert res["image"] < 5e-6 and res["contribution"] < 5e-6 and res["colour"] < 5e-6, res
+    assert res["flips"] == 0 and res["colour_off_gaussians"] == 0, res
+    assert (res["split_leaves"] > 0) == split, res
+
+
+def test_overloaded_leaves_are_split_like_the_reference(emu):
+    """3 000 Gaussians crowded into the centre of a 96 x 64 image, max_gaussians_per_tile = 400: the centre leaves split once
+    or twice.  Image, contributions, colours and the visible set of the reference, to rounding."""
+    res = run_vs_oracle(3000, 31, 96, 64, 80.0, 2, scale=(0.004, 0.03), t_floor=0.0, max_gaussians_per_tile=400, xyz_scale=0.3)
+    _tight(res)
+
+
+def test_split_down_to_children_the_reference_drops(emu):
+    """max_gaussians_per_tile = 20: the splitting only ends at children narrower than two pixels, which the reference drops
+    without painting them (gauss_render.py:301)."""
+    res = run_vs_oracle(3000, 31, 96, 64, 80.0, 1, scale=(0.004, 0.03), t_floor=0.0, max_gaussians_per_tile=20, xyz_scale=0.15)
+    _tight(res)
+
+
+def test_odd_sized_image_with_split_leaves(emu):
+    """333 x 187: odd splits at several levels (children reaching beyond their parents), leaves split on top of that."""
+    res = run_vs_oracle(2500, 5, 333, 187, 300.0, 2, scale=(0.004, 0.03), t_floor=0.0, max_gaussians_per_tile=300, xyz_scale=0.35)
+    _tight(res)
+
+
+def test_default_floor_mode_splits_too(emu):
+    """The production blend (transmittance floor 1e-6, dual-list kernel) over a split tree."""
+    res = run_vs_oracle(3000, 32, 96, 64, 80.0, 2, scale=(0.004, 0.03), t_floor=1e-6, max_gaussians_per_tile=400, xyz_scale=0.3)
+    assert res["image"] < 1e-4 and res["contribution"] < 1e-4 and res["flips"] == 0 and res["split_leaves"] > 0, res
+    assert res["colour_off_gaussians"] <= 2, res            # (arg-max pixels whose contributions tie to ~1e-6, see render_checks)
+
+
+def test_pipeline_leaves_overloaded_leaves_to_the_flush(emu, monkeypatch):
+    """Capture / replay path: the gate keeps the overloaded leaves out of the batched blend (k_tile_gate), the host hears of
+    it through the pinned counts and renders their children at flush() under the camera's own slot."""
+    import gauss_render
+    gauss_render.clear_context_pool()
+    monkeypatch.setattr(gauss_render, "PIPELINE_IN_EMULATOR", True)
+    monkeypatch.setattr(gauss_render, "PIPELINE_STREAMS", 2)
+    monkeypatch.setattr(gauss_render, "CAMERA_BATCH", 2)
+    res = run_vs_oracle(3000, 31, 96, 64, 80.0, 5, scale=(0.004, 0.03), t_floor=0.0, max_gaussians_per_tile=400, xyz_scale=0.3,
+                        pipelined=True)
+    assert res["contribution"] < 5e-6 and res["colour"] < 5e-6 and res["flips"] == 0 and res["colour_off_gaussians"] == 0, res
+    assert res["split_leaves"] > 0, res
+    gauss_render.clear_context_pool()
+
+
+def test_keys_widen_in_place(emu):
+    """g2pc_raster_repack_keys: 12-bit tile field -> 14 bits, camera slot / tile sequence / pixel kept; empty and rebased keys too."""
+    import gauss_render  # noqa: F401  (binds the rasteriser's entry points)
+    nv = emu
+    slot, seq, pix = np.array([1, 5, 63, 0, 9]), np.array([0, 4095, 17, 0, 300]), np.array([0, 4095, 7, 0, 99])
+    contrib = np.array([0.5, 0.25, 1e-3, 0.75, 0.0], np.float32).view(np.uint32).astype(np.uint64)
+
+    def pack(bits):
+        order = (slot.astype(np.uint64) << (12 + bits)) | (seq.astype(np.uint64) << 12) | pix.astype(np.uint64)
+        return (contrib << 32) | ((~order) & np.uint64(0xFFFFFFFF))
+
+    keys = pack(12)
+    keys[4] = 0                                              # never seen
+    t = torch.from_numpy(keys.view(np.int64).copy())
+    assert nv.lib().g2pc_raster_repack_keys(nv.ptr(t), len(keys), 12, 14, None) == 0
+    want = pack(14)
+    want[4] = 0
+    assert np.array_equal(t.numpy().view(np.uint64), want)
+    assert nv.lib().g2pc_raster_repack_keys(nv.ptr(t), len(keys), 14, 12, None) != 0        # narrowing is refused
+
+
+def test_sequence_numbers_beyond_the_key_field_widen_the_renderer(emu):
+    """A tree whose leaves and split children need more than 4 096 sequence numbers: the renderer widens its keys in place."""
+    res = run_vs_oracle(1500, 8, 256, 160, 220.0, 1, scale=(0.004, 0.03), t_floor=0.0, max_tile_size=4,
+                        max_gaussians_per_tile=40, xyz_scale=0.3)
+    assert res["seq_bits"] > 12 and res["split_leaves"] > 0, res
+    assert res["image"] < 5e-6 and res["contribution"] < 5e-6 and res["flips"] == 0, res

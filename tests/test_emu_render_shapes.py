@@ -25,21 +25,20 @@ def test_shapes_vs_oracle(emu, monkeypatch, n, w, h, scale, sub, floor):
 
 def test_more_than_4096_leaf_tiles(emu, monkeypatch):
     """16 384 quad-tree leaves (640 x 400 at max_tile_size 5 -- what 7680 x 4320 is at the default 60): the packed keys widen
-    their tile field to 14 bits (63 cameras per key epoch).  Contributions, colours and visibility against the oracle
-    (reference: gauss_render.py:290-335 with render()'s max_tile_size).  The IMAGE agrees except on a few pixels of this
-    sparse scene (400 Gaussians under 16 384 leaves): the reference paints an interior quad-tree node that holds no Gaussian
-    with the background and never visits its children (gauss_render.py:311-314), and a child sticks out of an odd-sized
-    parent by one pixel (ceil / floor at :321-334) -- a Gaussian that reaches only into that pixel is blended by the fixed
-    leaf layout and skipped by the reference.  Same class as the data-dependent leaf split: it shows at
-    5-10 pixel leaves (5e-4 of the pixels, <= 2e-3), not at the default 60."""
+    their tile field to 14 bits (63 cameras per key epoch).  Image, contributions, colours and visibility against the oracle
+    (reference: gauss_render.py:290-335 with render()'s max_tile_size).  This sparse scene (400 Gaussians under 16 384
+    leaves) also meets the reference's empty-node rule: an interior quad-tree node that holds no Gaussian is painted with the
+    background and its children are never visited (gauss_render.py:311-314), while a child reaches one pixel beyond an
+    odd-sized parent (ceil / floor at :321-334) -- a Gaussian that reaches only into that pixel is skipped with the leaf
+    (k_tile_gate / _static_plan; the leaf grid alone left 5e-4 of the image's pixels off by up to 2e-3 here)."""
     import gauss_render
     from render_checks import run_vs_oracle
     monkeypatch.setattr(gauss_render, "BLEND_SUBBLOCKS", 2)
     res = run_vs_oracle(400, 515, 640, 400, 600.0, 2, scale=(0.004, 0.05), t_floor=1e-6, max_tile_size=5)
     assert res["seq_bits"] == 14
     assert res["contribution"] < 1e-5 and res["flips"] == 0, res
-    assert res["image"] < 5e-3 and res["image_frac_off"] < 1e-3, res
-    assert res["colour"] < 5e-3 and res["colour_off_gaussians"] <= 3, res       # (a colour IS the colour of one such pixel)
+    assert res["image"] < 1e-5 and res["image_frac_off"] == 0.0, res
+    assert res["colour_off_gaussians"] <= 3, res       # (arg-max pixels tying to ~1e-6 under the default floor, see render_checks)
 
 
 def test_nothing_in_front_of_the_camera(emu):

@@ -1,0 +1,44 @@
+"""-m gpu: the reference's data-dependent quad-tree (gauss_render.py:290-335) on the MI355X through the C ABI -- overloaded
+leaves split level by level, leaves under empty nodes skipped -- against oracle/ref_render.py (pinned to the untouched
+reference); the CPU-emulator twins of these cases are in tests/test_emu_quadtree.py."""
+import pytest
+
+from render_checks import run_vs_oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_overloaded_leaves_are_split_like_the_reference():
+    res = run_vs_oracle(3000, 31, 96, 64, 80.0, 2, device=DEV, scale=(0.004, 0.03), t_floor=0.0, max_gaussians_per_tile=400,
+                        xyz_scale=0.3)
+    print(res)
+    assert res["image"] < 5e-6 and res["contribution"] < 5e-6 and res["colour"] < 5e-6, res
+    assert res["flips"] == 0 and res["colour_off_gaussians"] == 0 and res["split_leaves"] > 0, res
+
+
+def test_split_down_to_dropped_children_on_an_odd_image():
+    res = run_vs_oracle(2500, 5, 333, 187, 300.0, 2, device=DEV, scale=(0.004, 0.03), t_floor=0.0, max_gaussians_per_tile=40,
+                        xyz_scale=0.2)
+    print(res)
+    assert res["image"] < 5e-6 and res["contribution"] < 5e-6 and res["flips"] == 0 and res["split_leaves"] > 0, res
+
+
+def test_leaves_under_empty_nodes_are_skipped():
+    """Sparse scene under 16 384 five-pixel leaves: the empty-node rule (gauss_render.py:311-314) decides pixels here."""
+    res = run_vs_oracle(400, 515, 640, 400, 600.0, 2, device=DEV, scale=(0.004, 0.05), t_floor=0.0, max_tile_size=5)
+    print(res)
+    assert res["image"] < 5e-6 and res["image_frac_off"] == 0.0 and res["contribution"] < 5e-6 and res["flips"] == 0, res
+    assert res["colour_off_gaussians"] == 0, res
+
+
+def test_pipeline_leaves_overloaded_leaves_to_the_flush():
+    """Graph replay: the gate keeps overloaded leaves out of the batched blend, flush() renders their children."""
+    import gauss_render
+    gauss_render.clear_context_pool()
+    res = run_vs_oracle(3000, 31, 96, 64, 80.0, 7, device=DEV, scale=(0.004, 0.03), t_floor=0.0, max_gaussians_per_tile=400,
+                        xyz_scale=0.3, pipelined=True)
+    print(res)
+    assert res["contribution"] < 5e-6 and res["colour"] < 5e-6 and res["flips"] == 0 and res["colour_off_gaussians"] == 0, res
+    assert res["split_leaves"] > 0, res
+    gauss_render.clear_context_pool()
