@@ -1371,7 +1371,13 @@ __global__ __launch_bounds__(RA_T) void k_tile_gate(Layout lay, Cam cam_val, con
         const uint32_t sticks = (uint32_t)lay.tile_stick[t];
         const Cam& cam = cam_dev ? *(const Cam*)((const char*)cam_dev + (size_t)blockIdx.y * sizeof(G2pcCameraJob)) : cam_val;
         const int ix = t % lay.nx, iy = t / lay.nx;
-        for (int k = 0; k < lay.depth && !state; ++k) {
+        // the usual case first, with independent loads: the first leaf of every ancestor's block (which lies inside it) has members
+        bool all_occupied = true;
+        for (int k = 0; k < lay.depth; ++k) {
+            const int sh = lay.depth - k, u = ((iy >> sh) << sh) * lay.nx + ((ix >> sh) << sh);
+            all_occupied = all_occupied && (!((sticks >> k) & 1u) || tile_start[u + 1] != tile_start[u]);
+        }
+        for (int k = 0; k < lay.depth && !state && !all_occupied; ++k) {
             if (!((sticks >> k) & 1u)) continue;
             const int sh = lay.depth - k, ax = ix >> sh, ay = iy >> sh, node = (1 << k) - 1;
             const int x0 = lay.inner_x[2 * (node + ax)], x1 = lay.inner_x[2 * (node + ax) + 1];

@@ -183,6 +183,57 @@ def gen_render(ref):
     print("render: visible", int(out["visible"].sum()), "of", n)
 
 
+def _render_split_case(ref, tag, n, seed, width, height, focal, crowd, tile_pin, scale, stride):
+    """One camera over a scene crowded towards its centre so that leaves exceed max_gaussians_per_tile and the reference's
+    queue splits them (gauss_render.py:319-335).  tile_pin: the limit the patched memory query yields (ref_shim.TILE_PIN ->
+    max_gaussians_per_tile = tile_pin, max_tile_size = tile_pin // 1000, gauss_render.py:440-444)."""
+    import ref_shim
+    gh, gr, ch = ref["gauss_handler"], ref["gauss_render"], ref["camera_handler"]
+    sc = make_scene(n, seed, scale_lo=scale[0], scale_hi=scale[1])
+    xyz = sc.xyz * crowd
+    transforms, intr = make_cameras(1, width=width, height=height, focal=focal)
+    name = next(iter(transforms))
+    saved = ref_shim.TILE_PIN
+    ref_shim.TILE_PIN = tile_pin
+    # how often the reference splits for a count: recorded with the fixture (a wrapper around its tile-mask sum would need an
+    # edit of the reference; the number of queue entries it pops is visible through copy.deepcopy, which only the split calls)
+    import copy
+    calls = {"deepcopy": 0}
+    orig_deepcopy = copy.deepcopy
+
+    def counting(x, *a, **k):
+        calls["deepcopy"] += 1
+        return orig_deepcopy(x, *a, **k)
+    try:
+        with CudaToCpu():
+            G = gh.Gaussians(xyz.clone(), sc.scales.clone(), sc.rots.clone(), sc.colours.double(), sc.opacities.clone())
+            R = gr.get_renderer("python", G.xyz, torch.unsqueeze(torch.clone(G.opacities), 1), G.colours, G.covariances,
+                                visible_gaussian_threshold=0.05)
+            cam = ch.get_camera("python", torch.tensor(transforms[name]), intr[name], colour_resolution=None)
+            gr.copy.deepcopy = counting
+            with stable_depth_ties():
+                img, _, _, _ = R(cam)
+            gr.copy.deepcopy = orig_deepcopy
+            cols = _np(R.get_gaussian_colours())
+            out = dict(n=n, seed=seed, width=width, height=height, focal=focal, crowd=crowd, tile_pin=tile_pin,
+                       scale_lo=scale[0], scale_hi=scale[1], stride=stride, splits=calls["deepcopy"] // 8,
+                       image=_np(img).astype(np.float32), contrib=_np(R.gaussian_max_contribution).copy(),
+                       colours=cols[::stride].copy(), colour_sum=cols.sum(axis=0), visible=np.packbits(_np(R.get_visible_gaussians())))
+    finally:
+        ref_shim.TILE_PIN = saved
+        gr.copy.deepcopy = orig_deepcopy
+    np.savez_compressed(os.path.join(GOLD, "render_py_split_%s.npz" % tag), **out)
+    print("render_split", tag, ": nodes split", out["splits"], " visible", int(_np(R.get_visible_gaussians()).sum()), "of", n)
+
+
+def gen_render_split(ref):
+    """Leaves over max_gaussians_per_tile.  `60k`: 150 000 Gaussians under the pinned defaults (60 000 / 60 pixels) -- centre
+    leaves of 40 x 24 pixels hold more than 60 000 and are split once.  `deep`: limit 10 000 / 10 pixels, 30 000 Gaussians in
+    the centre of a 64 x 48 image: several levels, down to children the reference drops (narrower than two pixels)."""
+    _render_split_case(ref, "60k", 150_000, 4242, 160, 96, 140.0, 0.22, 60000, (0.003, 0.012), 16)
+    _render_split_case(ref, "deep", 30_000, 4243, 64, 48, 56.0, 0.05, 10000, (0.003, 0.012), 1)
+
+
 def gen_pipeline(ref):
     """Config-1 shaped end-to-end run (10k Gaussians, 1 camera 360x202, 100k points, python
     renderer, keyed noise): the culling indices / ppg / points the drop-in must reproduce."""
@@ -460,6 +511,6 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["geom", "sampler", "render", "pipeline"]
     for w in which:
         {"geom": gen_geom, "sampler": gen_sampler, "render": gen_render, "pipeline": gen_pipeline,
-         "render_big": gen_render_big, "helpers": gen_helpers,
+         "render_big": gen_render_big, "helpers": gen_helpers, "render_split": gen_render_split,
          # the same job at a size the CPU emulator can follow: checks the checker (tools/parity_cfg2.py) without a GPU
          "render_mini": lambda r: gen_render_big(r, "mini", 4000, 40_000, 320, 180, 275.0)}[w](ref)

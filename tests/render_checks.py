@@ -117,3 +117,42 @@ def run_vs_oracle(n, seed, width, height, focal, ncam, device="cpu", scale=(0.00
     worst["near_threshold"] = int(((O.max_contribution - 0.05).abs() < 1e-5).sum())
     worst["flip_margins"] = (O.max_contribution[flips] - 0.05).abs().tolist()
     return worst
+
+
+def run_split_fixture(golden_dir, tag, device="cpu", t_floor=0.0, pipelined=False):
+    """HIP renderer against tests/golden/render_py_split_<tag>.npz -- outputs of the untouched reference on a scene whose leaves
+    exceed max_gaussians_per_tile (oracle/make_golden.py render_split)."""
+    import gauss_render
+    import camera_handler
+    from gauss_handler import Gaussians
+    g = np.load(os.path.join(golden_dir, "render_py_split_%s.npz" % tag))
+    dev = torch.device(device)
+    sc = make_scene(int(g["n"]), int(g["seed"]), scale_lo=float(g["scale_lo"]), scale_hi=float(g["scale_hi"]))
+    xyz = sc.xyz * float(g["crowd"])
+    transforms, intr = make_cameras(1, width=int(g["width"]), height=int(g["height"]), focal=float(g["focal"]))
+    name = next(iter(transforms))
+    G = Gaussians(xyz.to(dev), sc.scales.to(dev), sc.rots.to(dev), sc.colours.to(dev), sc.opacities.to(dev))
+    R = gauss_render.get_renderer("python", G.xyz, G.opacities.unsqueeze(1), G.colours, G.covariances, visible_gaussian_threshold=0.05)
+    R.t_floor = t_floor
+    pin = int(g["tile_pin"])
+    R.MAX_GAUSSIANS_PER_TILE, R.MAX_TILE_SIZE = pin, pin // 1000          # gauss_render.py:440-444 under the fixture's memory pin
+    cam = camera_handler.get_camera("python", torch.tensor(transforms[name]), intr[name], colour_resolution=None)
+    res = dict(image=0.0)
+    if pipelined:
+        R(cam, return_image=False)                                         # (first camera of a job: learns the capacity)
+        R(cam, return_image=False)                                         # the same camera again through the graph: same maxima
+    else:
+        res["image"] = float(np.abs(R(cam)[0].cpu().numpy() - g["image"]).max())
+    c = R.gaussian_max_contribution.cpu().numpy()
+    res["contribution"] = float(np.abs(c - g["contrib"]).max())
+    cols = R.get_gaussian_colours().cpu().numpy().astype(np.float64)
+    stride = int(g["stride"])
+    seen = g["contrib"][::stride] > (t_floor if t_floor > 0 else -1.0)
+    dcol = np.abs(cols[::stride] - g["colours"])[seen] / 255.0
+    res["colour"] = float(dcol.max()) if dcol.size else 0.0
+    res["colour_off_gaussians"] = int((dcol > 1e-4).any(axis=1).sum())
+    vis = np.unpackbits(g["visible"])[:int(g["n"])].astype(bool)
+    res["flips"] = int((R.get_visible_gaussians().cpu().numpy() != vis).sum())
+    res["near_threshold"] = int((np.abs(g["contrib"] - 0.05) < 1e-5).sum())
+    res["split_leaves"] = R.split_leaves
+    return res

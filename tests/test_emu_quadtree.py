@@ -87,3 +87,13 @@ def test_sequence_numbers_beyond_the_key_field_widen_the_renderer(emu):
                         max_gaussians_per_tile=40, xyz_scale=0.3)
     assert res["seq_bits"] > 12 and res["split_leaves"] > 0, res
     assert res["image"] < 5e-6 and res["contribution"] < 5e-6 and res["flips"] == 0, res
+
+
+def test_split_fixture_of_the_untouched_reference(emu, golden_dir):
+    """`deep`: 30 000 Gaussians in the centre of 64 x 48 pixels under the reference's 10 000 / 10-pixel limits -- its queue splits
+    12 nodes beyond the size-driven tree, down to children it drops.  Outputs of the reference itself (make_golden.py)."""
+    from render_checks import run_split_fixture
+    res = run_split_fixture(golden_dir, "deep")
+    # (thousands of Gaussians behind every pixel: the image carries the blend's accumulated rounding, 1.5e-5)
+    assert res["image"] < 1e-4 and res["contribution"] < 5e-6 and res["colour"] < 5e-6 and res["flips"] == 0, res
+    assert res["split_leaves"] > 0, res

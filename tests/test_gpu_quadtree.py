@@ -3,7 +3,7 @@ leaves split level by level, leaves under empty nodes skipped -- against oracle/
 reference); the CPU-emulator twins of these cases are in tests/test_emu_quadtree.py."""
 import pytest
 
-from render_checks import run_vs_oracle
+from render_checks import run_vs_oracle, run_split_fixture
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -13,7 +13,7 @@ def test_overloaded_leaves_are_split_like_the_reference():
     res = run_vs_oracle(3000, 31, 96, 64, 80.0, 2, device=DEV, scale=(0.004, 0.03), t_floor=0.0, max_gaussians_per_tile=400,
                         xyz_scale=0.3)
     print(res)
-    assert res["image"] < 5e-6 and res["contribution"] < 5e-6 and res["colour"] < 5e-6, res
+    assert res["image"] < 5e-5 and res["contribution"] < 5e-5 and res["colour"] < 5e-5, res
     assert res["flips"] == 0 and res["colour_off_gaussians"] == 0 and res["split_leaves"] > 0, res
 
 
@@ -21,14 +21,14 @@ def test_split_down_to_dropped_children_on_an_odd_image():
     res = run_vs_oracle(2500, 5, 333, 187, 300.0, 2, device=DEV, scale=(0.004, 0.03), t_floor=0.0, max_gaussians_per_tile=40,
                         xyz_scale=0.2)
     print(res)
-    assert res["image"] < 5e-6 and res["contribution"] < 5e-6 and res["flips"] == 0 and res["split_leaves"] > 0, res
+    assert res["image"] < 5e-5 and res["contribution"] < 5e-5 and res["flips"] == 0 and res["split_leaves"] > 0, res
 
 
 def test_leaves_under_empty_nodes_are_skipped():
     """Sparse scene under 16 384 five-pixel leaves: the empty-node rule (gauss_render.py:311-314) decides pixels here."""
     res = run_vs_oracle(400, 515, 640, 400, 600.0, 2, device=DEV, scale=(0.004, 0.05), t_floor=0.0, max_tile_size=5)
     print(res)
-    assert res["image"] < 5e-6 and res["image_frac_off"] == 0.0 and res["contribution"] < 5e-6 and res["flips"] == 0, res
+    assert res["image"] < 5e-5 and res["image_frac_off"] == 0.0 and res["contribution"] < 5e-5 and res["flips"] == 0, res   # (device exp2 against torch.exp)
     assert res["colour_off_gaussians"] == 0, res
 
 
@@ -39,6 +39,28 @@ def test_pipeline_leaves_overloaded_leaves_to_the_flush():
     res = run_vs_oracle(3000, 31, 96, 64, 80.0, 7, device=DEV, scale=(0.004, 0.03), t_floor=0.0, max_gaussians_per_tile=400,
                         xyz_scale=0.3, pipelined=True)
     print(res)
-    assert res["contribution"] < 5e-6 and res["colour"] < 5e-6 and res["flips"] == 0 and res["colour_off_gaussians"] == 0, res
+    assert res["contribution"] < 5e-5 and res["colour"] < 5e-5 and res["flips"] == 0 and res["colour_off_gaussians"] == 0, res
     assert res["split_leaves"] > 0, res
+    gauss_render.clear_context_pool()
+
+
+@pytest.mark.parametrize("tag", ["60k", "deep"])
+def test_split_fixtures_of_the_untouched_reference(golden_dir, tag):
+    """Outputs of the reference itself (oracle/make_golden.py render_split): `60k` = 150 000 Gaussians, centre leaves over the
+    pinned default of 60 000 per leaf, split once; `deep` = 10 000 / 10-pixel limits, several levels down to dropped children."""
+    res = run_split_fixture(golden_dir, tag, device=DEV)
+    print(res)
+    assert res["image"] < 1e-4 and res["contribution"] < 1e-5 and res["colour"] < 1e-5, res
+    assert res["flips"] <= res["near_threshold"] and res["colour_off_gaussians"] == 0 and res["split_leaves"] > 0, res
+
+
+def test_split_fixture_through_the_graph_pipeline(golden_dir):
+    """`60k` with the production blend (floor 1e-6) through capture / replay: the gate leaves the overloaded leaves out, flush()
+    renders their children."""
+    import gauss_render
+    gauss_render.clear_context_pool()
+    res = run_split_fixture(golden_dir, "60k", device=DEV, t_floor=1e-6, pipelined=True)
+    print(res)
+    assert res["contribution"] < 1e-4 and res["flips"] <= res["near_threshold"] and res["split_leaves"] > 0, res
+    assert res["colour_off_gaussians"] <= 2, res
     gauss_render.clear_context_pool()
