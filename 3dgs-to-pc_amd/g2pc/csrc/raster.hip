@@ -1352,6 +1352,9 @@ __device__ __forceinline__ bool rect_in_node(const float r[4], int x0, int x1, i
 //    (tile_stick, a handful of border leaves) are examined: first the other leaves of the ancestor's block, and only if all
 //    of those inside it are empty the members of the sticking-out ones, with the reference's own predicate.
 // tile_range[t] = the instances the blend walks: [first, end), empty for a gated leaf.  One thread per leaf.
+// (Cost beside the blends of the other streams: 16 us per launch against 6 for the count check it replaces -- not its loads,
+// which go out in one round, but its 94 VGPRs: five blend waves leave 32 of a SIMD's 512 free, so its waves start when a
+// blend wave retires.  The job time does not see it, profiles/r03zo_*.)
 __global__ __launch_bounds__(RA_T) void k_tile_gate(Layout lay, Cam cam_val, const Cam* __restrict__ cam_dev,
                                                    const float* __restrict__ means3D, const float* __restrict__ cov9,
                                                    const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ inst_g,
@@ -1361,24 +1364,30 @@ __global__ __launch_bounds__(RA_T) void k_tile_gate(Layout lay, Cam cam_val, con
     tile_start = seg(tile_start, cs); inst_g = seg(inst_g, cs); tile_range = seg(tile_range, cs); tile_state = seg(tile_state, cs);
     const int t = blockIdx.x * RA_T + threadIdx.x;
     if (t >= T) return;
-    const uint32_t first = tile_start[t], end = tile_start[t + 1], cnt = end - first;
+    // the usual answer with ONE round of independent loads: the first leaf of an ancestor's block lies inside that ancestor,
+    // so its having members settles the level (bit k of `vacant`: it has none)
+    const int ix = t % lay.nx, iy = t / lay.nx;
+    const uint32_t sticks = (uint32_t)lay.tile_stick[t];         // (depth 0: any readable table, no bit is looked at)
+    uint32_t lo[8], hi[8], vacant = 0u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {                 // (levels beyond the tree read the leaf itself: every load is unconditional)
+        const int sh = k < lay.depth ? lay.depth - k : 0, u = ((iy >> sh) << sh) * lay.nx + ((ix >> sh) << sh);
+        lo[k] = tile_start[u]; hi[k] = tile_start[u + 1];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) vacant |= ((k < lay.depth && lo[k] == hi[k]) ? 1u : 0u) << k;
+    uint32_t first = tile_start[t], end = tile_start[t + 1];
+    G2PC_PIN(vacant); G2PC_PIN(first);            // keep all loads in ONE round (else they sink behind the leaf's own count)
+    const uint32_t cnt = end - first;
     uint32_t state = 0u;
     if (limit && cnt > limit) {
         state = 1u;
         if (flag) atomicMax(flag, cnt);
         if (count_host) count_host[4 * blockIdx.y + 2] = cnt;          // pinned, through its device mapping: "some leaf of this camera"
-    } else if (cnt && lay.tile_stick && lay.tile_stick[t]) {
-        const uint32_t sticks = (uint32_t)lay.tile_stick[t];
+    } else if (cnt && (sticks & vacant)) {
         const Cam& cam = cam_dev ? *(const Cam*)((const char*)cam_dev + (size_t)blockIdx.y * sizeof(G2pcCameraJob)) : cam_val;
-        const int ix = t % lay.nx, iy = t / lay.nx;
-        // the usual case first, with independent loads: the first leaf of every ancestor's block (which lies inside it) has members
-        bool all_occupied = true;
-        for (int k = 0; k < lay.depth; ++k) {
-            const int sh = lay.depth - k, u = ((iy >> sh) << sh) * lay.nx + ((ix >> sh) << sh);
-            all_occupied = all_occupied && (!((sticks >> k) & 1u) || tile_start[u + 1] != tile_start[u]);
-        }
-        for (int k = 0; k < lay.depth && !state && !all_occupied; ++k) {
-            if (!((sticks >> k) & 1u)) continue;
+        for (int k = 0; k < lay.depth && !state; ++k) {
+            if (!(((sticks & vacant) >> k) & 1u)) continue;
             const int sh = lay.depth - k, ax = ix >> sh, ay = iy >> sh, node = (1 << k) - 1;
             const int x0 = lay.inner_x[2 * (node + ax)], x1 = lay.inner_x[2 * (node + ax) + 1];
             const int y0 = lay.inner_y[2 * (node + ay)], y1 = lay.inner_y[2 * (node + ay) + 1];
@@ -1667,7 +1676,8 @@ static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t*
         }
         hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T), (unsigned)bt.n), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start, l_eff, gshift, bt.cs);
         Layout glay = lay;
-        if (!sc.means3D) glay.tile_stick = nullptr;       // no scene: leaves under empty nodes are not looked for
+        // no scene / no tree tables: leaves under empty nodes are not looked for (depth 0; the kernel's loads stay unconditional)
+        if (!sc.means3D || !lay.tile_stick) { glay.depth = 0; glay.tile_stick = lay.tile_seq; }
         hipLaunchKernelGGL(k_tile_gate, dim3(cdiv(T, RA_T), (unsigned)bt.n), dim3(RA_T), 0, s, glay, sc.cam_val, sc.cam_dev, sc.means3D,
                            sc.cov9, tile_start, blend_list, gmask, T, max_per_tile, A.tile_range, A.tile_state, overflow_flag,
                            sc.count_host, bt.cs);

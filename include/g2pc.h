@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define G2PC_ABI_VERSION 3
+#define G2PC_ABI_VERSION 4
 
 #define G2PC_OK 0
 #define G2PC_ERR_ARG (-1)

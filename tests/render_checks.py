@@ -147,10 +147,18 @@ def run_split_fixture(golden_dir, tag, device="cpu", t_floor=0.0, pipelined=Fals
     res["contribution"] = float(np.abs(c - g["contrib"]).max())
     cols = R.get_gaussian_colours().cpu().numpy().astype(np.float64)
     stride = int(g["stride"])
-    seen = g["contrib"][::stride] > (t_floor if t_floor > 0 else -1.0)
-    dcol = np.abs(cols[::stride] - g["colours"])[seen] / 255.0
+    # colours are compared where the reference's contribution is a normal float well above underflow: below ~1e-30 the products
+    # T * alpha of a crowded leaf are denormal or flushed to zero depending on the host's / device's exp and multiply, and a
+    # Gaussian the reference leaves at "never seen" (0, no colour) may carry a 1e-40 contribution and a colour here, or the
+    # other way round (reported as colour_off_tiny; no threshold a user could set separates them)
+    cs = g["contrib"][::stride]
+    seen = cs > max(t_floor, 1e-30)
+    dall = np.abs(cols[::stride] - g["colours"]) / 255.0
+    dcol = dall[seen]
     res["colour"] = float(dcol.max()) if dcol.size else 0.0
     res["colour_off_gaussians"] = int((dcol > 1e-4).any(axis=1).sum())
+    res["colour_off_tiny"] = int((dall[~seen & (cs >= (t_floor if t_floor > 0 else 0.0))] > 1e-4).any(axis=1).sum())
+    res["tiny"] = int((~seen).sum())
     vis = np.unpackbits(g["visible"])[:int(g["n"])].astype(bool)
     res["flips"] = int((R.get_visible_gaussians().cpu().numpy() != vis).sum())
     res["near_threshold"] = int((np.abs(g["contrib"] - 0.05) < 1e-5).sum())

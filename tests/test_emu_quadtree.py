@@ -97,3 +97,28 @@ def test_split_fixture_of_the_untouched_reference(emu, golden_dir):
     # (thousands of Gaussians behind every pixel: the image carries the blend's accumulated rounding, 1.5e-5)
     assert res["image"] < 1e-4 and res["contribution"] < 5e-6 and res["colour"] < 5e-6 and res["flips"] == 0, res
     assert res["split_leaves"] > 0, res
+
+
+def test_tile_shards_share_the_children_of_split_leaves(emu):
+    """Multi-GPU with fewer cameras than ranks: every rank bins the camera, blends its share of the leaves AND its share of
+    the children of split leaves; the maximum of the ranks' packed keys (what the visibility exchange computes) is the
+    single-renderer state bit for bit -- children carry the same sequence numbers on every rank."""
+    import gauss_render
+    import camera_handler
+    from gauss_handler import Gaussians
+    from g2pc.synth import make_scene, make_cameras
+    sc = make_scene(3000, 31, scale_lo=0.004, scale_hi=0.03)
+    tr, intr = make_cameras(2, width=96, height=64, focal=80.0)
+    G = Gaussians(sc.xyz * 0.3, sc.scales, sc.rots, sc.colours, sc.opacities)
+    keys, split = [], []
+    for shard in (None, (0, 2), (1, 2)):
+        R = gauss_render.get_renderer("python", G.xyz, G.opacities.unsqueeze(1), G.colours, G.covariances, tile_shard=shard)
+        R.MAX_GAUSSIANS_PER_TILE = 400
+        for name in tr:
+            R(camera_handler.get_camera("python", torch.tensor(tr[name]), intr[name]))
+        R.flush()
+        keys.append(R.best_key.numpy().view(np.uint64).copy())
+        split.append(R.split_leaves)
+    assert split[0] > 0 and split[1] == split[0] and split[2] == split[0]       # (children seen, not children blended)
+    assert np.array_equal(np.maximum(keys[1], keys[2]), keys[0])
+    assert not np.array_equal(keys[1], keys[0])
