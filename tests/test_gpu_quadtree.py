@@ -18,7 +18,7 @@ def test_overloaded_leaves_are_split_like_the_reference():
 
 
 def test_split_down_to_dropped_children_on_an_odd_image():
-    res = run_vs_oracle(2500, 5, 333, 187, 300.0, 2, device=DEV, scale=(0.004, 0.03), t_floor=0.0, max_gaussians_per_tile=40,
+    res = run_vs_oracle(2500, 5, 333, 187, 300.0, 2, device=DEV, scale=(0.004, 0.03), t_floor=0.0, max_gaussians_per_tile=120,
                         xyz_scale=0.2)
     print(res)
     assert res["image"] < 5e-5 and res["contribution"] < 5e-5 and res["flips"] == 0 and res["split_leaves"] > 0, res
