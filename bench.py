@@ -115,7 +115,7 @@ def algorithmic_bytes(workload, n, n_kept, m, cams, stats):
     return b
 
 
-ROCPROF_STATS_FILE = "profiles/r03zu_render_s1_kernel_stats.csv"   # rocprofv3 --kernel-trace --stats of `bench.py --streams 1 --no-parity --no-extra --no-cpu-baseline`
+ROCPROF_STATS_FILE = "profiles/r03zn_s1_kernel_stats.csv"   # rocprofv3 --kernel-trace --stats of `bench.py --streams 1 --no-parity --no-extra --no-cpu-baseline`
 
 
 def rocprof_kernel_avg(region):
