@@ -122,3 +122,38 @@ def test_tile_shards_share_the_children_of_split_leaves(emu):
     assert split[0] > 0 and split[1] == split[0] and split[2] == split[0]       # (children seen, not children blended)
     assert np.array_equal(np.maximum(keys[1], keys[2]), keys[0])
     assert not np.array_equal(keys[1], keys[0])
+
+
+def test_graph_pipeline_skips_leaves_under_empty_nodes(emu, monkeypatch):
+    """Odd splits at every level (333 x 187 under 12-pixel leaves) over a sparse scene: leaves whose members all sit in the strip
+    beyond an empty ancestor are gated on the device in the replayed graphs exactly as in the two-call path (same keys)."""
+    import gauss_render
+    import camera_handler
+    from gauss_handler import Gaussians
+    from g2pc.synth import make_scene, make_cameras
+    sc = make_scene(150, 515, scale_lo=0.004, scale_hi=0.05)
+    tr, intr = make_cameras(4, width=333, height=187, focal=300.0)
+    G = Gaussians(sc.xyz, sc.scales, sc.rots, sc.colours, sc.opacities)
+    monkeypatch.setattr(gauss_render, "PIPELINE_STREAMS", 2)
+    monkeypatch.setattr(gauss_render, "CAMERA_BATCH", 2)
+    out, gated = [], 0
+    for pipelined in (False, True):
+        gauss_render.clear_context_pool()
+        monkeypatch.setattr(gauss_render, "PIPELINE_IN_EMULATOR", pipelined)
+        R = gauss_render.get_renderer("python", G.xyz, G.opacities.unsqueeze(1), G.colours, G.covariances)
+        R.MAX_TILE_SIZE = 12
+        if not pipelined:                      # count the leaves the plan of the two-call path finds dead although they have members
+            plan = R._static_plan
+            def counting(cam, lay, counts, states, _plan=plan):
+                nonlocal gated
+                r = _plan(cam, lay, counts, states)
+                gated += int((r["dead"] & (counts > 0)).sum())
+                return r
+            R._static_plan = counting
+        for name in tr:
+            R(camera_handler.get_camera("python", torch.tensor(tr[name]), intr[name]), return_image=not pipelined)
+        R.flush()
+        out.append((R.best_key.numpy().copy(), R.get_gaussian_colours().numpy().copy()))
+    gauss_render.clear_context_pool()
+    assert gated > 0                           # the scene really meets the rule
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
