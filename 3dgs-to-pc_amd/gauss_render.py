@@ -531,6 +531,12 @@ class GaussHipRenderer():
         self.flush()
         if not dist.is_initialized() or dist.get_world_size(group) == 1:
             return
+        # the keys of all ranks must share one tile-field width: a rank whose cameras needed a wider one (more leaves, split
+        # leaves) widened on its own -- the others follow before the keys meet
+        bits = torch.tensor([self.seq_bits], dtype=torch.int32, device=self.device)
+        dist.all_reduce(bits, op=dist.ReduceOp.MAX, group=group)
+        if int(bits.item()) > self.seq_bits:
+            self._ensure_seq_room(1 << int(bits.item()))
         global_key = self.best_key.clone()
         dist.all_reduce(global_key, op=dist.ReduceOp.MAX, group=group)
         rank = dist.get_rank(group)

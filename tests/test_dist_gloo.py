@@ -278,3 +278,73 @@ def test_visibility_exchange_is_idempotent(tmp_path, renderer):
         np.testing.assert_allclose(R.get_total_gaussian_contributions().numpy(), got["total"], rtol=1e-5, atol=1e-6)
     finally:
         nv._LIB, nv._EMULATED = saved
+
+
+def _run_split_on_one_rank(rank, world, port, out_dir):
+    for p in (os.path.join(ROOT, "3dgs-to-pc_amd"), os.path.join(ROOT, "oracle"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from g2pc import _native as nv
+    nv._inject_for_tests(os.path.join(HERE, "hipemu", "libg2pc_emu.so"))
+    from g2pc.synth import make_scene, make_cameras
+    from gauss_handler import Gaussians
+    import camera_handler
+    import gauss_render
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sc = make_scene(1500, 8, scale_lo=0.004, scale_hi=0.03)
+    tr, intr = make_cameras(2, width=256, height=160, focal=220.0)
+    G = Gaussians(sc.xyz * 0.3, sc.scales, sc.rots, sc.colours, sc.opacities)
+    R = gauss_render.get_renderer("python", G.xyz, G.opacities.unsqueeze(1), G.colours, G.covariances)
+    R.MAX_TILE_SIZE, R.MAX_GAUSSIANS_PER_TILE = 4, 40            # 4 096 leaves; split children push past the 12-bit tile field
+    name = sorted(tr)[rank]
+    if rank == 1:
+        R.MAX_GAUSSIANS_PER_TILE = 1 << 30                       # rank 1's camera splits nothing: its keys stay 12 bits wide
+    R(camera_handler.get_camera("python", torch.tensor(tr[name]), intr[name]), return_image=False, slot=rank + 1)
+    R.flush()
+    bits_before = R.seq_bits
+    R.all_reduce_visibility()
+    np.savez(os.path.join(out_dir, "split_rank%d.npz" % rank), keys=R.best_key.numpy(), colours=R.get_gaussian_colours().numpy(),
+             bits_before=bits_before, bits_after=R.seq_bits)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_agree_on_the_key_width_before_the_exchange(tmp_path):
+    """One rank's camera splits leaves and widens its keys' tile field (12 -> 13 bits), the other's does not: the exchange
+    brings every rank to the widest field first (g2pc_raster_repack_keys) and ends in the single-process state."""
+    from emu_util import build_emu
+    build_emu()
+    port = 41500 + (os.getpid() % 2000)
+    mp.spawn(_run_split_on_one_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "split_rank0.npz"), np.load(tmp_path / "split_rank1.npz")
+    assert int(a["bits_before"]) > 12 and int(b["bits_before"]) == 12 and int(a["bits_after"]) == int(b["bits_after"]) == int(a["bits_before"])
+    assert np.array_equal(a["keys"], b["keys"]) and np.array_equal(a["colours"], b["colours"])
+    # single process, both cameras, the wide field from the start
+    for p in (os.path.join(ROOT, "3dgs-to-pc_amd"), os.path.join(ROOT, "oracle"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from g2pc import _native as nv
+    saved = (nv._LIB, nv._EMULATED)
+    nv._inject_for_tests(os.path.join(HERE, "hipemu", "libg2pc_emu.so"))
+    try:
+        from g2pc.synth import make_scene, make_cameras
+        from gauss_handler import Gaussians
+        import camera_handler
+        import gauss_render
+        sc = make_scene(1500, 8, scale_lo=0.004, scale_hi=0.03)
+        tr, intr = make_cameras(2, width=256, height=160, focal=220.0)
+        G = Gaussians(sc.xyz * 0.3, sc.scales, sc.rots, sc.colours, sc.opacities)
+        R = gauss_render.get_renderer("python", G.xyz, G.opacities.unsqueeze(1), G.colours, G.covariances)
+        R.MAX_TILE_SIZE, R.MAX_GAUSSIANS_PER_TILE = 4, 40
+        R.seq_bits = int(a["bits_after"])
+        for rank, name in enumerate(sorted(tr)):
+            if rank == 1:
+                R.MAX_GAUSSIANS_PER_TILE = 1 << 30
+            R(camera_handler.get_camera("python", torch.tensor(tr[name]), intr[name]), return_image=False, slot=rank + 1)
+        R.flush()
+        assert np.array_equal(R.best_key.numpy(), a["keys"]) and np.array_equal(R.get_gaussian_colours().numpy(), a["colours"])
+    finally:
+        nv._LIB, nv._EMULATED = saved

@@ -157,3 +157,9 @@ def test_graph_pipeline_skips_leaves_under_empty_nodes(emu, monkeypatch):
     gauss_render.clear_context_pool()
     assert gated > 0                           # the scene really meets the rule
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+def test_an_image_that_is_one_overloaded_leaf(emu):
+    """40 x 30 pixels: no size-driven split at all; the single leaf holds too many Gaussians and is split on its own."""
+    res = run_vs_oracle(3000, 31, 40, 30, 36.0, 1, scale=(0.004, 0.03), t_floor=0.0, max_gaussians_per_tile=400, xyz_scale=0.3)
+    _tight(res)
