@@ -1380,11 +1380,7 @@ __global__ __launch_bounds__(RA_T) void k_tile_gate(Layout lay, Cam cam_val, con
     G2PC_PIN(vacant); G2PC_PIN(first);            // keep all loads in ONE round (else they sink behind the leaf's own count)
     const uint32_t cnt = end - first;
     uint32_t state = 0u;
-    if (limit && cnt > limit) {
-        state = 1u;
-        if (flag) atomicMax(flag, cnt);
-        if (count_host) count_host[4 * blockIdx.y + 2] = cnt;          // pinned, through its device mapping: "some leaf of this camera"
-    } else if (cnt && (sticks & vacant)) {
+    if (cnt && (sticks & vacant)) {               // (first: a leaf the queue never reaches is not split either)
         const Cam& cam = cam_dev ? *(const Cam*)((const char*)cam_dev + (size_t)blockIdx.y * sizeof(G2pcCameraJob)) : cam_val;
         for (int k = 0; k < lay.depth && !state; ++k) {
             if (!(((sticks & vacant) >> k) & 1u)) continue;
@@ -1408,6 +1404,11 @@ __global__ __launch_bounds__(RA_T) void k_tile_gate(Layout lay, Cam cam_val, con
                     }
             if (!occupied) state = 2u | ((uint32_t)k << 8);
         }
+    }
+    if (!state && limit && cnt > limit) {
+        state = 1u;
+        if (flag) atomicMax(flag, cnt);
+        if (count_host) count_host[4 * blockIdx.y + 2] = cnt;          // pinned, through its device mapping: "some leaf of this camera"
     }
     tile_range[t] = make_uint2(first, state ? first : end);
     tile_state[t] = state;
