@@ -174,6 +174,7 @@ __global__ __launch_bounds__(RA_T) void k_gather_u32(const uint32_t* __restrict_
 }
 
 // K3: one (tile, gaussian) instance per overlapped tile, emitted in depth order (rasterizer_impl.cu:69-110)
+template <bool WIDE>      // WIDE: 16-bit tile coordinates, two words per Gaussian (native-semantics images beyond 4 096 pixels)
 __global__ __launch_bounds__(RA_T) void k_duplicate(const uint32_t* __restrict__ sorted_idx,
                                                    const uint32_t* __restrict__ offsets,
                                                    const uint32_t* __restrict__ rect, long n, int nx,
@@ -188,8 +189,14 @@ __global__ __launch_bounds__(RA_T) void k_duplicate(const uint32_t* __restrict__
     uint32_t off = offsets[p], end = offsets[p + 1];
     if (end == off) return;
     uint32_t g = sorted_idx[p];
-    uint32_t rc = rect[g];
-    int ix0 = rc & 255, ix1 = (rc >> 8) & 255, iy0 = (rc >> 16) & 255, iy1 = rc >> 24;
+    int ix0, ix1, iy0, iy1;
+    if (WIDE) {
+        const uint32_t rx = rect[2 * (size_t)g], ry = rect[2 * (size_t)g + 1];
+        ix0 = rx & 0xFFFF; ix1 = rx >> 16; iy0 = ry & 0xFFFF; iy1 = ry >> 16;
+    } else {
+        const uint32_t rc = rect[g];
+        ix0 = rc & 255; ix1 = (rc >> 8) & 255; iy0 = (rc >> 16) & 255; iy1 = rc >> 24;
+    }
     for (int iy = iy0; iy <= iy1; ++iy)
         for (int ix = ix0; ix <= ix1; ++ix) {
             if (gshift) {
@@ -987,14 +994,14 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_cu(Cam cam, int grid_x, int
                                                        float3 campos, long n, uint32_t* __restrict__ depth_key,
                                                        uint32_t* __restrict__ index, uint32_t* __restrict__ tiles_touched,
                                                        float4* __restrict__ rec, uint32_t* __restrict__ rect,
-                                                       int32_t* __restrict__ radii) {
+                                                       int32_t* __restrict__ radii, int wide) {
 #pragma clang fp contract(off)
     long i = (long)blockIdx.x * RA_T + threadIdx.x;
     if (i >= n) return;
     const float x = means3D[3 * i], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
     const float* V = cam.V;
     const float* P = cam.P;
-    uint32_t key = 0xFFFFFFFFu, touched = 0, rc = 0;
+    uint32_t key = 0xFFFFFFFFu, touched = 0, rc = 0, rc_hi = 0;
     int rad = 0;
     // Everything that decides an INTEGER of the reference (radius, tile rectangle, depth bits -> order) is evaluated
     // below with the reference's own expressions, operation by operation in source order, every operation rounded on its
@@ -1053,7 +1060,12 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_cu(Cam cam, int grid_x, int
             x1 = min(grid_x, max(0, x1)); y1 = min(grid_y, max(0, y1));
             if ((x1 - x0) * (y1 - y0) != 0) {
                 touched = (uint32_t)((x1 - x0) * (y1 - y0));
-                rc = (uint32_t)x0 | ((uint32_t)(x1 - 1) << 8) | ((uint32_t)y0 << 16) | ((uint32_t)(y1 - 1) << 24);
+                if (wide) {                    // grids beyond 256 tiles per axis: 16-bit tile coordinates in two words
+                    rc = (uint32_t)x0 | ((uint32_t)(x1 - 1) << 16);
+                    rc_hi = (uint32_t)y0 | ((uint32_t)(y1 - 1) << 16);
+                } else {
+                    rc = (uint32_t)x0 | ((uint32_t)(x1 - 1) << 8) | ((uint32_t)y0 << 16) | ((uint32_t)(y1 - 1) << 24);
+                }
                 key = __float_as_uint(tz0);
                 rad = r;
                 const float sc = LOG2E;
@@ -1104,7 +1116,7 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_cu(Cam cam, int grid_x, int
     depth_key[i] = key;
     index[i] = (uint32_t)i;
     tiles_touched[i] = touched;
-    rect[i] = rc;
+    if (wide) { rect[2 * i] = rc; rect[2 * i + 1] = rc_hi; } else rect[i] = rc;
     radii[i] = rad;
 }
 
@@ -1545,6 +1557,8 @@ static Layout to_layout(const G2pcTileLayout* l) {
     k.depth = tree ? l->depth : 0; k.inner_x = l->inner_x; k.inner_y = l->inner_y; k.tile_stick = tree ? l->tile_stick : nullptr;
     return k;
 }
+// native-semantics tile grids beyond 256 x 256 (images beyond 4 096 pixels a side): tile rectangles take two words per Gaussian
+static bool cu_wide_grid(int gx, int gy) { return gx > 256 || gy > 256; }
 static int bits_for_tiles(unsigned t) { int b = 1; while ((1u << b) < t && b < 31) ++b; return b; }
 // packed visibility keys: the tile-sequence field is seq_bits wide (12 .. 14), the camera slot gets the 20 - seq_bits above it
 static bool layout_keys_ok(const G2pcTileLayout* l) {
@@ -1667,7 +1681,7 @@ static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t*
     const uint32_t* blend_list = gshift ? tile_sorted : g_sorted;
     if (phases & 1) {
         if (L > 0) {
-            hipLaunchKernelGGL(k_duplicate, dim3(cdiv(n, RA_T), (unsigned)bt.n), dim3(RA_T), 0, s, fb.sorted_idx, fb.offsets, fb.rect, n, lay.nx,
+            hipLaunchKernelGGL(k_duplicate<false>, dim3(cdiv(n, RA_T), (unsigned)bt.n), dim3(RA_T), 0, s, fb.sorted_idx, fb.offsets, fb.rect, n, lay.nx,
                                inst_tile, inst_g, l_eff, gshift, bt.cs);
             int rc = gshift ? sort_pairs_u32(inst_tile, nullptr, tile_sorted, nullptr, tile_tmp, nullptr, L, gshift,
                                              gshift + bits_for_tiles((unsigned)T), sort_ws, sort_bytes, s, l_eff, bt)
@@ -1957,7 +1971,7 @@ int g2pc_raster_front_cu(const G2pcCamera* cam, const float* means3D, const floa
     G2PC_REQUIRE(!shs || (sh_degree >= 0 && sh_degree <= 3 && sh_coeffs >= (sh_degree + 1) * (sh_degree + 1)), G2PC_ERR_ARG,
                  "SH degree / coefficient count mismatch");
     const int gx = (cam->width + 15) / 16, gy = (cam->height + 15) / 16;
-    G2PC_REQUIRE(gx <= 256 && gy <= 256, G2PC_ERR_UNSUPPORTED, "image larger than 4096 pixels per side");
+    G2PC_REQUIRE(gx <= 65535 && gy <= 65535, G2PC_ERR_UNSUPPORTED, "image larger than 1048560 pixels per side");
     hipStream_t s = (hipStream_t)stream;
     Arena ar(ws, ws_bytes);
     uint32_t* key = ar.get<uint32_t>((size_t)n);
@@ -1972,7 +1986,7 @@ int g2pc_raster_front_cu(const G2pcCamera* cam, const float* means3D, const floa
     G2PC_REQUIRE(ar.ok(), G2PC_ERR_WORKSPACE, "workspace too small");
     hipLaunchKernelGGL(k_preprocess_cu, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, to_cam(cam), gx, gy, means3D, cov6, opacity,
                        colours_precomp, shs, (int)sh_degree, (int)sh_coeffs, make_float3(campos[0], campos[1], campos[2]),
-                       (long)n, key, idx, touched, (float4*)rec, rect, radii);
+                       (long)n, key, idx, touched, (float4*)rec, rect, radii, cu_wide_grid(gx, gy) ? 1 : 0);
     int rc = sort_pairs_u32(key, idx, key_sorted, sorted_idx, ktmp, vtmp, n, 0, 32, sort_ws, sort_bytes, s);
     if (rc) return rc;
     rc = scan_exclusive_u32(touched, offsets, n, scan_ws, scan_bytes, s, sorted_idx);
@@ -2023,8 +2037,12 @@ int g2pc_raster_back_cu_tiles(const G2pcCamera* cam, const int32_t* mask, int64_
     }
     hipLaunchKernelGGL(k_init_camera_state_cu, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, (unsigned long long*)cam_key, (uint32_t*)cam_surf, (long)n);
     if (L > 0) {
-        hipLaunchKernelGGL(k_duplicate, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, sorted_idx, offsets, rect, (long)n, gx,
-                           inst_tile, inst_g, (const uint32_t*)nullptr, gshift, (size_t)0);
+        if (cu_wide_grid(gx, gy))
+            hipLaunchKernelGGL(k_duplicate<true>, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, sorted_idx, offsets, rect, (long)n, gx,
+                               inst_tile, inst_g, (const uint32_t*)nullptr, gshift, (size_t)0);
+        else
+            hipLaunchKernelGGL(k_duplicate<false>, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, sorted_idx, offsets, rect, (long)n, gx,
+                               inst_tile, inst_g, (const uint32_t*)nullptr, gshift, (size_t)0);
         int rc = gshift ? sort_pairs_u32(inst_tile, nullptr, tile_sorted, nullptr, tile_tmp, nullptr, L, gshift,
                                          gshift + bits_for_tiles((unsigned)T), sort_ws, sort_bytes, s)
                         : sort_pairs_u32(inst_tile, inst_g, tile_sorted, g_sorted, tile_tmp, g_tmp, L, 0,
@@ -2087,8 +2105,12 @@ int g2pc_raster_back_cu_dev(const G2pcCamera* cam, const int32_t* mask, int64_t 
     hipLaunchKernelGGL(k_init_camera_state_cu, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, (unsigned long long*)cam_key, (uint32_t*)cam_surf, (long)n);
     const int gshift = packed_instance_shift((long)n, T);
     const uint32_t gmask = gshift ? ((1u << gshift) - 1u) : 0xFFFFFFFFu;
-    hipLaunchKernelGGL(k_duplicate, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, sorted_idx, offsets, rect, (long)n, gx, inst_tile, inst_g,
-                       (const uint32_t*)l_eff, gshift, (size_t)0);
+    if (cu_wide_grid(gx, gy))
+        hipLaunchKernelGGL(k_duplicate<true>, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, sorted_idx, offsets, rect, (long)n, gx, inst_tile, inst_g,
+                           (const uint32_t*)l_eff, gshift, (size_t)0);
+    else
+        hipLaunchKernelGGL(k_duplicate<false>, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, sorted_idx, offsets, rect, (long)n, gx, inst_tile, inst_g,
+                           (const uint32_t*)l_eff, gshift, (size_t)0);
     int rc = gshift ? sort_pairs_u32(inst_tile, nullptr, tile_sorted, nullptr, tile_tmp, nullptr, L, gshift,
                                      gshift + bits_for_tiles((unsigned)T), sort_ws, sort_bytes, s, l_eff)
                     : sort_pairs_u32(inst_tile, inst_g, tile_sorted, g_sorted, tile_tmp, g_tmp, L, 0, bits_for_tiles((unsigned)T),

@@ -85,7 +85,8 @@ class _CuScratch:
     def __init__(self, n, dev, stream=None, pipelined=False):
         f32, i32 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.int32, device=dev)
         self.rec = torch.empty((n, 16), **f32)                    # one 64-byte blend record per Gaussian
-        self.rect, self.sorted, self.offsets = torch.empty(n, **i32), torch.empty(n, **i32), torch.empty(n + 1, **i32)
+        # (rect: two words per Gaussian once the image exceeds 4096 pixels a side, include/g2pc.h g2pc_raster_front_cu)
+        self.rect, self.sorted, self.offsets = torch.empty(2 * n, **i32), torch.empty(n, **i32), torch.empty(n + 1, **i32)
         self.radii = torch.empty(n, **i32)
         self.cam_key = torch.empty(n, dtype=torch.int64, device=dev)
         self.cam_surf = torch.empty(n, **i32)

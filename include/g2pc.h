@@ -425,7 +425,8 @@ int g2pc_raster_debug_chunk_work(uint32_t* buf);
  * (sh f32[n, sh_coeffs, 3], degree <= 3, forward.cu:22-73).  cam->view = viewmatrix, cam->proj = FULL projmatrix
  * (view @ proj), cam->tan_fovx/y; focal = W / (2 tan_fovx) (rasterizer_impl.cu:229-230).
  * front: rec f32[n,16] (one 64-byte record per Gaussian: (x, y, conic a, b), (conic c, opacity, depth, radius), (r, g, b, -),
- * pad), rect u32[n], radii i32[n], sorted_idx u32[n], offsets u32[n+1] out. */
+ * pad), rect u32[n] (u32[2n] for images beyond 4096 pixels a side: tile rectangles then take 16-bit coordinates, two
+ * words per Gaussian), radii i32[n], sorted_idx u32[n], offsets u32[n+1] out. */
 int g2pc_raster_front_cu(const G2pcCamera* cam, const float* means3D, const float* cov6, const float* opacity,
                          const float* colours_precomp, const float* shs, int32_t sh_degree, int32_t sh_coeffs,
                          const float* campos, int64_t n, float* rec, uint32_t* rect, int32_t* radii,

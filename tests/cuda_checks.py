@@ -46,9 +46,14 @@ def run_golden_case(name, device="cpu"):
         assert abs(cam.tanfovx - float(case.cam(i, "tanfovx"))) < 1e-7 and abs(cam.tanfovy - float(case.cam(i, "tanfovy"))) < 1e-7
         cam = cam._replace(tanfovx=float(case.cam(i, "tanfovx")), tanfovy=float(case.cam(i, "tanfovy")), **stored)
         colour, radii, invd, dep = R.forward(cam, return_per_camera=True)
-        rc = R._sync.rect.cpu().numpy().astype(np.int64)            # x0 | (x1-1) << 8 | y0 << 16 | (y1-1) << 24, 0 = no tile
         rad = radii.cpu().numpy()
-        touched = np.where(rad > 0, (((rc >> 8) & 255) - (rc & 255) + 1) * (((rc >> 24) & 255) - ((rc >> 16) & 255) + 1), 0)
+        rc = R._sync.rect.cpu().numpy().astype(np.int64)
+        if max(case.recipe["width"], case.recipe["height"]) > 4096:  # two words: x0 | (x1-1) << 16, y0 | (y1-1) << 16
+            rx, ry = rc[0:2 * len(rad):2], rc[1:2 * len(rad):2]
+            touched = np.where(rad > 0, ((rx >> 16) - (rx & 0xFFFF) + 1) * ((ry >> 16) - (ry & 0xFFFF) + 1), 0)
+        else:                                                        # x0 | (x1-1) << 8 | y0 << 16 | (y1-1) << 24, 0 = no tile
+            rc = rc[:len(rad)]
+            touched = np.where(rad > 0, (((rc >> 8) & 255) - (rc & 255) + 1) * (((rc >> 24) & 255) - ((rc >> 16) & 255) + 1), 0)
         rec = R._sync.rec.cpu().numpy().reshape(-1, 16)             # (px, py, qa, qb), (qc, opacity, depth, radius), ...
         got = dict(radii=rad, num_rendered=R.last["num_rendered"], tiles_touched=touched.astype(np.uint32),
                    means2D=rec[:, 0:2], depths=rec[:, 6], conic_scaled=rec[:, 2:5],

@@ -9,7 +9,8 @@ from emu_util import emu  # noqa: F401
 from cuda_checks import run_cuda_case, assert_cuda_matches, run_golden_case
 
 
-@pytest.mark.parametrize("name", ["n6000_333x187", "n6000_sh3_320x176", "n20000_mask_320x176", "n6000_nosurf_333x187"])
+@pytest.mark.parametrize("name", ["n6000_333x187", "n6000_sh3_320x176", "n20000_mask_320x176", "n6000_nosurf_333x187",
+                                  "n40000_wide_4128x48"])
 def test_cuda_semantics_vs_reference_golden(emu, name):
     """radii / num_rendered / tiles_touched / arg-max pixels bit for bit, floats to 1e-4 (tests/cu_golden.py)."""
     reps, st, case = run_golden_case(name)
