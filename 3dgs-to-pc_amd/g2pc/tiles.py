@@ -10,6 +10,11 @@ parent) produces leaves of uniform depth that are the cartesian product of two 1
 bottom-right per split) is kept as `tile_seq`; it decides which tile wins ties of the running maximum and
 which tile's colour an overlapped pixel finally shows.
 
+The tree's two DATA-DEPENDENT rules are decided per camera on top of that leaf grid: `_tree_tables` describes the tree above
+the leaves (interior node extents, which leaves reach beyond which ancestor) for the rasteriser's gate, which skips leaves
+under empty nodes (gauss_render.py:311-314); `child_layout` builds the next level below the nodes the reference splits for
+their Gaussian count (:319-335) -- used by GaussHipRenderer._render_tree.
+
 `grid_layout` is the regular 16x16 grid of the native rasteriser (config.h:15-17, auxiliary.h:45-55).
 """
 from __future__ import annotations

@@ -6,8 +6,9 @@ call sites gauss_to_pc.py:429-513).  Rendering runs in libg2pc.so (HIP, gfx950):
 
   renderer_type "python"        -> the pure-torch renderer's SEMANTICS (gauss_render.py:215-465: quad-tree leaf
                                    tiles pinned to max_tile_size=60 / max_gaussians_per_tile=60000, the defaults of
-                                   ``render()``; strict rect overlap; alpha clip only; colour of the winning tile)
-                                   on the tile-binned HIP rasteriser.  This is the parity target of the project.
+                                   ``render()``, leaves over the limit split and empty nodes not descended into as
+                                   the reference's queue does; strict rect overlap; alpha clip only; colour of the
+                                   winning tile) on the tile-binned HIP rasteriser.  This is the parity target of the project.
   renderer_type "cuda" / "hip"  -> the native rasteriser's semantics (16x16 tiles, alpha cut-offs, surface distance).
 
 There is no torch fallback: without libg2pc.so every call raises.
