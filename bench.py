@@ -519,6 +519,20 @@ def main():
                 "k1", "cov3d_rows_differing", "camera_matrix_bits_differing", "reference_tie_rule", "reference_tie_spread",
                 "gaussians", "resolution", "t_floor", "oracle", "check_seconds")}
             out["parity"]["ppg_equal"] = full.get("ppg_mismatch_given_ref_contrib") == 0
+        # ... and the reference's DATA-DEPENDENT quad-tree (leaves over max_gaussians_per_tile split, gauss_render.py:319-335)
+        # against outputs of the untouched reference on a scene that meets it: 150 000 Gaussians crowded into 160 x 96 pixels,
+        # the same fixture tests/test_gpu_quadtree.py holds the renderer to (tests/render_checks.py::run_split_fixture)
+        fx = os.path.join(ROOT, "tests", "golden", "render_py_split_60k.npz")
+        if "parity" in out and os.path.isfile(fx) and not emulate:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from render_checks import run_split_fixture
+            gauss_render.clear_context_pool()
+            q = run_split_fixture(os.path.dirname(fx), "60k", device=str(device))
+            gauss_render.clear_context_pool()
+            out["parity"]["quadtree_split_fixture"] = {
+                "fixture": "tests/golden/render_py_split_60k.npz", "children_of_split_leaves": q["split_leaves"],
+                "contrib_max": q["contribution"], "image_max": q["image"], "colour_max_above_1e-30": q["colour"],
+                "mask_flips": q["flips"], "colours_differing_below_1e-30": q["colour_off_tiny"]}
     if not a.no_cpu_baseline and world == 1:          # the CPU baseline is a 1-GPU companion figure (rank 0, N = 1 only)
         out["cpu_baseline"] = cpu_baseline(workload, a.gaussians, a.cameras if workload != "sample" else 0, a.points,
                                            **(dict(n=3000, pts=20_000) if emulate else {}))
