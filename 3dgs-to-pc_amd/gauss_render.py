@@ -832,7 +832,10 @@ class GaussHipRenderer():
         # (this runtime refuses event-record nodes inside a captured graph)
         exact = 8 if self.t_floor == 0.0 else 0      # to-the-letter mode: the blend kernel with the reference's operation order
         split = on_gpu and PIPELINE_MODE.startswith("split")
-        key = (id(lay), self.capacity, (1 if (nv.PROFILE is not None or split) else 3) | exact, batch, self.seq_bits)
+        # (the gate's limit is a kernel argument baked into the captured launches: renderers with another limit -- the pool
+        # hands slots and graphs from job to job -- capture their own)
+        key = (id(lay), self.capacity, (1 if (nv.PROFILE is not None or split) else 3) | exact, batch, self.seq_bits,
+               int(self.MAX_GAUSSIANS_PER_TILE or 0))
         if sl.graph_key != key:
             if key in sl.graphs:
                 sl.graph, sl.graph_key = sl.graphs[key], key

@@ -163,3 +163,35 @@ def test_an_image_that_is_one_overloaded_leaf(emu):
     """40 x 30 pixels: no size-driven split at all; the single leaf holds too many Gaussians and is split on its own."""
     res = run_vs_oracle(3000, 31, 40, 30, 36.0, 1, scale=(0.004, 0.03), t_floor=0.0, max_gaussians_per_tile=400, xyz_scale=0.3)
     _tight(res)
+
+
+def test_pooled_graphs_are_not_reused_across_tile_limits(emu, monkeypatch):
+    """The context pool hands captured graphs from one renderer to the next; the gate's max_gaussians_per_tile is an argument
+    baked into those launches, so a renderer with another limit must capture its own (same scene: default limit first -- no
+    split --, then a low one through the SAME pooled context)."""
+    import gauss_render
+    import camera_handler
+    from gauss_handler import Gaussians
+    from g2pc.synth import make_scene, make_cameras
+    gauss_render.clear_context_pool()
+    monkeypatch.setattr(gauss_render, "PIPELINE_IN_EMULATOR", True)
+    monkeypatch.setattr(gauss_render, "PIPELINE_STREAMS", 2)
+    monkeypatch.setattr(gauss_render, "CAMERA_BATCH", 2)
+    sc = make_scene(3000, 31, scale_lo=0.004, scale_hi=0.03)
+    tr, intr = make_cameras(5, width=96, height=64, focal=80.0)
+    G = Gaussians(sc.xyz * 0.3, sc.scales, sc.rots, sc.colours, sc.opacities)
+    split, keys = [], []
+    for limit in (60000, 400, 400):
+        if len(split) == 2:
+            gauss_render.clear_context_pool()          # third run: the low limit on a fresh context, for comparison
+        R = gauss_render.get_renderer("python", G.xyz, G.opacities.unsqueeze(1), G.colours, G.covariances)
+        R.MAX_GAUSSIANS_PER_TILE = limit
+        for name in tr:
+            R(camera_handler.get_camera("python", torch.tensor(tr[name]), intr[name]), return_image=False)
+        R.flush()
+        split.append(R.split_leaves)
+        keys.append(R.best_key.numpy().copy())
+        R.close()
+    gauss_render.clear_context_pool()
+    assert split[0] == 0 and split[1] > 0 and split[1] == split[2]
+    assert np.array_equal(keys[1], keys[2])
