@@ -449,6 +449,16 @@ class GaussHipRenderer():
     def state_ptrs(self):
         return nv.ptr(self.best_key), nv.ptr(self.gaussian_colours)
 
+    @staticmethod
+    def reference_limits(free_bytes):
+        """(max_tile_size, max_gaussians_per_tile) as the reference's __call__ derives them from the free device memory
+        (gauss_render.py:440-444: 175 000 bytes per Gaussian, tile side = a thousandth of the count) -- before its retry loop,
+        which lowers both by 5 / 5 000 for every allocation that fails (:447-463) and so depends on the GPU it runs on.  This
+        renderer follows render()'s defaults (MAX_TILE_SIZE = 60, MAX_GAUSSIANS_PER_TILE = 60 000, what the fixtures are pinned
+        to); to follow a particular card instead:  r.MAX_TILE_SIZE, r.MAX_GAUSSIANS_PER_TILE = r.reference_limits(24 << 30)."""
+        max_gaussians = int(free_bytes / 175000)
+        return max_gaussians // 1000, max_gaussians
+
     def close(self):
         """Finish the cameras in flight and hand the device-side context back to the pool (idempotent)."""
         ctx = getattr(self, "ctx", None)

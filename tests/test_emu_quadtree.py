@@ -195,3 +195,14 @@ def test_pooled_graphs_are_not_reused_across_tile_limits(emu, monkeypatch):
     gauss_render.clear_context_pool()
     assert split[0] == 0 and split[1] > 0 and split[1] == split[2]
     assert np.array_equal(keys[1], keys[2])
+
+
+def test_limits_of_another_card(emu):
+    """reference_limits(): the tile limits the reference's __call__ would take from a card's free memory (gauss_render.py:440-444);
+    the renderer follows any such pair like the oracle's queue does."""
+    import gauss_render
+    assert gauss_render.GaussHipRenderer.reference_limits(60000 * 175000) == (60, 60000)        # the pin of every fixture
+    size, count = gauss_render.GaussHipRenderer.reference_limits(24 << 30)
+    assert (size, count) == (147, 147256)
+    res = run_vs_oracle(800, 21, 333, 187, 300.0, 1, scale=(0.004, 0.05), t_floor=0.0, max_tile_size=size, max_gaussians_per_tile=count)
+    _tight(res, split=False)
