@@ -198,7 +198,10 @@ class _DeviceLayout:
         self.t = {k: torch.from_numpy(np.ascontiguousarray(lay[k])).to(device) for k in names}
         if seq_count:
             self.t["tile_seq"] = self.t["tile_seq"] + int(seq_base)
-        self.seq_bits = max(12, int(np.ceil(np.log2(max(lay["nx"] * lay["ny"], 2)))))   # tile-sequence bits its keys need
+        # tile-sequence bits its keys need: the leaves plus a quarter as many children of split leaves (a camera that needs more
+        # widens the renderer's keys in place -- possible only while the camera slots in use fit the wider field's range)
+        T = lay["nx"] * lay["ny"]
+        self.seq_bits = min(14, max(12, int(np.ceil(np.log2(max(T + T // 4, 2))))))
         self.c = _Layout(nx=lay["nx"], ny=lay["ny"], num_chunks=len(lay["chunk_tile"]),
                          chunk_subblocks=lay["chunk_subblocks"], seq_bits=self.seq_bits, seq_base=int(seq_base),
                          seq_count=int(seq_count), depth=int(lay.get("depth", 0)) if self.has_tree else 0,

@@ -294,11 +294,11 @@ def _run_split_on_one_rank(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    sc = make_scene(1500, 8, scale_lo=0.004, scale_hi=0.03)
+    sc = make_scene(4000, 8, scale_lo=0.004, scale_hi=0.03)
     tr, intr = make_cameras(2, width=256, height=160, focal=220.0)
-    G = Gaussians(sc.xyz * 0.3, sc.scales, sc.rots, sc.colours, sc.opacities)
+    G = Gaussians(sc.xyz * 0.6, sc.scales, sc.rots, sc.colours, sc.opacities)
     R = gauss_render.get_renderer("python", G.xyz, G.opacities.unsqueeze(1), G.colours, G.covariances)
-    R.MAX_TILE_SIZE, R.MAX_GAUSSIANS_PER_TILE = 4, 40            # 4 096 leaves; split children push past the 12-bit tile field
+    R.MAX_TILE_SIZE, R.MAX_GAUSSIANS_PER_TILE = 8, 8             # 1 024 leaves; > 3 072 split children push past the 12-bit tile field
     name = sorted(tr)[rank]
     if rank == 1:
         R.MAX_GAUSSIANS_PER_TILE = 1 << 30                       # rank 1's camera splits nothing: its keys stay 12 bits wide
@@ -334,11 +334,11 @@ def test_ranks_agree_on_the_key_width_before_the_exchange(tmp_path):
         from gauss_handler import Gaussians
         import camera_handler
         import gauss_render
-        sc = make_scene(1500, 8, scale_lo=0.004, scale_hi=0.03)
+        sc = make_scene(4000, 8, scale_lo=0.004, scale_hi=0.03)
         tr, intr = make_cameras(2, width=256, height=160, focal=220.0)
-        G = Gaussians(sc.xyz * 0.3, sc.scales, sc.rots, sc.colours, sc.opacities)
+        G = Gaussians(sc.xyz * 0.6, sc.scales, sc.rots, sc.colours, sc.opacities)
         R = gauss_render.get_renderer("python", G.xyz, G.opacities.unsqueeze(1), G.colours, G.covariances)
-        R.MAX_TILE_SIZE, R.MAX_GAUSSIANS_PER_TILE = 4, 40
+        R.MAX_TILE_SIZE, R.MAX_GAUSSIANS_PER_TILE = 8, 8
         R.seq_bits = int(a["bits_after"])
         for rank, name in enumerate(sorted(tr)):
             if rank == 1:

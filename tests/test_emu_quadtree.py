@@ -82,10 +82,11 @@ def test_keys_widen_in_place(emu):
 
 
 def test_sequence_numbers_beyond_the_key_field_widen_the_renderer(emu):
-    """A tree whose leaves and split children need more than 4 096 sequence numbers: the renderer widens its keys in place."""
-    res = run_vs_oracle(1500, 8, 256, 160, 220.0, 1, scale=(0.004, 0.03), t_floor=0.0, max_tile_size=4,
-                        max_gaussians_per_tile=40, xyz_scale=0.3)
-    assert res["seq_bits"] > 12 and res["split_leaves"] > 0, res
+    """A tree whose leaves and split children need more than 4 096 sequence numbers (1 024 leaves, 4 504 children under a limit of
+    8 Gaussians per leaf): the renderer, which started with a 12-bit tile field, widens its keys in place."""
+    res = run_vs_oracle(4000, 8, 256, 160, 220.0, 1, scale=(0.004, 0.03), t_floor=0.0, max_tile_size=8,
+                        max_gaussians_per_tile=8, xyz_scale=0.6)
+    assert res["seq_bits"] == 13 and res["split_leaves"] > 3072, res
     assert res["image"] < 5e-6 and res["contribution"] < 5e-6 and res["flips"] == 0, res
 
 
