@@ -5,6 +5,8 @@ Runs the UNTOUCHED reference (/root/reference, python renderer + sampler) on CPU
 oracle/ref_shim.py on seeded synthetic inputs and stores inputs' seeds + the reference's outputs.
 /root/reference only exists in the authoring container; the fixtures travel, this script is the
 committed provenance.  Usage:   python oracle/make_golden.py [geom] [sampler] [render] [pipeline]
+                                                         [helpers] [render_big] [render_mini] [render_split]
+(render_split: scenes whose leaves exceed max_gaussians_per_tile -- the reference's count-driven quad-tree split.)
 """
 import json
 import os
