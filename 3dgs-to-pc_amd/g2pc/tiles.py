@@ -47,20 +47,25 @@ def _chunks_of_tile(nsbx: int, nsby: int, subblocks: int):
     return out
 
 
-def _finish(xs, ws, ys, hs, seq_of, subblocks=None, tile_shard=None) -> Dict[str, np.ndarray]:
+def _finish(xs, ws, ys, hs, seq_of, subblocks=None, tile_shard=None, blended=None) -> Dict[str, np.ndarray]:
+    """seq_of: {(x0, y0): FIFO position} or an int array [ny*nx].  blended (optional): the only tiles that get blend work
+    (the children of split nodes inside a level's interval product, child_layout)."""
     subblocks = SUBBLOCKS_PER_CHUNK if subblocks is None else subblocks
     nx, ny = len(xs), len(ys)
     T = nx * ny
-    tile_seq = np.zeros((T,), dtype=np.int32)
-    for iy in range(ny):
-        for ix in range(nx):
-            tile_seq[iy * nx + ix] = seq_of[(xs[ix], ys[iy])]
+    if isinstance(seq_of, np.ndarray):
+        tile_seq = seq_of.astype(np.int32)
+    else:
+        tile_seq = np.zeros((T,), dtype=np.int32)
+        for iy in range(ny):
+            for ix in range(nx):
+                tile_seq[iy * nx + ix] = seq_of[(xs[ix], ys[iy])]
     order = np.argsort(tile_seq, kind="stable")
     # compress the FIFO sequence numbers to 0..T-1 (only their order matters)
     rank = np.empty((T,), dtype=np.int32)
     rank[order] = np.arange(T, dtype=np.int32)
     seq_tile = order.astype(np.int32)
-    pix = np.array([ws[t % nx] * hs[t // nx] for t in range(T)], dtype=np.int64)
+    pix = (np.asarray(hs, np.int64)[:, None] * np.asarray(ws, np.int64)[None, :]).reshape(-1)
     off = np.zeros((T + 1,), dtype=np.int64)
     off[1:] = np.cumsum(pix)
     # Blend work list.  Dispatch order = block index, and block b runs on XCD b % 8 (observed, speed only):
@@ -74,7 +79,7 @@ def _finish(xs, ws, ys, hs, seq_of, subblocks=None, tile_shard=None) -> Dict[str
         ix, iy = t % nx, t // nx
         cx, cy = xs[ix] + ws[ix] / 2.0, ys[iy] + hs[iy] / 2.0
         return ((cx - W / 2.0) / W) ** 2 + ((cy - H / 2.0) / H) ** 2
-    order_t = sorted(range(T), key=dist)
+    order_t = sorted(range(T) if blended is None else blended, key=dist)
     if tile_shard is not None:
         # multi-GPU with fewer cameras than ranks: every rank renders every camera but blends only its share of the
         # tiles (dealt out in the centre-out order, so dense and sparse tiles are spread evenly); preprocess, sort and
@@ -175,7 +180,7 @@ def _tree_tables(width: int, height: int, lay) -> Dict[str, np.ndarray]:
     return dict(depth=depth, inner_x=inner_x, inner_y=inner_y, tile_stick=stick)
 
 
-def child_layout(width: int, height: int, parents, subblocks=None, tile_shard=None):
+def child_layout(width: int, height: int, parents, subblocks=None):
     """The next quad-tree level below a set of split nodes, as a tile layout.
 
     parents: list of (x0, y0, w, h, order) -- the nodes the reference splits (gauss_render.py:319-335), `order` any sortable
@@ -183,7 +188,8 @@ def child_layout(width: int, height: int, parents, subblocks=None, tile_shard=No
     intervals with the distinct child row intervals (children narrower or lower than 2 pixels are dropped, :301), and
     children[i] = (tile index, x0, y0, w, h, order + (c,)) lists the tiles that ARE children of a parent, in FIFO order
     (c = 0 top-left, 1 bottom-left, 2 top-right, 3 bottom-right, :325-333).  The other tiles of the product are not part of
-    the tree: the caller masks them out (tile_mask, chunk list)."""
+    the tree: they get no blend work here and the caller masks them out of the image (tile_mask); a caller that shards the
+    tiles over ranks deals the children out itself (GaussHipRenderer._render_tree)."""
     xi, yi, kids = {}, {}, []
     for (x0, y0, w, h, order) in parents:
         cx = split_interval(x0, w, width)
@@ -199,15 +205,11 @@ def child_layout(width: int, height: int, parents, subblocks=None, tile_shard=No
         return None, []
     xs, ys = sorted(xi), sorted(yi)
     kids.sort(key=lambda k: k[4])
-    seq_of = {(x, y): len(kids) for x in xs for y in ys}            # tiles outside the tree: after every child (never blended)
-    for s, (kx, ky, _, _, _) in enumerate(kids):
-        seq_of[(kx, ky)] = s
-    lay = _finish(xs, [xi[x] for x in xs], ys, [yi[y] for y in ys], seq_of, subblocks, None)
     colx, rowy = {x: i for i, x in enumerate(xs)}, {y: i for i, y in enumerate(ys)}
     children = [(rowy[ky] * len(xs) + colx[kx], kx, ky, kw, kh, order) for (kx, ky, kw, kh, order) in kids]
-    if tile_shard is not None:
-        r, w_ = tile_shard
-        children = children[r::w_]
+    seq = np.full((len(xs) * len(ys),), len(kids), dtype=np.int32)  # tiles outside the tree: after every child (never blended)
+    seq[[c[0] for c in children]] = np.arange(len(kids), dtype=np.int32)
+    lay = _finish(xs, [xi[x] for x in xs], ys, [yi[y] for y in ys], seq, subblocks, None, blended=[c[0] for c in children])
     return lay, children
 
 
