@@ -94,3 +94,31 @@ def test_cameras_without_read_back_equal_one_at_a_time(emu, monkeypatch):
             assert torch.allclose(x, z, rtol=1e-6, atol=1e-7)
         else:
             assert torch.equal(x, z)
+
+
+def test_pipelined_path_on_an_image_wider_than_4096_pixels(emu, monkeypatch):
+    """258 x 3 tiles (4 128 x 48 pixels): 16-bit tile coordinates, two rect words per Gaussian, through the device-resident
+    binning of the pipelined path as well as through the two-call path -- the same running state."""
+    import torch
+    import camera_handler
+    import gaussian_pointcloud_rasterization as gpr
+    from g2pc.synth import make_scene, make_cameras
+    sc = make_scene(20000, 9, scale_lo=0.004, scale_hi=0.03)
+    tr, intr = make_cameras(3, width=4128, height=48, focal=3600.0)
+
+    def run(pipelined):
+        monkeypatch.setattr(gpr, "PIPELINE_IN_EMULATOR", pipelined)
+        monkeypatch.setattr(gpr, "PIPELINE_STREAMS", 2)
+        R = gpr.GaussianRasterizer(sc.xyz, torch.zeros_like(sc.xyz), sc.opacities.unsqueeze(1), colors_precomp=sc.colours,
+                                   scales=torch.exp(sc.scales), rotations=sc.rots, visible_gaussian_threshold=0.05,
+                                   surface_distance_std=2.0, calculate_surface_distance=True)
+        for k in sorted(tr):
+            R(camera_handler.get_camera("cuda", torch.tensor(tr[k]), intr[k]), return_image=False)
+        R.flush()
+        return (R.gaussian_max_contribution.clone(), R.gaussian_total_contribution.clone(), R.gaussian_colours.clone(),
+                R.gaussian_min_surface_distance.clone())
+
+    a, b = run(False), run(True)
+    assert float(a[0].max()) > 0.05                      # something was really rendered
+    for x, z in zip(a, b):
+        assert torch.equal(x, z)
