@@ -123,6 +123,10 @@ def python_quadtree_layout(width: int, height: int, max_tile_size: int = 60, sub
             queue.append((list(s), list(size)))
             continue
         leaves.append((start[1], start[0], size[0], size[1]))       # x0, y0, w, h in FIFO order
+    if not leaves:
+        # (every branch ends in nodes narrower than two pixels, which the reference drops, gauss_render.py:301: it paints nothing)
+        raise NotImplementedError("no quad-tree leaf survives for %dx%d / %d: every node gets narrower than two pixels before "
+                                  "both sides fit the tile limit" % (width, height, max_tile_size))
     xs = sorted({(l[0], l[2]) for l in leaves})
     ys = sorted({(l[1], l[3]) for l in leaves})
     if len({x for x, _ in xs}) != len(xs) or len({y for y, _ in ys}) != len(ys) or len(xs) * len(ys) != len(leaves):
@@ -185,19 +189,21 @@ def child_layout(width: int, height: int, parents, subblocks=None):
 
     parents: list of (x0, y0, w, h, order) -- the nodes the reference splits (gauss_render.py:319-335), `order` any sortable
     key that reproduces their FIFO order.  Returns (layout, children): the layout is the product of the distinct child column
-    intervals with the distinct child row intervals (children narrower or lower than 2 pixels are dropped, :301), and
+    intervals with the distinct child row intervals (the children of a node no larger than 2 pixels a side are dropped, :301), and
     children[i] = (tile index, x0, y0, w, h, order + (c,)) lists the tiles that ARE children of a parent, in FIFO order
     (c = 0 top-left, 1 bottom-left, 2 top-right, 3 bottom-right, :325-333).  The other tiles of the product are not part of
     the tree: they get no blend work here and the caller masks them out of the image (tile_mask); a caller that shards the
     tiles over ranks deals the children out itself (GaussHipRenderer._render_tree)."""
     xi, yi, kids = {}, {}, []
     for (x0, y0, w, h, order) in parents:
+        if ceil(w / 2) <= 1 or ceil(h / 2) <= 1:
+            continue        # the reference drops a node by its size BEFORE clipping it to the image (:301, :304-305): all four go
         cx = split_interval(x0, w, width)
         cy = split_interval(y0, h, height)
         for c, (a, b) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+            # (a child the image border clips to ONE pixel stays in the queue: nothing can be a member of it, so the reference
+            # paints it with the background over whatever an earlier node left there)
             (kx, kw), (ky, kh) = cx[a], cy[b]
-            if kw <= 1 or kh <= 1:
-                continue
             if xi.setdefault(kx, kw) != kw or yi.setdefault(ky, kh) != kh:
                 raise NotImplementedError("children of different widths share a first column")
             kids.append((kx, ky, kw, kh, tuple(order) + (c,)))

@@ -103,9 +103,14 @@ def run_vs_oracle(n, seed, width, height, focal, ncam, device="cpu", scale=(0.00
     worst["contribution"] = float(dc.max())
     worst["contribution_frac_off"] = float((dc > 1e-4).float().mean())
     dcol = (R.get_gaussian_colours().cpu().double() - O.get_gaussian_colours()).abs() / 255.0
-    seen = O.max_contribution > (t_floor if t_floor > 0 else -1.0)
-    worst["colour"] = float(dcol[seen].max())
-    worst["colour_frac_off"] = float((dcol[seen] > 1e-4).float().mean())
+    # colours are compared where the reference's contribution is a normal float: a DENORMAL contribution (< 1.2e-38, a product
+    # T * alpha of a crowded leaf that underflowed) still counts as "seen" in the reference's strict `>` against 0, while the
+    # blend's candidate filter starts at FLT_MIN -- such a Gaussian carries a colour there and none here (colour_off_tiny)
+    seen = O.max_contribution > max(t_floor, 1e-30)
+    tiny = (O.max_contribution <= 1e-30) & (O.max_contribution >= (t_floor if t_floor > 0 else 0.0))
+    worst["colour_off_tiny"] = int((dcol[tiny] > 1e-4).any(dim=1).sum())
+    worst["colour"] = float(dcol[seen].max()) if bool(seen.any()) else 0.0
+    worst["colour_frac_off"] = float((dcol[seen] > 1e-4).float().mean()) if bool(seen.any()) else 0.0
     # Gaussians whose colour is off: each is one flipped arg-max between pixels whose contributions tie to ~1e-6 (the
     # colour is the rendered colour of the winning pixel), image and contributions unaffected
     worst["colour_off_gaussians"] = int((dcol[seen] > 1e-4).any(dim=1).sum())

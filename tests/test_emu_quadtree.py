@@ -207,3 +207,27 @@ def test_limits_of_another_card(emu):
     assert (size, count) == (147, 147256)
     res = run_vs_oracle(800, 21, 333, 187, 300.0, 1, scale=(0.004, 0.05), t_floor=0.0, max_tile_size=size, max_gaussians_per_tile=count)
     _tight(res, split=False)
+
+
+@pytest.mark.parametrize("case", [
+    # (n, seed, width, height, max_tile_size, max_gaussians_per_tile, crowding, largest scale)
+    (1638, 1047, 318, 197, 14, 15, 1.0, 0.06),      # children the image border clips to ONE pixel: kept (and painted), :301 vs :304
+    (2013, 1008, 376, 229, 60, 15, 0.4, 0.02),      # 3 212 children under 60-pixel leaves
+    (2498, 1024, 395, 130, 25, 60, 1.0, 0.06),      # 5 892 children, odd sizes on both axes
+    (2160, 1015, 60, 144, 6, 15, 0.15, 0.02),       # portrait image, 6-pixel leaves
+    (979, 1016, 47, 101, 60, 60, 0.15, 0.06),       # a single size-driven split
+])
+def test_random_trees_against_the_oracle(emu, case):
+    """Cases kept from tools/experiments/quadtree_fuzz.py (300 random image sizes / limits / crowdings, all equal to the oracle)."""
+    n, seed, w, h, mt, mg, crowd, hi = case
+    res = run_vs_oracle(n, seed, w, h, 0.9 * w, 1, scale=(0.004, hi), t_floor=0.0, max_tile_size=mt, max_gaussians_per_tile=mg,
+                        xyz_scale=crowd)
+    assert res["image"] < 2e-5 and res["contribution"] < 2e-5 and res["flips"] == 0 and res["colour_off_gaussians"] <= 2, res
+
+
+def test_image_whose_quad_tree_has_no_leaf(emu):
+    """A very flat image under a small tile limit: every branch reaches nodes narrower than two pixels, which the reference
+    drops, before both sides fit the limit -- nothing is ever rendered there; the layout says so instead of failing obscurely."""
+    from g2pc import tiles
+    with pytest.raises(NotImplementedError, match="no quad-tree leaf"):
+        tiles.python_quadtree_layout(400, 6, 3)

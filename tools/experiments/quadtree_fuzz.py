@@ -1,0 +1,28 @@
+"""CPU (emulator): random image sizes, tile limits, Gaussian counts and crowding through the renderer's quad-tree path against
+oracle/ref_render.py (whose queue is the reference's).  usage: python tools/experiments/quadtree_fuzz.py <seed> <cases>
+Round 3: 300 cases; found the no-leaf layout crash and the children the image border clips to one pixel (kept, painted)."""
+import sys, time, json
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [os.path.join(ROOT, 'tests'), os.path.join(ROOT, '3dgs-to-pc_amd'), os.path.join(ROOT, 'oracle')]
+import numpy as np
+from g2pc import _native as nv
+from emu_util import build_emu
+nv._inject_for_tests(build_emu())
+from render_checks import run_vs_oracle
+rng = np.random.default_rng(int(sys.argv[1]))
+bad = 0
+for it in range(int(sys.argv[2])):
+    W = int(rng.integers(40, 420)); H = int(rng.integers(30, 260))
+    mt = int(rng.choice([6, 9, 14, 25, 60])); mg = int(rng.choice([15, 60, 250, 1000]))
+    n = int(rng.integers(300, 2500)); crowd = float(rng.choice([0.15, 0.4, 1.0]))
+    sc = (0.004, float(rng.choice([0.02, 0.06])))
+    t = time.time()
+    try:
+        res = run_vs_oracle(n, 1000 + it, W, H, 0.9 * W, 1, scale=sc, t_floor=0.0, max_tile_size=mt, max_gaussians_per_tile=mg, xyz_scale=crowd)
+    except NotImplementedError as e:
+        print(it, W, H, mt, mg, n, crowd, "NotImplemented:", str(e)[:70]); continue
+    ok = res["image"] < 2e-5 and res["contribution"] < 2e-5 and res["flips"] == 0 and res["colour_off_gaussians"] <= 2
+    bad += (not ok)
+    print(it, W, H, mt, mg, n, crowd, "split", res["split_leaves"], "img %.1e c %.1e col %.1e" % (res["image"], res["contribution"], res["colour"]), "OK" if ok else "MISMATCH", "%.1fs" % (time.time() - t), flush=True)
+print("mismatches", bad)
