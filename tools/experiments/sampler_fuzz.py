@@ -1,0 +1,52 @@
+"""CPU (emulator): the whole sampling path (covariances -> magnitudes -> distribute -> sample) on random scenes, budgets, binned
+/ exact mode, Mahalanobis limits and attempt counts against the oracle (ref_gauss.generate_pointcloud with the same keyed noise).
+usage: python tools/experiments/sampler_fuzz.py <seed> <cases>.  Round 3: 400 cases, same rows in the same order every time."""
+import os
+import sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [os.path.join(ROOT, 'tests'), os.path.join(ROOT, '3dgs-to-pc_amd'), os.path.join(ROOT, 'oracle')]
+import numpy as np, torch
+from g2pc import _native as nv
+from emu_util import build_emu
+nv._inject_for_tests(build_emu())
+import ref_gauss as RG
+from np_philox import keyed_normals
+from g2pc import ops
+from g2pc.synth import make_scene
+rng = np.random.default_rng(int(sys.argv[1]))
+bad = 0
+for it in range(int(sys.argv[2])):
+    n = int(rng.integers(2, 3000)); num_points = int(rng.integers(1, 60)) * n // int(rng.integers(1, 8)) + int(rng.integers(0, 50))
+    exact = bool(rng.integers(0, 2)); std = float(rng.choice([0.5, 1.0, 2.0, 3.5])); attempts = int(rng.integers(1, 7))
+    seed = int(rng.integers(0, 2**31)); lo = float(rng.choice([0.002, 0.01])); hi = lo * float(rng.choice([2, 10, 100]))
+    sc = make_scene(n, 5000 + it, scale_lo=lo, scale_hi=hi)
+    t = time.time()
+    try:
+        cov, _, nrm = ops.build_covariances(sc.scales, sc.rots, 1.0, want_normals=True)
+        mags = ops.gaussian_magnitudes(cov, sc.opacities)
+        _, ppg, stats = ops.distribute_points(mags, num_points)
+        try:
+            out = ops.sample_pointcloud(sc.xyz, cov, sc.colours * 255, nrm, ppg, None, exact=exact, std=std, attempts=attempts, seed=seed, want_index=True, stats=stats)
+            err_dev = None
+        except ValueError as e:
+            err_dev = str(e)[:50]
+        try:
+            ref = RG.generate_pointcloud(sc.xyz, cov, sc.colours * 255, nrm, sc.opacities, num_points, std=std, exact=exact, attempts=attempts, ppg=ppg,
+                                         eps_fn=lambda gids, a, k: keyed_normals(seed, gids[:, None], a, np.arange(k)[None, :]))
+            err_ref = None
+        except Exception as e:
+            err_ref = type(e).__name__ + " " + str(e)[:40]
+        if err_dev or err_ref:
+            ok = bool(err_dev) and bool(err_ref)
+            print(it, n, num_points, exact, std, attempts, "raised: dev", err_dev, "| ref", err_ref, "OK" if ok else "MISMATCH"); bad += (not ok); continue
+        got = out.points.numpy(); want = ref["points"].numpy()
+        ok = got.shape == want.shape and (got.size == 0 or float(np.abs(got - want).max()) < 1e-4)
+        if ok and "colours" in ref:
+            ok = float(np.abs(out.colours.numpy() - ref["colours"].numpy()).max()) < 1e-3 if got.size else True
+        bad += (not ok)
+        print(it, n, num_points, exact, std, attempts, "rows", got.shape[0], want.shape[0], "OK" if ok else "MISMATCH", "%.1fs" % (time.time() - t), flush=True)
+    except Exception as e:
+        bad += 1
+        import traceback; traceback.print_exc()
+        print(it, n, num_points, exact, std, attempts, "EXC", type(e).__name__, str(e)[:100])
+print("mismatches", bad)
