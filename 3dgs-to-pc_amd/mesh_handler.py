@@ -89,9 +89,9 @@ def knn_mean_distance(points, k=NB_NEIGHBORS):
         dims_l = _dims(extent, cell)
         cells = dims_l[0] * dims_l[1] * dims_l[2]
         dims = (C.c_int32 * 3)(*dims_l)
-        if cell_start is None or cell_start.numel() < cells + 1:
+        if cell_start is None or cell_start.numel() < cells + 2:
             cell_start = None
-            cell_start = torch.empty((cells + 1,), dtype=torch.int32, device=dev)
+            cell_start = torch.empty((cells + 2,), dtype=torch.int32, device=dev)    # (the range kernel also leaves m at [cells + 1])
         nv.check(L.g2pc_outlier_grid_build(nv.ptr(pts), m, C.byref(origin), cell, C.byref(dims), nv.ptr(sorted_pos),
                                            nv.ptr(cell_start), nv.ptr(occupied), nv.ptr(ws), ws_bytes, stream),
                  "outlier_grid_build")

@@ -124,7 +124,7 @@ int g2pc_scatter_ones_u8(const uint32_t* index, int64_t m, uint8_t* dst, int64_t
  * (grid origin[3], dims[3], dims[0]*dims[1]*dims[2] < 2^31; points outside the grid are clamped into its border cells,
  * which stays exact -- the shell bounds only rely on the cell index growing with the coordinate -- so the grid may cover
  * a robust quantile box instead of the bounding box when a few far-away points would otherwise dictate the cell size)
- * -> sorted_pos f32[m,4] (x, y, z, original index bits) in cell order, cell_start u32[cells+1], and
+ * -> sorted_pos f32[m,4] (x, y, z, original index bits) in cell order, cell_start u32[cells+2] (exclusive offsets; [cells] = [cells+1] = m), and
  * (optional) the number of non-empty cells in *occupied (device) so the caller can refine the resolution;
  * _knn_mean_distance searches growing shells of cells until the k-th distance is provably final and writes the
  * mean distance of point i (original order) to avg[i] (f64).  k <= 32.  slack: absolute safety margin subtracted from

@@ -78,3 +78,29 @@ def test_cli_clean_pointcloud(emu, tmp_path):
     keep, _ = ref_clean.statistical_outlier_mask(ref_clean.knn_mean_distance(pts), 10.0)
     assert len(clean) == int(keep.sum())
     assert np.array_equal(np.stack([clean["x"], clean["y"], clean["z"]], 1), pts[keep])
+
+
+def test_grid_build_writes_exactly_cells_plus_two_offsets(emu):
+    """g2pc_outlier_grid_build's cell_start holds cells + 2 words (exclusive offsets, the last two = m): found by
+    tools/experiments/knn_fuzz.py when the driver still allocated cells + 1 and the range kernel wrote one word past it."""
+    import ctypes as C
+    import mesh_handler  # noqa: F401  (binds the entry points)
+    nv = emu
+    L = nv.lib()
+    rng = np.random.default_rng(3)
+    m = 500
+    pts = torch.from_numpy((rng.uniform(-1, 1, size=(m, 3)) * np.array([1.0, 1e-3, 50.0])).astype(np.float32))
+    dims_l = [3, 1, 40]
+    cells = dims_l[0] * dims_l[1] * dims_l[2]
+    guard = 0x7FFFFFFF
+    cell_start = torch.full((cells + 2 + 8,), guard, dtype=torch.int32)
+    sorted_pos = torch.empty((m, 4), dtype=torch.float32)
+    wb = L.g2pc_outlier_grid_workspace(m)
+    ws = nv.workspace(wb, "cpu")
+    origin = (C.c_float * 3)(-1.0, -1e-3, -50.0)
+    dims = (C.c_int32 * 3)(*dims_l)
+    nv.check(L.g2pc_outlier_grid_build(nv.ptr(pts), m, C.byref(origin), C.c_float(2.6), C.byref(dims), nv.ptr(sorted_pos),
+                                       nv.ptr(cell_start), None, nv.ptr(ws), wb, None), "grid_build")
+    cs = cell_start.numpy()
+    assert (cs[cells + 2:] == guard).all() and cs[cells] == m and cs[cells + 1] == m and cs[0] == 0
+    assert (np.diff(cs[:cells + 1]) >= 0).all()
