@@ -9,6 +9,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def build_emu() -> str:
+    if os.environ.get("G2PC_EMU_LIB"):          # a prebuilt variant, e.g. the AddressSanitizer build of tools/emu_asan.sh
+        return os.environ["G2PC_EMU_LIB"]
     out = subprocess.run(["bash", os.path.join(HERE, "hipemu", "build_emu.sh")], capture_output=True, text=True)
     if out.returncode != 0:
         raise RuntimeError("emulator build failed:\n" + out.stdout + out.stderr)
