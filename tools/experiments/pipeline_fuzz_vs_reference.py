@@ -2,7 +2,7 @@
 cameras -> colours -> cull unrendered -> filter -> validate_covariances -> generate_pointcloud with keyed noise, run on the CPU
 under oracle/ref_shim.py exactly as oracle/make_golden.py::gen_pipeline runs it) against the product's modules through the
 emulator, on random small jobs (scene size, cameras, image size, point budget, binned / exact, Mahalanobis limit, attempts,
-visibility threshold).  usage: python tools/experiments/pipeline_fuzz_vs_reference.py <seed> <cases>.  Round 3: 68 jobs -- the
+visibility threshold).  usage: python tools/experiments/pipeline_fuzz_vs_reference.py <seed> <cases>.  Round 3: 108 jobs (40 of them with min_opacity / bounding box / cull_large_percentage set) -- the
 same culling mask, the same validate mask, the same number of points, xyz to 1.2e-7 and rgb (0..255) to 7.6e-5 in every one."""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,6 +26,8 @@ for it in range(int(sys.argv[2])):
     num_points = int(n * rng.integers(1, 15)); exact = bool(rng.integers(0, 2)); std = float(rng.choice([1.0, 2.0])); attempts = int(rng.integers(1, 6))
     thr = float(rng.choice([0.0, 0.05, 0.2])); hi = float(rng.choice([0.02, 0.06])); seed = 8000 + it; noise_seed = int(rng.integers(0, 2**31))
     sc = make_scene(n, seed, scale_lo=0.004, scale_hi=hi)
+    min_op = float(rng.choice([0.0, 0.2, 0.6])); cull_large = float(rng.choice([0.0, 0.0, 0.1]))
+    bmin = [-0.8, -0.9, -1.0] if rng.random() < 0.3 else None; bmax = [0.9, 0.7, 0.8] if rng.random() < 0.3 else None
     transforms, intr = make_cameras(ncam, width=W, height=H, focal=0.9 * W)
     t0 = time.time()
     gh, gr, ch, rg2p = (ref[k] for k in ("gauss_handler", "gauss_render", "camera_handler", "gauss_to_pc"))
@@ -39,7 +41,11 @@ for it in range(int(sys.argv[2])):
                 R(cam)
         G.colours = R.get_gaussian_colours()
         G.add_gaussians_to_cull(R.get_visible_gaussians())
-        G.apply_min_opacity(0.0); G.apply_bounding_box(None, None)
+        G.apply_min_opacity(min_op); G.apply_bounding_box(bmin, bmax)
+        try:
+            G.cull_large_gaussians(cull_large); r_cl_err = None
+        except Exception as e:
+            r_cl_err = type(e).__name__
         r_culled = G.filter_gaussians()
         r_contrib = R.get_total_gaussian_contributions()[r_culled]
         r_keep = G.validate_covariances()
@@ -62,7 +68,9 @@ for it in range(int(sys.argv[2])):
         PR(camera_handler.get_camera("python", torch.tensor(transforms[name]), intr[name], colour_resolution=None))
     P.colours = PR.get_gaussian_colours()
     P.add_gaussians_to_cull(PR.get_visible_gaussians())
-    P.apply_min_opacity(0.0); P.apply_bounding_box(None, None)
+    P.apply_min_opacity(min_op); P.apply_bounding_box(bmin, bmax)
+    if r_cl_err is None:
+        P.cull_large_gaussians(cull_large)
     culled = P.filter_gaussians()
     contrib = PR.get_total_gaussian_contributions()[culled]
     keep = P.validate_covariances()
@@ -73,7 +81,7 @@ for it in range(int(sys.argv[2])):
         p_err = None
     except Exception as e:
         p_err = type(e).__name__
-    tag = "n %d cams %d %dx%d pts %d exact %s std %.0f att %d thr %.2f" % (n, ncam, W, H, num_points, exact, std, attempts, thr)
+    tag = "op %.1f cl %.1f bb %s %s n %d cams %d %dx%d pts %d exact %s std %.0f att %d thr %.2f" % (min_op, cull_large, bmin is not None, bmax is not None, n, ncam, W, H, num_points, exact, std, attempts, thr)
     if r_err or p_err:
         ok = (r_err is not None) and (p_err is not None)
         bad += (not ok); print(it, tag, "raised ref", r_err, "product", p_err, "OK" if ok else "MISMATCH", flush=True); continue
