@@ -1,6 +1,6 @@
 """CPU (emulator): the whole sampling path (covariances -> magnitudes -> distribute -> sample) on random scenes, budgets, binned
 / exact mode, Mahalanobis limits and attempt counts against the oracle (ref_gauss.generate_pointcloud with the same keyed noise).
-usage: python tools/experiments/sampler_fuzz.py <seed> <cases>.  Round 3: 460 cases, same rows in the same order -- but for ONE draw (seed 102, case 42) whose Mahalanobis distance is 1.0000001 by
+usage: python tools/experiments/sampler_fuzz.py <seed> <cases>.  Round 3: 660 cases, same rows in the same order -- but for TWO draws (seed 102 case 42, seed 1002 case 137), the first of which has a Mahalanobis distance of 1.0000001 by
 torch.inverse's rounding and 1.0 by the kernel's cofactor inverse, against a limit of 1.0 (inverse_order_probe.py: torch's
 inverse cannot be reproduced bit for bit)."""
 import os
