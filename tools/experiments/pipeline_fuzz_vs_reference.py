@@ -2,7 +2,7 @@
 cameras -> colours -> cull unrendered -> filter -> validate_covariances -> generate_pointcloud with keyed noise, run on the CPU
 under oracle/ref_shim.py exactly as oracle/make_golden.py::gen_pipeline runs it) against the product's modules through the
 emulator, on random small jobs (scene size, cameras, image size, point budget, binned / exact, Mahalanobis limit, attempts,
-visibility threshold).  usage: python tools/experiments/pipeline_fuzz_vs_reference.py <seed> <cases>.  Round 3: 108 jobs (40 of them with min_opacity / bounding box / cull_large_percentage set) -- the
+visibility threshold).  usage: python tools/experiments/pipeline_fuzz_vs_reference.py <seed> <cases>.  Round 3: 178 jobs (110 of them with min_opacity / bounding box / cull_large_percentage set) -- the
 same culling mask, the same validate mask, the same number of points, xyz to 1.2e-7 and rgb (0..255) to 7.6e-5 in every one."""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
