@@ -515,7 +515,7 @@ def main():
             out["parity"] = {k: full.get(k) for k in (
                 "mask_flips", "near_threshold_1e-5", "contrib_max", "contrib_frac_gt_1e-4", "colour_max", "colour_frac_gt_1e-4",
                 "image_max", "image_frac_gt_1e-4", "culled_equal", "ppg_mismatch_given_ref_contrib", "ppg_mismatch_end_to_end",
-                "sample_points", "sample_points_ref", "sample_xyz_max", "sample_rgb_max", "sample_rows_compared", "sample_rows_unmatched", "cameras",
+                "sample_points", "sample_points_ref", "sample_xyz_max", "sample_rgb_max", "sample_rows_compared", "sample_rows_unmatched", "sample_rows_order_shifted", "cameras",
                 "k1", "cov3d_rows_differing", "camera_matrix_bits_differing", "reference_tie_rule", "reference_tie_spread",
                 "gaussians", "resolution", "t_floor", "oracle", "check_seconds")}
             out["parity"]["ppg_equal"] = full.get("ppg_mismatch_given_ref_contrib") == 0

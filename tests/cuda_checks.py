@@ -26,7 +26,7 @@ def run_golden_case(name, device="cpu"):
     G = Gaussians(sc.xyz.to(dev), sc.scales.to(dev), sc.rots.to(dev), sc.colours.to(dev), sc.opacities.to(dev))
     # the reference's own 3-D covariances (its torch.exp is SLEEF's, within an ulp of -- not equal to -- any other exp): the
     # rasteriser is compared on identical inputs; Gaussians' own covariance build is held to the geometry fixtures
-    c6 = torch.from_numpy(case.z["state_cov6"])
+    c6 = torch.from_numpy(case.cov6(G.covariances.reshape(-1, 9)[:, [0, 1, 2, 4, 5, 8]].cpu().numpy()))
     cov = c6[:, [0, 1, 2, 1, 3, 4, 2, 4, 5]].reshape(-1, 3, 3).contiguous().to(dev)
     assert float((G.covariances - cov).abs().max()) < 1e-6 * float(cov.abs().max())
     R = gauss_render.get_renderer("cuda", G.xyz, G.opacities.unsqueeze(1), G.colours, cov,
@@ -56,7 +56,7 @@ def run_golden_case(name, device="cpu"):
             touched = np.where(rad > 0, (((rc >> 8) & 255) - (rc & 255) + 1) * (((rc >> 24) & 255) - ((rc >> 16) & 255) + 1), 0)
         rec = R._sync.rec.cpu().numpy().reshape(-1, 16)             # (px, py, qa, qb), (qc, opacity, depth, radius), ...
         got = dict(radii=rad, num_rendered=R.last["num_rendered"], tiles_touched=touched.astype(np.uint32),
-                   means2D=rec[:, 0:2], depths=rec[:, 6], conic_scaled=rec[:, 2:5],
+                   means2D=rec[:, 0:2], depths=rec[:, 6], conic_scaled=rec[:, 2:5], opacity=rec[:, 5], rgb=rec[:, 8:11],
                    out_color=colour.cpu().numpy(), out_depth=dep.cpu().numpy(), out_invdepth=invd.cpu().numpy(),
                    gauss_contributions=R.last["contributions"].cpu().numpy(), gauss_pixels=R.last["pixels"].cpu().numpy(),
                    gauss_surface_distances=R.last["surface_distances"].cpu().numpy())

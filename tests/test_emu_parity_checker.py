@@ -21,3 +21,27 @@ def test_parity_checker_on_mini_job(emu):
     assert r["ppg_mismatch_given_ref_contrib"] == 0
     assert r["sample_points"] == r["sample_points_ref"] and r["sample_rows_unmatched"] == 0
     assert r["sample_xyz_max"] < 1e-4 and r["sample_rgb_max"] < 1e-4
+
+
+def test_row_matching_survives_shifted_order():
+    """An accept/reject flip removes one row of ours and adds another elsewhere: every later row sits one place off.  The
+    matched-row comparison must still pair every reference row with its point and compare THAT row's colour."""
+    import numpy as np
+    import parity_cfg2
+    rng = np.random.default_rng(5)
+    ref = rng.random((6400, 3)).astype(np.float32)
+    rgb = (rng.random((6400, 3)) * 255).astype(np.float32)
+    ours = np.delete(ref, 1000, axis=0)                     # a point lost ...
+    ours = np.insert(ours, 5000, [[9, 9, 9]], axis=0)       # ... and one gained further on: rows 1000..4999 are shifted by one
+    ours_rgb = np.insert(np.delete(rgb, 1000, axis=0), 5000, [[1, 2, 3]], axis=0)
+    rr = np.arange(0, 6400, 64)
+    r = parity_cfg2.match_rows(ours, ours_rgb, ref[::64], rgb[::64], rr)
+    assert r["sample_rows_unmatched"] == 0 and r["sample_xyz_max"] == 0.0 and r["sample_rgb_max"] == 0.0, r
+    assert r["sample_rows_order_shifted"]["count"] == len([x for x in rr if 1000 < x <= 5000])
+    assert r["sample_rows_order_shifted"]["first_row"] == 1024 and r["sample_rows_order_shifted"]["max_offset"] == 1
+    bad = ours_rgb.copy()
+    bad[2047] += 3.0                                        # the matched row of reference row 2048
+    assert parity_cfg2.match_rows(ours, bad, ref[::64], rgb[::64], rr)["sample_rgb_max"] > 1e-2
+    # a reference row with no counterpart at all is reported, not silently dropped
+    gone = np.delete(ours, 2047, axis=0)
+    assert parity_cfg2.match_rows(gone, np.delete(ours_rgb, 2047, axis=0), ref[::64], rgb[::64], rr)["sample_rows_unmatched"] == 1

@@ -26,6 +26,21 @@ def test_cuda_semantics_vs_reference_golden(name):
     cu_golden.assert_state(st, case)
 
 
+@pytest.mark.parametrize("name", cu_golden.BIG_CASES)
+def test_cuda_semantics_vs_reference_golden_at_configs4_size(name):
+    """BASELINE configs[4] at ITS OWN size: the bench scene (1 M Gaussians, SH degree 3, surface distance), cameras 0 and 17 of
+    the bench's 50-camera rig, against the reference's own rasteriser compiled for the host (oracle/make_golden_cu.py, 7.5 M
+    instances per camera).  Every integer of every Gaussian (radii, tiles touched, instance count, seen / reached bits,
+    arg-max pixels), K1's floats of every Gaussian by fingerprint, image / depth maps at every 16th pixel, per-Gaussian
+    floats at every 4th Gaussian, the binding's final state and its three getter masks in full."""
+    reps, st, case = run_golden_case(name, DEV)
+    for rep in reps:
+        print(json.dumps(rep))
+        cu_golden.assert_camera(rep, case, image_tol=5e-5)
+    print(json.dumps(st))
+    cu_golden.assert_state(st, case)
+
+
 @pytest.mark.parametrize("n,w,h,f,ncam,sh,surf,mask", [
     (6000, 320, 180, 275.0, 3, False, True, False),
     (4000, 333, 187, 280.0, 2, True, True, True),          # partial edge tiles + SH degree 3 + mask

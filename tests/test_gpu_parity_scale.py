@@ -33,4 +33,4 @@ def test_configs2_scene_two_cameras_against_reference(t_floor):
     if t_floor is None:
         assert abs(r["sample_points"] - r["sample_points_ref"]) <= 16, r          # a flipped accept/reject can cost a point
         assert r["sample_rows_unmatched"] <= max(2, 1e-4 * r["sample_rows_compared"]) and r["sample_xyz_max"] < 1e-4, r
-        assert r["sample_rgb_max"] is None or r["sample_rgb_max"] < 1e-4, r
+        assert r["sample_rgb_max"] is not None and r["sample_rgb_max"] < 1e-4, r

@@ -16,7 +16,9 @@ SURVEY.md §8(d) asks to be reported with every number:
                                        the reference's contributions (isolates the allocation: expected 0)
   ppg_mismatch_end_to_end              the same from our own render (contributions differ by ~1e-6 -> a few +-1)
   sample_*                             the 10 M-point cloud sampled from the reference's kept set with the same keyed
-                                       noise: point count, rows compared (every 64th), max |xyz| and |rgb| difference
+                                       noise: point count, rows compared (every 64th), max |xyz| and |rgb| difference of the
+                                       MATCHED rows (same position, or the row a few places off that holds the same point when an
+                                       accept/reject flip shifted the order: sample_rows_order_shifted)
   k1_mismatch / radius_mismatch        per camera: Gaussians whose projected mean (x, y), radius or view depth differ IN ANY
                                        BIT from what the reference's renderer computed (one fingerprint byte per Gaussian in
                                        the fixture), and whose radius differs; cov3d_rows_differing: rows of the 3-D
@@ -82,6 +84,35 @@ def _k1_report(g, k, cam, xyz, cov, n):
                cov2d_mismatch=int((k1_hash8(*[c2[:, j] for j in range(4)]) != g["cam%d_cov2d_hash8" % k]).sum()))
     s = slice(None, None, 64)
     out["means2D_s64_bit_mismatch"] = int((np.stack([z(mx), z(my)], 1)[s].view(np.uint32) != g["cam%d_means2D_s64" % k].view(np.uint32)).any(axis=1).sum())
+    return out
+
+
+def match_rows(ours, ours_rgb, q, qc, rr, win=8, tol=1e-4):
+    """Reference rows `q` (xyz) / `qc` (rgb, 0..255) that sat at positions `rr` of the reference's cloud, against OUR cloud:
+    each is matched to the row of ours that holds the same point -- looked for within `win` places of its own position
+    first, by kd-tree otherwise -- and xyz AND rgb are compared with the matched row.  Returns the sample_* gates."""
+    lim = min(rr.shape[0], q.shape[0])
+    q, qc, rr = q[:lim], qc[:lim], rr[:lim]
+    match = np.full(lim, -1, dtype=np.int64)
+    for off in sorted(range(-win, win + 1), key=abs):
+        cand = np.clip(rr + off, 0, ours.shape[0] - 1)
+        hit = (match < 0) & (np.abs(ours[cand] - q).max(axis=1) <= tol)
+        match[hit] = cand[hit]
+    left = np.nonzero(match < 0)[0]
+    if left.size:
+        from scipy.spatial import cKDTree
+        dist, idx = cKDTree(ours).query(q[left], k=1)
+        ok = dist <= tol
+        match[left[ok]] = idx[ok]
+    found = match >= 0
+    out = {"sample_rows_compared": int(lim), "sample_rows_unmatched": int((~found).sum())}
+    out["sample_xyz_max"] = float(np.abs(ours[match[found]] - q[found]).max()) if found.any() else None
+    # a row's colour is its Gaussian's: an xyz match that belonged to another Gaussian would show here
+    out["sample_rgb_max"] = float(np.abs(ours_rgb[match[found]] - qc[found]).max() / 255.0) if found.any() else None
+    shifted = found & (match != rr)
+    out["sample_rows_order_shifted"] = {
+        "first_row": int(rr[np.nonzero(shifted)[0][0]]) if shifted.any() else None, "count": int(shifted.sum()),
+        "max_offset": int(np.abs(match - rr)[found].max()) if found.any() else None}
     return out
 
 
@@ -198,29 +229,27 @@ def run(device="cuda:0", t_floor=None, sampler=True, tag="1m"):
                                                 seed=int(s["noise_seed"]))
         out["sample_points"], out["sample_points_ref"] = int(pts.shape[0]), int(s["m"])
         direct_ok = False
+        ours = pts.cpu().numpy()
+        ours_rgb = cols2.cpu().numpy()
+        ref_rows = np.arange(0, int(s["m"]), 64)
         if pts.shape[0] == int(s["m"]):
-            p = pts[::64].cpu().numpy()
-            dx = np.abs(p - s["points_s64"]).max(axis=1)
-            out["sample_rows_compared"] = int(p.shape[0])
+            dx = np.abs(ours[::64] - s["points_s64"]).max(axis=1)
+            out["sample_rows_compared"] = int(dx.shape[0])
             out["sample_rows_same_position"] = int((dx <= 1e-4).sum())
             direct_ok = bool((dx <= 1e-4).all())
             if direct_ok:
                 out["sample_xyz_max"] = float(dx.max())
                 out["sample_rows_unmatched"] = 0
-                out["sample_rgb_max"] = float(np.abs(cols2[::64].cpu().numpy() - s["colours_s64"]).max() / 255.0)
+                out["sample_rows_order_shifted"] = {"first_row": None, "count": 0}
+                out["sample_rgb_max"] = float(np.abs(ours_rgb[::64] - s["colours_s64"]).max() / 255.0)
         if not direct_ok:
-            # An accept/reject decision within fp32 rounding of the 2-sigma threshold (~3 per 1e6 draws between the
+            # An accept/reject decision within fp32 rounding of the 2-sigma threshold (~1 per 1e7 draws between the
             # reference's torch.inverse route and any other evaluation) changes one Gaussian's d in
-            # one attempt and shifts every later row of that section by one: compare as SETS instead -- every reference
-            # row (every 64th of the cloud, bounded at 40 000) must have a point of ours within 1e-4.
-            from scipy.spatial import cKDTree
-            tree = cKDTree(pts.cpu().numpy())
-            q = s["points_s64"][:40000]
-            dist, _ = tree.query(q, k=1)
-            out["sample_rows_compared"] = int(q.shape[0])
-            out["sample_rows_unmatched"] = int((dist > 1e-4).sum())
-            out["sample_xyz_max"] = float(np.sort(dist)[-1 - out["sample_rows_unmatched"]]) if out["sample_rows_unmatched"] < q.shape[0] else None
-            out["sample_rgb_max"] = None
+            # one attempt and shifts every later row of that section by one.  Every reference row (every 64th of the cloud)
+            # is therefore matched to OUR row holding the same point -- searched in a window around its own position first
+            # (a shift moves a row by the handful of flips in front of it), by kd-tree otherwise -- and both its xyz and its
+            # RGB are compared with that row; where the matched row sits (its offset) says how far the order was shifted.
+            out.update(match_rows(ours, ours_rgb, s["points_s64"], s["colours_s64"], ref_rows))
     out["reference_cpu_seconds_per_camera"] = [float(x) for x in g["seconds_per_camera"]]
     out["reference_cpu_threads"] = int(g["threads"])
     out["check_seconds"] = time.perf_counter() - t_start
