@@ -23,16 +23,38 @@ _LOCK = threading.Lock()
 
 
 def warmup(device, semantics=("python", "cuda")):
-    """Idempotent per (process, device).  Returns the seconds it took (0.0 when already warm)."""
+    """Idempotent per (process, device).  Returns the seconds it took (0.0 when already warm).
+
+    The warm-up is an optimisation, never a reason to fail a conversion: whatever it raises is logged and swallowed (the
+    real job then simply pays the first-use costs itself).  It runs with `device` as the CURRENT device of the calling
+    thread -- torch.cuda.set_device is per thread, and a daemon thread of rank r > 0 would otherwise pin buffers, create
+    events and launch libg2pc's kernels (which take the current device) on GPU 0 -- and as a single-process job: under
+    torch.distributed the miniature must not issue collectives from a side thread while the ranks are busy elsewhere."""
     import time
-    key = str(torch.device(device))
+    device = torch.device(device)
+    key = str(device)
     with _LOCK:
         if _DONE.get(key):
             return 0.0
         t0 = time.perf_counter()
-        _run(torch.device(device), semantics)
-        if torch.device(device).type == "cuda":
-            torch.cuda.synchronize(device)
+        try:
+            if device.type == "cuda":
+                with torch.cuda.device(device):
+                    _run(device, semantics)
+                    torch.cuda.synchronize(device)
+            else:
+                _run(device, semantics)
+        except Exception as e:                              # noqa: BLE001 -- see docstring
+            import sys
+            import traceback
+            print("g2pc warm-up failed (%s: %s); continuing without it" % (type(e).__name__, e), file=sys.stderr)
+            if __import__("os").environ.get("G2PC_WARMUP_DEBUG"):
+                traceback.print_exc()
+            try:
+                import gauss_render
+                gauss_render.clear_context_pool()
+            except Exception:                               # noqa: BLE001
+                pass
         _DONE[key] = True
         return time.perf_counter() - t0
 
@@ -60,7 +82,7 @@ def _run(device, semantics):
             renderer_type=sem, num_points=4000, prioritise_visible_gaussians=True, mahalanobis_distance_std=2.0,
             camera_skip_rate=0, render_colours=True, min_opacity=0.0, bounding_box_min=None, bounding_box_max=None,
             calculate_normals=True, cull_large_percentage=0.0, remove_unrendered_gaussians=True, colour_resolution=64,
-            max_sh_degree=3, exact_num_points=False, visibility_threshold=0.0, surface_distance_std=2.0 if cu else None,
+            max_sh_degree=3, exact_num_points=False, visibility_threshold=0.01, surface_distance_std=2.0 if cu else None,
             generate_mesh=False, quiet=True, device=str(device))
-        convert_gaussians_to_pc(g, tr, intr, None, s, seed=1, keep_render_context=False)
+        convert_gaussians_to_pc(g, tr, intr, None, s, seed=1, keep_render_context=False, single_process=True)
     gauss_render.clear_context_pool()       # the miniature's device context is of no use to a real scene

@@ -407,7 +407,14 @@ class GaussHipRenderer():
         self.device = means3D.device
         self.semantics = semantics
         self.visible_gaussian_threshold = visible_gaussian_threshold
-        self.t_floor = DEFAULT_T_FLOOR if t_floor is None else float(t_floor)
+        # Transmittance floor: visits below 2^-25 / pixels with T below the floor are dropped, which leaves every
+        # contribution >= the floor bit-identical.  The visibility test is the reference's strict `>` against the threshold
+        # (gauss_render.py:249-252, running max :387): with a threshold AT OR BELOW the floor a Gaussian whose contributions
+        # are all tiny is visible (and coloured) in the reference and would be neither here -- so the default floor applies
+        # only above it; the API's own default threshold (0.0, gauss_render.py:467-468) therefore takes the to-the-letter blend.
+        if t_floor is None:
+            t_floor = DEFAULT_T_FLOOR if float(visible_gaussian_threshold) > DEFAULT_T_FLOOR else 0.0
+        self.t_floor = float(t_floor)
         # (rank, world): blend only this rank's share of every camera's tiles (multi-GPU jobs with fewer cameras than
         # ranks; the images returned then hold this rank's tiles only)
         self.tile_shard = tuple(tile_shard) if tile_shard is not None and tile_shard[1] > 1 else None
@@ -509,6 +516,12 @@ class GaussHipRenderer():
         return self.gaussian_colours * 255
 
     def get_gaussians_above_contribution_threshold(self, contribution_threshold):
+        if self.t_floor > 0.0 and float(contribution_threshold) <= self.t_floor and self.camera_slot > 0:
+            import warnings
+            warnings.warn("contribution threshold %g is not above the transmittance floor %g the cameras were blended with: "
+                          "Gaussians whose contributions all lie below the floor are missing from the mask (construct the "
+                          "renderer with visible_gaussian_threshold <= the floor, or t_floor=0, for the reference's result)"
+                          % (contribution_threshold, self.t_floor))
         return self.gaussian_max_contribution > contribution_threshold
 
     def get_visible_gaussians(self):

@@ -161,7 +161,7 @@ def generate_pointcloud(gaussians, num_points, contributions=None, mahalanobis_d
 
 
 def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, pointcloud_settings, seed=None,
-                            group=None, render_shs=False, keep_render_context=True):
+                            group=None, render_shs=False, keep_render_context=True, single_process=False):
     """The body of convert_3dgs_to_pc (gauss_to_pc.py:414-601) on already-loaded data:
     `gaussians` is a gauss_handler.Gaussians, transforms / intrinsics are name -> 4x4 c2w / [w, h, fx, fy].
     Under torch.distributed (one process per GPU) the cameras are split over the ranks, the per-Gaussian
@@ -170,11 +170,13 @@ def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, poin
     render_shs=True hands gaussians.shs to the native rasteriser (SH evaluated per camera, forward.cu:22-73); the
     reference's convert_3dgs_to_pc never does (gauss_to_pc.py:429-432) and renders the DC colours.
     keep_render_context=False releases the renderer's pooled device context (scene copies, workspaces, captured camera
-    graphs) before sampling -- what a one-shot conversion wants; a process converting scene after scene keeps it."""
+    graphs) before sampling -- what a one-shot conversion wants; a process converting scene after scene keeps it.
+    single_process=True ignores an initialised torch.distributed (no camera split, no collective): the process warm-up's
+    miniature job runs on every rank by itself (g2pc/warmup.py)."""
     from g2pc.dist import rank_world
     s = pointcloud_settings
     device = gaussians.xyz.device
-    rank, world = rank_world(group)
+    rank, world = (0, 1) if single_process else rank_world(group)
 
     # Calculate Gaussian Normals
     if s.calculate_normals:

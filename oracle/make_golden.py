@@ -329,18 +329,22 @@ class CaptureK1:
         return out
 
 
-def gen_render_big(ref, tag="1m", n=1_000_000, num_points=10_000_000, width=1280, height=720, focal=1100.0):
+def gen_render_big(ref, tag="1m", n=1_000_000, num_points=10_000_000, width=1280, height=720, focal=1100.0, rig=50,
+                   cam_ids=(0, 17), compact=False):
     """BASELINE configs[2] at FULL size: the bench scene (1 M Gaussians, seed 1234+3), cameras 0 and 17 of the
     50-camera rig at 1280x720, untouched reference python renderer on CPU (~minutes per camera), then the
     reference's cull -> validate -> magnitudes -> distribute_points(10 M).  Stored compactly: the final
     running-max contribution of every Gaussian (f32; after camera 0: every 8th), bit-packed visible mask, colours of every 16th Gaussian,
-    every 4th pixel (x and y) of both images, points-per-Gaussian of the kept set (u16)."""
+    every 4th pixel (x and y) of both images, points-per-Gaussian of the kept set (u16).
+    tag "5m" (render_5m) = BASELINE configs[3]'s scene at ITS size: 5 M Gaussians, camera 17 of the 200-camera rig, 50 M points;
+    `compact`: the final contributions at every 4th Gaussian (visible / culled masks in full), K1 and cov2d in ONE fingerprint
+    byte per Gaussian, the 3-D covariance fingerprint at every 4th."""
     import time
     gh, gr, ch, g2p = (ref[k] for k in ("gauss_handler", "gauss_render", "camera_handler", "gauss_to_pc"))
     seed = 1234 + 3
-    cam_ids = [0, 17]
+    cam_ids = list(cam_ids)
     sc = make_scene(n, seed)
-    transforms, intr = make_cameras(50, width=width, height=height, focal=focal)
+    transforms, intr = make_cameras(rig, width=width, height=height, focal=focal)
     names = sorted(transforms)
     with CudaToCpu():
         G = gh.Gaussians(sc.xyz.clone(), sc.scales.clone(), sc.rots.clone(), sc.colours.double(),
@@ -383,8 +387,9 @@ def gen_render_big(ref, tag="1m", n=1_000_000, num_points=10_000_000, width=1280
                        "cam%d_proj" % k: _np(cam.projection_matrix).astype(np.float32),
                        "cam%d_fov_focal" % k: np.array([cam.FoVx, cam.FoVy, cam.focal_x, cam.focal_y], dtype=np.float64),
                        "cam%d_in_mask_bits" % k: np.packbits(f["in_mask"]),
-                       "cam%d_k1_hash8" % k: k1_hash8(f["means2D"][:, 0], f["means2D"][:, 1], f["radii"][:, 0], f["depth"]),
-                       "cam%d_cov2d_hash8" % k: k1_hash8(*[f["cov2d"][:, j] for j in range(4)]),
+                       "cam%d_k1_hash8" % k: k1_hash8(f["means2D"][:, 0], f["means2D"][:, 1], f["radii"][:, 0], f["depth"],
+                                                      *([f["cov2d"][:, j] for j in range(4)] if compact else [])),
+                       **({} if compact else {"cam%d_cov2d_hash8" % k: k1_hash8(*[f["cov2d"][:, j] for j in range(4)])}),
                        "cam%d_radius_div3_u8" % k: np.minimum(f["radii"][:, 0] / 3.0, 255).astype(np.uint8),
                        "cam%d_means2D_s64" % k: f["means2D"][::64].copy(), "cam%d_depth_s64" % k: f["depth"][::64].copy(),
                        "cam%d_cov2d_s64" % k: f["cov2d"][::64].copy()})
@@ -408,7 +413,7 @@ def gen_render_big(ref, tag="1m", n=1_000_000, num_points=10_000_000, width=1280
         k1["tie_rule"] = "stable"
         visible = _np(R.get_visible_gaussians())
         c9 = _np(G.covariances).reshape(n, 9)
-        k1["cov3d_hash8"] = k1_hash8(*[c9[:, j] for j in (0, 1, 2, 4, 5, 8)])
+        k1["cov3d_hash8"] = k1_hash8(*[c9[:: 4 if compact else 1, j] for j in (0, 1, 2, 4, 5, 8)])
         k1["cov3d_s64"] = c9[::64].astype(np.float32)
         G.colours = R.get_gaussian_colours()
         G.add_gaussians_to_cull(R.get_visible_gaussians())
@@ -431,15 +436,18 @@ def gen_render_big(ref, tag="1m", n=1_000_000, num_points=10_000_000, width=1280
         sample_seconds = time.perf_counter() - t0
         print("render_big: sampler %d points in %.1f s" % (pts.shape[0], sample_seconds), flush=True)
     assert float(ppg.max()) < 65535
+    cs = 4 if compact else 1           # compact: every 256th row of the cloud, every 4th contribution
     np.savez_compressed(os.path.join(GOLD, "sample_cfg2_%s.npz" % tag), n=n, seed=seed, noise_seed=noise_seed,
                         num_points=num_points, m=pts.shape[0], sample_seconds=sample_seconds,
                         kept_colours=_np(G.colours).astype(np.float32), kept_contrib=_np(contrib).astype(np.float32),
                         kept_cov=_np(G.covariances).astype(np.float32),
-                        points_s64=_np(pts)[::64].copy(), colours_s64=_np(cols)[::64].astype(np.float32))
+                        row_stride=64 * cs,
+                        points_s64=_np(pts)[::64 * cs].copy(), colours_s64=_np(cols)[::64 * cs].astype(np.float32))
     np.savez_compressed(os.path.join(GOLD, "render_py_cfg2_%s.npz" % tag), n=n, seed=seed, cam_ids=np.array(cam_ids),
                         width=width, height=height, focal=focal,
                         num_points=num_points, threads=torch.get_num_threads(), seconds_per_camera=np.array(secs),
-                        images_s4=np.stack(imgs), contrib_cam0_s8=contribs[0][::8].copy(), contrib_final=contribs[1],
+                        rig=rig, compact=int(compact), contrib_stride=cs,
+                        images_s4=np.stack(imgs), contrib_cam0_s8=contribs[0][::8].copy(), contrib_final=contribs[-1][::cs].copy(),
                         visible_bits=np.packbits(visible), colours_s16=colours[::16].astype(np.float32),
                         culled_bits=np.packbits(_np(culled)), keep_bits=np.packbits(_np(keep)),
                         ppg_u16=_np(ppg).astype(np.uint16), ppg_sum=float(ppg.sum()), **k1)
@@ -514,5 +522,7 @@ if __name__ == "__main__":
     for w in which:
         {"geom": gen_geom, "sampler": gen_sampler, "render": gen_render, "pipeline": gen_pipeline,
          "render_big": gen_render_big, "helpers": gen_helpers, "render_split": gen_render_split,
+         # BASELINE configs[3] at its own size: 5 M Gaussians, one camera of the 200-camera rig, distribute_points(50 M) + sampler
+         "render_5m": lambda r: gen_render_big(r, "5m", 5_000_000, 50_000_000, rig=200, cam_ids=(17,), compact=True),
          # the same job at a size the CPU emulator can follow: checks the checker (tools/parity_cfg2.py) without a GPU
          "render_mini": lambda r: gen_render_big(r, "mini", 4000, 40_000, 320, 180, 275.0)}[w](ref)

@@ -169,3 +169,68 @@ def run_split_fixture(golden_dir, tag, device="cpu", t_floor=0.0, pipelined=Fals
     res["near_threshold"] = int((np.abs(g["contrib"] - 0.05) < 1e-5).sum())
     res["split_leaves"] = R.split_leaves
     return res
+
+
+def run_hidden_behind_wall(device="cpu", threshold=0.0, t_floor=None):
+    """Visibility at the API's default threshold (0.0, gauss_render.py:467-468): `get_visible_gaussians` is a strict `>`
+    against the running maximum (:249-252, :387), so a Gaussian ALL of whose contributions lie in (0, 2^-25) -- here: small
+    Gaussians behind 66 translucent layers that cover the image, transmittance ~1e-10 -- is visible and coloured in the reference.
+    Returns the masks of the renderer under test (constructed through get_renderer with `threshold`, floor left to the
+    renderer unless given) and of the oracle, plus the oracle's contributions."""
+    import gauss_render
+    import camera_handler
+    import ref_gauss as RG
+    import ref_render as RR
+    dev = torch.device(device)
+    g = torch.Generator().manual_seed(11)
+    transforms, intr = make_cameras(1, width=96, height=64, focal=80.0)       # one camera at (3.5, 0, 0) looking down -x
+    nw = 66                               # more layers than one 64-entry batch of a tile's list: a floor ends the walk before them
+    wall_x = 1.0 - 0.01 * torch.arange(nw)
+    wall = torch.stack([wall_x, torch.zeros(nw), torch.zeros(nw)], dim=1)
+    hidden = torch.cat([torch.full((40, 1), -0.5), (torch.rand((40, 2), generator=g) - 0.5) * 0.3], dim=1)
+    free = torch.cat([torch.full((24, 1), 1.5), (torch.rand((24, 2), generator=g) - 0.5) * 1.6], dim=1)  # in front of the wall
+    xyz = torch.cat([wall, hidden, free]).float()
+    n = xyz.shape[0]
+    scales = torch.log(torch.cat([torch.full((nw, 3), 6.0), torch.full((40, 3), 0.02), torch.full((24, 3), 0.03)])).float()
+    rots = torch.tensor([[1.0, 0.0, 0.0, 0.0]]).repeat(n, 1)
+    opac = torch.cat([torch.full((nw,), 0.3), torch.full((40,), 0.8), torch.full((24,), 0.6)]).float()
+    colours = torch.rand((n, 3), generator=g).float()
+    cov = RG.covariances(scales, rots)
+    R = gauss_render.get_renderer("python", xyz.to(dev), opac.unsqueeze(1).to(dev), colours.to(dev), cov.to(dev),
+                                  visible_gaussian_threshold=threshold)
+    if t_floor is not None:
+        R.t_floor = t_floor
+    O = RR.PythonRendererOracle(xyz, opac.unsqueeze(1), colours.double(), cov, threshold=threshold)
+    name = next(iter(transforms))
+    cam = camera_handler.get_camera("python", torch.tensor(transforms[name]), intr[name], colour_resolution=None)
+    ocam = RR.get_camera(torch.tensor(transforms[name]), intr[name], colour_resolution=None)
+    cam.world_view_transform, cam.projection_matrix = ocam.world_view_transform, ocam.projection_matrix
+    cam.FoVx, cam.FoVy, cam.focal_x, cam.focal_y = ocam.FoVx, ocam.FoVy, ocam.focal_x, ocam.focal_y
+    R(cam)
+    O(ocam)
+    oc = O.max_contribution
+    dcol = ((R.get_gaussian_colours().cpu().double() - O.get_gaussian_colours()).abs() / 255.0).max(dim=1)[0]
+    return dict(t_floor=R.t_floor, mask=R.get_visible_gaussians().cpu(), ref_mask=O.get_visible_gaussians(), ref_contrib=oc,
+                contrib=R.gaussian_max_contribution.cpu(), colour_err=dcol,
+                hidden_tiny=int(((oc > 0) & (oc < 2.0 ** -25))[nw:nw + 40].sum()))
+
+
+def assert_hidden_behind_wall(device="cpu"):
+    # threshold 0 (the API default): the renderer must pick the to-the-letter blend by itself and agree with the reference
+    r = run_hidden_behind_wall(device, threshold=0.0)
+    assert r["hidden_tiny"] >= 20, r["hidden_tiny"]              # the scene does hold Gaussians with contributions in (0, 2^-25)
+    assert r["t_floor"] == 0.0
+    assert bool((r["mask"] == r["ref_mask"]).all()), (r["mask"] != r["ref_mask"]).nonzero().flatten().tolist()
+    seen = r["ref_contrib"] > 1e-30
+    assert float(r["colour_err"][seen].max()) < 1e-4
+    rel = ((r["contrib"] - r["ref_contrib"]).abs() / r["ref_contrib"].clamp(min=1e-30))[seen]
+    assert float(rel.max()) < 1e-3, float(rel.max())              # (relative: the contributions at stake are ~1e-12)
+    # a threshold below the default floor as well
+    r = run_hidden_behind_wall(device, threshold=1e-7)
+    assert r["t_floor"] == 0.0 and bool((r["mask"] == r["ref_mask"]).all())
+    # above the floor the default floor stays on and the mask is the reference's too
+    r = run_hidden_behind_wall(device, threshold=0.05)
+    assert r["t_floor"] > 0.0 and bool((r["mask"] == r["ref_mask"]).all())
+    # ... and this is the hole the rule closes: the floor FORCED on at threshold 0 loses the hidden Gaussians
+    r = run_hidden_behind_wall(device, threshold=0.0, t_floor=1e-6)
+    assert int((r["mask"] != r["ref_mask"]).sum()) >= 20

@@ -23,7 +23,7 @@ def _settings(num_points, renderer="python"):
         surface_distance_std=2.0 if renderer == "cuda" else None, generate_mesh=False, quiet=True, device="cpu")
 
 
-def _run(rank, world, port, out_dir, renderer="python", epoch=255, ncam=3):
+def _run(rank, world, port, out_dir, renderer="python", epoch=255, ncam=3, warm_rank=None):
     for p in (os.path.join(ROOT, "3dgs-to-pc_amd"), os.path.join(ROOT, "oracle"), HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -40,6 +40,15 @@ def _run(rank, world, port, out_dir, renderer="python", epoch=255, ncam=3):
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
         dist.init_process_group("gloo", rank=rank, world_size=world)
+    if warm_rank is not None and rank == warm_rank:
+        # the process warm-up on ONE rank only, on a side thread as the CLI starts it: were its miniature job to split cameras
+        # or all-reduce (it did until round 4: group=None picked up the initialised world), this rank would wait for a
+        # collective the other never enters
+        from g2pc import warmup as wu
+        os.environ["G2PC_WARMUP_GAUSSIANS"] = "96"
+        t = wu.warmup_in_background("cpu", (renderer,))
+        t.join(timeout=240)
+        assert not t.is_alive() and wu._DONE.get("cpu")
     sc = make_scene(1200, 91, scale_lo=0.01, scale_hi=0.06)
     transforms, intr = make_cameras(ncam, width=180, height=101, focal=155.0)
     G = Gaussians(sc.xyz, sc.scales, sc.rots, sc.colours, sc.opacities)
@@ -85,6 +94,30 @@ def test_eight_rank_pipeline_equals_single_process(tmp_path, ncam):
         rows = np.concatenate([d["points"], d["colours"], d["normals"]], axis=1)
         return rows[np.lexsort(rows.T[::-1])]
     assert np.array_equal(canon(a), canon(b))
+
+
+def test_warm_up_under_torch_distributed_is_a_single_process_job(tmp_path):
+    """g2pc.warmup runs its miniature as a single-process job whatever torch.distributed says."""
+    from emu_util import build_emu
+    build_emu()
+    _run(0, 1, 0, str(tmp_path))
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_run, args=(2, port, str(tmp_path), "python", 255, 3, 1), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "python_w1_e255.npz"), np.load(tmp_path / "python_w2_e255.npz")
+    rows = lambda d: np.concatenate([d["points"], d["colours"], d["normals"]], axis=1)
+    ca, cb = rows(a), rows(b)
+    assert ca.shape == cb.shape and np.array_equal(ca[np.lexsort(ca.T[::-1])], cb[np.lexsort(cb.T[::-1])])
+
+
+def test_warm_up_failures_do_not_fail_the_job(monkeypatch, capsys):
+    from g2pc import warmup as wu
+
+    def boom(device, semantics):
+        raise RuntimeError("no such kernel")
+    monkeypatch.setattr(wu, "_run", boom)
+    monkeypatch.setattr(wu, "_DONE", {})
+    assert wu.warmup("cpu") >= 0.0 and wu._DONE.get("cpu")
+    assert "warm-up failed" in capsys.readouterr().err
 
 
 def test_two_rank_pipeline_cuda_semantics(tmp_path):

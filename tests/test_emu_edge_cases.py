@@ -149,3 +149,11 @@ def test_cull_large_gaussians_drops_the_largest(emu):
     # exact ties: the stable sort keeps index order
     t = torch.tensor([3.0, 1.0, 3.0, 0.0, 1.0, 3.0], dtype=torch.float64)
     assert ops.argsort_f64_nonnegative(t).tolist() == [3, 1, 4, 0, 2, 5]
+
+
+def test_threshold_at_or_below_the_floor_takes_the_exact_blend(emu):
+    """get_renderer's default visible_gaussian_threshold is 0.0 and the visibility test a strict `>`
+    (/root/reference/gauss_render.py:249-252, :387, :467-468): Gaussians whose contributions all lie in (0, 2^-25) are visible
+    there; the renderer drops its transmittance floor by itself whenever the threshold does not lie above it."""
+    from render_checks import assert_hidden_behind_wall
+    assert_hidden_behind_wall("cpu")
