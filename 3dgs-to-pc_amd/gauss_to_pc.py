@@ -161,7 +161,8 @@ def generate_pointcloud(gaussians, num_points, contributions=None, mahalanobis_d
 
 
 def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, pointcloud_settings, seed=None,
-                            group=None, render_shs=False, keep_render_context=True, single_process=False):
+                            group=None, render_shs=False, keep_render_context=True, single_process=False,
+                            stage_times=None):
     """The body of convert_3dgs_to_pc (gauss_to_pc.py:414-601) on already-loaded data:
     `gaussians` is a gauss_handler.Gaussians, transforms / intrinsics are name -> 4x4 c2w / [w, h, fx, fy].
     Under torch.distributed (one process per GPU) the cameras are split over the ranks, the per-Gaussian
@@ -172,11 +173,26 @@ def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, poin
     keep_render_context=False releases the renderer's pooled device context (scene copies, workspaces, captured camera
     graphs) before sampling -- what a one-shot conversion wants; a process converting scene after scene keeps it.
     single_process=True ignores an initialised torch.distributed (no camera split, no collective): the process warm-up's
-    miniature job runs on every rank by itself (g2pc/warmup.py)."""
+    miniature job runs on every rank by itself (g2pc/warmup.py).
+    stage_times: a dict to fill with this rank's milliseconds per stage (setup, camera_loop, exchange, fixed, sample, cameras
+    rendered); the device is synchronised at every stage boundary, so only diagnostics passes ask for it (bench.py's
+    `per_rank` block)."""
     from g2pc.dist import rank_world
     s = pointcloud_settings
     device = gaussians.xyz.device
     rank, world = (0, 1) if single_process else rank_world(group)
+
+    import time as _time
+    _t_last = [_time.perf_counter()]
+
+    def _stage(name):
+        if stage_times is None:
+            return
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+        now = _time.perf_counter()
+        stage_times[name] = stage_times.get(name, 0.0) + (now - _t_last[0]) * 1e3
+        _t_last[0] = now
 
     # Calculate Gaussian Normals
     if s.calculate_normals:
@@ -220,6 +236,8 @@ def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, poin
             # (16384 leaf tiles; 63 cameras per epoch instead of 255)
             gaussian_renderer.seq_bits = 14
             epoch = min(CAMERA_EPOCH, gaussian_renderer.camera_epoch)
+        _stage("setup_ms")
+        _rendered = 0
         for cam_index, (img_name, transform) in enumerate(transforms.items()):
             epochs = getattr(gaussian_renderer, "needs_camera_epochs", False)
             if world > 1:
@@ -234,12 +252,18 @@ def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, poin
                 camera = get_camera(s.renderer_type, torch.tensor(list(transform)), intrinsics[img_name],
                                     colour_resolution=s.colour_resolution, sh_degree=s.max_sh_degree, white_bkgd=True, mask=mask)
             # Render new image and Gaussian contributions (the image itself is not used by the pipeline)
+            _rendered += 1
             if world > 1:
                 gaussian_renderer(camera, return_image=False, slot=(cam_index % epoch if epochs else cam_index) + 1)
             else:
                 gaussian_renderer(camera, return_image=False)
+        if stage_times is not None:
+            gaussian_renderer.get_gaussian_colours()          # drains the cameras in flight and resolves the colours
+            stage_times["cameras"] = _rendered
+        _stage("camera_loop_ms")
         if world > 1:
             gaussian_renderer.all_reduce_visibility(group)
+        _stage("exchange_ms")
 
         if not s.quiet:
             print()
@@ -298,6 +322,7 @@ def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, poin
         total_gaussian_contributions = gaussians.select(total_gaussian_contributions)      # [invalid_gaussian_indices]
 
     num_sample_attempts = 5 if not s.exact_num_points else 100
+    _stage("fixed_ms")
 
     if not s.quiet:
         print()
@@ -313,6 +338,7 @@ def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, poin
                                                    shard=(rank, world))
 
     total_point_cloud = PointCloudData(points=points, colours=colours, normals=normals)
+    _stage("sample_ms")
 
     surface_point_cloud = None
 

@@ -34,3 +34,26 @@ def test_configs2_scene_two_cameras_against_reference(t_floor):
         assert abs(r["sample_points"] - r["sample_points_ref"]) <= 16, r          # a flipped accept/reject can cost a point
         assert r["sample_rows_unmatched"] <= max(2, 1e-4 * r["sample_rows_compared"]) and r["sample_xyz_max"] < 1e-4, r
         assert r["sample_rgb_max"] is not None and r["sample_rgb_max"] < 1e-4, r
+
+
+def test_configs3_scene_one_camera_against_reference():
+    """BASELINE configs[3] at ITS OWN size -- 5 M Gaussians (the > 2 M code path: radix depth sort, multi-level scans, pair
+    instances), camera 17 of the 200-camera rig at 1280x720, cull -> validate -> magnitudes -> distribute_points(50 M) ->
+    sampler -- against the untouched reference (oracle/make_golden.py render_5m: 394 s for the camera, 85 s for the 50 M-point
+    cloud on 8 CPU threads).  The fixture is compact: visible / culled / keep masks and K1 fingerprints for ALL 5 M Gaussians,
+    contributions at every 4th, colours at every 16th, cloud rows at every 256th."""
+    import parity_cfg2
+    assert parity_cfg2.available("5m")
+    r = parity_cfg2.run("cuda:0", tag="5m")
+    print(r)
+    assert r["gaussians"] == 5_000_000 and r["rig"] == 200
+    assert r["mask_flips"] == 0 and r["culled_equal"], r
+    assert r["contrib_max"] < 1e-5 and r["contrib_frac_gt_1e-4"] == 0.0, r
+    assert r["image_max"] < 1e-4 and r["image_frac_gt_1e-4"] == 0.0, r
+    assert r["colour_max"] < 1e-4 and r["colour_frac_gt_1e-4"] == 0.0, r
+    assert all(k["in_mask_flips"] == 0 and k["k1_mismatch"] <= 15 and k["radius_mismatch"] <= 15 for k in r["k1"]), r["k1"]
+    assert r["keep_equal"] and r["ppg_mismatch_given_ref_contrib"] == 0, r
+    assert 0 <= r["ppg_mismatch_end_to_end"] <= 25 and r["ppg_max_abs_diff_end_to_end"] <= 1, r
+    assert abs(r["sample_points"] - r["sample_points_ref"]) <= 64, r
+    assert r["sample_rows_unmatched"] <= max(2, 1e-4 * r["sample_rows_compared"]) and r["sample_xyz_max"] < 1e-4, r
+    assert r["sample_rgb_max"] is not None and r["sample_rgb_max"] < 1e-4, r

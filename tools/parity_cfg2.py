@@ -79,9 +79,14 @@ def _k1_report(g, k, cam, xyz, cov, n):
     h = k1_hash8(z(mx), z(my), z(rad), view[:, 2].cpu().numpy())
     r3 = np.minimum(z(rad) / 3.0, 255).astype(np.uint8)
     c2 = cov2d.reshape(n, 4).cpu().numpy()
-    out = dict(in_mask_flips=int((m != ref_m).sum()), k1_mismatch=int((h != g["cam%d_k1_hash8" % k]).sum()),
-               radius_mismatch=int((r3 != g["cam%d_radius_div3_u8" % k]).sum()),
-               cov2d_mismatch=int((k1_hash8(*[c2[:, j] for j in range(4)]) != g["cam%d_cov2d_hash8" % k]).sum()))
+    if "cam%d_cov2d_hash8" % k in g.files:
+        out = dict(in_mask_flips=int((m != ref_m).sum()), k1_mismatch=int((h != g["cam%d_k1_hash8" % k]).sum()),
+                   radius_mismatch=int((r3 != g["cam%d_radius_div3_u8" % k]).sum()),
+                   cov2d_mismatch=int((k1_hash8(*[c2[:, j] for j in range(4)]) != g["cam%d_cov2d_hash8" % k]).sum()))
+    else:           # compact fixtures (5 M Gaussians): projected mean, radius, depth AND cov2d in one fingerprint byte
+        h = k1_hash8(z(mx), z(my), z(rad), view[:, 2].cpu().numpy(), *[c2[:, j] for j in range(4)])
+        out = dict(in_mask_flips=int((m != ref_m).sum()), k1_mismatch=int((h != g["cam%d_k1_hash8" % k]).sum()),
+                   radius_mismatch=int((r3 != g["cam%d_radius_div3_u8" % k]).sum()))
     s = slice(None, None, 64)
     out["means2D_s64_bit_mismatch"] = int((np.stack([z(mx), z(my)], 1)[s].view(np.uint32) != g["cam%d_means2D_s64" % k].view(np.uint32)).any(axis=1).sum())
     return out
@@ -130,14 +135,16 @@ def run(device="cuda:0", t_floor=None, sampler=True, tag="1m"):
     width, height, focal = (int(g["width"]), int(g["height"]), float(g["focal"])) if "width" in g.files else (1280, 720, 1100.0)
     dev = torch.device(device)
     sc = make_scene(n, seed)
-    transforms, intr = make_cameras(50, width=width, height=height, focal=focal)
+    rig = int(g["rig"]) if "rig" in g.files else 50
+    cs = int(g["contrib_stride"]) if "contrib_stride" in g.files else 1       # compact fixtures: every cs-th contribution
+    transforms, intr = make_cameras(rig, width=width, height=height, focal=focal)
     names = sorted(transforms)
     G = Gaussians(sc.xyz.to(dev), sc.scales.to(dev), sc.rots.to(dev), sc.colours.to(dev), sc.opacities.to(dev))
     R = gauss_render.get_renderer("python", G.xyz, torch.unsqueeze(torch.clone(G.opacities), 1), G.colours,
                                   G.covariances, visible_gaussian_threshold=0.05)
     if t_floor is not None:
         R.t_floor = float(t_floor)
-    out = {"gaussians": n, "cameras": [int(c) for c in g["cam_ids"]], "resolution": "%dx%d" % (width, height),
+    out = {"gaussians": n, "cameras": [int(c) for c in g["cam_ids"]], "rig": rig, "resolution": "%dx%d" % (width, height),
            "t_floor": float(R.t_floor), "oracle": "untouched reference on CPU (oracle/make_golden.py render_big)"}
     if "tie_spread" in g.files:
         # how far the reference lands from ITSELF when torch.sort (stable=False) orders depth ties its own way instead of
@@ -149,7 +156,9 @@ def run(device="cuda:0", t_floor=None, sampler=True, tag="1m"):
     has_k1 = "cam0_view" in g.files
     if has_k1:
         c9 = G.covariances.reshape(n, 9).cpu().numpy()
-        out["cov3d_rows_differing"] = int((k1_hash8(*[c9[:, j] for j in (0, 1, 2, 4, 5, 8)]) != g["cov3d_hash8"]).sum())
+        hs = n // int(g["cov3d_hash8"].shape[0]) if g["cov3d_hash8"].shape[0] < n else 1      # compact: every 4th row
+        out["cov3d_rows_differing"] = int((k1_hash8(*[c9[::hs, j] for j in (0, 1, 2, 4, 5, 8)]) != g["cov3d_hash8"]).sum())
+        out["cov3d_rows_compared"] = int(g["cov3d_hash8"].shape[0])
         out["k1"] = []
     for k, ci in enumerate(g["cam_ids"]):
         name = names[int(ci)]
@@ -173,21 +182,22 @@ def run(device="cuda:0", t_floor=None, sampler=True, tag="1m"):
             out["contrib_cam0_max"] = float(np.abs(c0 - g["contrib_cam0_s8"]).max())
     out["image_max"], out["image_frac_gt_1e-4"] = img_max, img_frac
     c = R.gaussian_max_contribution.cpu().numpy()
-    ref_c = g["contrib_final"]
-    dc = np.abs(c - ref_c)
+    ref_c = g["contrib_final"]                      # every cs-th Gaussian (cs = 1: all of them)
+    dc = np.abs(c[::cs] - ref_c)
     out["contrib_max"], out["contrib_frac_gt_1e-4"] = float(dc.max()), float((dc > 1e-4).mean())
+    out["contrib_compared"] = int(ref_c.shape[0])
     vis = R.get_visible_gaussians().cpu().numpy()
-    ref_vis = _bits(g["visible_bits"], n)
+    ref_vis = _bits(g["visible_bits"], n)           # the mask itself: all n Gaussians
     flips = np.nonzero(vis != ref_vis)[0]
     out["mask_flips"] = int(flips.size)
-    out["mask_flip_margins"] = [float(x) for x in np.abs(ref_c[flips] - 0.05)[:16]]
+    out["mask_flip_margins"] = [float(x) for x in np.abs(c[flips] - 0.05)[:16]]
     out["near_threshold_1e-5"] = int((np.abs(ref_c - 0.05) < 1e-5).sum())
     out["visible"] = int(ref_vis.sum())
     cols = (R.get_gaussian_colours().cpu().numpy() / 255.0)[::16]
     ref_cols = g["colours_s16"] / 255.0
     # below the floor a Gaussian may stay colourless; with floor 0 the same holds where the transmittance is at the edge of
     # fp32 (contributions < 1e-12: T underflows to 0 a few list entries earlier or later than the reference's cumprod)
-    seen = ref_c[::16] > max(R.t_floor, 1e-12)
+    seen = (ref_c[::16 // cs] if 16 % cs == 0 else c[::16]) > max(R.t_floor, 1e-12)
     dcol = np.abs(cols - ref_cols)[seen]
     out["colour_max"], out["colour_frac_gt_1e-4"] = float(dcol.max()), float((dcol.max(axis=1) > 1e-4).mean())
 
@@ -231,9 +241,10 @@ def run(device="cuda:0", t_floor=None, sampler=True, tag="1m"):
         direct_ok = False
         ours = pts.cpu().numpy()
         ours_rgb = cols2.cpu().numpy()
-        ref_rows = np.arange(0, int(s["m"]), 64)
+        rs = int(s["row_stride"]) if "row_stride" in s.files else 64
+        ref_rows = np.arange(0, int(s["m"]), rs)
         if pts.shape[0] == int(s["m"]):
-            dx = np.abs(ours[::64] - s["points_s64"]).max(axis=1)
+            dx = np.abs(ours[::rs] - s["points_s64"]).max(axis=1)
             out["sample_rows_compared"] = int(dx.shape[0])
             out["sample_rows_same_position"] = int((dx <= 1e-4).sum())
             direct_ok = bool((dx <= 1e-4).all())
@@ -241,7 +252,7 @@ def run(device="cuda:0", t_floor=None, sampler=True, tag="1m"):
                 out["sample_xyz_max"] = float(dx.max())
                 out["sample_rows_unmatched"] = 0
                 out["sample_rows_order_shifted"] = {"first_row": None, "count": 0}
-                out["sample_rgb_max"] = float(np.abs(ours_rgb[::64] - s["colours_s64"]).max() / 255.0)
+                out["sample_rgb_max"] = float(np.abs(ours_rgb[::rs] - s["colours_s64"]).max() / 255.0)
         if not direct_ok:
             # An accept/reject decision within fp32 rounding of the 2-sigma threshold (~1 per 1e7 draws between the
             # reference's torch.inverse route and any other evaluation) changes one Gaussian's d in
