@@ -166,7 +166,47 @@ def pmc_valu(region, a):
     if not rec:
         return None
     return {"insts": rec["SQ_INSTS_VALU"], "cycles_per_inst": 4.0 * rec["SQ_ACTIVE_INST_VALU"] / rec["SQ_INSTS_VALU"],
-            "source": PMC_SQ_FILE}
+            "wave_cycles": 4.0 * rec["SQ_WAVE_CYCLES"], "source": PMC_SQ_FILE}
+
+
+GPU_CLOCK_HZ = 2.4e9
+SIMDS = 1024                       # 256 CUs x 4 SIMDs
+VALU_RATES_FILE = "profiles/r02c_valu_rates.json"     # tools/experiments/ubench: issue rates measured on the MI355X
+
+
+def valu_roof(valu, launch_s, kernel_substring):
+    """The VALU side of the blend's roofline, every figure recomputable from the line: wave64 VALU instructions per launch
+    (committed SQ PMC pass) over the launch duration, against
+      * the ARCHITECTURAL issue rate: one wave-instruction per 2 cycles and SIMD (MI355X_MICROARCH.md, Wave scheduling: "a
+        wave issues each VALU instruction over 2 cycles") = 1024 SIMDs x 2.4 GHz / 2;
+      * the MIX-AWARE rate: what `v_fma_f32` sustains with 8 waves per SIMD in the issue-rate micro-benchmark
+        (profiles/r02c_valu_rates.json: 2.45 cycles).
+    `busy_frac` is the share of the launch in which the VALU was busy at all (4 x SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU cycles
+    per instruction: round 3 printed this as `frac` -- it is not a roofline fraction).  avg_resident_waves_per_simd =
+    4 x SQ_WAVE_CYCLES / 1024 SIMDs / launch cycles; vgpr / max_waves_per_simd from the shipped code object."""
+    ach = valu["insts"] / launch_s
+    arch = SIMDS * GPU_CLOCK_HZ / 2.0
+    mix_cycles = 2.45
+    try:
+        rates = json.load(open(os.path.join(ROOT, VALU_RATES_FILE)))
+        mix_cycles = float(rates["v_fma_f32 @8 waves/SIMD"]["cycles_at_2.4GHz"])
+    except Exception:
+        pass
+    out = {"wave_insts_per_launch": valu["insts"], "achieved": ach, "unit": "wave-instructions/s", "source": valu["source"],
+           "peak_architectural": arch, "frac_architectural": ach / arch,
+           "peak_mix_aware": SIMDS * GPU_CLOCK_HZ / mix_cycles, "frac_mix_aware": ach / (SIMDS * GPU_CLOCK_HZ / mix_cycles),
+           "mix_cycles_per_inst": mix_cycles, "mix_source": VALU_RATES_FILE,
+           "busy_frac": ach / (SIMDS * GPU_CLOCK_HZ / valu["cycles_per_inst"]),
+           "avg_resident_waves_per_simd": valu["wave_cycles"] / SIMDS / (launch_s * GPU_CLOCK_HZ)}
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from kernel_meta import kernel_meta
+        km = kernel_meta(kernel_substring)
+        if km:
+            out.update(vgpr=km["vgpr_count"], lds_bytes=km["group_segment_fixed_size"], max_waves_per_simd=km["max_waves_per_simd"])
+    except Exception:
+        pass
+    return out
 
 
 def cpu_baseline(workload, full_n, full_cams, full_points, n=200_000, pts=1_000_000):
@@ -266,8 +306,136 @@ def extra_sample_line(a, device):
                         "frac": b / dt / 1e9 / HBM_PEAK_GBS}}
 
 
+def relaunch_for_gpus(a):
+    """`python bench.py --gpus N` without a torch.distributed environment: re-execute under torch.distributed.run (one rank
+    per GPU, RCCL).  Never falls through to a one-rank run that would print n_gpus: 1 for an N-GPU request."""
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if a.gpus > 1 and a.gpus != world:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world), file=sys.stderr)
+        sys.exit(2)
+
+
+def extra_render_line(a, device, workload, t_floor=None, steps=3, warm=2):
+    """BASELINE configs[4] (`render_cuda`: native-rasteriser semantics, SH degree 3, surface distance, exact points) or the
+    to-the-letter mode of configs[2] (`render`, t_floor = 0: no transmittance floor, k_blend_py_pk), timed like the main
+    workload -- `steps` whole jobs between synchronisations, inputs resident -- with the roofline of ITS dominant kernel:
+    launch duration from HIP events on the launch stream around that kernel alone (one camera in flight), algorithmic bytes
+    56 L + 32 W H per launch."""
+    import gauss_render
+    from g2pc import _native as nv
+    from g2pc.synth import make_scene, make_cameras
+    saved_floor = gauss_render.DEFAULT_T_FLOOR
+    if t_floor is not None:
+        gauss_render.DEFAULT_T_FLOOR = t_floor
+    gauss_render.clear_context_pool()
+    try:
+        scene = make_scene(a.gaussians, 1234 + 3, device=device, with_sh=(workload == "render_cuda"))
+        cams = make_cameras(a.cameras)
+        for w in range(warm):
+            one_step(scene, cams, workload, a.points, device, seed=500 + w)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pts = 0
+        for i in range(steps):
+            pts += one_step(scene, cams, workload, a.points, device, seed=600 + i)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        out = {"value": pts / steps / dt, "unit": "points/s", "ms_per_step": dt * 1e3, "steps": steps, "warmup": warm}
+        # the dominant kernel alone on the device: three cameras of the rig, one at a time
+        names = sorted(cams[0])[:3]
+        wh = 1280 * 720
+        if workload == "render_cuda":
+            import camera_handler
+            from gauss_handler import Gaussians
+            g = Gaussians(scene.xyz, scene.scales, scene.rots, scene.colours.clone(), scene.opacities, shs=scene.shs)
+            R = gauss_render.get_renderer("cuda", g.xyz, g.opacities.unsqueeze(1), g.colours, g.covariances, shs=g.shs,
+                                          visible_gaussian_threshold=0.05, surface_distance_std=2.0, calculate_surface_distance=True)
+            nv.PROFILE = {}
+            Ls = []
+            for rep in range(2):
+                nv.PROFILE.clear()
+                Ls = []
+                for i, nm in enumerate(names):
+                    cam = camera_handler.get_camera("cuda", torch.tensor(cams[0][nm]), cams[1][nm], colour_resolution=1280, sh_degree=3)
+                    c, campos, mask = R._camera(cam)
+                    sc = R._sync
+                    R._front(sc, c, campos, cam.sh_degree)
+                    L = int(sc.offsets[R.n].item())
+                    Ls.append(L)
+                    R._back(sc, c, mask, L, i, 1, "raster_bin_cu")
+                    R._back(sc, c, mask, L, i, 2, "raster_blend_cu")
+                    R._back(sc, c, mask, L, i, 4, "raster_update_cu")
+                torch.cuda.synchronize()
+            prof = nv.profile_summary()
+            nv.PROFILE = None
+            kernel, region, L_avg = "g2pc::k_blend_cu", "raster_blend_cu", float(np.mean(Ls))
+            del R
+        else:
+            saved = gauss_render.PIPELINE_STREAMS
+            gauss_render.PIPELINE_STREAMS = 1
+            gauss_render.RENDER_STATS.clear()
+            sub = ({k: cams[0][k] for k in names}, {k: cams[1][k] for k in names})
+            nv.PROFILE = {}
+            one_step(scene, sub, workload, a.points, device, seed=700)
+            torch.cuda.synchronize()
+            nv.PROFILE.clear()
+            gauss_render.RENDER_STATS.clear()
+            one_step(scene, sub, workload, a.points, device, seed=701)
+            torch.cuda.synchronize()
+            prof = nv.profile_summary()
+            nv.PROFILE = None
+            gauss_render.PIPELINE_STREAMS = saved
+            kernel, region = "g2pc::k_blend_py_pk<4>" if t_floor == 0.0 else BLEND_KERNEL, "raster_blend"
+            L_avg = float(np.mean([x[0] for x in gauss_render.RENDER_STATS])) if gauss_render.RENDER_STATS else float("nan")
+            gauss_render.RENDER_STATS.clear()
+        if region in prof and prof[region][0] > 0:
+            launches, ms = prof[region]
+            per_launch = 56.0 * L_avg + 32.0 * wh
+            ach = per_launch / (ms / launches * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ms / launches, "launches_timed": launches,
+                               "algorithmic_bytes_per_launch": per_launch, "instances_per_camera": L_avg,
+                               "avg_launch_ms_source": "HIP events on the launch stream around the kernel alone, cameras %s of the rig" % names}
+        return out
+    finally:
+        gauss_render.DEFAULT_T_FLOOR = saved_floor
+        gauss_render.clear_context_pool()
+
+
+def per_rank_stages(scene, cams, workload, total_points, device, world):
+    """One UNTIMED job with the device synchronised at every stage boundary (convert_gaussians_to_pc(stage_times=...)),
+    gathered from all ranks: what each rank spent in its camera loop, the visibility exchange, the per-job fixed work and
+    its sampling shard -- the breakdown a measured 1 -> N curve is read against."""
+    from gauss_handler import Gaussians
+    from gauss_to_pc import convert_gaussians_to_pc
+    g = Gaussians(scene.xyz, scene.scales, scene.rots, scene.colours.clone(), scene.opacities, shs=scene.shs)
+    st = {}
+    transforms, intr = cams if cams is not None else (None, None)
+    convert_gaussians_to_pc(g, transforms, intr, None, settings(workload, total_points, device), seed=950,
+                            render_shs=(workload == "render_cuda"), stage_times=st)
+    st = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in st.items()}
+    if world > 1:
+        import torch.distributed as dist
+        st["rank"] = dist.get_rank()
+        allst = [None] * world
+        dist.all_gather_object(allst, st)
+        return allst
+    st["rank"] = 0
+    return [st]
+
+
 def main():
     a = parse()
+    relaunch_for_gpus(a)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -416,6 +584,11 @@ def main():
         prof_alone = profile_pass(1) if workload == "render" else prof
         gauss_render.RENDER_STATS[:] = timed_stats
 
+    per_rank = None
+    if not a.no_profile_pass and workload != "sample":
+        per_rank = per_rank_stages(scene, cams, workload, total_points, device, world)   # every rank takes part (collectives inside)
+        gauss_render.RENDER_STATS[:] = timed_stats
+
     tot = torch.tensor([float(points), dt], dtype=torch.float64, device=device)
     if world > 1:
         import torch.distributed as dist
@@ -464,13 +637,7 @@ def main():
                     if name == "raster_blend" else None}
             valu = pmc_valu(name, a)
             if valu is not None:
-                # the bound that applies to this kernel: VALU issue.  wave64 instructions per launch from the committed SQ
-                # PMC pass, 4 SIMDs x 256 CUs issuing one wave-instruction per 4.3 cycles (measured: ACTIVE_INST_VALU /
-                # INSTS_VALU) at 2.4 GHz
-                peak = 1024 * 2.4e9 / valu["cycles_per_inst"]
-                roof["valu"] = {"wave_insts_per_launch": valu["insts"], "achieved": valu["insts"] / (ms / launches * 1e-3),
-                                "peak": peak, "unit": "wave-instructions/s", "source": valu["source"],
-                                "frac": valu["insts"] / (ms / launches * 1e-3) / peak}
+                roof["valu"] = valu_roof(valu, ms / launches * 1e-3, BLEND_KERNEL.split("::")[-1].split("<")[0])
     stats = gauss_render.RENDER_STATS[-(len(gauss_render.RENDER_STATS) // max(a.steps, 1)):] if gauss_render.RENDER_STATS else []
     b_total = algorithmic_bytes(workload, a.gaussians, a.gaussians, points / max(a.steps, 1), cams, stats)
     job_hbm = {"algorithmic_bytes_per_step": b_total, "achieved": b_total / (dt / a.steps) / 1e9, "peak": HBM_PEAK_GBS,
@@ -497,12 +664,27 @@ def main():
         "regions_ms_per_step": {k: v[1] for k, v in sorted(prof.items())},
         "regions_note": "HIP-event spans of ONE untimed job after the timed loop (production stream count: spans of different "
                         "cameras overlap, their sum may exceed ms_per_step); the timed loop itself records no events",
+        "per_rank": per_rank,
+        "per_rank_note": "one untimed job with the device synchronised at every stage boundary: milliseconds per rank for renderer "
+                         "set-up, the camera loop (cameras = how many this rank rendered), the RCCL visibility exchange, the per-job "
+                         "fixed work (getters, cull, filter, validate) and the rank's sampling shard",
+        "rccl_world_size": (__import__("torch").distributed.get_world_size() if world > 1 else 1),
         "first_job_ms": first_job_ms,
         "process_warmup_ms": warmup_s * 1e3,
         "first_job_points_per_s": (first_job_points * world / (first_job_ms * 1e-3)) if first_job_ms else None,
     }
     if world == 1 and workload == "render" and not config4 and not a.no_extra and not a.camera_subset:
         out["extra_workloads"] = {"sample": extra_sample_line(a, device)}
+        if not emulate and (a.gaussians, a.cameras) == (1_000_000, 50):
+            # the figures README / DESIGN quote beside the headline, measured by THIS command on THIS box
+            x = extra_render_line(a, device, "render_cuda")
+            x["config"] = ("configs[4]: 1M Gaussians, 50 cameras, native-rasteriser semantics, SH degree 3, surface_distance_std=2.0, "
+                           "exact_num_points, 10M points")
+            out["extra_workloads"]["render_cuda"] = x
+            x = extra_render_line(a, device, "render", t_floor=0.0)
+            x["config"] = ("configs[2] with blend_transmittance_floor = 0: the reference's python-renderer semantics to the letter "
+                           "(no visit dropped, k_blend_py_pk)")
+            out["extra_workloads"]["exact"] = x
     if world == 1 and workload == "render" and not a.no_parity:
         # parity gates, outside the timed region: the same scene, cameras 0 and 17 of the same rig, against
         # outputs of the untouched reference (tests/golden/*_cfg2_1m.npz); tools/parity_cfg2.py documents every key

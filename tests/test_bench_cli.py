@@ -47,3 +47,27 @@ def test_bench_two_ranks_under_torch_distributed_run():
     d = _line(r.stdout)                      # exactly ONE line, from rank 0
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["cameras"] == 4 and d["config"]["cameras_per_gpu"] == 2       # the job is split, not multiplied
+
+
+def test_bare_gpus_flag_relaunches_itself_under_torch_distributed_run():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment used to run ONE rank and print
+    n_gpus: 1.  It now re-executes itself under torch.distributed.run; the line carries the per-rank stage breakdown."""
+    from emu_util import build_emu
+    build_emu()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, env=_env(), cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and d["rccl_world_size"] == 2
+    pr = d["per_rank"]
+    assert [x["rank"] for x in pr] == [0, 1] and sum(x["cameras"] for x in pr) == 4
+    for x in pr:
+        for k in ("setup_ms", "camera_loop_ms", "exchange_ms", "fixed_ms", "sample_ms"):
+            assert x[k] >= 0.0, (k, x)
+
+
+def test_gpus_flag_that_disagrees_with_the_launch_fails():
+    env = dict(_env(), WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
