@@ -113,6 +113,41 @@ __device__ __forceinline__ Normal3 keyed_normal3(unsigned seed_lo, unsigned seed
     return o;
 }
 
+// ---- exp(x) in double from IEEE operations only, rounded ONCE to f32 ----------------------------------------------------
+// k = rint(x log2 e), r = x - k ln2 (two-part ln2: exact products), exp(r) by its Taylor series to r^14 (|r| <= 0.347:
+// truncation 1e-19) in Horner form with explicit fma, scaled by 2^k.  The double result is within ~2e-16 of exp(x), so its
+// rounding to float IS the correctly rounded f32 exponential except where exp(x) lies within 2e-16 of a rounding boundary
+// (~1e-8 of all arguments) -- and, unlike a library exp (the device's double exp landed 1.6 % of its results on the other
+// side of an f32 rounding boundary: 7.5 % of the covariance rows differed from the host build's, 2.8 % now, the same rows on
+// the MI355X and in the CPU emulator build), it is the SAME function on every target: only +, *, fma, rint.
+__device__ __forceinline__ float exp_cr(float xf) {
+    const double x = (double)xf;
+    if (!(x > -104.0)) return x != x ? xf : 0.0f;                 // below the smallest denormal (NaN passes through)
+    if (x > 88.8) return __builtin_inff();
+    const double kd = rint(x * 1.4426950408889634074);
+    double r = fma(-kd, 6.93147180369123816490e-01, x);
+    r = fma(-kd, 1.90821492927058770002e-10, r);
+    double p = 1.1470745597729725e-11;                            // 1/14!
+    p = fma(p, r, 1.6059043836821613e-10);                        // 1/13!
+    p = fma(p, r, 2.08767569878681e-09);                          // 1/12!
+    p = fma(p, r, 2.505210838544172e-08);                         // 1/11!
+    p = fma(p, r, 2.755731922398589e-07);                         // 1/10!
+    p = fma(p, r, 2.7557319223985893e-06);                        // 1/9!
+    p = fma(p, r, 2.48015873015873e-05);                          // 1/8!
+    p = fma(p, r, 0.0001984126984126984);                         // 1/7!
+    p = fma(p, r, 0.001388888888888889);                          // 1/6!
+    p = fma(p, r, 0.008333333333333333);                          // 1/5!
+    p = fma(p, r, 0.041666666666666664);                          // 1/4!
+    p = fma(p, r, 0.16666666666666666);                           // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const long long k = (long long)kd;                            // |k| <= 151: 2^k is a normal double
+    union { long long i; double d; } two_k;
+    two_k.i = (k + 1023) << 52;
+    return (float)(p * two_k.d);
+}
+
 // ---- symmetric 3x3 eigenvalues (trigonometric closed form, fp64) --------------------------------
 __device__ __forceinline__ void sym3_eigvals(double a00, double a01, double a02, double a11, double a12,
                                              double a22, double e[3]) {

@@ -34,9 +34,10 @@ __global__ __launch_bounds__(GEO_T) void k_build_cov(const float* __restrict__ l
 #pragma unroll
             for (int b = 0; b < 3; ++b) rotmat[9 * i + 3 * a + b] = R[a][b];
     }
-    // exp in double, rounded once: the correctly rounded f32 exponential.  torch.exp on the CPU (MKL VML, high-accuracy mode)
-    // returns it for 98.9 % of its arguments (measured, tools/torch_order_probe.py); a 1-ulp f32 expf would halve that.
-    float e[3] = {(float)exp((double)(mod * s0)), (float)exp((double)(mod * s1)), (float)exp((double)(mod * s2))};
+    // exp in double from IEEE operations only, rounded once (exp_cr, g2pc_device.inl): the correctly rounded f32 exponential,
+    // bit for bit the same on the device and in the CPU build.  torch.exp on the CPU (MKL VML, high-accuracy mode) returns it
+    // for 98.9 % of its arguments (measured, tools/torch_order_probe.py); a 1-ulp f32 expf would halve that.
+    float e[3] = {exp_cr(mod * s0), exp_cr(mod * s1), exp_cr(mod * s2)};
     float L[3][3];
 #pragma unroll
     for (int a = 0; a < 3; ++a)

@@ -870,6 +870,221 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_dl(Layout lay, const int32_t*
     }
 }
 
+// K6 (PY), two-wave form of the dual-list kernel (round 4): one 128-thread block per chunk, wave w blends sub-block w.
+// A batch is 128 list entries, one per thread; each is tested against BOTH sub-blocks and appended -- in depth order:
+// wave 0's survivors before wave 1's -- to the lists it can touch; then every wave walks only ITS list.  Loads, tests,
+// (pixel, Gaussian) visits and every floating-point operation are those of k_blend_py_dl (results bit-identical), but a
+// chunk's serial chain is half as long: a lone wave issues one VALU instruction per ~6 cycles whatever its instruction-level
+// parallelism (profiles/r02c_valu_rates.json: 6.1 cycles with one wave per SIMD, 3.4 with two, 2.45 with eight), and a
+// launch lasts as long as its longest walk -- the tail of the single-wave kernel is 2 waves per SIMD on
+// average, here the same work is spread over twice the waves.  Two barriers per batch (lists complete / lists consumed).
+template <int U>
+__global__ __launch_bounds__(2 * BL_T) __attribute__((amdgpu_waves_per_eu(5))) void k_blend_py_2w(Layout lay, const int32_t* __restrict__ chunk_tile,
+                                                         const int32_t* __restrict__ chunk_pix0,
+                                                         const uint2* __restrict__ tile_range,
+                                                         const uint32_t* __restrict__ inst_g, uint32_t gmask,
+                                                         const float4* __restrict__ rec,
+                                                         unsigned long long* __restrict__ best_key, uint32_t order_base,
+                                                         float t_floor, float bg, float* __restrict__ tilebuf,
+                                                         uint32_t* __restrict__ chunk_work,
+                                                         const G2pcCameraJob* __restrict__ job, size_t cs) {
+    const unsigned chunk_i = blockIdx.z * gridDim.y + blockIdx.y;       // camera = blockIdx.x, chunk in (y, z)
+    if ((int)chunk_i >= lay.num_chunks) return;
+    tile_range = seg_at(tile_range, cs, blockIdx.x); inst_g = seg_at(inst_g, cs, blockIdx.x); rec = seg_at(rec, cs, blockIdx.x);
+    if (job) {
+        job += blockIdx.x;
+        order_base = job->camera_slot << (12 + lay.seq_bits); t_floor = job->t_floor; bg = job->cam.bg[0];
+        const unsigned long long tb = ((unsigned long long)job->tilebuf_hi << 32) | job->tilebuf_lo;
+        if (tb) tilebuf = (float*)tb;
+    }
+    const unsigned long long clk0 = chunk_work ? wall_clock64() : 0ull;     // diagnostics only
+    constexpr int NB = 2 * BL_BATCH;                // list entries per batch
+    __shared__ float4 s_a[2][NB + 4];               // A, B, C, Lu
+    __shared__ float4 s_b[2][NB + 4];               // Lv, K, red, green
+    __shared__ float2 s_c[2][NB + 4];               // blue, max(running maximum, FLT_MIN)
+    __shared__ uint32_t s_g[2][NB];
+    __shared__ int s_cnt[2][2][2];                  // [parity of the batch][wave][list] survivors
+    __shared__ int s_done[2];                       // sub-block saturated (or absent)
+    const int tile = chunk_tile[chunk_i];
+    const uint32_t sbpair = (uint32_t)chunk_pix0[chunk_i];    // a | b << 16, b = 0xFFFF: none
+    const int ix = tile % lay.nx, iy = tile / lay.nx;
+    const int x0 = lay.xs[ix], w = lay.ws[ix], y0 = lay.ys[iy], h = lay.hs[iy];
+    const int nsbx = (w + 7) >> 3;
+    const uint32_t order_tile = order_base | ((uint32_t)lay.tile_seq[tile] << 12);
+    const unsigned tid = threadIdx.x, lane = tid & 63;
+    const int wv = (int)(tid >> 6);                 // this wave's sub-block / list
+    const int lx = lane & 7, ly = lane >> 3;
+    const float uu = (float)lx - 3.5f, vv = (float)ly - 3.5f;
+
+    float ox[2], oy[2], rx1[2], ry1[2];
+    bool dn[2];                                     // block-uniform view of s_done, one batch old
+    int mypix = -1;
+    float T = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int sb = (int)((sbpair >> (16 * j)) & 0xFFFFu);
+        const bool present = sb != 0xFFFF;
+        const int sx = present ? (sb % nsbx) * 8 : 0, sy = present ? (sb / nsbx) * 8 : 0;
+        ox[j] = (float)(x0 + sx) + 3.5f;
+        oy[j] = (float)(y0 + sy) + 3.5f;
+        rx1[j] = (float)(x0 + (sx + 7 > w - 1 ? w - 1 : sx + 7));   // the cull rectangle stops at the tile's edge
+        ry1[j] = (float)(y0 + (sy + 7 > h - 1 ? h - 1 : sy + 7));
+        dn[j] = !present;
+        if (j == wv) {
+            const int x = sx + lx, y = sy + ly;
+            const bool valid = present && (x < w) && (y < h);
+            mypix = valid ? y * w + x : -1;
+            T = valid ? 1.0f : 0.0f;
+        }
+    }
+    bool mydone = dn[wv];
+    if (lane == 0) s_done[wv] = mydone ? 1 : 0;
+    const bool cull = t_floor > 0.0f;        // t_floor = 0 is the to-the-letter mode: nothing is skipped
+
+    const uint2 se = tile_range[tile];        // k_tile_gate: [first, end) of the tile's instances, empty for a gated tile
+    const uint32_t start = se.x, end = se.y;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t g_cur = 0, g_nxt = 0;
+    bool v_cur = (start + tid) < end, v_nxt = (start + NB + tid) < end;
+    if (v_cur) g_cur = inst_g[start + tid] & gmask;
+    if (v_nxt) g_nxt = inst_g[start + NB + tid] & gmask;
+    float4 r0 = zero4, r1 = zero4, r2 = zero4;
+    uint32_t gmb = 0x7F000000u;
+    if (v_cur) {
+        r0 = rec[4 * (size_t)g_cur];
+        r1 = rec[4 * (size_t)g_cur + 1];
+        r2 = rec[4 * (size_t)g_cur + 2];
+        gmb = ((const uint32_t*)best_key)[2 * (size_t)g_cur + 1];   // live running maximum
+    }
+    uint32_t processed = 0, visits = 0;
+    int par = 0;
+    for (uint32_t b = start; b < end; b += NB, par ^= 1) {
+        processed = b + NB - start;
+        // (1) test this thread's entry against both sub-blocks, count the survivors per wave
+        bool keep[2];
+        unsigned long long kept[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            keep[j] = !dn[j] && v_cur && (!cull || chunk_may_touch(r0, r1, r2.w, ox[j] - 3.5f, rx1[j], oy[j] - 3.5f, ry1[j]));
+            kept[j] = __ballot(keep[j] ? 1 : 0);
+        }
+        if (lane == 0) { s_cnt[par][wv][0] = __popcll(kept[0]); s_cnt[par][wv][1] = __popcll(kept[1]); }
+        __syncthreads();                    // counts and s_done published; both waves have left the previous batch's lists
+        dn[0] = s_done[0] != 0;
+        dn[1] = s_done[1] != 0;
+        if (dn[0] && dn[1]) break;          // block-uniform
+        int total[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c0 = s_cnt[par][0][j];
+            total[j] = c0 + s_cnt[par][1][j];
+            if (keep[j] && !dn[j]) {
+                const int pos = (wv ? c0 : 0) + __popcll(kept[j] & ((1ull << lane) - 1ull));
+                const float mx = r0.x - ox[j], my = r0.y - oy[j];
+                const float A = r0.z, B = r0.w, C = r1.x;
+                const float h1 = fmaf(A, mx, B * my);                                     // A mx + B my
+                const float Lu = -(fmaf(A, mx, h1)), Lv = -(fmaf(2.0f * C, my, B * mx));
+                const float K = fmaf(h1, mx, fmaf(C * my, my, -25.5f - r2.w));            // ... + log2(opacity)
+                s_a[j][pos] = make_float4(A, B, C, Lu);
+                s_b[j][pos] = make_float4(Lv, K, r2.x, r2.y);
+                s_c[j][pos] = make_float2(r2.z, fmaxf(__uint_as_float(gmb), 1.17549435e-38f));
+                s_g[j][pos] = g_cur;
+            }
+            if (wv == j && lane < (unsigned)U) {            // the last trip reads up to U - 1 entries past the end: alpha = 0 ones
+                s_a[j][total[j] + lane] = zero4;
+                s_b[j][total[j] + lane] = make_float4(0.f, -INFINITY, 0.f, 0.f);
+                s_c[j][total[j] + lane] = make_float2(0.f, 1.17549435e-38f);
+            }
+        }
+        // loads of the next batch (records) and the one after (ids): they complete under this batch's walk
+        g_cur = g_nxt;
+        v_cur = v_nxt;
+        v_nxt = (b + 2 * NB + tid) < end;
+        g_nxt = 0;
+        if (v_nxt) g_nxt = inst_g[b + 2 * NB + tid] & gmask;
+        r0 = zero4; r1 = zero4; r2 = zero4; gmb = 0x7F000000u;
+        if (v_cur) {
+            r0 = rec[4 * (size_t)g_cur];
+            r1 = rec[4 * (size_t)g_cur + 1];
+            r2 = rec[4 * (size_t)g_cur + 2];
+            gmb = ((const uint32_t*)best_key)[2 * (size_t)g_cur + 1];   // live running maximum
+        }
+        __syncthreads();                    // lists complete
+        // (2) this wave walks its own list
+        if (!mydone) {
+            const int cnt = total[wv];
+            visits += (uint32_t)cnt;
+            for (int k0 = 0; k0 < cnt; k0 += U) {
+                float alpha[U], contrib[U];
+                float4 qb[U];
+                float2 qc[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float4 a = s_a[wv][k0 + u];
+                    qb[u] = s_b[wv][k0 + u];
+                    qc[u] = s_c[wv][k0 + u];
+                    float t1 = fmaf(a.x, uu, a.w);
+                    t1 = fmaf(a.y, vv, t1);
+                    const float t2 = fmaf(a.z, vv, qb[u].x);
+                    float pw = fmaf(uu, t1, qb[u].y);
+                    pw = fmaf(vv, t2, pw);
+                    alpha[u] = fminf(__builtin_amdgcn_exp2f(pw), 0.99f);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    G2PC_PIN(alpha[u]);
+                    G2PC_PIN(qb[u].z); G2PC_PIN(qb[u].w); G2PC_PIN(qc[u].x); G2PC_PIN(qc[u].y);
+                }
+                bool any_cand = false;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    contrib[u] = T * alpha[u];
+                    cr = fmaf(contrib[u], qb[u].z, cr);
+                    cg = fmaf(contrib[u], qb[u].w, cg);
+                    cb = fmaf(contrib[u], qc[u].x, cb);
+                    T -= contrib[u];
+                    any_cand = any_cand || (contrib[u] >= qc[u].y);
+                }
+                if (__any(any_cand ? 1 : 0)) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (__any(contrib[u] >= qc[u].y)) {
+                            const uint32_t bits = __float_as_uint(contrib[u]);
+                            const uint32_t m = wave_max_u32_dpp(bits);
+                            const unsigned long long at_max = __ballot(bits == m);      // lowest lane = lowest pixel index
+                            const uint32_t pm = (uint32_t)__builtin_amdgcn_readlane(mypix, __ffsll(at_max) - 1);
+                            if (lane == 0) {
+                                unsigned long long key = ((unsigned long long)m << 32) | (unsigned long long)(uint32_t)(~(order_tile | pm));
+                                atomicMax(&best_key[s_g[wv][k0 + u]], key);
+                            }
+                        }
+                    }
+                }
+            }
+            mydone = __all(T <= t_floor ? 1 : 0) != 0;      // see k_blend_py
+            if (mydone && lane == 0) s_done[wv] = 1;         // read by both waves after the next batch's first barrier
+        }
+    }
+    if (chunk_work && lane == 0) {
+        uint32_t* cw = chunk_work + 8 * (size_t)chunk_i;
+        if (wv == 0) {
+            cw[0] = end - start;
+            cw[1] = processed;
+            cw[2] = (uint32_t)clk0;
+            cw[4] = g2pc_hw_id();
+            cw[5] = g2pc_xcc_id();
+        }
+        atomicMax(&cw[3], (uint32_t)(wall_clock64() - clk0));
+        atomicAdd(&cw[6], visits);
+    }
+    if (mypix >= 0) {
+        float* out = tilebuf + 3 * (size_t)lay.tile_pix_off[tile];
+        out[3 * (size_t)mypix + 0] = fmaf(T, bg, cr);
+        out[3 * (size_t)mypix + 1] = fmaf(T, bg, cg);
+        out[3 * (size_t)mypix + 2] = fmaf(T, bg, cb);
+    }
+}
+
 // K7 (PY): running update of the per-Gaussian colour: Gaussians whose best key was set by this camera slot take
 // the colour of the winning (tile, pixel) from that tile's own rendered colours (gauss_render.py:387-395).
 __global__ __launch_bounds__(RA_T) void k_update_colours_py(Layout lay, const unsigned long long* __restrict__ best_key,
@@ -1575,7 +1790,7 @@ struct PyFrontBuffers { float4* rec; uint32_t *rect, *sorted_idx, *offsets; };  
 static size_t py_front_ws(long n) {
     return align_up((size_t)n * 4) * 6 + sort_workspace(n) + scan_workspace(n) + bucket_sort_workspace(n) + 4096;
 }
-static int g_blend_variant = 1;               // 2 sub-blocks per wave: 1 = dual-list kernel (k_blend_py_dl), 0 = packed kernel (k_blend_py_pk)
+static int g_blend_variant = 1;               // 2 sub-blocks per chunk: 2 = two-wave dual-list kernel (k_blend_py_2w, one wave per sub-block), 1 = dual-list kernel (k_blend_py_dl), 0 = packed kernel (k_blend_py_pk)
 static int g_depth_bucket_sort = 1;           // captured camera path: 1 = bucket sort of the depth keys, 0 = radix (g2pc_set_depth_sort)
 // Packed tile-sort instances: when the tile id and the Gaussian index share one 32-bit word (tile << gshift | index) the
 // stable sort by tile moves keys only -- half the traffic of the two passes -- and the blend masks the index out.
@@ -1710,7 +1925,15 @@ static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t*
                 // operation order (k_blend_py_pk); the dual-list kernel's expanded exponent differs by up to ~2e-5 relative
                 // in alpha.  A captured camera reads t_floor from its device job: the caller says so with phase bit 8.
                 const bool exact = ba.job ? ((phases & 8) != 0) : (ba.t_floor == 0.0f);
-                if (g_blend_variant == 1 && !exact) G2PC_BLEND(k_blend_py_dl<4>);
+                if (g_blend_variant == 3 && !exact)
+                    hipLaunchKernelGGL((k_blend_py_2w<2>), dim3((unsigned)bt.n, chunks_y, cdiv(layout->num_chunks, chunks_y)), dim3(2 * BL_T), 0, s,
+                                       lay, layout->chunk_tile, layout->chunk_pix0, A.tile_range, blend_list, gmask, (const float4*)fb.rec,
+                                       best_key, ba.camera_slot << (12 + lay.seq_bits), ba.t_floor, ba.bg, tilebuf, g_chunk_work, ba.job, bt.cs);
+                else if (g_blend_variant == 2 && !exact)
+                    hipLaunchKernelGGL((k_blend_py_2w<4>), dim3((unsigned)bt.n, chunks_y, cdiv(layout->num_chunks, chunks_y)), dim3(2 * BL_T), 0, s,
+                                       lay, layout->chunk_tile, layout->chunk_pix0, A.tile_range, blend_list, gmask, (const float4*)fb.rec,
+                                       best_key, ba.camera_slot << (12 + lay.seq_bits), ba.t_floor, ba.bg, tilebuf, g_chunk_work, ba.job, bt.cs);
+                else if (g_blend_variant == 1 && !exact) G2PC_BLEND(k_blend_py_dl<4>);
                 else G2PC_BLEND(k_blend_py_pk<4>);
                 break;
             }

@@ -337,8 +337,8 @@ def gen_render_big(ref, tag="1m", n=1_000_000, num_points=10_000_000, width=1280
     running-max contribution of every Gaussian (f32; after camera 0: every 8th), bit-packed visible mask, colours of every 16th Gaussian,
     every 4th pixel (x and y) of both images, points-per-Gaussian of the kept set (u16).
     tag "5m" (render_5m) = BASELINE configs[3]'s scene at ITS size: 5 M Gaussians, camera 17 of the 200-camera rig, 50 M points;
-    `compact`: the final contributions at every 4th Gaussian (visible / culled masks in full), K1 and cov2d in ONE fingerprint
-    byte per Gaussian, the 3-D covariance fingerprint at every 4th."""
+    `compact`: the final contributions at every 4th Gaussian (visible / culled masks in full), the K1 fingerprint byte for every
+    Gaussian, the cov2d and 3-D covariance fingerprints at every 4th."""
     import time
     gh, gr, ch, g2p = (ref[k] for k in ("gauss_handler", "gauss_render", "camera_handler", "gauss_to_pc"))
     seed = 1234 + 3
@@ -387,9 +387,10 @@ def gen_render_big(ref, tag="1m", n=1_000_000, num_points=10_000_000, width=1280
                        "cam%d_proj" % k: _np(cam.projection_matrix).astype(np.float32),
                        "cam%d_fov_focal" % k: np.array([cam.FoVx, cam.FoVy, cam.focal_x, cam.focal_y], dtype=np.float64),
                        "cam%d_in_mask_bits" % k: np.packbits(f["in_mask"]),
-                       "cam%d_k1_hash8" % k: k1_hash8(f["means2D"][:, 0], f["means2D"][:, 1], f["radii"][:, 0], f["depth"],
-                                                      *([f["cov2d"][:, j] for j in range(4)] if compact else [])),
-                       **({} if compact else {"cam%d_cov2d_hash8" % k: k1_hash8(*[f["cov2d"][:, j] for j in range(4)])}),
+                       "cam%d_k1_hash8" % k: k1_hash8(f["means2D"][:, 0], f["means2D"][:, 1], f["radii"][:, 0], f["depth"]),
+                       # (cov2d inherits every last-bit difference of the 3-D covariance, i.e. of torch's MKL exp: kept
+                       # apart from the K1 fingerprint; compact fixtures hold it for every 4th Gaussian)
+                       "cam%d_cov2d_hash8" % k: k1_hash8(*[f["cov2d"][:: 4 if compact else 1, j] for j in range(4)]),
                        "cam%d_radius_div3_u8" % k: np.minimum(f["radii"][:, 0] / 3.0, 255).astype(np.uint8),
                        "cam%d_means2D_s64" % k: f["means2D"][::64].copy(), "cam%d_depth_s64" % k: f["depth"][::64].copy(),
                        "cam%d_cov2d_s64" % k: f["cov2d"][::64].copy()})

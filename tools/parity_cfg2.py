@@ -79,14 +79,11 @@ def _k1_report(g, k, cam, xyz, cov, n):
     h = k1_hash8(z(mx), z(my), z(rad), view[:, 2].cpu().numpy())
     r3 = np.minimum(z(rad) / 3.0, 255).astype(np.uint8)
     c2 = cov2d.reshape(n, 4).cpu().numpy()
-    if "cam%d_cov2d_hash8" % k in g.files:
-        out = dict(in_mask_flips=int((m != ref_m).sum()), k1_mismatch=int((h != g["cam%d_k1_hash8" % k]).sum()),
-                   radius_mismatch=int((r3 != g["cam%d_radius_div3_u8" % k]).sum()),
-                   cov2d_mismatch=int((k1_hash8(*[c2[:, j] for j in range(4)]) != g["cam%d_cov2d_hash8" % k]).sum()))
-    else:           # compact fixtures (5 M Gaussians): projected mean, radius, depth AND cov2d in one fingerprint byte
-        h = k1_hash8(z(mx), z(my), z(rad), view[:, 2].cpu().numpy(), *[c2[:, j] for j in range(4)])
-        out = dict(in_mask_flips=int((m != ref_m).sum()), k1_mismatch=int((h != g["cam%d_k1_hash8" % k]).sum()),
-                   radius_mismatch=int((r3 != g["cam%d_radius_div3_u8" % k]).sum()))
+    hs = n // int(g["cam%d_cov2d_hash8" % k].shape[0])            # compact fixtures: the cov2d fingerprint of every 4th Gaussian
+    out = dict(in_mask_flips=int((m != ref_m).sum()), k1_mismatch=int((h != g["cam%d_k1_hash8" % k]).sum()),
+               radius_mismatch=int((r3 != g["cam%d_radius_div3_u8" % k]).sum()),
+               cov2d_mismatch=int((k1_hash8(*[c2[::hs, j] for j in range(4)]) != g["cam%d_cov2d_hash8" % k]).sum()),
+               cov2d_compared=int(g["cam%d_cov2d_hash8" % k].shape[0]))
     s = slice(None, None, 64)
     out["means2D_s64_bit_mismatch"] = int((np.stack([z(mx), z(my)], 1)[s].view(np.uint32) != g["cam%d_means2D_s64" % k].view(np.uint32)).any(axis=1).sum())
     return out
@@ -232,6 +229,8 @@ def run(device="cuda:0", t_floor=None, sampler=True, tag="1m"):
     mags2 = G2.get_gaussian_magnitudes(contributions=kc)
     ppg2 = ops.distribute_points(mags2, int(g["num_points"]))[1].cpu().numpy().astype(np.int64)
     out["ppg_mismatch_given_ref_contrib"] = int((ppg2 != ref_ppg).sum())
+    out["ppg_max_abs_diff_given_ref_contrib"] = int(np.abs(ppg2 - ref_ppg).max())
+    out["ppg_mean_quota"] = float(ref_ppg.mean())
     if sampler:
         pts, cols2, _ = g2p.generate_pointcloud(G2, int(g["num_points"]), exact_num_points=False,
                                                 mahalanobis_distance_std=2.0, calculate_normals=False,
