@@ -7,6 +7,19 @@
 #define G2PC_PIN(x) asm volatile("" : "+v"(x))
 #endif
 
+// Constant address space (LLVM addrspace 4): memory that no thread writes while the kernel runs.  A load through such a
+// pointer with a wave-uniform address is selected as a SCALAR load (s_load_dword*: scalar cache, result in SGPRs) instead of
+// a vector load that fetches the same bytes for 64 lanes.  (The CPU build of these sources ignores it.)
+#if defined(__clang__)
+#define G2PC_CONSTANT __attribute__((address_space(4)))
+typedef float g2pc_f4v __attribute__((ext_vector_type(4)));     // plain vector types: loadable through any address space
+typedef float g2pc_f2v __attribute__((ext_vector_type(2)));
+#else
+#define G2PC_CONSTANT
+typedef float g2pc_f4v __attribute__((vector_size(16)));
+typedef float g2pc_f2v __attribute__((vector_size(8)));
+#endif
+
 namespace g2pc {
 
 __device__ __forceinline__ void wave_sync() {

@@ -39,6 +39,7 @@ C3 = [-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.37317633259
 # a Gaussian ALL of whose contributions are below 2^-25 is never seen (key 0, no colour), where the reference's strict
 # `>` against the initial 0 marks it as rendered with a contribution < 3e-8; it is far below any usable threshold.
 DEFAULT_T_FLOOR = 1e-6
+AUTO_SLOT_EPOCH = 63        # camera slots per key epoch when the renderer numbers the cameras itself (= the epoch at 14 tile bits)
 BLEND_SUBBLOCKS = None     # 8x8 sub-blocks per blend wave (None -> g2pc.tiles.SUBBLOCKS_PER_CHUNK)
 RENDER_STATS = []          # (instances L, tile-sort passes, W*H) of every camera rendered (bench.py reads this)
 
@@ -504,6 +505,12 @@ class GaussHipRenderer():
     def gaussian_max_contribution(self):
         self.flush()
         # (the getters of one job -- visible mask, total contributions -- read the same state: unpacked once per render)
+        return self._contributions().clone()          # callers own what they get (the cache below stays private)
+
+    def _contributions(self):
+        """Contributions unpacked from the keys, cached until the next render / exchange / rebase (read-only: shared by the
+        getters of one job)."""
+        self.flush()
         if self._contrib is None:
             out = torch.empty((self.n,), dtype=torch.float32, device=self.device)
             nv.check(nv.lib().g2pc_raster_contributions(nv.ptr(self.best_key), self.n, nv.ptr(out),
@@ -522,13 +529,13 @@ class GaussHipRenderer():
                           "Gaussians whose contributions all lie below the floor are missing from the mask (construct the "
                           "renderer with visible_gaussian_threshold <= the floor, or t_floor=0, for the reference's result)"
                           % (contribution_threshold, self.t_floor))
-        return self.gaussian_max_contribution > contribution_threshold
+        return self._contributions() > contribution_threshold
 
     def get_visible_gaussians(self):
         return self.get_gaussians_above_contribution_threshold(self.visible_gaussian_threshold)
 
     def get_surface_gaussians(self):
-        c = self.gaussian_max_contribution
+        c = self._contributions()
         return c > torch.mean(c)
 
     def get_total_gaussian_contributions(self):
@@ -562,6 +569,14 @@ class GaussHipRenderer():
         # leaves) widened on its own -- the others follow before the keys meet
         bits = torch.tensor([self.seq_bits], dtype=torch.int32, device=self.device)
         dist.all_reduce(bits, op=dist.ReduceOp.MAX, group=group)
+        # can every rank widen to that?  Decided TOGETHER: a rank that cannot must not raise while the others go on to the next
+        # collective (they would wait for it for ever)
+        ok = torch.tensor([1 if self._seq_room_ok(int(bits.item())) else 0], dtype=torch.int32, device=self.device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 0:
+            raise ValueError("visibility exchange: some rank's camera slots do not fit the %d-bit tile field another rank's "
+                             "cameras needed (start every rank at renderer.seq_bits = 14, as convert_gaussians_to_pc does)"
+                             % int(bits.item()))
         if int(bits.item()) > self.seq_bits:
             self._ensure_seq_room(1 << int(bits.item()))
         global_key = self.best_key.clone()
@@ -588,6 +603,7 @@ class GaussHipRenderer():
         self.flush()
         nv.check(nv.lib().g2pc_raster_rebase_keys(nv.ptr(self.best_key), self.n, nv.stream_handle(self.device)), "rebase")
         self.camera_slot = 0
+        self._contrib = None
 
     def _camera_struct(self, camera, cam=None):
         cam = _Camera() if cam is None else cam
@@ -715,15 +731,22 @@ class GaussHipRenderer():
                                % int(((states == 1) != over).sum() + ((((states & 0xFF) == 2) & has) != (dead & has)).sum()))
         return dict(overloaded=over, dead=dead, fills=fills)
 
+    def _seq_room_ok(self, need):
+        return need <= 14 and self.camera_slot <= (1 << (20 - need)) - 1
+
     def _ensure_seq_room(self, top):
         """The packed keys' tile field must hold sequence numbers below `top` (leaves + the children of split leaves)."""
         need = max(12, int(np.ceil(np.log2(max(top, 2)))))
         if need <= self.seq_bits:
             return
-        if need > 14 or self.camera_slot > (1 << (20 - need)) - 1:
-            raise NotImplementedError("a camera's quad-tree needs %d leaf sequence numbers: beyond the %s of the packed "
-                                      "visibility keys (set renderer.seq_bits = 14 before the first camera)"
-                                      % (top, "14-bit tile field" if need > 14 else "camera slots left at that width"))
+        if not self._seq_room_ok(need):
+            # a format limit (16 384 leaves + children per camera), or a CALLER-assigned slot beyond the wider layout's epoch
+            # (slots the renderer assigns itself never are: AUTO_SLOT_EPOCH); multi-rank jobs reach this decision together
+            # (all_reduce_visibility) so that no rank raises while the others enter a collective
+            raise ValueError("a camera's quad-tree needs %d leaf sequence numbers: beyond the %s of the packed "
+                             "visibility keys (set renderer.seq_bits = 14 before the first camera and keep caller-assigned "
+                             "slots within its 63-camera epoch)"
+                             % (top, "14-bit tile field" if need > 14 else "camera slots left at that width"))
         nv.check(nv.lib().g2pc_raster_repack_keys(self.state_ptrs()[0], self.n, self.seq_bits, need,
                                                   nv.stream_handle(self.device)), "raster_repack_keys")
         self.seq_bits = need
@@ -758,7 +781,13 @@ class GaussHipRenderer():
             level.c.seq_bits = self.seq_bits
             self._front(sc, cam, level)
             n_inst = int(sc.offsets[self.n].item())
-            self._back(sc, cam, level, slot, n_inst, image, 1, "raster_bin")
+            # the level's layout is the PRODUCT of the children's column and row intervals: the gate only looks at the tiles that
+            # ARE children (tile_mask) -- a non-tree tile over the limit is no "overloaded leaf" and reports no load
+            is_child = np.zeros((level.num_tiles,), bool)
+            is_child[[c[0] for c in children]] = True
+            gate = level.only(is_child)
+            gate.c.seq_bits = self.seq_bits
+            self._back(sc, cam, gate, slot, n_inst, image, 1, "raster_bin")
             counts, states = self._tile_states(sc, level, n_inst)
             enabled = np.zeros((level.num_tiles,), bool)
             parents = []
@@ -1011,7 +1040,10 @@ class GaussHipRenderer():
                 raise ValueError("camera slot must be in [1, %d]" % self.camera_epoch)
             self.camera_slot = int(slot)
         else:
-            if self.camera_slot >= self.camera_epoch:
+            # slots the renderer assigns itself stay within the epoch of the WIDEST key layout (14-bit tile field: 63 cameras):
+            # a camera whose split leaves need a wider tile field later can then always be widened in place, in the middle of a
+            # flush too (_ensure_seq_room), whatever the slot in use.  A rebase costs a flush and one pass over the keys.
+            if self.camera_slot >= min(self.camera_epoch, AUTO_SLOT_EPOCH):
                 self.rebase_keys()
             self.camera_slot += 1
         slot = self.camera_slot

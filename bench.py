@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--scene-scales", type=float, nargs=2, default=None, metavar=("LO", "HI"),
                     help="diagnostic: Gaussian scale range of the synthetic scene (default 0.002 0.02 = SURVEY.md's)")
     ap.add_argument("--no-context-pool", action="store_true", help="tuning aid: every job captures its camera graphs anew")
-    ap.add_argument("--blend-variant", type=int, default=None, choices=[None, 0, 1, 2, 3], help="tuning aid: 2 / 3 = two-wave (unroll 4 / 2) dual-list kernel (one wave per sub-block), 1 = dual-list blend kernel, 0 = packed kernel")
+    ap.add_argument("--blend-variant", type=int, default=None, choices=[None, 0, 1, 2, 3, 4, 5], help="tuning aid: 2 / 3 = two-wave (unroll 4 / 2) dual-list kernel (one wave per sub-block), 1 = dual-list blend kernel, 0 = packed kernel")
     ap.add_argument("--depth-sort", default=None, choices=[None, "bucket", "radix"], help="tuning aid: depth order of the captured camera path")
     ap.add_argument("--streams", type=int, default=0, help="tuning aid: camera batches in flight (HIP streams) of the renderer")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the untimed region / kernel profile passes after the timed loop")
@@ -171,7 +171,7 @@ def pmc_valu(region, a):
 
 GPU_CLOCK_HZ = 2.4e9
 SIMDS = 1024                       # 256 CUs x 4 SIMDs
-VALU_RATES_FILE = "profiles/r02c_valu_rates.json"     # tools/experiments/ubench: issue rates measured on the MI355X
+VALU_RATES_FILE = "profiles/archive/r02c_valu_rates.json"     # tools/experiments/ubench: issue rates measured on the MI355X
 
 
 def valu_roof(valu, launch_s, kernel_substring):
@@ -180,7 +180,7 @@ def valu_roof(valu, launch_s, kernel_substring):
       * the ARCHITECTURAL issue rate: one wave-instruction per 2 cycles and SIMD (MI355X_MICROARCH.md, Wave scheduling: "a
         wave issues each VALU instruction over 2 cycles") = 1024 SIMDs x 2.4 GHz / 2;
       * the MIX-AWARE rate: what `v_fma_f32` sustains with 8 waves per SIMD in the issue-rate micro-benchmark
-        (profiles/r02c_valu_rates.json: 2.45 cycles).
+        (profiles/archive/r02c_valu_rates.json: 2.45 cycles).
     `busy_frac` is the share of the launch in which the VALU was busy at all (4 x SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU cycles
     per instruction: round 3 printed this as `frac` -- it is not a roofline fraction).  avg_resident_waves_per_simd =
     4 x SQ_WAVE_CYCLES / 1024 SIMDs / launch cycles; vgpr / max_waves_per_simd from the shipped code object."""

@@ -1,12 +1,13 @@
 """The blend kernel variants of the python-semantics renderer (g2pc_set_blend_variant) must agree: 1 = dual-list single-wave
-kernel (default), 2 / 3 = two-wave form (one wave per 8x8 sub-block, 128-entry batches; unroll 4 / 2).  Same loads, tests and
+kernel (default), 2 / 3 = two-wave form (one wave per 8x8 sub-block, 128-entry batches; unroll 4 / 2), 4 / 5 = scalar-gather form
+(A, B, C and colour of a list entry through scalar loads of its record, unroll 4 / 2).  Same loads, tests and
 floating-point operations per (pixel, Gaussian) visit, so every contribution at or above the transmittance floor, every
 colour and every pixel must be BIT-identical; below the floor the variants may stop a saturated sub-block a batch apart."""
 import numpy as np
 import torch
 
 
-def run_variants(device, golden_dir, variants=(1, 2, 3), t_floor=1e-6, pipelined=False):
+def run_variants(device, golden_dir, variants=(1, 2, 3, 4, 5), t_floor=1e-6, pipelined=False):
     from g2pc import _native as nv
     import gauss_render
     from render_checks import run_render_case, assert_render_matches

@@ -137,6 +137,29 @@ def test_two_rank_pipeline_cuda_semantics(tmp_path):
         assert float((np.abs(ca - cb) > 1e-5).any(axis=1).mean()) < 0.01
 
 
+@pytest.mark.parametrize("ncam", [5, 11])
+def test_eight_rank_pipeline_cuda_semantics(tmp_path, ncam):
+    """The native-rasteriser semantics on the 8-rank node shape.  ncam = 5 < 8 ranks: every rank renders every camera, blends
+    the 16x16 tiles `rank, rank + 8, ...` and the ranks merge EACH camera before its running-state update (MAX of the packed
+    keys, MIN of the surface distances, SUM of the images) -- the running SUM of contributions then sees the camera's global
+    maximum on every rank.  ncam = 11 > 8: cameras dealt over the ranks, one exchange at the end (total contribution = a float
+    SUM whose order differs from the single process: the allocation may move by a point or two)."""
+    from emu_util import build_emu
+    build_emu()
+    _run(0, 1, 0, str(tmp_path), "cuda", 255, ncam)
+    port = 39500 + (os.getpid() % 2000) + ncam
+    mp.spawn(_run, args=(8, port, str(tmp_path), "cuda", 255, ncam), nprocs=8, join=True)
+    a, b = np.load(tmp_path / "cuda_w1_e255.npz"), np.load(tmp_path / "cuda_w8_e255.npz")
+    assert abs(a["points"].shape[0] - b["points"].shape[0]) <= 16 and a["points"].shape[0] > 10000
+    if a["points"].shape == b["points"].shape:
+        rows = lambda d: np.concatenate([d["points"], d["colours"], d["normals"]], axis=1)
+        ca, cb = rows(a), rows(b)
+        ca, cb = ca[np.lexsort(ca.T[::-1])], cb[np.lexsort(cb.T[::-1])]
+        assert float((np.abs(ca - cb) > 1e-5).any(axis=1).mean()) < 0.01
+        if ncam == 5:            # tile split: per-camera merges are exact (MAX / MIN / one writer per pixel): the same cloud
+            assert np.array_equal(ca, cb)
+
+
 def test_two_rank_pipeline_across_camera_epochs(tmp_path):
     """More cameras than the 8-bit camera-order field holds (epoch shrunk to 2 for the test): the ranks all-reduce and
     rebase the keys at every epoch boundary; the result must still equal the single-process run."""

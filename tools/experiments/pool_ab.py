@@ -44,5 +44,5 @@ for mode in sys.argv[1:]:
     elif mode == "first_alone_off":
         gauss_render.FIRST_CAMERA_ALONE = False; continue
     elif mode.startswith("skip"):
-        gauss_render.POOL_SKIP_FIRST_JOBS = int(mode[4:]); continue
+        gauss_render._EXPERIMENT_SKIP = int(mode[4:]); continue      # (the G2PC_POOL_SKIP_FIRST_JOBS knob)
     run(mode)
