@@ -83,23 +83,28 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_py(Cam cam_val, const Cam* 
                                                        const float* __restrict__ colours,
                                                        float4* __restrict__ rec, uint32_t* __restrict__ rect, size_t cs,
                                                        BucketHdr* __restrict__ mm, uint32_t mm_slots) {
-    // device-resident camera: lets ONE captured launch sequence serve every camera.  Staged through LDS once per block
-    // (per-thread loads of the 172-byte struct made this kernel 6x slower than the by-value variant).
+    // device-resident camera: lets ONE captured launch sequence serve every camera (scalar loads, see below).
     // Batched launch (grid.y cameras): camera c's job is the c-th G2pcCameraJob, its outputs live in the c-th arena.
     // mm != nullptr: the depth keys go to the bucket sort (prims.hip), whose first pass -- the range of the keys -- is folded
     // in here: every block leaves (max ~key, max key) in slot blockIdx.x % mm_slots of the (zeroed) header.
-    __shared__ Cam s_cam;
     __shared__ uint32_t s_mm[2];
     depth_key_rev = seg(depth_key_rev, cs); index_rev = seg(index_rev, cs); tiles_touched = seg(tiles_touched, cs);
     rec = seg(rec, cs); rect = seg(rect, cs); mm = seg(mm, cs);
     if (threadIdx.x == 0) { s_mm[0] = 0u; s_mm[1] = 0u; }
+    // Device-resident camera (round 4): read through the constant address space -- the job was written before the launch
+    // sequence started and no kernel modifies it -- so the 43 words arrive by SCALAR loads and live in SGPRs.  (Until round 4
+    // they were staged through LDS: every matrix element then sat in a VGPR, 50 VGPRs against 36 for the by-value variant.)
+    Cam cam_s = cam_val;
     if (CAM_ON_DEVICE) {
-        cam_dev = (const Cam*)((const char*)cam_dev + (size_t)blockIdx.y * sizeof(G2pcCameraJob));
-        if (threadIdx.x < sizeof(Cam) / 4) ((uint32_t*)&s_cam)[threadIdx.x] = ((const uint32_t*)cam_dev)[threadIdx.x];
+        const uint32_t G2PC_CONSTANT* cw =
+            (const uint32_t G2PC_CONSTANT*)((const char*)cam_dev + (size_t)blockIdx.y * sizeof(G2pcCameraJob));
+        uint32_t* dst = (uint32_t*)&cam_s;
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(Cam) / 4); ++k) dst[k] = cw[k];
     }
-    if (CAM_ON_DEVICE || mm) __syncthreads();
+    if (mm) __syncthreads();
     long i = (long)blockIdx.x * RA_T + threadIdx.x;
-    const Cam& cam = CAM_ON_DEVICE ? s_cam : cam_val;
+    const Cam& cam = cam_s;
     uint32_t key = 0xFFFFFFFFu, touched = 0, rc = 0;
     if (i < n) {
     const float x = means3D[3 * i], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
