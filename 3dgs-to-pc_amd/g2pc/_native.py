@@ -17,7 +17,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libg2pc.so")
-ABI_VERSION = 5
+ABI_VERSION = 4
 
 _LIB: Optional[C.CDLL] = None
 _EMULATED = False
@@ -62,9 +62,6 @@ _PROTOS["g2pc_sampler_scan_counts"] = (C.c_int, [_vp, _vp, _i64, _i32, _vp, _sz,
 _PROTOS["g2pc_sampler_sections"] = (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i64, C.c_int, _vp, _vp, _vp, _vp])
 _PROTOS["g2pc_sampler_emit_rows"] = (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _u64, _u64, _vp, _vp,
                                                _i64, _vp, _vp, _vp, _vp, _vp])
-_PROTOS["g2pc_sampler_emit_plan_workspace"] = (_sz, [_i64])
-_PROTOS["g2pc_sampler_emit_rows_planned"] = (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _u64, _u64, _vp, _vp,
-                                                       _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp])
 _PROTOS["g2pc_eval_sh"] = (C.c_int, [_i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp])
 _PROTOS["g2pc_build_covariance_2d"] = (C.c_int, [_vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _vp, _vp])
 _PROTOS["g2pc_projection_ndc"] = (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp])

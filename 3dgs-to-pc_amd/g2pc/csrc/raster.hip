@@ -652,7 +652,7 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_pk(Layout lay, const int32_t*
 // -- five FMAs per pixel instead of seven operations, and the opacity multiply rides in K.  Rounding differs from the
 // reference's order of operations by ~eps * (|exponent| + |A| 50): <= 2e-5 relative in alpha for the sharpest Gaussians
 // the 0.3-pixel dilation admits, ~3e-6 typically (the reference's own dx = pixel - mean carries eps * |mean| already).
-template <int U, int PADV = 0>        // PADV: experiment -- claim VGPRs up to v(PADV-1) so that fewer blend waves fit a SIMD (room for head kernels)
+template <int U>
 __global__ __launch_bounds__(BL_T) void k_blend_py_dl(Layout lay, const int32_t* __restrict__ chunk_tile,
                                                      const int32_t* __restrict__ chunk_pix0,
                                                      const uint2* __restrict__ tile_range,
@@ -662,10 +662,6 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_dl(Layout lay, const int32_t*
                                                      float t_floor, float bg, float* __restrict__ tilebuf,
                                                      uint32_t* __restrict__ chunk_work,
                                                      const G2pcCameraJob* __restrict__ job, size_t cs) {
-#if defined(__clang__)
-    if (PADV == 104) asm volatile("" ::: "v103");
-    if (PADV == 128) asm volatile("" ::: "v127");
-#endif
     const unsigned chunk_i = blockIdx.z * gridDim.y + blockIdx.y;       // the blends: camera = blockIdx.x, chunk in (y, z)
     if ((int)chunk_i >= lay.num_chunks) return;
     tile_range = seg_at(tile_range, cs, blockIdx.x); inst_g = seg_at(inst_g, cs, blockIdx.x); rec = seg_at(rec, cs, blockIdx.x);
@@ -2175,9 +2171,7 @@ static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t*
                 // operation order (k_blend_py_pk); the dual-list kernel's expanded exponent differs by up to ~2e-5 relative
                 // in alpha.  A captured camera reads t_floor from its device job: the caller says so with phase bit 8.
                 const bool exact = ba.job ? ((phases & 8) != 0) : (ba.t_floor == 0.0f);
-                if (g_blend_variant == 6 && !exact) G2PC_BLEND(k_blend_py_dl<4, 104>);
-                else if (g_blend_variant == 7 && !exact) G2PC_BLEND(k_blend_py_dl<4, 128>);
-                else if (g_blend_variant == 4 && !exact) G2PC_BLEND(k_blend_py_sg<4>);
+                if (g_blend_variant == 4 && !exact) G2PC_BLEND(k_blend_py_sg<4>);
                 else if (g_blend_variant == 5 && !exact) G2PC_BLEND(k_blend_py_sg<2>);
                 else if (g_blend_variant == 3 && !exact)
                     hipLaunchKernelGGL((k_blend_py_2w<2>), dim3((unsigned)bt.n, chunks_y, cdiv(layout->num_chunks, chunks_y)), dim3(2 * BL_T), 0, s,

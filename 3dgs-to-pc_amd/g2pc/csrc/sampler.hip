@@ -443,47 +443,12 @@ __device__ __forceinline__ void wave_store_rows3(float* __restrict__ s_rows /* [
     wave_sync();
 }
 
-// Where every emission block starts (round 4).  A block of k_emit_rows used to find its first section by a binary search
-// over sec_base (11 DEPENDENT global loads for ~1 200 sections) and the owner of its first row by a block-wide search of
-// the attempt's scan (3 more dependent rounds) -- ~13 us of latency in front of ~2 us of work per 1 024-row block.  Here
-// one THREAD per block does both searches; the ~10 000 threads' loads overlap, the emission blocks start from the table.
-// plan[b] = (first section, owner position of the block's first row -- 0 for a means section or a block beyond M).
-__global__ __launch_bounds__(SM_T) void k_emit_plan(const uint32_t* __restrict__ bin_start, int B, int A, long gv,
-                                                   const uint32_t* __restrict__ dscan, const int64_t* __restrict__ sec_base,
-                                                   long rows_capacity, long num_blocks, uint2* __restrict__ plan) {
-    const long blk = (long)blockIdx.x * SM_T + threadIdx.x;
-    if (blk >= num_blocks) return;
-    const int S = B * (1 + A);
-    long M = (long)sec_base[S];
-    if (M > rows_capacity) M = rows_capacity;
-    const long row0 = blk * ER_ROWS;
-    if (row0 >= M) { plan[blk] = make_uint2((uint32_t)S, 0u); return; }
-    int lo = 0, hi = S;
-    while (lo < hi) {                                   // first section that ends after row0
-        const int mid = (lo + hi) >> 1;
-        if (sec_base[mid + 1] <= (int64_t)row0) lo = mid + 1; else hi = mid;
-    }
-    const int si = lo, b = si / (1 + A), sct = si % (1 + A);
-    uint32_t p_first = 0u;
-    if (sct > 0) {
-        const long sb = (long)sec_base[si];
-        const uint32_t* sc = dscan + (size_t)(sct - 1) * (size_t)(gv + 1);
-        const uint32_t bs0 = bin_start[b], bs1 = bin_start[b + 1];
-        const uint32_t t = sc[bs0] + (uint32_t)((sb > row0 ? sb : row0) - sb);
-        uint32_t l = bs0, h = bs1;                      // largest p in [bs0, bs1) with sc[p] <= t (sc[bs0] <= t)
-        while (h - l > 1) { const uint32_t mid = l + ((h - l) >> 1); if (sc[mid] <= t) l = mid; else h = mid; }
-        p_first = l;
-    }
-    plan[blk] = make_uint2((uint32_t)si, p_first);
-}
-
 __global__ __launch_bounds__(ER_T) void k_emit_rows(
     const float* __restrict__ means, const float* __restrict__ cov9, const float* __restrict__ colours,
     const float* __restrict__ normals, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ bin_start, int B,
     int A, long gv, int attempt0, unsigned seed_lo, unsigned seed_hi, uint64_t gid_base,
     const uint32_t* __restrict__ dscan, const int64_t* __restrict__ sec_base, float* __restrict__ out_points,
-    float* __restrict__ out_colours, float* __restrict__ out_normals, int32_t* __restrict__ out_gauss, long rows_capacity,
-    const uint2* __restrict__ plan) {
+    float* __restrict__ out_colours, float* __restrict__ out_normals, int32_t* __restrict__ out_gauss, long rows_capacity) {
     __shared__ uint32_t s_win[ER_WIN + 1];
     __shared__ float s_rows[ER_T / kWave][192];
     const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -493,20 +458,12 @@ __global__ __launch_bounds__(ER_T) void k_emit_rows(
     const long row0 = (long)blockIdx.x * ER_ROWS;
     if (row0 >= M) return;
     const long row1 = row0 + ER_ROWS < M ? row0 + ER_ROWS : M;
-    // first section that ends after row0: from the block plan (k_emit_plan), else sec_base is monotone: a binary search
-    // (every thread finds the same index)
+    // first section that ends after row0: sec_base is monotone, so a binary search (every thread finds the same index)
     int lo = 0, hi = S;
-    uint32_t planned_first = 0u;
-    if (plan) {
-        const uint2 pl = plan[blockIdx.x];
-        lo = (int)pl.x; planned_first = pl.y;
-    } else {
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (sec_base[mid + 1] <= (int64_t)row0) lo = mid + 1; else hi = mid;
-        }
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (sec_base[mid + 1] <= (int64_t)row0) lo = mid + 1; else hi = mid;
     }
-    const int si_first = lo;
     int si = lo;
     for (; si < S; ++si) {
         const long sb = (long)sec_base[si], se = (long)sec_base[si + 1];
@@ -522,7 +479,7 @@ __global__ __launch_bounds__(ER_T) void k_emit_rows(
             sc0 = sc[bs0];
             // owner of the first row, then a window of the scan from there (relative to the section)
             const uint32_t t_first = sc0 + (uint32_t)(r_lo - sb);
-            p_first = (plan && si == si_first) ? planned_first : block_search_le(sc, bs0, bs1, t_first);
+            p_first = block_search_le(sc, bs0, bs1, t_first);
             wlen = (bs1 - p_first) < (uint32_t)ER_WIN ? (bs1 - p_first) : (uint32_t)ER_WIN;
             __syncthreads();                        // previous section's readers are done with the window
             for (uint32_t j = threadIdx.x; j <= wlen; j += ER_T) s_win[j] = sc[p_first + j];
@@ -769,33 +726,6 @@ int g2pc_sampler_sections(const uint32_t* bin_start, const int32_t* quota, int32
 
 /* Row-balanced emission of the whole cloud (means and every attempt's rows) in one launch: `rows_capacity` >= M is the
  * size the output arrays were allocated for (the launch covers it; blocks beyond the real M, read from sec_base, exit). */
-size_t g2pc_sampler_emit_plan_workspace(int64_t rows_capacity) {
-    return rows_capacity > 0 ? (size_t)g2pc::cdiv((long)rows_capacity, g2pc::ER_ROWS) * sizeof(uint2) : 0;
-}
-
-/* The same with the per-block start table built first (k_emit_plan; ABI 5): plan_ws >= g2pc_sampler_emit_plan_workspace(). */
-int g2pc_sampler_emit_rows_planned(const float* means, const float* cov9, const float* colours, const float* normals,
-                                   const uint32_t* perm, const uint32_t* bin_start, int32_t num_bins, int32_t attempt0,
-                                   int32_t attempts, int64_t gv, uint64_t seed, uint64_t gid_base, const uint32_t* dscan,
-                                   const int64_t* sec_base, int64_t rows_capacity, float* out_points, float* out_colours,
-                                   float* out_normals, int32_t* out_gauss, void* plan_ws, size_t plan_bytes, void* stream) {
-    using namespace g2pc;
-    G2PC_REQUIRE(means && cov9 && colours && perm && bin_start && sec_base && out_points && out_colours, G2PC_ERR_ARG,
-                 "bad arguments");
-    G2PC_REQUIRE(!out_normals || normals, G2PC_ERR_ARG, "normals requested but not given");
-    G2PC_REQUIRE(attempts == 0 || dscan, G2PC_ERR_ARG, "missing scans");
-    if (rows_capacity <= 0 || num_bins <= 0) return G2PC_OK;
-    G2PC_REQUIRE(plan_ws && plan_bytes >= g2pc_sampler_emit_plan_workspace(rows_capacity), G2PC_ERR_WORKSPACE, "plan workspace too small");
-    const long blocks = cdiv((long)rows_capacity, ER_ROWS);
-    hipLaunchKernelGGL(k_emit_plan, dim3(cdiv(blocks, SM_T)), dim3(SM_T), 0, (hipStream_t)stream, bin_start, (int)num_bins,
-                       (int)attempts, (long)gv, dscan, sec_base, (long)rows_capacity, blocks, (uint2*)plan_ws);
-    hipLaunchKernelGGL(k_emit_rows, dim3(blocks), dim3(ER_T), 0, (hipStream_t)stream, means, cov9, colours,
-                       normals, perm, bin_start, (int)num_bins, (int)attempts, (long)gv, (int)attempt0, (unsigned)seed,
-                       (unsigned)(seed >> 32), gid_base, dscan, sec_base, out_points, out_colours, out_normals, out_gauss,
-                       (long)rows_capacity, (const uint2*)plan_ws);
-    return check_launch("g2pc_sampler_emit_rows_planned");
-}
-
 int g2pc_sampler_emit_rows(const float* means, const float* cov9, const float* colours, const float* normals,
                            const uint32_t* perm, const uint32_t* bin_start, int32_t num_bins, int32_t attempt0,
                            int32_t attempts, int64_t gv, uint64_t seed, uint64_t gid_base, const uint32_t* dscan,
@@ -810,7 +740,7 @@ int g2pc_sampler_emit_rows(const float* means, const float* cov9, const float* c
     hipLaunchKernelGGL(k_emit_rows, dim3(cdiv(rows_capacity, ER_ROWS)), dim3(ER_T), 0, (hipStream_t)stream, means, cov9, colours,
                        normals, perm, bin_start, (int)num_bins, (int)attempts, (long)gv, (int)attempt0, (unsigned)seed,
                        (unsigned)(seed >> 32), gid_base, dscan, sec_base, out_points, out_colours, out_normals, out_gauss,
-                       (long)rows_capacity, (const uint2*)nullptr);
+                       (long)rows_capacity);
     return check_launch("g2pc_sampler_emit_rows");
 }
 

@@ -421,13 +421,11 @@ def sample_pointcloud(xyz: torch.Tensor, cov: torch.Tensor, colours: torch.Tenso
                                      nv.ptr(sec_base), C_void(info), nv.ptr(remaining), st), "sampler_sections")
     pts, cols, nrm, gidx = outputs(rows_ub)
     if rows_ub > 0 and gv > 0 and B > 0:
-        pb = L.g2pc_sampler_emit_plan_workspace(rows_ub)
-        pws = nv.workspace(pb, dev)
         with nv.region("sampler_emit", dev):
-            nv.check(L.g2pc_sampler_emit_rows_planned(nv.ptr(xyz), nv.ptr(cov), nv.ptr(colours), nv.ptr(normals), nv.ptr(perm),
-                                                      nv.ptr(bin_start), B, 0, A, gv, int(seed), int(gid_base), nv.ptr(dscan),
-                                                      nv.ptr(sec_base), rows_ub, nv.ptr(pts), nv.ptr(cols), nv.ptr(nrm),
-                                                      nv.ptr(gidx), nv.ptr(pws), pb, st), "sampler_emit_rows_planned")
+            nv.check(L.g2pc_sampler_emit_rows(nv.ptr(xyz), nv.ptr(cov), nv.ptr(colours), nv.ptr(normals), nv.ptr(perm),
+                                              nv.ptr(bin_start), B, 0, A, gv, int(seed), int(gid_base), nv.ptr(dscan),
+                                              nv.ptr(sec_base), rows_ub, nv.ptr(pts), nv.ptr(cols), nv.ptr(nrm),
+                                              nv.ptr(gidx), st), "sampler_emit_rows")
     sync()                                                        # round trip #2: how many points came out
     M = int(info[0]) if B > 0 else 0
     assert 0 <= M <= rows_ub, (M, rows_ub)

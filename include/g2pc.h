@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define G2PC_ABI_VERSION 5
+#define G2PC_ABI_VERSION 4
 
 #define G2PC_OK 0
 #define G2PC_ERR_ARG (-1)
@@ -223,16 +223,6 @@ int g2pc_sampler_emit_rows(const float* means, const float* cov9, const float* c
                            int32_t attempts, int64_t gv, uint64_t seed, uint64_t gid_base, const uint32_t* dscan,
                            const int64_t* sec_base, int64_t rows_capacity, float* out_points, float* out_colours,
                            float* out_normals, int32_t* out_gauss, void* stream);
-/* ABI 5: the same emission with the per-block start table built on the device first (one thread per 1 024-row block finds
- * the block's first section and the owner of its first row; the emission blocks then start without their two dependent
- * searches: 200 -> ~100 us for the 10 M-row cloud of configs[1]).  plan_ws: g2pc_sampler_emit_plan_workspace(rows_capacity)
- * bytes of device memory.  Replaces the same reference lines as g2pc_sampler_emit_rows (gauss_to_pc.py:247-258). */
-size_t g2pc_sampler_emit_plan_workspace(int64_t rows_capacity);
-int g2pc_sampler_emit_rows_planned(const float* means, const float* cov9, const float* colours, const float* normals,
-                                   const uint32_t* perm, const uint32_t* bin_start, int32_t num_bins, int32_t attempt0,
-                                   int32_t attempts, int64_t gv, uint64_t seed, uint64_t gid_base, const uint32_t* dscan,
-                                   const int64_t* sec_base, int64_t rows_capacity, float* out_points, float* out_colours,
-                                   float* out_normals, int32_t* out_gauss, void* plan_ws, size_t plan_bytes, void* stream);
 
 /* --- stand-alone helpers of the python renderer (the reference's public gauss_render functions) ------------------
  * eval_sh (gauss_render.py:43-99): sh f32[n, channels, coeffs] (coefficient index on the LAST axis, as the
