@@ -41,6 +41,7 @@ struct Layout {         // device pointers of G2pcTileLayout
     int depth;                        // quad-tree info (python semantics): nx == ny == 1 << depth, 0 = none
     const int32_t *inner_x, *inner_y; // [(1 << depth) - 1][2] inclusive pixel extents of the interior nodes per axis
     const int32_t* tile_stick;        // [ny*nx] bit k: the leaf reaches beyond its level-k ancestor (nullptr = none does)
+    int walk_cap;                     // DIAGNOSTIC (g2pc_debug_set_walk_cap): the dual-list blend stops a walk after this many batches (0 = never; results are then WRONG)
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -853,6 +854,7 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_dl(Layout lay, const int32_t*
             if (!done[j]) done[j] = __all(T[j] <= t_floor ? 1 : 0) != 0;      // see k_blend_py
         }
         if (done[0] && done[1]) break;
+        if (lay.walk_cap && processed >= (uint32_t)lay.walk_cap * BL_BATCH) break;      // diagnostic: truncated walk
     }
     if (chunk_work && lane == 0) {                 // diagnostics (+ when and where this wave ran: 100 MHz clock, HW_ID, XCC_ID)
         uint32_t* cw = chunk_work + 8 * (size_t)chunk_i;
@@ -2008,8 +2010,10 @@ static Cam to_cam(const G2pcCamera* c) {
     k.lim_x = c->lim_x; k.lim_y = c->lim_y;
     return k;
 }
+static int g_walk_cap = 0;        // diagnostic only, see Layout::walk_cap
 static Layout to_layout(const G2pcTileLayout* l) {
     Layout k;
+    k.walk_cap = g_walk_cap;
     k.nx = l->nx; k.ny = l->ny; k.num_chunks = l->num_chunks; k.seq_bits = l->seq_bits ? l->seq_bits : 12; k.xs = l->xs; k.ws = l->ws; k.ys = l->ys; k.hs = l->hs;
     k.tile_seq = l->tile_seq; k.seq_tile = l->seq_tile; k.tile_pix_off = l->tile_pix_off;
     k.seq_base = l->seq_count ? l->seq_base : 0; k.seq_count = l->seq_count ? l->seq_count : l->nx * l->ny;
@@ -2377,6 +2381,7 @@ int g2pc_raster_repack_keys(unsigned long long* best_key, int64_t n, int32_t old
 
 /* diagnostics: see g2pc.h */
 int g2pc_raster_debug_chunk_work(uint32_t* buf) { g2pc::g_chunk_work = buf; return G2PC_OK; }
+int g2pc_debug_set_walk_cap(int batches) { g2pc::g_walk_cap = batches > 0 ? batches : 0; return G2PC_OK; }
 
 /* depth order of the capture-safe camera call: 1 = range-normalised bucket sort + in-LDS bitonic (default), 0 = 4-pass
  * radix.  Identical results; a camera whose depths pile up (bucket overflow) is skipped and reported through

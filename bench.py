@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--blend-streams", type=int, default=0, help="tuning aid (split modes): blend streams the batches alternate over")
     ap.add_argument("--camera-batch", type=int, default=0, help="tuning aid: cameras per launch sequence (1 = one camera per graph)")
     ap.add_argument("--camera-subset", type=int, default=0, help="profiling aid: render only the first k cameras of the rig")
+    ap.add_argument("--walk-cap", type=int, default=0, help="DIAGNOSTIC: truncate every blend walk after this many 64-entry batches (wrong results; what do long walks cost?)")
     ap.add_argument("--t-floor", type=float, default=None, help="blend transmittance floor (default: gauss_render.DEFAULT_T_FLOOR)")
     return ap.parse_args()
 
@@ -490,6 +491,8 @@ def main():
         nv.lib().g2pc_set_sort_tuning(a.sort_bits, a.sort_small)
     if a.blend_variant is not None:
         nv.lib().g2pc_set_blend_variant(a.blend_variant)
+    if a.walk_cap:
+        nv.lib().g2pc_debug_set_walk_cap(a.walk_cap)
     if a.depth_sort:
         nv.lib().g2pc_set_depth_sort(1 if a.depth_sort == "bucket" else 0)
     if a.blend_subblocks:

@@ -417,6 +417,9 @@ int g2pc_raster_rebase_keys(unsigned long long* best_key, int64_t n, void* strea
 /* diagnostics: when non-NULL, the PY blend records per chunk, in u32[8*num_chunks] (batch 1): [0] tile list length, [1] entries
  * walked; the dual-list kernel also [2] start and [3] duration on the 100 MHz wall clock, [4] HW_ID, [5] XCC_ID of its wave, [6] (Gaussian, sub-block) visits after the cull */
 int g2pc_raster_debug_chunk_work(uint32_t* buf);
+/* diagnostics: the dual-list PY blend stops every tile walk after `batches` 64-entry batches (0 = off).  The results are
+ * WRONG; the knob exists to measure what the long walks cost a pipelined job (bench.py --walk-cap). */
+int g2pc_debug_set_walk_cap(int batches);
 /* --- native-rasteriser ("cuda") semantics: _C.rasterize_gaussians (rasterize_points.h:18-41) ----------------------
  * Deterministic spec of SURVEY.md §8(a.5): 16x16 tiles, near cull z_view <= 0.2, radius ceil(3 sqrt(lambda_max)),
  * stable (tile, depth) order, alpha rules (power > 0 skip, min(0.99, .), alpha < 1/255 skip, T(1-alpha) < 1e-4 stop),
