@@ -2175,7 +2175,8 @@ static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t*
                 // operation order (k_blend_py_pk); the dual-list kernel's expanded exponent differs by up to ~2e-5 relative
                 // in alpha.  A captured camera reads t_floor from its device job: the caller says so with phase bit 8.
                 const bool exact = ba.job ? ((phases & 8) != 0) : (ba.t_floor == 0.0f);
-                if (g_blend_variant == 4 && !exact) G2PC_BLEND(k_blend_py_sg<4>);
+                if (g_blend_variant == 6 && !exact) G2PC_BLEND(k_blend_py_dl<2>);
+                else if (g_blend_variant == 4 && !exact) G2PC_BLEND(k_blend_py_sg<4>);
                 else if (g_blend_variant == 5 && !exact) G2PC_BLEND(k_blend_py_sg<2>);
                 else if (g_blend_variant == 3 && !exact)
                     hipLaunchKernelGGL((k_blend_py_2w<2>), dim3((unsigned)bt.n, chunks_y, cdiv(layout->num_chunks, chunks_y)), dim3(2 * BL_T), 0, s,

@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--scene-scales", type=float, nargs=2, default=None, metavar=("LO", "HI"),
                     help="diagnostic: Gaussian scale range of the synthetic scene (default 0.002 0.02 = SURVEY.md's)")
     ap.add_argument("--no-context-pool", action="store_true", help="tuning aid: every job captures its camera graphs anew")
-    ap.add_argument("--blend-variant", type=int, default=None, choices=[None, 0, 1, 2, 3, 4, 5], help="tuning aid: 2 / 3 = two-wave (unroll 4 / 2) dual-list kernel (one wave per sub-block), 1 = dual-list blend kernel, 0 = packed kernel")
+    ap.add_argument("--blend-variant", type=int, default=None, choices=[None, 0, 1, 2, 3, 4, 5, 6], help="tuning aid: 2 / 3 = two-wave (unroll 4 / 2) dual-list kernel (one wave per sub-block), 1 = dual-list blend kernel, 0 = packed kernel")
     ap.add_argument("--depth-sort", default=None, choices=[None, "bucket", "radix"], help="tuning aid: depth order of the captured camera path")
     ap.add_argument("--streams", type=int, default=0, help="tuning aid: camera batches in flight (HIP streams) of the renderer")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the untimed region / kernel profile passes after the timed loop")

@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 
-def run_variants(device, golden_dir, variants=(1, 2, 3, 4, 5), t_floor=1e-6, pipelined=False):
+def run_variants(device, golden_dir, variants=(1, 2, 3, 4, 5, 6), t_floor=1e-6, pipelined=False):
     from g2pc import _native as nv
     import gauss_render
     from render_checks import run_render_case, assert_render_matches
