@@ -41,6 +41,7 @@ struct Layout {         // device pointers of G2pcTileLayout
     int depth;                        // quad-tree info (python semantics): nx == ny == 1 << depth, 0 = none
     const int32_t *inner_x, *inner_y; // [(1 << depth) - 1][2] inclusive pixel extents of the interior nodes per axis
     const int32_t* tile_stick;        // [ny*nx] bit k: the leaf reaches beyond its level-k ancestor (nullptr = none does)
+    const uint8_t* tile_force;        // [ny*nx] non-zero: always split when it holds a Gaussian (nullptr = none)
     int walk_cap;                     // DIAGNOSTIC (g2pc_debug_set_walk_cap): the dual-list blend stops a walk after this many batches (0 = never; results are then WRONG)
 };
 
@@ -1880,9 +1881,11 @@ __global__ __launch_bounds__(RA_T) void k_tile_gate(Layout lay, Cam cam_val, con
     // a tile of a child level that is no child of a split node (the level's layout is the PRODUCT of the child intervals) is
     // not part of the tree: it is never blended (its chunks are not in the work list) and must not report a load either
     const bool in_tree = !lay.tile_mask || lay.tile_mask[t] != 0;
-    if (!state && limit && cnt > limit && in_tree) {
+    // ... and a node the size rule has not finished with (tile_force) is split whenever it holds a Gaussian (:319: `or` of the two)
+    const bool over = limit && cnt > limit, forced = lay.tile_force && lay.tile_force[t] != 0 && cnt > 0;
+    if (!state && (over || forced) && in_tree) {
         state = 1u;
-        if (flag) atomicMax(flag, cnt);
+        if (flag && over) atomicMax(flag, cnt);
         if (count_host) count_host[4 * blockIdx.y + 2] = cnt;          // pinned, through its device mapping: "some leaf of this camera"
     }
     tile_range[t] = make_uint2(first, state ? first : end);
@@ -2018,6 +2021,7 @@ static Layout to_layout(const G2pcTileLayout* l) {
     k.tile_seq = l->tile_seq; k.seq_tile = l->seq_tile; k.tile_pix_off = l->tile_pix_off;
     k.seq_base = l->seq_count ? l->seq_base : 0; k.seq_count = l->seq_count ? l->seq_count : l->nx * l->ny;
     k.tile_mask = l->tile_mask;
+    k.tile_force = l->tile_force;
     const bool tree = l->depth > 0 && l->inner_x && l->inner_y && l->tile_stick && l->nx == (1 << l->depth) && l->ny == (1 << l->depth);
     k.depth = tree ? l->depth : 0; k.inner_x = l->inner_x; k.inner_y = l->inner_y; k.tile_stick = tree ? l->tile_stick : nullptr;
     return k;

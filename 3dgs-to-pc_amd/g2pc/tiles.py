@@ -10,6 +10,8 @@ parent) produces leaves of uniform depth that are the cartesian product of two 1
 bottom-right per split) is kept as `tile_seq`; it decides which tile wins ties of the running maximum and
 which tile's colour an overlapped pixel finally shows.
 
+(Image sizes whose border nodes fit the limit a level before the interior ones: see python_quadtree_layout, `tile_force`.)
+
 The tree's two DATA-DEPENDENT rules are decided per camera on top of that leaf grid: `_tree_tables` describes the tree above
 the leaves (interior node extents, which leaves reach beyond which ancestor) for the rasteriser's gate, which skips leaves
 under empty nodes (gauss_render.py:311-314); `child_layout` builds the next level below the nodes the reference splits for
@@ -103,43 +105,60 @@ def _finish(xs, ws, ys, hs, seq_of, subblocks=None, tile_shard=None, blended=Non
 
 def python_quadtree_layout(width: int, height: int, max_tile_size: int = 60, subblocks=None,
                            tile_shard=None) -> Dict[str, np.ndarray]:
-    queue = [([0, 0], [width, height])]          # ([row, col], [w, h]) as in the reference
-    leaves = []
+    """The size-driven part of the reference's queue (split while a side exceeds max_tile_size) as a tile layout.
+
+    Every node of one depth has the same nominal size -- children are ceil(size / 2) on both sides -- and only the nodes the
+    image's right / bottom border clips are smaller.  Usually all nodes reach the limit at the same depth and the leaves are
+    the product of two interval families.  When the border nodes fit the limit one level EARLIER than the interior ones
+    (e.g. 961 pixels: the nominal width of depth 4 is 61 > 60, the last column is clipped to 46) the layout is the product at
+    that shallower depth with `tile_force[t] = 1` on the nodes that are still too large: the renderer splits those for every
+    camera exactly as it splits a leaf holding too many Gaussians (level by level, child_layout), which is what the reference's
+    queue does with them -- a node without Gaussians is painted and dropped BEFORE its size is looked at (gauss_render.py:311-319)."""
+    queue = [([0, 0], [width, height], 0)]       # ([row, col], [w, h], depth) as in the reference
+    by_depth = {}                                # depth -> [(x0, y0, w, h, is_leaf)] in FIFO order
     while queue:
-        start, size = queue.pop(0)
+        start, size, depth = queue.pop(0)
         if size[0] <= 1 or size[1] <= 1:          # gauss_render.py:301
             continue
         size = [min(size[0], width - start[1]), min(size[1], height - start[0])]
-        if size[0] > max_tile_size or size[1] > max_tile_size:
+        big = size[0] > max_tile_size or size[1] > max_tile_size
+        by_depth.setdefault(depth, []).append((start[1], start[0], size[0], size[1], not big))
+        if big:
             size = [ceil(size[0] / 2), ceil(size[1] / 2)]
             s = list(start)
-            queue.append((list(s), list(size)))
+            queue.append((list(s), list(size), depth + 1))
             s[0] += floor(size[1])
-            queue.append((list(s), list(size)))
+            queue.append((list(s), list(size), depth + 1))
             s[0] -= floor(size[1])
             s[1] += floor(size[0])
-            queue.append((list(s), list(size)))
+            queue.append((list(s), list(size), depth + 1))
             s[0] += floor(size[1])
-            queue.append((list(s), list(size)))
-            continue
-        leaves.append((start[1], start[0], size[0], size[1]))       # x0, y0, w, h in FIFO order
-    if not leaves:
+            queue.append((list(s), list(size), depth + 1))
+    leaf_depths = [d for d, nodes in by_depth.items() if any(n[4] for n in nodes)]
+    if not leaf_depths:
         # (every branch ends in nodes narrower than two pixels, which the reference drops, gauss_render.py:301: it paints nothing)
         raise NotImplementedError("no quad-tree leaf survives for %dx%d / %d: every node gets narrower than two pixels before "
                                   "both sides fit the tile limit" % (width, height, max_tile_size))
-    xs = sorted({(l[0], l[2]) for l in leaves})
-    ys = sorted({(l[1], l[3]) for l in leaves})
-    if len({x for x, _ in xs}) != len(xs) or len({y for y, _ in ys}) != len(ys) or len(xs) * len(ys) != len(leaves):
-        raise NotImplementedError("quad-tree leaves are not a product of intervals for %dx%d / %d" % (width, height, max_tile_size))
+    d0 = min(leaf_depths)
+    nodes = by_depth[d0]                          # the shallowest level holding a leaf: its leaves + the nodes still too large
+    xs = sorted({(n[0], n[2]) for n in nodes})
+    ys = sorted({(n[1], n[3]) for n in nodes})
+    if len({x for x, _ in xs}) != len(xs) or len({y for y, _ in ys}) != len(ys) or len(xs) * len(ys) != len(nodes):
+        raise NotImplementedError("quad-tree level %d is not a product of intervals for %dx%d / %d (nodes narrower than two "
+                                  "pixels were dropped)" % (d0, width, height, max_tile_size))
     wof, hof = dict(xs), dict(ys)
-    seq_of = {}
-    for s, (x0, y0, w, h) in enumerate(leaves):
+    seq_of, force_of = {}, {}
+    for s, (x0, y0, w, h, leaf) in enumerate(nodes):
         if wof[x0] != w or hof[y0] != h:
-            raise NotImplementedError("non-uniform quad-tree leaves")
+            raise NotImplementedError("non-uniform quad-tree level")
         seq_of[(x0, y0)] = s
+        force_of[(x0, y0)] = 0 if leaf else 1
     lay = _finish([x for x, _ in xs], [w for _, w in xs], [y for y, _ in ys], [h for _, h in ys], seq_of, subblocks,
                   tile_shard)
     lay.update(_tree_tables(width, height, lay))
+    force = np.array([force_of[(x, y)] for (y, _) in ys for (x, _) in xs], dtype=np.uint8)
+    if force.any():
+        lay["tile_force"] = force                 # [ny*nx]: 1 = larger than max_tile_size, always split (G2pcTileLayout.tile_force)
     return lay
 
 
@@ -185,38 +204,52 @@ def _tree_tables(width: int, height: int, lay) -> Dict[str, np.ndarray]:
 
 
 def child_layout(width: int, height: int, parents, subblocks=None):
-    """The next quad-tree level below a set of split nodes, as a tile layout.
+    """The next quad-tree level below a set of split nodes, as tile layouts.
 
     parents: list of (x0, y0, w, h, order) -- the nodes the reference splits (gauss_render.py:319-335), `order` any sortable
-    key that reproduces their FIFO order.  Returns (layout, children): the layout is the product of the distinct child column
-    intervals with the distinct child row intervals (the children of a node no larger than 2 pixels a side are dropped, :301), and
-    children[i] = (tile index, x0, y0, w, h, order + (c,)) lists the tiles that ARE children of a parent, in FIFO order
-    (c = 0 top-left, 1 bottom-left, 2 top-right, 3 bottom-right, :325-333).  The other tiles of the product are not part of
-    the tree: they get no blend work here and the caller masks them out of the image (tile_mask); a caller that shards the
-    tiles over ranks deals the children out itself (GaussHipRenderer._render_tree)."""
+    key that reproduces their FIFO order.  Returns a list of RUNS [(layout, children), ...] in FIFO order (usually one): a
+    run's layout is the product of the distinct child column intervals with the distinct child row intervals (the children
+    of a node no larger than 2 pixels a side are dropped, :301), and children[i] = (tile index, x0, y0, w, h, order + (c,))
+    lists the tiles that ARE children of a parent, in FIFO order (c = 0 top-left, 1 bottom-left, 2 top-right, 3 bottom-right,
+    :325-333).  The other tiles of the product are not part of the tree: they get no blend work and the caller masks them out
+    of the gate and the image (tile_mask); a caller that shards the tiles over ranks deals the children out itself
+    (GaussHipRenderer._render_tree).
+
+    Why runs: nodes of one level that descend from ancestors of different sizes (a 13-pixel node split for its size beside a
+    12-pixel leaf split for its Gaussian count) overlap by more than the usual pixel, and their children may START at the same
+    column / row with DIFFERENT sizes -- which no product of intervals holds.  The parents are therefore cut, in FIFO order,
+    into maximal runs whose children are compatible; the caller renders the runs one after the other, which is the reference's
+    own order (sequence numbers and painting order across runs stay FIFO).  [] = every child is dropped."""
+    runs = []
     xi, yi, kids = {}, {}, []
-    for (x0, y0, w, h, order) in parents:
+
+    def close():
+        nonlocal xi, yi, kids
+        if kids:
+            xs, ys = sorted(xi), sorted(yi)
+            colx, rowy = {x: i for i, x in enumerate(xs)}, {y: i for i, y in enumerate(ys)}
+            children = [(rowy[ky] * len(xs) + colx[kx], kx, ky, kw, kh, order) for (kx, ky, kw, kh, order) in kids]
+            seq = np.full((len(xs) * len(ys),), len(kids), dtype=np.int32)  # tiles outside the tree: after every child (never blended)
+            seq[[c[0] for c in children]] = np.arange(len(kids), dtype=np.int32)
+            lay = _finish(xs, [xi[x] for x in xs], ys, [yi[y] for y in ys], seq, subblocks, None, blended=[c[0] for c in children])
+            runs.append((lay, children))
+        xi, yi, kids = {}, {}, []
+
+    for (x0, y0, w, h, order) in sorted(parents, key=lambda p: p[4]):
         if ceil(w / 2) <= 1 or ceil(h / 2) <= 1:
             continue        # the reference drops a node by its size BEFORE clipping it to the image (:301, :304-305): all four go
         cx = split_interval(x0, w, width)
         cy = split_interval(y0, h, height)
-        for c, (a, b) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
-            # (a child the image border clips to ONE pixel stays in the queue: nothing can be a member of it, so the reference
-            # paints it with the background over whatever an earlier node left there)
-            (kx, kw), (ky, kh) = cx[a], cy[b]
-            if xi.setdefault(kx, kw) != kw or yi.setdefault(ky, kh) != kh:
-                raise NotImplementedError("children of different widths share a first column")
+        # (a child the image border clips to ONE pixel stays in the queue: nothing can be a member of it, so the reference
+        # paints it with the background over whatever an earlier node left there)
+        four = [(cx[a], cy[b]) for (a, b) in ((0, 0), (0, 1), (1, 0), (1, 1))]
+        if any(xi.get(kx, kw) != kw or yi.get(ky, kh) != kh for ((kx, kw), (ky, kh)) in four):
+            close()         # a child of this parent starts where another one of another size does: next run
+        for c, ((kx, kw), (ky, kh)) in enumerate(four):
+            xi[kx], yi[ky] = kw, kh
             kids.append((kx, ky, kw, kh, tuple(order) + (c,)))
-    if not kids:
-        return None, []
-    xs, ys = sorted(xi), sorted(yi)
-    kids.sort(key=lambda k: k[4])
-    colx, rowy = {x: i for i, x in enumerate(xs)}, {y: i for i, y in enumerate(ys)}
-    children = [(rowy[ky] * len(xs) + colx[kx], kx, ky, kw, kh, order) for (kx, ky, kw, kh, order) in kids]
-    seq = np.full((len(xs) * len(ys),), len(kids), dtype=np.int32)  # tiles outside the tree: after every child (never blended)
-    seq[[c[0] for c in children]] = np.arange(len(kids), dtype=np.int32)
-    lay = _finish(xs, [xi[x] for x in xs], ys, [yi[y] for y in ys], seq, subblocks, None, blended=[c[0] for c in children])
-    return lay, children
+    close()
+    return runs
 
 
 def grid_layout(width: int, height: int, block: int = 16) -> Dict[str, np.ndarray]:

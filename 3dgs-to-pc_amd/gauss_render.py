@@ -62,7 +62,7 @@ class _Layout(C.Structure):
                 ("num_chunks", C.c_int32), ("chunk_tile", C.c_void_p), ("chunk_pix0", C.c_void_p),
                 ("chunk_subblocks", C.c_int32), ("seq_bits", C.c_int32),
                 ("seq_base", C.c_int32), ("seq_count", C.c_int32), ("tile_mask", C.c_void_p), ("depth", C.c_int32),
-                ("inner_x", C.c_void_p), ("inner_y", C.c_void_p), ("tile_stick", C.c_void_p)]
+                ("inner_x", C.c_void_p), ("inner_y", C.c_void_p), ("tile_stick", C.c_void_p), ("tile_force", C.c_void_p)]
 
 
 nv._RASTER_PROTOS.update({
@@ -197,13 +197,17 @@ class _DeviceLayout:
         self.has_tree = int(lay.get("depth", 0)) > 0
         if self.has_tree:
             names += ["inner_x", "inner_y", "tile_stick"]
+        self.forced = lay.get("tile_force")            # nodes still larger than max_tile_size: split for every camera
+        if self.forced is not None:
+            names += ["tile_force"]
         self.t = {k: torch.from_numpy(np.ascontiguousarray(lay[k])).to(device) for k in names}
         if seq_count:
             self.t["tile_seq"] = self.t["tile_seq"] + int(seq_base)
         # tile-sequence bits its keys need: the leaves plus a quarter as many children of split leaves (a camera that needs more
         # widens the renderer's keys in place -- possible only while the camera slots in use fit the wider field's range)
         T = lay["nx"] * lay["ny"]
-        self.seq_bits = min(14, max(12, int(np.ceil(np.log2(max(T + T // 4, 2))))))
+        reserve = T // 4 if lay.get("tile_force") is None else 4 * int(np.count_nonzero(lay["tile_force"]))   # children to come
+        self.seq_bits = min(14, max(12, int(np.ceil(np.log2(max(T + reserve, 2))))))
         self.c = _Layout(nx=lay["nx"], ny=lay["ny"], num_chunks=len(lay["chunk_tile"]),
                          chunk_subblocks=lay["chunk_subblocks"], seq_bits=self.seq_bits, seq_base=int(seq_base),
                          seq_count=int(seq_count), depth=int(lay.get("depth", 0)) if self.has_tree else 0,
@@ -697,6 +701,8 @@ class GaussHipRenderer():
         h = lay.host
         nx, ny, T = h["nx"], h["ny"], lay.num_tiles
         over = (counts > self.MAX_GAUSSIANS_PER_TILE) if self.MAX_GAUSSIANS_PER_TILE else np.zeros((T,), bool)
+        if lay.forced is not None:                 # nodes the size rule still splits (tiles.python_quadtree_layout)
+            over = over | ((lay.forced != 0) & (counts > 0))
         dead, fills = np.zeros((T,), bool), []
         d = int(h.get("depth", 0)) if lay.has_tree else 0
         if d > 0:
@@ -772,42 +778,43 @@ class GaussHipRenderer():
                    for t in np.nonzero(plan["overloaded"])[0]]
         seq_next = lay.num_tiles
         while parents:
-            host, children = tiles.child_layout(W, H, parents, BLEND_SUBBLOCKS)
-            if host is None:
-                break                                                   # every child is narrower than 2 pixels (:301)
-            if host["nx"] > 256 or host["ny"] > 256:
-                raise NotImplementedError("a quad-tree level with more than 256 tile intervals per axis")
-            self._ensure_seq_room(seq_next + len(children))
-            level = _DeviceLayout(host, self.device, seq_base=seq_next, seq_count=len(children))
-            level.c.seq_bits = self.seq_bits
-            self._front(sc, cam, level)
-            n_inst = int(sc.offsets[self.n].item())
-            # the level's layout is the PRODUCT of the children's column and row intervals: the gate only looks at the tiles that
-            # ARE children (tile_mask) -- a non-tree tile over the limit is no "overloaded leaf" and reports no load
-            is_child = np.zeros((level.num_tiles,), bool)
-            is_child[[c[0] for c in children]] = True
-            gate = level.only(is_child)
-            gate.c.seq_bits = self.seq_bits
-            self._back(sc, cam, gate, slot, n_inst, image, 1, "raster_bin")
-            counts, states = self._tile_states(sc, level, n_inst)
-            enabled = np.zeros((level.num_tiles,), bool)
+            runs = tiles.child_layout(W, H, parents, BLEND_SUBBLOCKS)   # usually ONE run (tiles.child_layout: why there may be more)
             parents = []
-            for (t, x0, y0, w, h_, order) in children:
-                if self.MAX_GAUSSIANS_PER_TILE and counts[t] > self.MAX_GAUSSIANS_PER_TILE:
-                    parents.append((x0, y0, w, h_, order))              # split again at the next level
-                else:
-                    enabled[t] = True                                   # blended (an empty child paints the background, :311-314)
-            if self.tile_shard is not None:                             # this rank's share of the children
-                mine = np.zeros_like(enabled)
-                mine[[c[0] for c in children][self.tile_shard[0]::self.tile_shard[1]]] = True
-                enabled &= mine
-            if enabled.any():
-                part = level.only(enabled)
-                part.c.seq_bits = self.seq_bits
-                self._back(sc, cam, part, slot, n_inst, image, 2, "raster_blend")
-                self._back(sc, cam, part, slot, n_inst, image, 4, "raster_update")
-            seq_next += len(children)
-            self.split_leaves += len(children)
+            for host, children in runs:                                 # (no run: every child is narrower than 2 pixels, :301)
+                if host["nx"] > 256 or host["ny"] > 256:
+                    raise NotImplementedError("a quad-tree level with more than 256 tile intervals per axis")
+                self._ensure_seq_room(seq_next + len(children))
+                level = _DeviceLayout(host, self.device, seq_base=seq_next, seq_count=len(children))
+                level.c.seq_bits = self.seq_bits
+                self._front(sc, cam, level)
+                n_inst = int(sc.offsets[self.n].item())
+                # the level's layout is the PRODUCT of the children's column and row intervals: the gate only looks at the tiles
+                # that ARE children (tile_mask) -- a non-tree tile over the limit is no "overloaded leaf" and reports no load
+                is_child = np.zeros((level.num_tiles,), bool)
+                is_child[[c[0] for c in children]] = True
+                gate = level.only(is_child)
+                gate.c.seq_bits = self.seq_bits
+                self._back(sc, cam, gate, slot, n_inst, image, 1, "raster_bin")
+                counts, states = self._tile_states(sc, level, n_inst)
+                enabled = np.zeros((level.num_tiles,), bool)
+                for (t, x0, y0, w, h_, order) in children:
+                    too_many = self.MAX_GAUSSIANS_PER_TILE and counts[t] > self.MAX_GAUSSIANS_PER_TILE
+                    too_large = counts[t] > 0 and (w > self.MAX_TILE_SIZE or h_ > self.MAX_TILE_SIZE)  # (:319, after the empty test :311)
+                    if too_many or too_large:
+                        parents.append((x0, y0, w, h_, order))          # split again at the next level
+                    else:
+                        enabled[t] = True                               # blended (an empty child paints the background, :311-314)
+                if self.tile_shard is not None:                         # this rank's share of the children
+                    mine = np.zeros_like(enabled)
+                    mine[[c[0] for c in children][self.tile_shard[0]::self.tile_shard[1]]] = True
+                    enabled &= mine
+                if enabled.any():
+                    part = level.only(enabled)
+                    part.c.seq_bits = self.seq_bits
+                    self._back(sc, cam, part, slot, n_inst, image, 2, "raster_blend")
+                    self._back(sc, cam, part, slot, n_inst, image, 4, "raster_update")
+                seq_next += len(children)
+                self.split_leaves += len(children)
 
     # ---- capture-and-replay pipeline ------------------------------------------------------------------------------
     def _capture(self, sl, lay, key):

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define G2PC_ABI_VERSION 4
+#define G2PC_ABI_VERSION 5
 
 #define G2PC_OK 0
 #define G2PC_ERR_ARG (-1)
@@ -303,6 +303,10 @@ typedef struct G2pcTileLayout {      /* HOST struct of DEVICE pointers: tiles = 
                                       * level k (0 = root) interval i at row (1 << k) - 1 + i */
     const int32_t* inner_y;          /* the same for rows */
     const int32_t* tile_stick;       /* [ny*nx]: bit k set = the leaf reaches beyond its level-k ancestor (odd splits) */
+    const uint8_t* tile_force;       /* ABI 5, optional [ny*nx]: non-zero = a node of the size-driven tree that is still larger than
+                                      * max_tile_size (image sizes whose border nodes fit the limit a level before the interior
+                                      * ones, gauss_render.py:319): the gate treats it like a leaf over max_per_tile whenever it
+                                      * holds a Gaussian -- empty range, state 1, its children rendered in further passes */
 } G2pcTileLayout;
 
 size_t g2pc_raster_front_workspace(int64_t n);

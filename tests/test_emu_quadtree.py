@@ -231,3 +231,30 @@ def test_image_whose_quad_tree_has_no_leaf(emu):
     from g2pc import tiles
     with pytest.raises(NotImplementedError, match="no quad-tree leaf"):
         tiles.python_quadtree_layout(400, 6, 3)
+
+
+@pytest.mark.parametrize("w,h,mt,n,crowd", [
+    (59, 56, 14, 900, 1.0),        # depth 2: interior nodes 15 wide (> 14), the border column clipped to 14
+    (121, 90, 60, 700, 1.0),       # 61 | 60: one half needs one more split than the other
+    (241, 130, 30, 1500, 0.5),     # 8 x 8 nodes, 32 of them still too large, crowded scene
+    (66, 97, 12, 800, 0.4),        # forced nodes that ALSO exceed max_gaussians_per_tile further down
+])
+def test_sizes_whose_border_nodes_stop_a_level_early(emu, monkeypatch, w, h, mt, n, crowd):
+    """Image sizes for which the reference's size-driven tree is not of uniform depth (the border nodes, clipped by the image,
+    fit max_tile_size one level before the interior ones: 7 % of all sizes at the default 60, e.g. every width 961 - 975 and
+    1921 - 1951): until round 4 the layout refused them.  The shallower level is the leaf grid, the nodes still too large are
+    split for every camera (G2pcTileLayout.tile_force) like leaves holding too many Gaussians -- in the two-call path and,
+    deferred to flush(), in the graph pipeline -- and the result is the oracle's (whose queue is the reference's, :290-335)."""
+    import gauss_render
+    from render_checks import run_vs_oracle
+    monkeypatch.setattr(gauss_render, "BLEND_SUBBLOCKS", 2)
+    from g2pc import tiles
+    assert "tile_force" in tiles.python_quadtree_layout(w, h, mt, 2)
+    for floor, pipelined in ((0.0, False), (1e-6, False), (1e-6, True)):
+        res = run_vs_oracle(n, 300 + n, w, h, 0.9 * w, 2, scale=(0.004, 0.05), t_floor=floor, max_tile_size=mt,
+                            max_gaussians_per_tile=60 if (w, h) == (66, 97) else None, xyz_scale=crowd, pipelined=pipelined)
+        assert res["split_leaves"] > 0
+        assert res["contribution"] < 1e-5 and res["flips"] == 0, (floor, pipelined, res)
+        if not pipelined:
+            assert res["image"] < 1e-5 and res["image_frac_off"] == 0.0, (floor, res)
+        assert res["colour_off_gaussians"] <= (3 if floor else 0), (floor, pipelined, res)

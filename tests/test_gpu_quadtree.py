@@ -64,3 +64,22 @@ def test_split_fixture_through_the_graph_pipeline(golden_dir):
     assert res["contribution"] < 1e-4 and res["flips"] <= res["near_threshold"] and res["split_leaves"] > 0, res
     assert res["colour_off_gaussians"] <= 2, res
     gauss_render.clear_context_pool()
+
+
+@pytest.mark.parametrize("w,h,mt,n,crowd", [(59, 56, 14, 900, 1.0), (241, 130, 30, 1500, 0.5), (66, 97, 12, 800, 0.4)])
+def test_sizes_whose_border_nodes_stop_a_level_early(monkeypatch, w, h, mt, n, crowd):
+    """Trees of non-uniform depth (G2pcTileLayout.tile_force) on the MI355X against the oracle: two-call path (exact and floor)
+    and the graph pipeline; the third case mixes nodes split for their size with leaves split for their count (several runs
+    per level, tiles.child_layout)."""
+    import gauss_render
+    from render_checks import run_vs_oracle
+    monkeypatch.setattr(gauss_render, "BLEND_SUBBLOCKS", 2)
+    for floor, pipelined in ((0.0, False), (1e-6, False), (1e-6, True)):
+        res = run_vs_oracle(n, 300 + n, w, h, 0.9 * w, 2, device="cuda:0", scale=(0.004, 0.05), t_floor=floor, max_tile_size=mt,
+                            max_gaussians_per_tile=60 if (w, h) == (66, 97) else None, xyz_scale=crowd, pipelined=pipelined)
+        print(floor, pipelined, res)
+        assert res["split_leaves"] > 0
+        assert res["contribution"] < 1e-5 and res["flips"] == 0, (floor, pipelined, res)
+        if not pipelined:
+            assert res["image"] < 1e-4 and res["image_frac_off"] < 1e-4, (floor, res)
+        assert res["colour_off_gaussians"] <= 3, (floor, pipelined, res)

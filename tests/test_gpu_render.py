@@ -69,7 +69,10 @@ def test_render_full_size_properties():
 
 
 @pytest.mark.parametrize("n,w,h,f,res", [(20_000, 1280, 720, 1100.0, None), (5_000, 1920, 1080, 1650.0, None),
-                                         (8_000, 1280, 720, 1100.0, 360)])
+                                         (8_000, 1280, 720, 1100.0, 360),
+                                         # 961 wide: the size-driven tree is not of uniform depth (interior nodes 61 > 60, the border
+                                         # column clipped to 46): 128 of the 256 nodes are split for every camera (tile_force)
+                                         (6_000, 961, 540, 830.0, None)])
 def test_render_vs_oracle_other_sizes(n, w, h, f, res):
     from render_checks import run_vs_oracle
     r = run_vs_oracle(n, 31 + n, w, h, f, 2, device=DEV, colour_resolution=res)
