@@ -281,6 +281,32 @@ PIPELINE_IN_EMULATOR = False      # tests: drive the capture / replay path throu
 CAPACITY_HEADROOM = 1.25          # instance capacity of the captured graphs relative to the largest count seen so far
 MIN_CAPACITY = 1 << 16
 _LAYOUT_CACHE = {}
+# Child levels of a camera's data-dependent quad-tree, keyed by (image size, the parents split, first sequence number, device):
+# cameras of one job mostly split the SAME nodes (image sizes with a non-uniform size-driven tree split the same interior
+# nodes for every camera), and building a level on the host (tiles.child_layout + its chunk lists) costs 3 - 20 ms.
+_CHILD_LEVEL_CACHE = {}
+_CHILD_LEVEL_CACHE_MAX = 64
+
+
+def _child_levels(W, H, parents, seq_next, device):
+    """[(level _DeviceLayout, children, gate pass-layout)] for the runs of tiles.child_layout (usually one), cached."""
+    key = (W, H, BLEND_SUBBLOCKS, int(seq_next), str(device), tuple(sorted((p[4], p[0], p[1], p[2], p[3]) for p in parents)))
+    hit = _CHILD_LEVEL_CACHE.get(key)
+    if hit is None:
+        hit, base = [], int(seq_next)
+        for host, children in tiles.child_layout(W, H, parents, BLEND_SUBBLOCKS):
+            if host["nx"] > 256 or host["ny"] > 256:
+                raise NotImplementedError("a quad-tree level with more than 256 tile intervals per axis")
+            level = _DeviceLayout(host, device, seq_base=base, seq_count=len(children))
+            is_child = np.zeros((level.num_tiles,), bool)
+            is_child[[c[0] for c in children]] = True
+            level.parts = {}                        # enabled mask (bytes) -> pass layout, see _render_tree
+            hit.append((level, children, level.only(is_child)))
+            base += len(children)
+        if len(_CHILD_LEVEL_CACHE) >= _CHILD_LEVEL_CACHE_MAX:
+            _CHILD_LEVEL_CACHE.pop(next(iter(_CHILD_LEVEL_CACHE)))
+        _CHILD_LEVEL_CACHE[key] = hit
+    return hit
 
 
 class _GraphSlot:
@@ -778,21 +804,15 @@ class GaussHipRenderer():
                    for t in np.nonzero(plan["overloaded"])[0]]
         seq_next = lay.num_tiles
         while parents:
-            runs = tiles.child_layout(W, H, parents, BLEND_SUBBLOCKS)   # usually ONE run (tiles.child_layout: why there may be more)
+            runs = _child_levels(W, H, parents, seq_next, self.device)  # usually ONE run (tiles.child_layout: why there may be more)
             parents = []
-            for host, children in runs:                                 # (no run: every child is narrower than 2 pixels, :301)
-                if host["nx"] > 256 or host["ny"] > 256:
-                    raise NotImplementedError("a quad-tree level with more than 256 tile intervals per axis")
+            for level, children, gate in runs:                          # (no run: every child is narrower than 2 pixels, :301)
                 self._ensure_seq_room(seq_next + len(children))
-                level = _DeviceLayout(host, self.device, seq_base=seq_next, seq_count=len(children))
                 level.c.seq_bits = self.seq_bits
                 self._front(sc, cam, level)
                 n_inst = int(sc.offsets[self.n].item())
                 # the level's layout is the PRODUCT of the children's column and row intervals: the gate only looks at the tiles
                 # that ARE children (tile_mask) -- a non-tree tile over the limit is no "overloaded leaf" and reports no load
-                is_child = np.zeros((level.num_tiles,), bool)
-                is_child[[c[0] for c in children]] = True
-                gate = level.only(is_child)
                 gate.c.seq_bits = self.seq_bits
                 self._back(sc, cam, gate, slot, n_inst, image, 1, "raster_bin")
                 counts, states = self._tile_states(sc, level, n_inst)
@@ -809,7 +829,12 @@ class GaussHipRenderer():
                     mine[[c[0] for c in children][self.tile_shard[0]::self.tile_shard[1]]] = True
                     enabled &= mine
                 if enabled.any():
-                    part = level.only(enabled)
+                    ek = enabled.tobytes()
+                    part = level.parts.get(ek)
+                    if part is None:
+                        if len(level.parts) >= 8:
+                            level.parts.clear()
+                        part = level.parts[ek] = level.only(enabled)
                     part.c.seq_bits = self.seq_bits
                     self._back(sc, cam, part, slot, n_inst, image, 2, "raster_blend")
                     self._back(sc, cam, part, slot, n_inst, image, 4, "raster_update")
