@@ -41,7 +41,8 @@ struct Layout {         // device pointers of G2pcTileLayout
     int depth;                        // quad-tree info (python semantics): nx == ny == 1 << depth, 0 = none
     const int32_t *inner_x, *inner_y; // [(1 << depth) - 1][2] inclusive pixel extents of the interior nodes per axis
     const int32_t* tile_stick;        // [ny*nx] bit k: the leaf reaches beyond its level-k ancestor (nullptr = none does)
-    const uint8_t* tile_force;        // [ny*nx] non-zero: always split when it holds a Gaussian (nullptr = none)
+    const uint8_t* tile_force;        // [ny*nx] non-zero: always split when it holds a Gaussian (nullptr = none); 2 = children follow statically
+    const int32_t* tile_parent;       // [ny*nx] child level of another layout: the parent tile there (-1 none), with G2pcCameraJob.alive
     int walk_cap;                     // DIAGNOSTIC (g2pc_debug_set_walk_cap): the dual-list blend stops a walk after this many batches (0 = never; results are then WRONG)
 };
 
@@ -1880,14 +1881,33 @@ __global__ __launch_bounds__(RA_T) void k_tile_gate(Layout lay, Cam cam_val, con
     }
     // a tile of a child level that is no child of a split node (the level's layout is the PRODUCT of the child intervals) is
     // not part of the tree: it is never blended (its chunks are not in the work list) and must not report a load either
-    const bool in_tree = !lay.tile_mask || lay.tile_mask[t] != 0;
-    // ... and a node the size rule has not finished with (tile_force) is split whenever it holds a Gaussian (:319: `or` of the two)
-    const bool over = limit && cnt > limit, forced = lay.tile_force && lay.tile_force[t] != 0 && cnt > 0;
-    if (!state && (over || forced) && in_tree) {
-        state = 1u;
-        if (flag && over) atomicMax(flag, cnt);
-        if (count_host) count_host[4 * blockIdx.y + 2] = cnt;          // pinned, through its device mapping: "some leaf of this camera"
+    bool in_tree = !lay.tile_mask || lay.tile_mask[t] != 0;
+    // Static child pass (round 4): a pass over a parent layout leaves "this node holds a Gaussian" per tile in the job's `alive`
+    // array; the child level's pass skips the children of nodes that held none (:311-314: never visited -- a Gaussian that
+    // reaches only into the pixel a child extends beyond its odd-sized parent must not be blended there)
+    uint8_t* alive = nullptr;
+    if (cam_dev) {
+        const G2pcCameraJob* jb = (const G2pcCameraJob*)((const char*)cam_dev + (size_t)blockIdx.y * sizeof(G2pcCameraJob));
+        alive = (uint8_t*)(((unsigned long long)jb->alive_hi << 32) | jb->alive_lo);
     }
+    if (alive) {
+        if (lay.tile_parent) {
+            const int p = lay.tile_parent[t];
+            if (p >= 0 && !alive[p]) in_tree = false;
+        } else {
+            alive[t] = cnt > 0 ? 1 : 0;
+        }
+    }
+    // ... and a node the size rule has not finished with (tile_force) is split whenever it holds a Gaussian (:319: `or` of the two)
+    const uint8_t force = lay.tile_force ? lay.tile_force[t] : (uint8_t)0;
+    const bool over = limit && cnt > limit, forced = force != 0 && cnt > 0;
+    if (!state && (over || forced) && in_tree) {
+        const bool follows = force == 2 && !over;          // its children come with the camera's static child pass
+        state = follows ? 3u : 1u;
+        if (flag && over) atomicMax(flag, cnt);
+        if (count_host && !follows) count_host[4 * blockIdx.y + 2] = cnt;   // pinned, through its device mapping: "some leaf of this camera"
+    }
+    if (!in_tree && lay.tile_parent) state = 4u;           // child of an empty node: never visited
     tile_range[t] = make_uint2(first, state ? first : end);
     tile_state[t] = state;
 }
@@ -2022,6 +2042,7 @@ static Layout to_layout(const G2pcTileLayout* l) {
     k.seq_base = l->seq_count ? l->seq_base : 0; k.seq_count = l->seq_count ? l->seq_count : l->nx * l->ny;
     k.tile_mask = l->tile_mask;
     k.tile_force = l->tile_force;
+    k.tile_parent = l->tile_parent;
     const bool tree = l->depth > 0 && l->inner_x && l->inner_y && l->tile_stick && l->nx == (1 << l->depth) && l->ny == (1 << l->depth);
     k.depth = tree ? l->depth : 0; k.inner_x = l->inner_x; k.inner_y = l->inner_y; k.tile_stick = tree ? l->tile_stick : nullptr;
     return k;

@@ -53,7 +53,7 @@ class _Camera(C.Structure):
 class _Job(C.Structure):
     """G2pcCameraJob: what a captured camera graph reads from device memory."""
     _fields_ = [("cam", _Camera), ("camera_slot", C.c_uint32), ("t_floor", C.c_float), ("tilebuf_lo", C.c_uint32),
-                ("tilebuf_hi", C.c_uint32), ("reserved", C.c_uint32)]
+                ("tilebuf_hi", C.c_uint32), ("reserved", C.c_uint32), ("alive_lo", C.c_uint32), ("alive_hi", C.c_uint32)]
 
 
 class _Layout(C.Structure):
@@ -62,7 +62,8 @@ class _Layout(C.Structure):
                 ("num_chunks", C.c_int32), ("chunk_tile", C.c_void_p), ("chunk_pix0", C.c_void_p),
                 ("chunk_subblocks", C.c_int32), ("seq_bits", C.c_int32),
                 ("seq_base", C.c_int32), ("seq_count", C.c_int32), ("tile_mask", C.c_void_p), ("depth", C.c_int32),
-                ("inner_x", C.c_void_p), ("inner_y", C.c_void_p), ("tile_stick", C.c_void_p), ("tile_force", C.c_void_p)]
+                ("inner_x", C.c_void_p), ("inner_y", C.c_void_p), ("tile_stick", C.c_void_p), ("tile_force", C.c_void_p),
+                ("tile_parent", C.c_void_p)]
 
 
 nv._RASTER_PROTOS.update({
@@ -220,6 +221,52 @@ class _DeviceLayout:
         """The same layout restricted to the tiles with enabled[t]: the blend walks only their chunks and the image
         assembly paints only their pixels (G2pcTileLayout.tile_mask)."""
         return _PassLayout(self, np.asarray(enabled, dtype=bool))
+
+    def static_pass(self, max_tile_size):
+        """Image sizes whose size-driven tree is not of uniform depth (tile_force): the nodes still too large are the same for
+        every camera, so their child level can go through the capture-and-replay pipeline as a SECOND pass of each camera
+        instead of the host-driven passes at flush().  Returns (pass A, pass B, this layout) or None:
+          pass A = this layout without the chunks of the forced nodes, tile_force = 2 ("children follow": the gate empties the
+                   node's range without reporting the camera) -- and the gate records which nodes hold a Gaussian (job.alive);
+          pass B = the child level of ALL forced nodes (tiles.child_layout, one run), sequence numbers continuing the leaves',
+                   tile_parent = the node each child descends from: the gate skips the children of nodes that held nothing,
+                   and reports (state 1 -> flush()'s host path) children that are still too large or hold too many Gaussians."""
+        if self.forced is None:
+            return None
+        if not hasattr(self, "_static"):
+            self._static = None
+            h = self.host
+            nx = h["nx"]
+            W = int(max(h["xs"] + h["ws"]))
+            H = int(max(h["ys"] + h["hs"]))
+            forced = np.asarray(self.forced) != 0
+            parents = [(int(h["xs"][t % nx]), int(h["ys"][t // nx]), int(h["ws"][t % nx]), int(h["hs"][t // nx]), (int(h["tile_seq"][t]),))
+                       for t in np.nonzero(forced)[0]]
+            tile_of = {(int(h["xs"][t % nx]), int(h["ys"][t // nx])): int(t) for t in np.nonzero(forced)[0]}
+            runs = _child_levels(W, H, parents, self.num_tiles, self.device)
+            if len(runs) == 1:
+                level, children, _ = runs[0]
+                pa = self.only(~forced)
+                pa.t["tile_force"] = torch.from_numpy(np.where(forced, 2, 0).astype(np.uint8)).to(self.device)
+                pa.c.tile_force = pa.t["tile_force"].data_ptr()
+                is_child = np.zeros((level.num_tiles,), bool)
+                parent = np.full((level.num_tiles,), -1, dtype=np.int32)
+                still = np.zeros((level.num_tiles,), dtype=np.uint8)
+                # children come four per parent, in the parents' FIFO order (tiles.child_layout): order[:-1] names the parent
+                by_order = {p[4]: tile_of[(p[0], p[1])] for p in parents}
+                for (t, x0, y0, w, hh, order) in children:
+                    is_child[t] = True
+                    parent[t] = by_order[tuple(order[:-1])]
+                    still[t] = 1 if (w > max_tile_size or hh > max_tile_size) else 0
+                pb = level.only(is_child)
+                pb.t["tile_parent"] = torch.from_numpy(parent).to(self.device)
+                pb.c.tile_parent = pb.t["tile_parent"].data_ptr()
+                if still.any():
+                    pb.t["tile_force"] = torch.from_numpy(still).to(self.device)
+                    pb.c.tile_force = pb.t["tile_force"].data_ptr()
+                pb.children = len(children)
+                self._static = (pa, pb, self)
+        return self._static
 
 
 class _PassLayout:
@@ -481,6 +528,8 @@ class GaussHipRenderer():
         self.deferred = {}            # camera slot -> layout of the pipelined cameras whose colours are resolved at flush()
         self.redo = []                # cameras that did not fit their graph's capacity: (camera struct, layout, slot)
         self.fixups = []              # cameras whose overloaded leaves still need their children rendered: (camera struct, layout, slot)
+        self.alive_rows = 0           # rows of the context's `alive` pool handed out since the last flush()
+        self.pass_b = []              # static child passes waiting for flush(): (camera struct, pass-B layout, slot, own layout, alive bytes)
         self.split_leaves = 0         # children of overloaded leaves rendered so far (the reference's count-driven split)
         self.rerendered = 0           # cameras that overflowed their graph's capacity and went through the two-call path
         self.layouts = {}
@@ -803,14 +852,30 @@ class GaussHipRenderer():
         parents = [(int(h["xs"][t % nx]), int(h["ys"][t // nx]), int(h["ws"][t % nx]), int(h["hs"][t // nx]), (int(h["tile_seq"][t]),))
                    for t in np.nonzero(plan["overloaded"])[0]]
         seq_next = lay.num_tiles
+        # A camera that already went through a STATIC child pass (image sizes with a non-uniform size-driven tree, static_pass)
+        # carries keys numbered as that pass numbers them: the children of ALL nodes still too large, in the nodes' FIFO order,
+        # whether a node held a Gaussian or not.  Its first level here uses the same level object (same numbers; the children
+        # of empty nodes are left out), the children of leaves split for their COUNT follow as a run of their own.
+        first, dead_parent = None, None
+        sp = lay.static_pass(self.MAX_TILE_SIZE) if (static_done and getattr(lay, "forced", None) is not None and self.tile_shard is None) else None
+        if sp is not None:
+            forced = np.asarray(lay.forced) != 0
+            node = lambda t: (int(h["xs"][t % nx]), int(h["ys"][t // nx]), int(h["ws"][t % nx]), int(h["hs"][t // nx]), (int(h["tile_seq"][t]),))
+            runs_f = _child_levels(W, H, [node(t) for t in np.nonzero(forced)[0]], seq_next, self.device)
+            dead_parent = {(int(h["tile_seq"][t]),) for t in np.nonzero(forced & ~plan["overloaded"])[0]}   # empty (or dead) forced nodes
+            counted = [node(t) for t in np.nonzero(plan["overloaded"] & ~forced)[0]]
+            first = list(runs_f) + (list(_child_levels(W, H, counted, seq_next + len(runs_f[0][1]), self.device)) if counted else [])
         while parents:
-            runs = _child_levels(W, H, parents, seq_next, self.device)  # usually ONE run (tiles.child_layout: why there may be more)
+            runs = first if first is not None else _child_levels(W, H, parents, seq_next, self.device)   # usually ONE run (tiles.child_layout)
+            skip_dead = dead_parent if first is not None else None
+            first = None
             parents = []
             for level, children, gate in runs:                          # (no run: every child is narrower than 2 pixels, :301)
                 self._ensure_seq_room(seq_next + len(children))
                 level.c.seq_bits = self.seq_bits
                 self._front(sc, cam, level)
                 n_inst = int(sc.offsets[self.n].item())
+                self._level_inst_max = max(getattr(self, "_level_inst_max", 0), n_inst)   # (capacity of a static child pass)
                 # the level's layout is the PRODUCT of the children's column and row intervals: the gate only looks at the tiles
                 # that ARE children (tile_mask) -- a non-tree tile over the limit is no "overloaded leaf" and reports no load
                 gate.c.seq_bits = self.seq_bits
@@ -818,6 +883,8 @@ class GaussHipRenderer():
                 counts, states = self._tile_states(sc, level, n_inst)
                 enabled = np.zeros((level.num_tiles,), bool)
                 for (t, x0, y0, w, h_, order) in children:
+                    if skip_dead and tuple(order[:-1]) in skip_dead:
+                        continue                                        # child of a node that held no Gaussian: never visited
                     too_many = self.MAX_GAUSSIANS_PER_TILE and counts[t] > self.MAX_GAUSSIANS_PER_TILE
                     too_large = counts[t] > 0 and (w > self.MAX_TILE_SIZE or h_ > self.MAX_TILE_SIZE)  # (:319, after the empty test :311)
                     if too_many or too_large:
@@ -849,8 +916,9 @@ class GaussHipRenderer():
         capacity, batch = key[1], key[3]
         # graphs of the same (layout, capacity) but another number of cameras share the slot's buffers and stay cached;
         # anything else (new capacity, new layout, new buffers) starts the slot afresh
-        if any(k[:2] != key[:2] for k in sl.graphs):
-            sl.release()
+        if any(k[1] != key[1] for k in sl.graphs):
+            sl.release()                           # (graphs of ANOTHER layout at the same capacity stay: a static child pass
+                                                   # alternates with its cameras' own layout, the buffers only ever grow)
         need = L.g2pc_raster_camera_workspace(self.n, capacity, lay.num_tiles) * sl.batch
         import contextlib
         with (torch.cuda.stream(sl.stream) if sl.on_gpu else contextlib.nullcontext()):   # allocate on the stream using them
@@ -887,21 +955,29 @@ class GaussHipRenderer():
         batch, sl.inflight = sl.inflight, None
         if sl.on_gpu:
             sl.update_done.synchronize()
-        for i, (cam, lay, slot, capacity) in enumerate(batch):
+        for i, (cam, lay, slot, capacity, orig, second) in enumerate(batch):
             num_inst, unsorted, overloaded = (int(sl.count_host[4 * i + j]) for j in range(3))
             if num_inst > capacity or unsorted:
                 # did not fit the graph's buffers, or the depth bucket sort met a pile-up of equal depths: the graph skipped
                 # the camera as a whole; render it again through the two-call path (radix depth sort, exact instance count)
                 if num_inst > capacity:
                     self.capacity = max(self.capacity, int(num_inst * CAPACITY_HEADROOM))
-                self.redo.append((cam, lay, slot))
+                self.redo.append((cam, orig, slot))            # (the camera's OWN layout: leaves and children, idempotent)
+                # a pass A that did not fit takes its pass B with it: the two-call path numbers the children as IT meets them
+                # (a pass B that did not fit wrote nothing: the graph skips the camera as a whole)
+                self.pass_b = [p for p in self.pass_b if p[2] != slot]
+                if second:
+                    self.split_leaves -= lay.children          # (flush() counts every staged pass B; the redo counts its own)
                 self.rerendered += 1
                 continue
             if overloaded:
-                # some leaf held more than max_gaussians_per_tile Gaussians: the graph left it out (k_tile_gate); its children
-                # are rendered at flush() -- the packed keys make the order of the passes irrelevant
-                self.fixups.append((cam, lay, slot))
-            self._note(lay, num_inst, cam.width, cam.height)
+                # some leaf held more than max_gaussians_per_tile Gaussians (or a child of the static pass is still too large):
+                # the graph left it out (k_tile_gate); its children are rendered at flush() -- the packed keys make the order of
+                # the passes irrelevant, and re-blending what a static child pass already blended changes nothing
+                if not any(f[2] == slot and f[1] is orig for f in self.fixups):
+                    self.fixups.append((cam, orig, slot))
+            if not second:
+                self._note(lay, num_inst, cam.width, cam.height)
 
     def _launch_batch(self, sl):
         """Replay the slot's graph for the cameras staged in its job array (a short last batch gets its own graph)."""
@@ -948,7 +1024,7 @@ class GaussHipRenderer():
                     nv.check(self._camera_call(sl, lay, key[1], 2 | exact, batch), "raster_cameras_py (blend)")
             if on_gpu:
                 sl.update_done.record(sl.stream)           # "this batch's blends are done" (the colours are resolved at flush)
-        sl.inflight, sl.staged = [(c, l, s_, key[1]) for (c, l, s_) in sl.staged], []
+        sl.inflight, sl.staged = [(c, l, s_, key[1], o, sec) for (c, l, s_, o, sec) in sl.staged], []
         sl.fill, sl.fill_lay = 0, None
         self.slot_next = (self.slot_next + 1) % len(self.slots)
 
@@ -958,8 +1034,10 @@ class GaussHipRenderer():
             self.flush()
         if self.capacity is None:                  # the first camera tells how many instances to expect
             self.flush()
+            self._level_inst_max = 0
             _, num_inst = self._render_sync(self._camera_struct(camera), lay, slot, False)
-            self.capacity = max(int(num_inst * CAPACITY_HEADROOM), MIN_CAPACITY)
+            # (an image size with a static child pass: the children's level holds more instances than the leaves')
+            self.capacity = max(int(max(num_inst, self._level_inst_max) * CAPACITY_HEADROOM), MIN_CAPACITY)
             return
         # (the batched scans take at most 2 M values per camera; larger scenes keep one camera per launch sequence)
         batch = max(1, min(int(CAMERA_BATCH), 8)) if self.n <= (2 << 20) else 1
@@ -974,9 +1052,40 @@ class GaussHipRenderer():
             self.slots[:] = first + [_GraphSlot(self.device, on_gpu, batch, stream=first[i % PIPELINE_STREAMS].stream)
                                      for i in range(PIPELINE_STREAMS * (per_stream - 1))]
             self.slot_next = 0
+        sp = lay.static_pass(self.MAX_TILE_SIZE) if (getattr(lay, "forced", None) is not None and self.tile_shard is None) else None
+        if sp is None:
+            self._stage(camera, lay, slot, lay)
+            return
+        # an image size whose size-driven tree is not of uniform depth: pass A now (the leaves; the gate notes which of the nodes
+        # still too large hold a Gaussian), pass B -- their children, the same layout for every camera -- when the cameras are
+        # flushed.  The packed-key atomicMax makes the order of the passes irrelevant.
+        pa, pb, _ = sp
+        self._ensure_seq_room(lay.num_tiles + pb.children)
+        pa.c.seq_bits = self.seq_bits
+        # one row of a persistent [256, tiles] byte array per pending camera (written by pass A's gate -- every entry --, read by
+        # pass B's): allocated once per renderer context, so no block of the caching allocator changes streams under it
+        pool = getattr(self.ctx, "alive_pool", None)
+        if pool is None or pool.shape[1] < lay.num_tiles:
+            if self.device.type == "cuda" and not nv.emulated():
+                torch.cuda.synchronize(self.device)
+            pool = self.ctx.alive_pool = torch.zeros((256, lay.num_tiles), dtype=torch.uint8, device=self.device)
+            if self.device.type == "cuda" and not nv.emulated():
+                torch.cuda.synchronize(self.device)
+        if self.alive_rows >= pool.shape[0]:
+            self.flush()
+        alive = pool[self.alive_rows]
+        self.alive_rows += 1
+        self._stage(camera, pa, slot, lay, alive=alive)
+        self.pass_b.append((self._camera_struct(camera), pb, slot, lay, alive))
+
+    def _stage(self, camera, lay, slot, orig, alive=None, second=False):
+        """Write one camera into the next free job of the pipeline (launching the batch when it is full).  lay: the layout this
+        pass blends; orig: the camera's own layout (what a re-render through the two-call path uses); alive: see static_pass;
+        second: a child pass staged from inside flush() (never flushes itself)."""
+        on_gpu = self.device.type == "cuda" and not nv.emulated()
         sl = self.slots[self.slot_next]
         if sl.fill and sl.fill_lay is not lay:
-            self._launch_batch(sl)                  # another image size: the staged cameras go as a short batch
+            self._launch_batch(sl)                  # another image size / pass: the staged cameras go as a short batch
             sl = self.slots[self.slot_next]
         if sl.fill == 0:
             self._retire(sl)                        # the job array is rewritten: its previous batch must be through
@@ -985,7 +1094,7 @@ class GaussHipRenderer():
         # order across the streams
         ring = self.ctx.cam_tilebufs
         limit = max(DEFERRED_MIN, min(DEFERRED_MAX, DEFERRED_BUDGET_BYTES // (lay.total_pixels * 12)))
-        if len(self.deferred) >= limit:
+        if not second and len(self.deferred) + len(self.pass_b) >= limit:
             self.flush()                           # resolve the colours of the cameras so far; their buffers are free again
             del ring[limit:]                       # a smaller image earlier in the job may have grown the ring past this limit
             sl = self.slots[self.slot_next]
@@ -1000,11 +1109,16 @@ class GaussHipRenderer():
                 ring[idx] = tb
         tb = ring[idx]
         job = sl.jobs[sl.fill]
-        self._camera_struct(camera, job.cam)                                        # rewrite the pinned job in place
+        if isinstance(camera, _Camera):
+            C.memmove(C.byref(job.cam), C.byref(camera), C.sizeof(_Camera))
+        else:
+            self._camera_struct(camera, job.cam)                                    # rewrite the pinned job in place
         job.camera_slot, job.t_floor = slot, self.t_floor
         job.tilebuf_lo, job.tilebuf_hi = tb.data_ptr() & 0xFFFFFFFF, tb.data_ptr() >> 32
-        self.deferred[slot] = (lay, tb)
-        sl.staged.append((_Camera.from_buffer_copy(job.cam), lay, slot))
+        ap = alive.data_ptr() if alive is not None else 0
+        job.alive_lo, job.alive_hi = ap & 0xFFFFFFFF, ap >> 32
+        self.deferred[(slot, id(lay))] = (lay, tb)
+        sl.staged.append((_Camera.from_buffer_copy(job.cam), lay, slot, orig, second))
         sl.fill += 1
         sl.fill_lay = lay
         if sl.fill == sl.batch:
@@ -1019,6 +1133,21 @@ class GaussHipRenderer():
                 self._launch_batch(sl)             # a short last batch
         for sl in self.slots:
             self._retire(sl)
+        if self.pass_b:
+            # static child passes (image sizes with a non-uniform size-driven tree): every camera's pass A is through, its
+            # `alive` bytes are written; the children go through the same pipeline, batched like cameras
+            pending, self.pass_b = self.pass_b, []
+            for (cam, pb, slot, orig, alive) in pending:
+                pb.c.seq_bits = self.seq_bits
+                self._stage(cam, pb, slot, orig, alive=alive, second=True)
+            for sl in self.slots:
+                if sl.fill:
+                    self._launch_batch(sl)
+            for sl in self.slots:
+                self._retire(sl)
+            self.split_leaves += sum(p[1].children for p in pending)
+            del pending
+        self.alive_rows = 0                        # (the alive rows are free again)
         if self.device.type == "cuda" and not nv.emulated():
             cur = torch.cuda.current_stream(self.device)
             for sl in self.slots:
@@ -1027,7 +1156,8 @@ class GaussHipRenderer():
                 cur.wait_stream(b)
         while self.redo:                           # cameras that overflowed their graph: two-call path, original slot
             cam, lay, slot = self.redo.pop(0)
-            self.deferred.pop(slot, None)          # ... which updates the colours it wins at once
+            for k in [k for k in self.deferred if k[0] == slot]:
+                self.deferred.pop(k)               # ... which updates the colours it wins at once
             lay.c.seq_bits = self.seq_bits         # (layouts are shared between renderers)
             self._render_sync(cam, lay, slot, False)
         while self.fixups:                         # cameras with overloaded leaves: the children of those leaves, original slot
@@ -1039,7 +1169,7 @@ class GaussHipRenderer():
         if self.deferred:
             # deferred colour resolve: one pass per layout over the Gaussians, colour = the winner camera's tile buffer
             by_layout = {}
-            for slot, (lay, tb) in self.deferred.items():
+            for (slot, _), (lay, tb) in self.deferred.items():
                 by_layout.setdefault(id(lay), (lay, []))[1].append((slot, tb))
             for lay, slots in by_layout.values():
                 lay.c.seq_bits = self.seq_bits

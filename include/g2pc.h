@@ -306,7 +306,11 @@ typedef struct G2pcTileLayout {      /* HOST struct of DEVICE pointers: tiles = 
     const uint8_t* tile_force;       /* ABI 5, optional [ny*nx]: non-zero = a node of the size-driven tree that is still larger than
                                       * max_tile_size (image sizes whose border nodes fit the limit a level before the interior
                                       * ones, gauss_render.py:319): the gate treats it like a leaf over max_per_tile whenever it
-                                      * holds a Gaussian -- empty range, state 1, its children rendered in further passes */
+                                      * holds a Gaussian -- empty range, state 1, its children rendered in further passes.
+                                      * Value 2: the same, but the children follow as a STATIC pass of the same launch plan
+                                      * (tile_parent below): state 3, not reported through count_host */
+    const int32_t* tile_parent;      /* ABI 5, optional [ny*nx]: this layout is the child level of another one; entry = the tile of
+                                      * that layout this tile is a child of (-1: none).  With G2pcCameraJob.alive: see there */
 } G2pcTileLayout;
 
 size_t g2pc_raster_front_workspace(int64_t n);
@@ -370,6 +374,12 @@ typedef struct G2pcCameraJob {       /* DEVICE (and pinned host staging) struct 
                                       * argument baked into a captured graph) -- lets a caller keep one buffer per camera and
                                       * resolve the winners' colours once, g2pc_raster_resolve_colours_py */
     uint32_t reserved;
+    uint32_t alive_lo, alive_hi;     /* ABI 5, optional: device address of u8[num_tiles of the PARENT layout].  A pass over a layout
+                                      * WITHOUT tile_parent writes "tile t holds a Gaussian" there (the gate, one byte per tile);
+                                      * a later pass of the same camera over a layout WITH tile_parent (the static child level of
+                                      * an image size whose size-driven tree is not of uniform depth) leaves out every tile whose
+                                      * parent held none -- the reference never visits the children of an empty node
+                                      * (gauss_render.py:311-314) */
 } G2pcCameraJob;
 size_t g2pc_raster_camera_workspace(int64_t n, int64_t capacity, int32_t num_tiles);
 /* After phase 1 of g2pc_raster_back_py (same ws, num_instances, num_tiles): Gaussians per tile (counts u32[T], optional) and

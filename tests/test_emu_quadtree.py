@@ -252,11 +252,45 @@ def test_sizes_whose_border_nodes_stop_a_level_early(emu, monkeypatch, w, h, mt,
     monkeypatch.setattr(gauss_render, "BLEND_SUBBLOCKS", 2)
     from g2pc import tiles
     assert "tile_force" in tiles.python_quadtree_layout(w, h, mt, 2)
-    for floor, pipelined in ((0.0, False), (1e-6, False), (1e-6, True)):
-        res = run_vs_oracle(n, 300 + n, w, h, 0.9 * w, 2, scale=(0.004, 0.05), t_floor=floor, max_tile_size=mt,
-                            max_gaussians_per_tile=60 if (w, h) == (66, 97) else None, xyz_scale=crowd, pipelined=pipelined)
+    tree_calls = []
+    real_tree = gauss_render.GaussHipRenderer._render_tree
+    monkeypatch.setattr(gauss_render.GaussHipRenderer, "_render_tree",
+                        lambda self, *a, **k: (tree_calls.append(1), real_tree(self, *a, **k))[1])
+    counted = (w, h) == (66, 97)                                    # this case ALSO has leaves over a per-tile limit
+    for floor, pipelined, cams in ((0.0, False, 2), (1e-6, False, 2), (1e-6, True, 5)):
+        # (the graph pipeline is off in the emulator unless asked for: with it, the nodes still too large go through the STATIC
+        # child pass -- pass A on the leaf grid, pass B on the children, gated on the device by pass A's counts -- and the
+        # host-driven level walk is only entered for cameras that overflow a COUNT limit)
+        monkeypatch.setattr(gauss_render, "PIPELINE_IN_EMULATOR", pipelined)
+        del tree_calls[:]
+        res = run_vs_oracle(n, 300 + n, w, h, 0.9 * w, cams, scale=(0.004, 0.05), t_floor=floor, max_tile_size=mt,
+                            max_gaussians_per_tile=60 if counted else None, xyz_scale=crowd, pipelined=pipelined)
         assert res["split_leaves"] > 0
         assert res["contribution"] < 1e-5 and res["flips"] == 0, (floor, pipelined, res)
         if not pipelined:
             assert res["image"] < 1e-5 and res["image_frac_off"] == 0.0, (floor, res)
+        elif not counted:
+            assert len(tree_calls) <= 1, tree_calls                 # (the single call is the oracle comparison's sync render)
         assert res["colour_off_gaussians"] <= (3 if floor else 0), (floor, pipelined, res)
+
+
+@pytest.mark.parametrize("headroom", [0.45, 0.8])
+def test_static_child_pass_cameras_that_overflow_their_graph(emu, monkeypatch, headroom):
+    """The static child pass of a forced-size image with graph buffers that are too small for some cameras: a camera whose
+    pass A does not fit takes its pass B with it (the two-call path numbers the children as it meets them -- two numberings
+    under one camera slot would leave keys no buffer resolves), a camera whose pass B does not fit is rendered again as a
+    whole over the leaves pass A already wrote.  Same result as the oracle's either way."""
+    import gauss_render
+    from render_checks import run_vs_oracle
+    gauss_render.clear_context_pool()
+    monkeypatch.setattr(gauss_render, "BLEND_SUBBLOCKS", 2)
+    monkeypatch.setattr(gauss_render, "PIPELINE_IN_EMULATOR", True)
+    monkeypatch.setattr(gauss_render, "CAPACITY_HEADROOM", headroom)
+    monkeypatch.setattr(gauss_render, "MIN_CAPACITY", 1)
+    seen = {}
+    real = gauss_render.GaussHipRenderer.flush
+    monkeypatch.setattr(gauss_render.GaussHipRenderer, "flush", lambda self: (real(self), seen.update(r=self.rerendered))[0])
+    res = run_vs_oracle(900, 1200, 59, 56, 0.9 * 59, 7, scale=(0.004, 0.05), t_floor=1e-6, max_tile_size=14, pipelined=True)
+    gauss_render.clear_context_pool()
+    assert seen["r"] >= 1, seen
+    assert res["contribution"] < 1e-5 and res["flips"] == 0 and res["colour_off_gaussians"] <= 3, res

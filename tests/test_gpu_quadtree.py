@@ -78,12 +78,24 @@ def test_sizes_whose_border_nodes_stop_a_level_early(monkeypatch, w, h, mt, n, c
     import gauss_render
     from render_checks import run_vs_oracle
     monkeypatch.setattr(gauss_render, "BLEND_SUBBLOCKS", 2)
-    for floor, pipelined in ((0.0, False), (1e-6, False), (1e-6, True)):
-        res = run_vs_oracle(n, 300 + n, w, h, 0.9 * w, 2, device="cuda:0", scale=(0.004, 0.05), t_floor=floor, max_tile_size=mt,
-                            max_gaussians_per_tile=60 if (w, h) == (66, 97) else None, xyz_scale=crowd, pipelined=pipelined)
-        print(floor, pipelined, res)
+    tree_calls = []
+    real_tree = gauss_render.GaussHipRenderer._render_tree
+    monkeypatch.setattr(gauss_render.GaussHipRenderer, "_render_tree",
+                        lambda self, *a, **k: (tree_calls.append(1), real_tree(self, *a, **k))[1])
+    counted = (w, h) == (66, 97)
+    for floor, pipelined, cams in ((0.0, False, 2), (1e-6, False, 2), (1e-6, True, 11)):
+        gauss_render.clear_context_pool()
+        del tree_calls[:]
+        res = run_vs_oracle(n, 300 + n, w, h, 0.9 * w, cams, device="cuda:0", scale=(0.004, 0.05), t_floor=floor, max_tile_size=mt,
+                            max_gaussians_per_tile=60 if counted else None, xyz_scale=crowd, pipelined=pipelined)
+        print(floor, pipelined, len(tree_calls), res)
         assert res["split_leaves"] > 0
         assert res["contribution"] < 1e-5 and res["flips"] == 0, (floor, pipelined, res)
         if not pipelined:
             assert res["image"] < 1e-4 and res["image_frac_off"] < 1e-4, (floor, res)
+        elif not counted:
+            # the nodes still too large went through the STATIC child pass (pass A + pass B in the graph pipeline): the
+            # host-driven level walk ran for the first camera (which sizes the graphs) and for no other
+            assert len(tree_calls) <= 1, tree_calls
         assert res["colour_off_gaussians"] <= 3, (floor, pipelined, res)
+    gauss_render.clear_context_pool()
