@@ -31,6 +31,7 @@ _PROTOS = {
     "g2pc_scan_workspace": (_sz, [_i64]),
     "g2pc_scan_exclusive_u32": (C.c_int, [_vp, _vp, _i64, _vp, _sz, _vp]),
     "g2pc_sort_workspace": (_sz, [_i64]),
+    "g2pc_debug_set_head_threads": (C.c_int, [C.c_int]),
     "g2pc_set_sort_tuning": (C.c_int, [C.c_int, _i64]),
     "g2pc_bucket_sort_workspace": (_sz, [_i64]),
     "g2pc_bucket_sort_u32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _sz, _vp]),

@@ -361,10 +361,15 @@ __global__ __launch_bounds__(RS_T) void k_radix_scatter(const uint32_t* __restri
 
 // pass geometry: digits of up to 11 bits (2048 LDS bins) when more than 8 bits have to be sorted, 4 keys per
 // thread for inputs that would otherwise leave CUs idle (<= 2M keys), else 8
-static int g_radix_wide_bits = 8;          // 8 or 11: digit width used when more than 8 bits are sorted (tuning knob)
+static int g_radix_wide_bits = 8;          // 8 or 11: digit width used when more than 8 bits are sorted (tuning knob); 10: ONE
+                                           // 10-bit pass for 9 - 10 bits (the tile sort of up to 1 024 leaves), else as 8
 static long g_radix_small_n = 2L << 20;    // inputs up to this size use 4 keys per thread
 static inline int radix_items(long n) { return n <= g_radix_small_n ? 4 : 8; }
-static inline int radix_maxbits(int total_bits) { return total_bits <= 8 ? 8 : g_radix_wide_bits; }
+static inline int radix_maxbits(int total_bits) {
+    if (total_bits <= 8) return 8;
+    if (g_radix_wide_bits == 10) return total_bits <= 10 ? 10 : 8;
+    return g_radix_wide_bits;
+}
 
 size_t sort_workspace(long n) {
     long nb = (n + RS_T * 4 - 1) / (RS_T * 4);
@@ -428,6 +433,9 @@ int sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* k
         if (maxbits == 8) {
             if (items == 4) radix_pass<8, 4>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc, n_dev, b);
             else radix_pass<8, 8>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc, n_dev, b);
+        } else if (maxbits == 10) {
+            if (items == 4) radix_pass<10, 4>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc, n_dev, b);
+            else radix_pass<10, 8>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc, n_dev, b);
         } else {
             if (items == 4) radix_pass<11, 4>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc, n_dev, b);
             else radix_pass<11, 8>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc, n_dev, b);
@@ -759,7 +767,7 @@ const char* g2pc_last_error(void) { return g2pc::g_err.c_str(); }
 int g2pc_abi_version(void) { return G2PC_ABI_VERSION; }
 
 int g2pc_set_sort_tuning(int wide_digit_bits, int64_t small_input_keys) {
-    if (wide_digit_bits != 8 && wide_digit_bits != 11) return G2PC_ERR_ARG;
+    if (wide_digit_bits != 8 && wide_digit_bits != 10 && wide_digit_bits != 11) return G2PC_ERR_ARG;
     g2pc::g_radix_wide_bits = wide_digit_bits;
     g2pc::g_radix_small_n = small_input_keys;
     return G2PC_OK;

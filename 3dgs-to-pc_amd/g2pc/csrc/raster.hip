@@ -19,6 +19,11 @@
 namespace g2pc {
 
 constexpr int RA_T = 256;
+// Block size of the python-semantics head kernels without block-level cooperation (k_preprocess_py, k_duplicate, k_tile_ranges).
+// A 256-thread block needs a free wave slot and its registers on all four SIMDs of ONE CU at the same moment -- rare while the
+// single-wave blocks of another camera's blend hold 5 x 92 of every SIMD's 512 VGPRs; a 64-thread block goes wherever one
+// wave fits (the reason k_bk_sort is one wave per block).  g2pc_debug_set_head_threads, 64 / 128 / 256.
+static int g_head_threads = RA_T;
 __global__ void k_tile_ranges(const uint32_t* __restrict__ tile_sorted, long L, int T, uint32_t* __restrict__ tile_start,
                               const uint32_t* __restrict__ l_dev, int gshift, size_t cs);
 constexpr float LOG2E = 1.4426950408889634f;
@@ -106,7 +111,7 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_py(Cam cam_val, const Cam* 
         for (int k = 0; k < (int)(sizeof(Cam) / 4); ++k) dst[k] = cw[k];
     }
     if (mm) __syncthreads();
-    long i = (long)blockIdx.x * RA_T + threadIdx.x;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // (block size: RA_T, or g_head_threads in the camera pipeline)
     const Cam& cam = cam_s;
     uint32_t key = 0xFFFFFFFFu, touched = 0, rc = 0;
     if (i < n) {
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(RA_T) void k_duplicate(const uint32_t* __restrict__
     // gshift > 0 (inst_g unused): ONE word per instance, tile << gshift | Gaussian -- the tile sort then moves keys only
     sorted_idx = seg(sorted_idx, cs); offsets = seg(offsets, cs); rect = seg(rect, cs); inst_tile = seg(inst_tile, cs);
     inst_g = seg(inst_g, cs); l_eff = seg(l_eff, cs);
-    long p = (long)blockIdx.x * RA_T + threadIdx.x;
+    long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     if (l_eff && *l_eff == 0u) return;          // capacity-sized launch: nothing to emit (or more than fits)
     uint32_t off = offsets[p], end = offsets[p + 1];
@@ -1781,7 +1786,7 @@ __global__ __launch_bounds__(RA_T) void k_tile_ranges(const uint32_t* __restrict
                                                      const uint32_t* __restrict__ l_dev, int gshift, size_t cs) {
     tile_sorted = seg(tile_sorted, cs); tile_start = seg(tile_start, cs); l_dev = seg(l_dev, cs);
     if (l_dev) L = (long)*l_dev;                 // capacity-sized launch, count on the device
-    long l = (long)blockIdx.x * RA_T + threadIdx.x;
+    long l = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (l > L) return;
     int prev = l == 0 ? -1 : (int)(tile_sorted[l - 1] >> gshift);      // gshift > 0: packed (tile << gshift | Gaussian) instances
     int cur = l == L ? T : (int)(tile_sorted[l] >> gshift);
@@ -2130,7 +2135,7 @@ static int py_front(const Cam& cam_val, const Cam* cam_dev, const G2pcTileLayout
     if (cam_dev && (jobs_host || hdr))
         hipLaunchKernelGGL(k_fetch_job, dim3((unsigned)bt.n), dim3(64), 0, s, (const uint32_t*)jobs_host, (uint32_t*)jobs_dev, hdr, bt.cs, plan);
     if (cam_dev)
-        hipLaunchKernelGGL(k_preprocess_py<true>, dim3(cdiv(n, RA_T), (unsigned)bt.n), dim3(RA_T), 0, s, cam_val, cam_dev, to_layout(layout),
+        hipLaunchKernelGGL(k_preprocess_py<true>, dim3(cdiv(n, g_head_threads), (unsigned)bt.n), dim3(g_head_threads), 0, s, cam_val, cam_dev, to_layout(layout),
                            means3D, cov9, opacity, n, key_rev, fold ? (uint32_t*)nullptr : idx_rev, touched, colours, fb.rec, fb.rect,
                            bt.cs, hdr, plan.nminmax);
     else
@@ -2171,7 +2176,7 @@ static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t*
     const uint32_t* blend_list = gshift ? tile_sorted : g_sorted;
     if (phases & 1) {
         if (L > 0) {
-            hipLaunchKernelGGL(k_duplicate<false>, dim3(cdiv(n, RA_T), (unsigned)bt.n), dim3(RA_T), 0, s, fb.sorted_idx, fb.offsets, fb.rect, n, lay.nx,
+            hipLaunchKernelGGL(k_duplicate<false>, dim3(cdiv(n, g_head_threads), (unsigned)bt.n), dim3(g_head_threads), 0, s, fb.sorted_idx, fb.offsets, fb.rect, n, lay.nx,
                                inst_tile, inst_g, l_eff, gshift, bt.cs);
             int rc = gshift ? sort_pairs_u32(inst_tile, nullptr, tile_sorted, nullptr, tile_tmp, nullptr, L, gshift,
                                              gshift + bits_for_tiles((unsigned)T), sort_ws, sort_bytes, s, l_eff, bt)
@@ -2179,7 +2184,7 @@ static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t*
                                              bits_for_tiles((unsigned)T), sort_ws, sort_bytes, s, l_eff, bt);
             if (rc) return rc;
         }
-        hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T), (unsigned)bt.n), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start, l_eff, gshift, bt.cs);
+        hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, g_head_threads), (unsigned)bt.n), dim3(g_head_threads), 0, s, tile_sorted, L, T, tile_start, l_eff, gshift, bt.cs);
         Layout glay = lay;
         // no scene / no tree tables: leaves under empty nodes are not looked for (depth 0; the kernel's loads stay unconditional)
         if (!sc.means3D || !lay.tile_stick) { glay.depth = 0; glay.tile_stick = lay.tile_seq; }
@@ -2407,6 +2412,11 @@ int g2pc_raster_repack_keys(unsigned long long* best_key, int64_t n, int32_t old
 
 /* diagnostics: see g2pc.h */
 int g2pc_raster_debug_chunk_work(uint32_t* buf) { g2pc::g_chunk_work = buf; return G2PC_OK; }
+int g2pc_debug_set_head_threads(int threads) {
+    if (threads != 64 && threads != 128 && threads != 256) return G2PC_ERR_ARG;
+    g2pc::g_head_threads = threads;
+    return G2PC_OK;
+}
 int g2pc_debug_set_walk_cap(int batches) { g2pc::g_walk_cap = batches > 0 ? batches : 0; return G2PC_OK; }
 
 /* depth order of the capture-safe camera call: 1 = range-normalised bucket sort + in-LDS bitonic (default), 0 = 4-pass

@@ -531,6 +531,7 @@ class GaussHipRenderer():
         self.alive_rows = 0           # rows of the context's `alive` pool handed out since the last flush()
         self.pass_b = []              # static child passes waiting for flush(): (camera struct, pass-B layout, slot, own layout, alive bytes)
         self.split_leaves = 0         # children of overloaded leaves rendered so far (the reference's count-driven split)
+        self.host_driven = 0          # pipelined cameras whose quad-tree levels were walked by the host at flush()
         self.rerendered = 0           # cameras that overflowed their graph's capacity and went through the two-call path
         self.layouts = {}
         self.last_stats = []          # (instances L, tile-sort passes, W*H) per rendered camera
@@ -1163,6 +1164,7 @@ class GaussHipRenderer():
         while self.fixups:                         # cameras with overloaded leaves: the children of those leaves, original slot
             cam, lay, slot = self.fixups.pop(0)
             lay.c.seq_bits = self.seq_bits
+            self.host_driven += 1
             self._render_sync(cam, lay, slot, False, static_done=True)
             self.last_stats.pop()                  # (noted when its batch retired)
             RENDER_STATS.pop()

@@ -44,7 +44,8 @@ size_t g2pc_scan_workspace(int64_t n);
 /* out[0..n] = exclusive prefix sums of in[0..n-1]; out[n] = total.  in may alias out. */
 int g2pc_scan_exclusive_u32(const uint32_t* in, uint32_t* out, int64_t n, void* ws, size_t ws_bytes, void* stream);
 size_t g2pc_sort_workspace(int64_t n);
-/* tuning: digit width (8 or 11 bits) for sorts of more than 8 bits; inputs up to small_input_keys use 4 keys/thread */
+/* tuning: digit width (8 or 11 bits) for sorts of more than 8 bits -- 10: one 10-bit pass for fields of 9 - 10 bits, passes of
+ * up to 8 bits otherwise --; inputs up to small_input_keys use 4 keys/thread */
 int g2pc_set_sort_tuning(int wide_digit_bits, int64_t small_input_keys);
 /* --- hipGraph capture of a sequence of g2pc_* calls --------------------------------------------------------------------
  * Every g2pc_* entry point only queues work on `stream` (no allocation, no synchronisation), so whatever is called
@@ -434,6 +435,9 @@ int g2pc_raster_debug_chunk_work(uint32_t* buf);
 /* diagnostics: the dual-list PY blend stops every tile walk after `batches` 64-entry batches (0 = off).  The results are
  * WRONG; the knob exists to measure what the long walks cost a pipelined job (bench.py --walk-cap). */
 int g2pc_debug_set_walk_cap(int batches);
+/* tuning: threads per block (64, 128 or 256 = default) of the python-semantics head kernels that need no block-level
+ * cooperation (preprocess, duplicate, tile ranges); set before the first camera of a process (captured graphs keep theirs) */
+int g2pc_debug_set_head_threads(int threads);
 /* --- native-rasteriser ("cuda") semantics: _C.rasterize_gaussians (rasterize_points.h:18-41) ----------------------
  * Deterministic spec of SURVEY.md §8(a.5): 16x16 tiles, near cull z_view <= 0.2, radius ceil(3 sqrt(lambda_max)),
  * stable (tile, depth) order, alpha rules (power > 0 skip, min(0.99, .), alpha < 1/255 skip, T(1-alpha) < 1e-4 stop),

@@ -106,6 +106,17 @@ def test_wide_radix_digits_and_zero_budget(emu):
         nv.lib().g2pc_set_sort_tuning(8, 1 << 21)
     order = np.argsort(keys, kind="stable")
     assert np.array_equal(vo.numpy().view(np.uint32), vals[order])
+    # wide_digit_bits = 10: ONE pass for a 9- or 10-bit field (the tile sort of 257 - 1 024 leaves), passes of up to 8 otherwise
+    for lo, hi in ((20, 29), (3, 13), (0, 32), (5, 12)):
+        try:
+            assert nv.lib().g2pc_set_sort_tuning(10, 1 << 21) == 0
+            ko, vo = ops.sort_pairs_u32(torch.from_numpy(keys.view(np.int32)), torch.from_numpy(vals.view(np.int32)), lo, hi)
+        finally:
+            nv.lib().g2pc_set_sort_tuning(8, 1 << 21)
+        field = (keys >> np.uint32(lo)) & np.uint32((1 << (hi - lo)) - 1 if hi - lo < 32 else 0xFFFFFFFF)
+        order = np.argsort(field, kind="stable")
+        assert np.array_equal(vo.numpy().view(np.uint32), vals[order]), (lo, hi)
+        assert np.array_equal(ko.numpy().view(np.uint32), keys[order]), (lo, hi)
     sizes = torch.tensor([1.0, 2.0, 3.0], dtype=torch.float64)
     p, _, st = ops.distribute_points(sizes, 1)             # budget smaller than the number of Gaussians
     assert p.tolist() == RG.distribute_points(sizes, 1).tolist()

@@ -8,15 +8,17 @@ from g2pc.synth import make_scene, make_cameras
 import gauss_render
 gauss_render.PIPELINE_STREAMS = 4
 dev = torch.device("cuda:0")
-WORKLOAD = sys.argv[1] if len(sys.argv) > 1 else "render"          # render | render_cuda
-scene = make_scene(1_000_000, 1237, device=dev, with_sh=(WORKLOAD == "render_cuda"))
-cams = make_cameras(50)
-for w in range(4):
-    bench.one_step(scene, cams, WORKLOAD, 10_000_000, dev, w)
+WORKLOAD = sys.argv[1] if len(sys.argv) > 1 else "render"          # render | render_cuda | config4 (= configs[3]: 5 M, 200 cameras)
+N, NCAM, POINTS = (5_000_000, 200, 50_000_000) if WORKLOAD == "config4" else (1_000_000, 50, 10_000_000)
+WORKLOAD = "render" if WORKLOAD == "config4" else WORKLOAD
+scene = make_scene(N, 1237, device=dev, with_sh=(WORKLOAD == "render_cuda"))
+cams = make_cameras(NCAM)
+for w in range(4 if N <= 1_000_000 else 2):
+    bench.one_step(scene, cams, WORKLOAD, POINTS, dev, w)
 torch.cuda.synchronize()
 t = time.perf_counter()
 pr = cProfile.Profile(); pr.enable()
-bench.one_step(scene, cams, WORKLOAD, 10_000_000, dev, 2)
+bench.one_step(scene, cams, WORKLOAD, POINTS, dev, 2)
 torch.cuda.synchronize()
 pr.disable()
 print("step wall ms", (time.perf_counter() - t) * 1e3)
