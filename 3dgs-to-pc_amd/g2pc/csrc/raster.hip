@@ -110,6 +110,11 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_py(Cam cam_val, const Cam* 
 #pragma unroll
         for (int k = 0; k < (int)(sizeof(Cam) / 4); ++k) dst[k] = cw[k];
     }
+    const uint8_t* alive = nullptr;          // child pass of a camera (G2pcCameraJob.alive + G2pcTileLayout.tile_parent)
+    if (CAM_ON_DEVICE && lay.tile_parent) {
+        const G2pcCameraJob* jb = (const G2pcCameraJob*)((const char*)cam_dev + (size_t)blockIdx.y * sizeof(G2pcCameraJob));
+        alive = (const uint8_t*)(((unsigned long long)jb->alive_hi << 32) | jb->alive_lo);
+    }
     if (mm) __syncthreads();
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // (block size: RA_T, or g_head_threads in the camera pipeline)
     const Cam& cam = cam_s;
@@ -143,8 +148,21 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_py(Cam cam_val, const Cam* 
         float k00 = c11 * idet, k11 = c00 * idet, k01 = -c01 * idet, k10 = -c10 * idet;
         const float sc = -0.5f * LOG2E;
         bool ok = (ix1 >= ix0) && (iy1 >= iy0) && (mx == mx) && (my == my) && (det == det);
-        if (ok) {
+        if (ok && alive) {
+            // child pass (tile_parent + the camera's `alive` bytes): only the children of the nodes the first pass split exist
+            // for this camera -- nothing is emitted, sorted or binned for the others (k_duplicate applies the same test)
+            uint32_t cnt = 0;
+            for (int iy = iy0; iy <= iy1; ++iy)
+                for (int ix = ix0; ix <= ix1; ++ix) {
+                    const int p = lay.tile_parent[iy * lay.nx + ix];
+                    cnt += (p >= 0 && alive[p]) ? 1u : 0u;
+                }
+            ok = cnt > 0;
+            touched = cnt;
+        } else if (ok) {
             touched = (uint32_t)((ix1 - ix0 + 1) * (iy1 - iy0 + 1));
+        }
+        if (ok) {
             rc = (uint32_t)ix0 | ((uint32_t)ix1 << 8) | ((uint32_t)iy0 << 16) | ((uint32_t)iy1 << 24);
             key = __float_as_uint(-pv[2]);                          // ascending = nearest first
         }
@@ -192,8 +210,16 @@ __global__ __launch_bounds__(RA_T) void k_duplicate(const uint32_t* __restrict__
                                                    const uint32_t* __restrict__ offsets,
                                                    const uint32_t* __restrict__ rect, long n, int nx,
                                                    uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ inst_g,
-                                                   const uint32_t* __restrict__ l_eff, int gshift, size_t cs) {
+                                                   const uint32_t* __restrict__ l_eff, int gshift, size_t cs,
+                                                   const int32_t* __restrict__ tile_parent,
+                                                   const G2pcCameraJob* __restrict__ jobs) {
     // gshift > 0 (inst_g unused): ONE word per instance, tile << gshift | Gaussian -- the tile sort then moves keys only
+    // tile_parent + jobs: a camera's child pass -- only the children of split nodes take instances (k_preprocess_py counted so)
+    const uint8_t* alive = nullptr;
+    if (tile_parent && jobs) {
+        const G2pcCameraJob* jb = jobs + blockIdx.y;
+        alive = (const uint8_t*)(((unsigned long long)jb->alive_hi << 32) | jb->alive_lo);
+    }
     sorted_idx = seg(sorted_idx, cs); offsets = seg(offsets, cs); rect = seg(rect, cs); inst_tile = seg(inst_tile, cs);
     inst_g = seg(inst_g, cs); l_eff = seg(l_eff, cs);
     long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -212,6 +238,7 @@ __global__ __launch_bounds__(RA_T) void k_duplicate(const uint32_t* __restrict__
     }
     for (int iy = iy0; iy <= iy1; ++iy)
         for (int ix = ix0; ix <= ix1; ++ix) {
+            if (alive) { const int p = tile_parent[iy * nx + ix]; if (p < 0 || !alive[p]) continue; }
             if (gshift) {
                 inst_tile[off] = ((uint32_t)(iy * nx + ix) << gshift) | g;
             } else {
@@ -1899,13 +1926,14 @@ __global__ __launch_bounds__(RA_T) void k_tile_gate(Layout lay, Cam cam_val, con
         if (lay.tile_parent) {
             const int p = lay.tile_parent[t];
             if (p >= 0 && !alive[p]) in_tree = false;
-        } else {
-            alive[t] = cnt > 0 ? 1 : 0;
         }
     }
     // ... and a node the size rule has not finished with (tile_force) is split whenever it holds a Gaussian (:319: `or` of the two)
     const uint8_t force = lay.tile_force ? lay.tile_force[t] : (uint8_t)0;
     const bool over = limit && cnt > limit, forced = force != 0 && cnt > 0;
+    // "this node is split for this camera": its children exist (tile_mask does not matter here: the static pass A masks the
+    // very nodes whose children follow)
+    if (alive && !lay.tile_parent) alive[t] = (!state && (over || forced)) ? 1 : 0;
     if (!state && (over || forced) && in_tree) {
         const bool follows = force == 2 && !over;          // its children come with the camera's static child pass
         state = follows ? 3u : 1u;
@@ -2177,7 +2205,8 @@ static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t*
     if (phases & 1) {
         if (L > 0) {
             hipLaunchKernelGGL(k_duplicate<false>, dim3(cdiv(n, g_head_threads), (unsigned)bt.n), dim3(g_head_threads), 0, s, fb.sorted_idx, fb.offsets, fb.rect, n, lay.nx,
-                               inst_tile, inst_g, l_eff, gshift, bt.cs);
+                               inst_tile, inst_g, l_eff, gshift, bt.cs, sc.cam_dev ? lay.tile_parent : (const int32_t*)nullptr,
+                               (const G2pcCameraJob*)sc.cam_dev);
             int rc = gshift ? sort_pairs_u32(inst_tile, nullptr, tile_sorted, nullptr, tile_tmp, nullptr, L, gshift,
                                              gshift + bits_for_tiles((unsigned)T), sort_ws, sort_bytes, s, l_eff, bt)
                             : sort_pairs_u32(inst_tile, inst_g, tile_sorted, g_sorted, tile_tmp, g_tmp, L, 0,
@@ -2551,10 +2580,10 @@ int g2pc_raster_back_cu_tiles(const G2pcCamera* cam, const int32_t* mask, int64_
     if (L > 0) {
         if (cu_wide_grid(gx, gy))
             hipLaunchKernelGGL(k_duplicate<true>, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, sorted_idx, offsets, rect, (long)n, gx,
-                               inst_tile, inst_g, (const uint32_t*)nullptr, gshift, (size_t)0);
+                               inst_tile, inst_g, (const uint32_t*)nullptr, gshift, (size_t)0, (const int32_t*)nullptr, (const G2pcCameraJob*)nullptr);
         else
             hipLaunchKernelGGL(k_duplicate<false>, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, sorted_idx, offsets, rect, (long)n, gx,
-                               inst_tile, inst_g, (const uint32_t*)nullptr, gshift, (size_t)0);
+                               inst_tile, inst_g, (const uint32_t*)nullptr, gshift, (size_t)0, (const int32_t*)nullptr, (const G2pcCameraJob*)nullptr);
         int rc = gshift ? sort_pairs_u32(inst_tile, nullptr, tile_sorted, nullptr, tile_tmp, nullptr, L, gshift,
                                          gshift + bits_for_tiles((unsigned)T), sort_ws, sort_bytes, s)
                         : sort_pairs_u32(inst_tile, inst_g, tile_sorted, g_sorted, tile_tmp, g_tmp, L, 0,
@@ -2619,10 +2648,10 @@ int g2pc_raster_back_cu_dev(const G2pcCamera* cam, const int32_t* mask, int64_t 
     const uint32_t gmask = gshift ? ((1u << gshift) - 1u) : 0xFFFFFFFFu;
     if (cu_wide_grid(gx, gy))
         hipLaunchKernelGGL(k_duplicate<true>, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, sorted_idx, offsets, rect, (long)n, gx, inst_tile, inst_g,
-                           (const uint32_t*)l_eff, gshift, (size_t)0);
+                           (const uint32_t*)l_eff, gshift, (size_t)0, (const int32_t*)nullptr, (const G2pcCameraJob*)nullptr);
     else
         hipLaunchKernelGGL(k_duplicate<false>, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, sorted_idx, offsets, rect, (long)n, gx, inst_tile, inst_g,
-                           (const uint32_t*)l_eff, gshift, (size_t)0);
+                           (const uint32_t*)l_eff, gshift, (size_t)0, (const int32_t*)nullptr, (const G2pcCameraJob*)nullptr);
     int rc = gshift ? sort_pairs_u32(inst_tile, nullptr, tile_sorted, nullptr, tile_tmp, nullptr, L, gshift,
                                      gshift + bits_for_tiles((unsigned)T), sort_ws, sort_bytes, s, l_eff)
                     : sort_pairs_u32(inst_tile, inst_g, tile_sorted, g_sorted, tile_tmp, g_tmp, L, 0, bits_for_tiles((unsigned)T),

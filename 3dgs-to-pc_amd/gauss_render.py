@@ -222,33 +222,68 @@ class _DeviceLayout:
         assembly paints only their pixels (G2pcTileLayout.tile_mask)."""
         return _PassLayout(self, np.asarray(enabled, dtype=bool))
 
-    def static_pass(self, max_tile_size):
-        """Image sizes whose size-driven tree is not of uniform depth (tile_force): the nodes still too large are the same for
-        every camera, so their child level can go through the capture-and-replay pipeline as a SECOND pass of each camera
-        instead of the host-driven passes at flush().  Returns (pass A, pass B, this layout) or None:
-          pass A = this layout without the chunks of the forced nodes, tile_force = 2 ("children follow": the gate empties the
-                   node's range without reporting the camera) -- and the gate records which nodes hold a Gaussian (job.alive);
-          pass B = the child level of ALL forced nodes (tiles.child_layout, one run), sequence numbers continuing the leaves',
-                   tile_parent = the node each child descends from: the gate skips the children of nodes that held nothing,
-                   and reports (state 1 -> flush()'s host path) children that are still too large or hold too many Gaussians."""
-        if self.forced is None:
+    def child_pass(self, max_tile_size, max_per_tile=0):
+        """The child level of this layout as a SECOND captured pass of a camera (instead of host-driven passes at flush()), or None.
+          static    image sizes whose size-driven tree is not of uniform depth (tile_force): the nodes still too large are the same
+                    for every camera.  Pass A = this layout without the chunks of those nodes, tile_force = 2 ("children follow":
+                    the gate empties the node without reporting the camera); pass B = the child level of ALL of them, for every
+                    camera.
+          on demand (uniform trees, max_per_tile set) the leaves a camera OVERLOADS differ from camera to camera: pass A = this
+                    layout as it is (the gate leaves an overloaded leaf out and reports the camera); pass B = the child level of
+                    ALL leaves, staged only for the cameras that reported.
+        In both, pass A's gate writes "this tile is split" per tile into the camera's `alive` bytes and pass B (tile_parent) exists
+        for the children of those tiles only: no instance is emitted for any other tile, and the gate reports (state 1 -> the host
+        path at flush()) children that are still too large or hold too many Gaussians.  Sequence numbers: the children of ALL
+        parent tiles in the parents' FIFO order continue the leaves' -- order-isomorphic to the reference's queue, which numbers
+        the children of the nodes it splits in that order (gauss_render.py:319-335)."""
+        static = self.forced is not None
+        if not static and not max_per_tile:
             return None
-        if not hasattr(self, "_static"):
-            self._static = None
-            h = self.host
+        if not hasattr(self, "_child_pass"):
+            self._child_pass = _ChildPass(self, static, max_tile_size)
+        cp = self._child_pass
+        return cp if cp.usable else None
+
+
+class _ChildPass:
+    def __init__(self, lay, static, max_tile_size):
+        self.lay, self.static, self.max_tile_size = lay, static, max_tile_size
+        h = lay.host
+        self.is_parent = (np.asarray(lay.forced) != 0) if static else np.ones((lay.num_tiles,), bool)
+        self.room = lay.num_tiles + 4 * int(self.is_parent.sum())        # sequence numbers: leaves + (at most) four children each
+        self.usable = self.room <= (1 << 14)
+        self._built = None
+        if static:
+            self.usable = self.usable and self.build() is not None        # (several runs: left to the host path)
+
+    def parents(self):
+        h = self.lay.host
+        nx = h["nx"]
+        return [(int(h["xs"][t % nx]), int(h["ys"][t // nx]), int(h["ws"][t % nx]), int(h["hs"][t // nx]), (int(h["tile_seq"][t]),))
+                for t in np.nonzero(self.is_parent)[0]]
+
+    def runs(self):
+        h = self.lay.host
+        return _child_levels(int(max(h["xs"] + h["ws"])), int(max(h["ys"] + h["hs"])), self.parents(), self.lay.num_tiles,
+                             self.lay.device)
+
+    def build(self):
+        """(pass A layout, pass B layout) -- built on first use (an on-demand pass costs nothing until a camera overloads a leaf)."""
+        if self._built is None:
+            self._built = False
+            lay, h = self.lay, self.lay.host
             nx = h["nx"]
-            W = int(max(h["xs"] + h["ws"]))
-            H = int(max(h["ys"] + h["hs"]))
-            forced = np.asarray(self.forced) != 0
-            parents = [(int(h["xs"][t % nx]), int(h["ys"][t // nx]), int(h["ws"][t % nx]), int(h["hs"][t // nx]), (int(h["tile_seq"][t]),))
-                       for t in np.nonzero(forced)[0]]
-            tile_of = {(int(h["xs"][t % nx]), int(h["ys"][t // nx])): int(t) for t in np.nonzero(forced)[0]}
-            runs = _child_levels(W, H, parents, self.num_tiles, self.device)
+            parents = self.parents()
+            tile_of = {(p[0], p[1]): int(t) for p, t in zip(parents, np.nonzero(self.is_parent)[0])}
+            runs = self.runs()
             if len(runs) == 1:
                 level, children, _ = runs[0]
-                pa = self.only(~forced)
-                pa.t["tile_force"] = torch.from_numpy(np.where(forced, 2, 0).astype(np.uint8)).to(self.device)
-                pa.c.tile_force = pa.t["tile_force"].data_ptr()
+                if self.static:
+                    pa = lay.only(~self.is_parent)
+                    pa.t["tile_force"] = torch.from_numpy(np.where(self.is_parent, 2, 0).astype(np.uint8)).to(lay.device)
+                    pa.c.tile_force = pa.t["tile_force"].data_ptr()
+                else:
+                    pa = lay
                 is_child = np.zeros((level.num_tiles,), bool)
                 parent = np.full((level.num_tiles,), -1, dtype=np.int32)
                 still = np.zeros((level.num_tiles,), dtype=np.uint8)
@@ -257,16 +292,17 @@ class _DeviceLayout:
                 for (t, x0, y0, w, hh, order) in children:
                     is_child[t] = True
                     parent[t] = by_order[tuple(order[:-1])]
-                    still[t] = 1 if (w > max_tile_size or hh > max_tile_size) else 0
+                    still[t] = 1 if (w > self.max_tile_size or hh > self.max_tile_size) else 0
                 pb = level.only(is_child)
-                pb.t["tile_parent"] = torch.from_numpy(parent).to(self.device)
+                pb.t["tile_parent"] = torch.from_numpy(parent).to(lay.device)
                 pb.c.tile_parent = pb.t["tile_parent"].data_ptr()
                 if still.any():
-                    pb.t["tile_force"] = torch.from_numpy(still).to(self.device)
+                    pb.t["tile_force"] = torch.from_numpy(still).to(lay.device)
                     pb.c.tile_force = pb.t["tile_force"].data_ptr()
                 pb.children = len(children)
-                self._static = (pa, pb, self)
-        return self._static
+                self.children_of = np.bincount(parent[parent >= 0], minlength=lay.num_tiles)     # children per parent tile
+                self._built = (pa, pb)
+        return self._built or None
 
 
 class _PassLayout:
@@ -529,9 +565,12 @@ class GaussHipRenderer():
         self.redo = []                # cameras that did not fit their graph's capacity: (camera struct, layout, slot)
         self.fixups = []              # cameras whose overloaded leaves still need their children rendered: (camera struct, layout, slot)
         self.alive_rows = 0           # rows of the context's `alive` pool handed out since the last flush()
+        self.on_demand = {}           # camera slot -> (child pass, alive bytes) of the cameras in flight whose pass B is staged on demand
         self.pass_b = []              # static child passes waiting for flush(): (camera struct, pass-B layout, slot, own layout, alive bytes)
         self.split_leaves = 0         # children of overloaded leaves rendered so far (the reference's count-driven split)
         self.host_driven = 0          # pipelined cameras whose quad-tree levels were walked by the host at flush()
+        self.child_pass_cameras = 0   # pipelined cameras whose overloaded leaves' children went through an on-demand child pass
+        self.passed_b = []
         self.rerendered = 0           # cameras that overflowed their graph's capacity and went through the two-call path
         self.layouts = {}
         self.last_stats = []          # (instances L, tile-sort passes, W*H) per rendered camera
@@ -853,25 +892,26 @@ class GaussHipRenderer():
         parents = [(int(h["xs"][t % nx]), int(h["ys"][t // nx]), int(h["ws"][t % nx]), int(h["hs"][t // nx]), (int(h["tile_seq"][t]),))
                    for t in np.nonzero(plan["overloaded"])[0]]
         seq_next = lay.num_tiles
-        # A camera that already went through a STATIC child pass (image sizes with a non-uniform size-driven tree, static_pass)
-        # carries keys numbered as that pass numbers them: the children of ALL nodes still too large, in the nodes' FIFO order,
-        # whether a node held a Gaussian or not.  Its first level here uses the same level object (same numbers; the children
-        # of empty nodes are left out), the children of leaves split for their COUNT follow as a run of their own.
-        first, dead_parent = None, None
-        sp = lay.static_pass(self.MAX_TILE_SIZE) if (static_done and getattr(lay, "forced", None) is not None and self.tile_shard is None) else None
-        if sp is not None:
-            forced = np.asarray(lay.forced) != 0
+        # A camera that already went through a captured CHILD PASS (_DeviceLayout.child_pass; static_done is that pass) carries
+        # keys numbered as the pass numbers them: the children of ALL its parent tiles in the parents' FIFO order, whether a
+        # parent was split for this camera or not.  Its first level here is the same level object (same numbers; the children
+        # of the tiles this camera did not split are left out); in the static form the children of leaves split for their COUNT
+        # follow as a run of their own.
+        first, dead_parent, runs_f = None, None, ()
+        cp = static_done if isinstance(static_done, _ChildPass) else None
+        if cp is not None:
             node = lambda t: (int(h["xs"][t % nx]), int(h["ys"][t // nx]), int(h["ws"][t % nx]), int(h["hs"][t // nx]), (int(h["tile_seq"][t]),))
-            runs_f = _child_levels(W, H, [node(t) for t in np.nonzero(forced)[0]], seq_next, self.device)
-            dead_parent = {(int(h["tile_seq"][t]),) for t in np.nonzero(forced & ~plan["overloaded"])[0]}   # empty (or dead) forced nodes
-            counted = [node(t) for t in np.nonzero(plan["overloaded"] & ~forced)[0]]
+            runs_f = cp.runs()
+            dead_parent = {(int(h["tile_seq"][t]),) for t in np.nonzero(cp.is_parent & ~plan["overloaded"])[0]}   # tiles not split
+            counted = [node(t) for t in np.nonzero(plan["overloaded"] & ~cp.is_parent)[0]]
             first = list(runs_f) + (list(_child_levels(W, H, counted, seq_next + len(runs_f[0][1]), self.device)) if counted else [])
         while parents:
             runs = first if first is not None else _child_levels(W, H, parents, seq_next, self.device)   # usually ONE run (tiles.child_layout)
             skip_dead = dead_parent if first is not None else None
+            counted_by_flush = len(runs_f) if first is not None else 0   # (a child pass's own level: flush() counted its children)
             first = None
             parents = []
-            for level, children, gate in runs:                          # (no run: every child is narrower than 2 pixels, :301)
+            for ri, (level, children, gate) in enumerate(runs):         # (no run: every child is narrower than 2 pixels, :301)
                 self._ensure_seq_room(seq_next + len(children))
                 level.c.seq_bits = self.seq_bits
                 self._front(sc, cam, level)
@@ -907,7 +947,8 @@ class GaussHipRenderer():
                     self._back(sc, cam, part, slot, n_inst, image, 2, "raster_blend")
                     self._back(sc, cam, part, slot, n_inst, image, 4, "raster_update")
                 seq_next += len(children)
-                self.split_leaves += len(children)
+                if ri >= counted_by_flush:
+                    self.split_leaves += len(children)
 
     # ---- capture-and-replay pipeline ------------------------------------------------------------------------------
     def _capture(self, sl, lay, key):
@@ -967,15 +1008,18 @@ class GaussHipRenderer():
                 # a pass A that did not fit takes its pass B with it: the two-call path numbers the children as IT meets them
                 # (a pass B that did not fit wrote nothing: the graph skips the camera as a whole)
                 self.pass_b = [p for p in self.pass_b if p[2] != slot]
-                if second:
-                    self.split_leaves -= lay.children          # (flush() counts every staged pass B; the redo counts its own)
+                self.on_demand.pop(slot, None)
                 self.rerendered += 1
                 continue
             if overloaded:
                 # some leaf held more than max_gaussians_per_tile Gaussians (or a child of the static pass is still too large):
                 # the graph left it out (k_tile_gate); its children are rendered at flush() -- the packed keys make the order of
                 # the passes irrelevant, and re-blending what a static child pass already blended changes nothing
-                if not any(f[2] == slot and f[1] is orig for f in self.fixups):
+                od = None if second else self.on_demand.get(slot)
+                if od is not None and od[0].build() is not None:
+                    # on-demand child pass: the children of ALL the leaves this camera overloaded go through the pipeline
+                    self.pass_b.append((cam, od[0], slot, orig, od[1]))
+                elif not any(f[2] == slot and f[1] is orig for f in self.fixups):
                     self.fixups.append((cam, orig, slot))
             if not second:
                 self._note(lay, num_inst, cam.width, cam.height)
@@ -1053,18 +1097,25 @@ class GaussHipRenderer():
             self.slots[:] = first + [_GraphSlot(self.device, on_gpu, batch, stream=first[i % PIPELINE_STREAMS].stream)
                                      for i in range(PIPELINE_STREAMS * (per_stream - 1))]
             self.slot_next = 0
-        sp = lay.static_pass(self.MAX_TILE_SIZE) if (getattr(lay, "forced", None) is not None and self.tile_shard is None) else None
-        if sp is None:
+        cp = lay.child_pass(self.MAX_TILE_SIZE, self.MAX_GAUSSIANS_PER_TILE) if (self.tile_shard is None and hasattr(lay, "child_pass")) else None
+        if cp is not None and cp.room > (1 << self.seq_bits):
+            # the keys' tile field must hold the children's sequence numbers BEFORE a camera is in flight with the narrower
+            # layout (the widening repacks every key and re-captures the graphs)
+            if self._seq_room_ok(max(12, int(np.ceil(np.log2(cp.room))))):
+                self.flush()
+                self._ensure_seq_room(cp.room)
+            else:
+                cp = None                          # (caller-assigned slots beyond the wider layout's epoch: the host path)
+        if cp is None:
             self._stage(camera, lay, slot, lay)
             return
-        # an image size whose size-driven tree is not of uniform depth: pass A now (the leaves; the gate notes which of the nodes
-        # still too large hold a Gaussian), pass B -- their children, the same layout for every camera -- when the cameras are
-        # flushed.  The packed-key atomicMax makes the order of the passes irrelevant.
-        pa, pb, _ = sp
-        self._ensure_seq_room(lay.num_tiles + pb.children)
-        pa.c.seq_bits = self.seq_bits
-        # one row of a persistent [256, tiles] byte array per pending camera (written by pass A's gate -- every entry --, read by
-        # pass B's): allocated once per renderer context, so no block of the caching allocator changes streams under it
+        # Child pass (_DeviceLayout.child_pass).  Static form -- an image size whose size-driven tree is not of uniform depth:
+        # pass A now (the leaves; the gate notes which of the nodes still too large it split), pass B -- their children, the same
+        # layout for every camera -- when the cameras are flushed.  On-demand form: pass A is the camera's own layout, pass B is
+        # staged at flush() for the cameras whose pass A reported an overloaded leaf (_retire).  The packed-key atomicMax makes
+        # the order of the passes irrelevant.
+        # One row of a persistent [256, tiles] byte array per pending camera (written by pass A's gate -- every entry --, read by
+        # pass B): allocated once per renderer context, so no block of the caching allocator changes streams under it
         pool = getattr(self.ctx, "alive_pool", None)
         if pool is None or pool.shape[1] < lay.num_tiles:
             if self.device.type == "cuda" and not nv.emulated():
@@ -1076,8 +1127,14 @@ class GaussHipRenderer():
             self.flush()
         alive = pool[self.alive_rows]
         self.alive_rows += 1
-        self._stage(camera, pa, slot, lay, alive=alive)
-        self.pass_b.append((self._camera_struct(camera), pb, slot, lay, alive))
+        if cp.static:
+            pa, pb = cp.build()
+            pa.c.seq_bits = self.seq_bits
+            self._stage(camera, pa, slot, lay, alive=alive)
+            self.pass_b.append((self._camera_struct(camera), cp, slot, lay, alive))
+        else:
+            self._stage(camera, lay, slot, lay, alive=alive)
+            self.on_demand[slot] = (cp, alive)
 
     def _stage(self, camera, lay, slot, orig, alive=None, second=False):
         """Write one camera into the next free job of the pipeline (launching the batch when it is full).  lay: the layout this
@@ -1134,20 +1191,25 @@ class GaussHipRenderer():
                 self._launch_batch(sl)             # a short last batch
         for sl in self.slots:
             self._retire(sl)
+        self.passed_b = []                         # (slot, child pass) of the cameras whose pass B went through the pipeline
         if self.pass_b:
-            # static child passes (image sizes with a non-uniform size-driven tree): every camera's pass A is through, its
-            # `alive` bytes are written; the children go through the same pipeline, batched like cameras
+            # child passes (static: every camera of an image size with a non-uniform size-driven tree; on demand: the cameras
+            # that overloaded a leaf): every camera's pass A is through, its `alive` bytes are written; the children go through
+            # the same pipeline, batched like cameras
             pending, self.pass_b = self.pass_b, []
-            for (cam, pb, slot, orig, alive) in pending:
+            for (cam, cp, slot, orig, alive) in pending:
+                pb = cp.build()[1]
                 pb.c.seq_bits = self.seq_bits
+                self.passed_b.append((slot, cp))
                 self._stage(cam, pb, slot, orig, alive=alive, second=True)
             for sl in self.slots:
                 if sl.fill:
                     self._launch_batch(sl)
             for sl in self.slots:
                 self._retire(sl)
-            self.split_leaves += sum(p[1].children for p in pending)
-            del pending
+        else:
+            pending = []
+        self.on_demand = {}
         self.alive_rows = 0                        # (the alive rows are free again)
         if self.device.type == "cuda" and not nv.emulated():
             cur = torch.cuda.current_stream(self.device)
@@ -1155,17 +1217,28 @@ class GaussHipRenderer():
                 cur.wait_stream(sl.stream)
             for b in self.ctx._blend_streams:
                 cur.wait_stream(b)
+        redone = {r[2] for r in self.redo}
+        for (cam, cp, slot, orig, alive) in pending:
+            if slot not in redone:                 # children rendered: those of the tiles the camera split (its alive bytes)
+                self.split_leaves += int(cp.children_of[alive[:cp.lay.num_tiles].cpu().numpy() != 0].sum())
+                self.child_pass_cameras += 0 if cp.static else 1
+        del pending
         while self.redo:                           # cameras that overflowed their graph: two-call path, original slot
             cam, lay, slot = self.redo.pop(0)
             for k in [k for k in self.deferred if k[0] == slot]:
                 self.deferred.pop(k)               # ... which updates the colours it wins at once
+            # (everything of the camera, children included, numbered as the two-call path meets them: no second numbering)
+            self.fixups = [f for f in self.fixups if f[2] != slot]
+            self.passed_b = [q for q in self.passed_b if q[0] != slot]
             lay.c.seq_bits = self.seq_bits         # (layouts are shared between renderers)
             self._render_sync(cam, lay, slot, False)
+        numbered = dict(self.passed_b)
         while self.fixups:                         # cameras with overloaded leaves: the children of those leaves, original slot
             cam, lay, slot = self.fixups.pop(0)
             lay.c.seq_bits = self.seq_bits
             self.host_driven += 1
-            self._render_sync(cam, lay, slot, False, static_done=True)
+            # (a camera that went through a child pass keeps that pass's sequence numbers: _render_tree)
+            self._render_sync(cam, lay, slot, False, static_done=numbered.get(slot, True))
             self.last_stats.pop()                  # (noted when its batch retired)
             RENDER_STATS.pop()
         if self.deferred:

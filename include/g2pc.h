@@ -311,7 +311,9 @@ typedef struct G2pcTileLayout {      /* HOST struct of DEVICE pointers: tiles = 
                                       * Value 2: the same, but the children follow as a STATIC pass of the same launch plan
                                       * (tile_parent below): state 3, not reported through count_host */
     const int32_t* tile_parent;      /* ABI 5, optional [ny*nx]: this layout is the child level of another one; entry = the tile of
-                                      * that layout this tile is a child of (-1: none).  With G2pcCameraJob.alive: see there */
+                                      * that layout this tile is a child of (-1: none).  With G2pcCameraJob.alive (see there): the
+                                      * child pass of a camera -- static (the children of tile_force nodes, every camera) or on
+                                      * demand (the children of the leaves a camera overloaded) */
 } G2pcTileLayout;
 
 size_t g2pc_raster_front_workspace(int64_t n);
@@ -376,11 +378,12 @@ typedef struct G2pcCameraJob {       /* DEVICE (and pinned host staging) struct 
                                       * resolve the winners' colours once, g2pc_raster_resolve_colours_py */
     uint32_t reserved;
     uint32_t alive_lo, alive_hi;     /* ABI 5, optional: device address of u8[num_tiles of the PARENT layout].  A pass over a layout
-                                      * WITHOUT tile_parent writes "tile t holds a Gaussian" there (the gate, one byte per tile);
-                                      * a later pass of the same camera over a layout WITH tile_parent (the static child level of
-                                      * an image size whose size-driven tree is not of uniform depth) leaves out every tile whose
-                                      * parent held none -- the reference never visits the children of an empty node
-                                      * (gauss_render.py:311-314) */
+                                      * WITHOUT tile_parent writes "tile t is split for this camera" there (the gate, one byte per
+                                      * tile: a tile_force node holding a Gaussian, or a leaf holding more than max_per_tile); a
+                                      * later pass of the same camera over the child level (a layout WITH tile_parent) exists for
+                                      * the children of those tiles only -- the preprocess counts, the duplication emits and the
+                                      * gate admits no other tile: the reference never visits the children of a node it did not
+                                      * split (gauss_render.py:311-335) */
 } G2pcCameraJob;
 size_t g2pc_raster_camera_workspace(int64_t n, int64_t capacity, int32_t num_tiles);
 /* After phase 1 of g2pc_raster_back_py (same ws, num_instances, num_tiles): Gaussians per tile (counts u32[T], optional) and

@@ -119,6 +119,7 @@ def run_vs_oracle(n, seed, width, height, focal, ncam, device="cpu", scale=(0.00
     worst["flips"] = int(flips.sum())
     worst["seq_bits"] = R.seq_bits
     worst["split_leaves"] = R.split_leaves
+    worst["host_driven"], worst["child_pass_cameras"] = R.host_driven, R.child_pass_cameras
     worst["near_threshold"] = int(((O.max_contribution - 0.05).abs() < 1e-5).sum())
     worst["flip_margins"] = (O.max_contribution[flips] - 0.05).abs().tolist()
     return worst

@@ -156,10 +156,22 @@ def test_graph_pipeline_skips_leaves_under_empty_nodes(emu, monkeypatch):
         for name in tr:
             R(camera_handler.get_camera("python", torch.tensor(tr[name]), intr[name]), return_image=not pipelined)
         R.flush()
-        out.append((R.best_key.numpy().copy(), R.get_gaussian_colours().numpy().copy()))
+        out.append((_unpacked(R.best_key.numpy(), R.seq_bits), R.get_gaussian_colours().numpy().copy()))
     gauss_render.clear_context_pool()
     assert gated > 0                           # the scene really meets the rule
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+def _unpacked(keys, seq_bits):
+    """(contribution bits, camera slot, tile sequence number, pixel) of packed visibility keys: the pipeline reserves room for
+    the children of an on-demand child pass in the tile field (5 x leaves), the two-call path widens it only when it must --
+    the same keys in two packings."""
+    k = keys.view(np.uint64)
+    order = (~k & np.uint64(0xFFFFFFFF)).astype(np.uint64)
+    seen = (k >> np.uint64(32)) != 0
+    return np.stack([(k >> np.uint64(32)), np.where(seen, order >> np.uint64(12 + seq_bits), 0),
+                     np.where(seen, (order >> np.uint64(12)) & np.uint64((1 << seq_bits) - 1), 0),
+                     np.where(seen, order & np.uint64(0xFFF), 0)], axis=1)
 
 
 def test_an_image_that_is_one_overloaded_leaf(emu):
@@ -293,4 +305,24 @@ def test_static_child_pass_cameras_that_overflow_their_graph(emu, monkeypatch, h
     res = run_vs_oracle(900, 1200, 59, 56, 0.9 * 59, 7, scale=(0.004, 0.05), t_floor=1e-6, max_tile_size=14, pipelined=True)
     gauss_render.clear_context_pool()
     assert seen["r"] >= 1, seen
+    assert res["contribution"] < 1e-5 and res["flips"] == 0 and res["colour_off_gaussians"] <= 3, res
+
+
+@pytest.mark.parametrize("w,h,n,crowd,limit,deeper", [(128, 64, 1500, 0.5, 500, False), (64, 96, 800, 0.4, 150, True)])
+def test_on_demand_child_pass_of_overloaded_leaves(emu, monkeypatch, w, h, n, crowd, limit, deeper):
+    """Leaves over max_gaussians_per_tile in the graph pipeline: the camera's pass A leaves them out, reports the camera and
+    notes the split leaves in its `alive` bytes; at flush() the child level of ALL leaves goes through the pipeline as the
+    camera's pass B, in which only the children of the split leaves exist (preprocess, duplication and gate look at the
+    parent's byte).  One level deep the host never walks a tree (first case); children that are overloaded again are reported
+    by pass B and finished by the host-driven levels, which keep pass B's sequence numbers (second case)."""
+    import gauss_render
+    from render_checks import run_vs_oracle
+    gauss_render.clear_context_pool()
+    monkeypatch.setattr(gauss_render, "BLEND_SUBBLOCKS", 2)
+    monkeypatch.setattr(gauss_render, "PIPELINE_IN_EMULATOR", True)
+    res = run_vs_oracle(n, 300 + n, w, h, 0.9 * w, 6, scale=(0.004, 0.05), t_floor=1e-6, max_tile_size=16,
+                        max_gaussians_per_tile=limit, xyz_scale=crowd, pipelined=True)
+    gauss_render.clear_context_pool()
+    assert res["child_pass_cameras"] >= 5 and res["split_leaves"] > 0, res
+    assert (res["host_driven"] > 0) == deeper, res
     assert res["contribution"] < 1e-5 and res["flips"] == 0 and res["colour_off_gaussians"] <= 3, res
