@@ -263,6 +263,7 @@ def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, poin
             # how many of them left the capture-and-replay path: children of split leaves / nodes rendered (quad-tree passes),
             # cameras rendered again because they did not fit their graph's buffers
             stage_times["split_children"] = int(getattr(gaussian_renderer, "split_leaves", 0))
+            stage_times["child_pass_cameras"] = int(getattr(gaussian_renderer, "child_pass_cameras", 0))
             stage_times["host_driven_cameras"] = int(getattr(gaussian_renderer, "host_driven", 0))
             stage_times["rerendered_cameras"] = int(getattr(gaussian_renderer, "rerendered", 0))
         _stage("camera_loop_ms")

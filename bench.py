@@ -327,7 +327,7 @@ def relaunch_for_gpus(a):
         sys.exit(2)
 
 
-def extra_render_line(a, device, workload, t_floor=None, steps=3, warm=2):
+def extra_render_line(a, device, workload, t_floor=None, steps=3, warm=2, sizes=None):
     """BASELINE configs[4] (`render_cuda`: native-rasteriser semantics, SH degree 3, surface distance, exact points) or the
     to-the-letter mode of configs[2] (`render`, t_floor = 0: no transmittance floor, k_blend_py_pk), timed like the main
     workload -- `steps` whole jobs between synchronisations, inputs resident -- with the roofline of ITS dominant kernel:
@@ -339,6 +339,9 @@ def extra_render_line(a, device, workload, t_floor=None, steps=3, warm=2):
     saved_floor = gauss_render.DEFAULT_T_FLOOR
     if t_floor is not None:
         gauss_render.DEFAULT_T_FLOOR = t_floor
+    if sizes is not None:                      # (gaussians, cameras, points) other than the main workload's
+        import argparse
+        a = argparse.Namespace(**dict(vars(a), gaussians=sizes[0], cameras=sizes[1], points=sizes[2]))
     gauss_render.clear_context_pool()
     try:
         scene = make_scene(a.gaussians, 1234 + 3, device=device, with_sh=(workload == "render_cuda"))
@@ -353,6 +356,13 @@ def extra_render_line(a, device, workload, t_floor=None, steps=3, warm=2):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         out = {"value": pts / steps / dt, "unit": "points/s", "ms_per_step": dt * 1e3, "steps": steps, "warmup": warm}
+        if sizes is not None:
+            # how the cameras of one (untimed) job went through the renderer: children of split leaves rendered, cameras whose
+            # quad-tree levels the host had to walk, cameras rendered again for want of room in their graph
+            st = per_rank_stages(scene, cams, workload, a.points, device, 1)[0]
+            out["quad_tree"] = {k: st.get(k) for k in ("cameras", "split_children", "child_pass_cameras", "host_driven_cameras",
+                                                       "rerendered_cameras")}
+            out["stages_ms"] = {k: st.get(k) for k in ("setup_ms", "camera_loop_ms", "fixed_ms", "sample_ms")}
         # the dominant kernel alone on the device: three cameras of the rig, one at a time
         names = sorted(cams[0])[:3]
         wh = 1280 * 720
@@ -692,6 +702,10 @@ def main():
             x["config"] = ("configs[2] with blend_transmittance_floor = 0: the reference's python-renderer semantics to the letter "
                            "(no visit dropped, k_blend_py_pk)")
             out["extra_workloads"]["exact"] = x
+            x = extra_render_line(a, device, "render", steps=2, warm=1, sizes=(5_000_000, 200, 50_000_000))
+            x["config"] = ("configs[3] on ONE GPU: 5M Gaussians, 200 cameras 1280x720, 50M points, python-renderer semantics (the "
+                           "8-GPU job of BASELINE.json; more than half of its cameras overload a leaf: on-demand child pass)")
+            out["extra_workloads"]["config4"] = x
     if world == 1 and workload == "render" and not a.no_parity:
         # parity gates, outside the timed region: the same scene, cameras 0 and 17 of the same rig, against
         # outputs of the untouched reference (tests/golden/*_cfg2_1m.npz); tools/parity_cfg2.py documents every key
