@@ -228,8 +228,13 @@ def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, poin
         unmasked = {k: v for k, v in transforms.items() if mask_images is None or k not in mask_images}
         if world > 1 and not split_tiles:
             unmasked = {k: v for i, (k, v) in enumerate(transforms.items()) if i % world == rank and k in unmasked}
-        rig = get_cameras(s.renderer_type, unmasked, intrinsics, colour_resolution=s.colour_resolution,
-                          sh_degree=s.max_sh_degree, white_bkgd=True)
+        # ... in two instalments: the first cameras now, the others when the loop first asks for one -- by then the first batch
+        # is on the device and the ~0.5 ms of host work (one batched inverse, one Camera object each) hides behind it
+        _names = list(unmasked)
+        _first = 2 * 2                                                     # (two pipeline batches)
+        rig = get_cameras(s.renderer_type, {k: unmasked[k] for k in _names[:_first]}, intrinsics,
+                          colour_resolution=s.colour_resolution, sh_degree=s.max_sh_degree, white_bkgd=True)
+        _later = {k: unmasked[k] for k in _names[_first:]}
         epoch = CAMERA_EPOCH
         if world > 1 and hasattr(gaussian_renderer, "seq_bits"):
             # every rank's keys must share one layout whatever cameras it renders: the widest tile field from the start
@@ -247,6 +252,11 @@ def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, poin
                 if not split_tiles and cam_index % world != rank:
                     continue
             camera = rig.get(img_name)
+            if camera is None and img_name in _later:
+                rig.update(get_cameras(s.renderer_type, _later, intrinsics, colour_resolution=s.colour_resolution,
+                                       sh_degree=s.max_sh_degree, white_bkgd=True))
+                _later = {}
+                camera = rig.get(img_name)
             if camera is None:
                 mask = mask_images[img_name].to(device)
                 camera = get_camera(s.renderer_type, torch.tensor(list(transform)), intrinsics[img_name],

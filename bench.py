@@ -702,7 +702,11 @@ def main():
             x["config"] = ("configs[2] with blend_transmittance_floor = 0: the reference's python-renderer semantics to the letter "
                            "(no visit dropped, k_blend_py_pk)")
             out["extra_workloads"]["exact"] = x
-            x = extra_render_line(a, device, "render", steps=2, warm=1, sizes=(5_000_000, 200, 50_000_000))
+            try:
+                x = extra_render_line(a, device, "render", steps=2, warm=1, sizes=(5_000_000, 200, 50_000_000))
+            except Exception as e:                 # (the largest job of the line: never at the price of the line itself)
+                x = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+                torch.cuda.empty_cache()
             x["config"] = ("configs[3] on ONE GPU: 5M Gaussians, 200 cameras 1280x720, 50M points, python-renderer semantics (the "
                            "8-GPU job of BASELINE.json; more than half of its cameras overload a leaf: on-demand child pass)")
             out["extra_workloads"]["config4"] = x

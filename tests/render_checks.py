@@ -169,6 +169,7 @@ def run_split_fixture(golden_dir, tag, device="cpu", t_floor=0.0, pipelined=Fals
     res["flips"] = int((R.get_visible_gaussians().cpu().numpy() != vis).sum())
     res["near_threshold"] = int((np.abs(g["contrib"] - 0.05) < 1e-5).sum())
     res["split_leaves"] = R.split_leaves
+    res["host_driven"], res["child_pass_cameras"] = R.host_driven, R.child_pass_cameras
     return res
 
 

@@ -67,6 +67,9 @@ def test_split_fixture_through_the_graph_pipeline(golden_dir):
     print(res)
     assert res["contribution"] < 1e-4 and res["flips"] <= res["near_threshold"] and res["split_leaves"] > 0, res
     assert res["colour_off_gaussians"] <= 2, res
+    # the pipelined camera's overloaded leaves went through the on-demand child pass (their children in a second captured
+    # pass, only the split leaves' children existing in it); leaves overloaded again are finished by the host levels
+    assert res["child_pass_cameras"] == 1, res
     gauss_render.clear_context_pool()
 
 
