@@ -125,6 +125,18 @@ def run_vs_oracle(n, seed, width, height, focal, ncam, device="cpu", scale=(0.00
     return worst
 
 
+def unpack_keys(keys, seq_bits):
+    """(contribution bits, camera slot, tile sequence number, pixel) of packed visibility keys ([n, 4] uint64).  The pipeline
+    reserves room for the children of an on-demand child pass in the tile field (5 x leaves: 13 bits at 1280 x 720), the
+    two-call path widens the field only when it must -- the same keys in two packings."""
+    k = np.ascontiguousarray(keys).view(np.uint64)
+    order = (~k & np.uint64(0xFFFFFFFF)).astype(np.uint64)
+    seen = (k >> np.uint64(32)) != 0
+    return np.stack([(k >> np.uint64(32)), np.where(seen, order >> np.uint64(12 + seq_bits), 0),
+                     np.where(seen, (order >> np.uint64(12)) & np.uint64((1 << seq_bits) - 1), 0),
+                     np.where(seen, order & np.uint64(0xFFF), 0)], axis=1)
+
+
 def run_split_fixture(golden_dir, tag, device="cpu", t_floor=0.0, pipelined=False):
     """HIP renderer against tests/golden/render_py_split_<tag>.npz -- outputs of the untouched reference on a scene whose leaves
     exceed max_gaussians_per_tile (oracle/make_golden.py render_split)."""

@@ -163,15 +163,8 @@ def test_graph_pipeline_skips_leaves_under_empty_nodes(emu, monkeypatch):
 
 
 def _unpacked(keys, seq_bits):
-    """(contribution bits, camera slot, tile sequence number, pixel) of packed visibility keys: the pipeline reserves room for
-    the children of an on-demand child pass in the tile field (5 x leaves), the two-call path widens it only when it must --
-    the same keys in two packings."""
-    k = keys.view(np.uint64)
-    order = (~k & np.uint64(0xFFFFFFFF)).astype(np.uint64)
-    seen = (k >> np.uint64(32)) != 0
-    return np.stack([(k >> np.uint64(32)), np.where(seen, order >> np.uint64(12 + seq_bits), 0),
-                     np.where(seen, (order >> np.uint64(12)) & np.uint64((1 << seq_bits) - 1), 0),
-                     np.where(seen, order & np.uint64(0xFFF), 0)], axis=1)
+    from render_checks import unpack_keys
+    return unpack_keys(keys, seq_bits)
 
 
 def test_an_image_that_is_one_overloaded_leaf(emu):

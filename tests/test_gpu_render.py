@@ -104,7 +104,10 @@ def test_pipelined_cameras_equal_synchronous(monkeypatch):
         for name in transforms:
             cam = camera_handler.get_camera("python", torch.tensor(transforms[name]), intr[name], colour_resolution=1280)
             R(cam, return_image=False)
-        states.append((R.gaussian_max_contribution.clone(), R.get_gaussian_colours().clone(), R.best_key.clone()))
+        # (keys unpacked: the pipeline reserves tile-field room for an on-demand child pass, the two-call path does not)
+        from render_checks import unpack_keys
+        states.append((R.gaussian_max_contribution.clone(), R.get_gaussian_colours().clone(),
+                       torch.from_numpy(unpack_keys(R.best_key.cpu().numpy(), R.seq_bits).astype(np.int64))))
     for a, b in zip(states[0], states[1]):
         assert torch.equal(a, b)
     for a, b in zip(states[1], states[2]):
