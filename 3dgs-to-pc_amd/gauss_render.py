@@ -1138,7 +1138,7 @@ class GaussHipRenderer():
 
     def _stage(self, camera, lay, slot, orig, alive=None, second=False):
         """Write one camera into the next free job of the pipeline (launching the batch when it is full).  lay: the layout this
-        pass blends; orig: the camera's own layout (what a re-render through the two-call path uses); alive: see static_pass;
+        pass blends; orig: the camera's own layout (what a re-render through the two-call path uses); alive: see _DeviceLayout.child_pass;
         second: a child pass staged from inside flush() (never flushes itself)."""
         on_gpu = self.device.type == "cuda" and not nv.emulated()
         sl = self.slots[self.slot_next]
