@@ -23,7 +23,7 @@ def _settings(num_points, renderer="python"):
         surface_distance_std=2.0 if renderer == "cuda" else None, generate_mesh=False, quiet=True, device="cpu")
 
 
-def _run(rank, world, port, out_dir, renderer="python", epoch=255, ncam=3, warm_rank=None):
+def _run(rank, world, port, out_dir, renderer="python", epoch=255, ncam=3, warm_rank=None, pipelined=False, tile_limit=None):
     for p in (os.path.join(ROOT, "3dgs-to-pc_amd"), os.path.join(ROOT, "oracle"), HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -36,6 +36,13 @@ def _run(rank, world, port, out_dir, renderer="python", epoch=255, ncam=3, warm_
     import gauss_to_pc
     from gauss_to_pc import convert_gaussians_to_pc
     gauss_to_pc.CAMERA_EPOCH = epoch
+    if pipelined or tile_limit:
+        import gauss_render
+        gauss_render.PIPELINE_IN_EMULATOR = bool(pipelined)          # the capture-and-replay camera pipeline, through the emulator
+        gauss_render.PIPELINE_STREAMS, gauss_render.CAMERA_BATCH = 2, 2
+        if tile_limit:
+            gauss_render.GaussHipRenderer.MAX_GAUSSIANS_PER_TILE = tile_limit
+            gauss_render.GaussHipRenderer.MAX_TILE_SIZE = 16
     if world > 1:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -55,8 +62,8 @@ def _run(rank, world, port, out_dir, renderer="python", epoch=255, ncam=3, warm_
     cloud, _ = convert_gaussians_to_pc(G, transforms, intr, None, _settings(12000, renderer), seed=5)
     full = gather_pointcloud(cloud, dst=0)
     if rank == 0:
-        np.savez(os.path.join(out_dir, "%s_w%d_e%d.npz" % (renderer, world, epoch)), points=full.points.numpy(), colours=full.colours.numpy(),
-                 normals=full.normals.numpy())
+        np.savez(os.path.join(out_dir, "%s_w%d_e%d%s.npz" % (renderer, world, epoch, "_p" if pipelined else "")), points=full.points.numpy(),
+                 colours=full.colours.numpy(), normals=full.normals.numpy())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -75,6 +82,26 @@ def test_two_rank_pipeline_equals_single_process(tmp_path):
         rows = np.concatenate([d["points"], d["colours"], d["normals"]], axis=1)
         return rows[np.lexsort(rows.T[::-1])]
     assert np.array_equal(canon(a), canon(b))          # identical multiset of (xyz, rgb, normal) rows
+
+
+def test_two_rank_graph_pipeline_with_overloaded_leaves(tmp_path):
+    """The capture-and-replay camera pipeline under torch.distributed (what a multi-GPU job runs; the other tests of this file
+    take the two-call path, the emulator's default): 7 cameras dealt over 2 ranks, leaves over a low max_gaussians_per_tile so
+    that every rank's cameras go through the on-demand child pass (pass B at the flush before the visibility exchange) with
+    caller-assigned camera slots and the 14-bit tile field of multi-rank jobs.  The gathered cloud is the cloud of ONE process
+    on the two-call path with the same limits."""
+    from emu_util import build_emu
+    build_emu()
+    _run(0, 1, 0, str(tmp_path), "python", 255, 7, None, False, 40)
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_run, args=(2, port, str(tmp_path), "python", 255, 7, None, True, 40), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "python_w1_e255.npz"), np.load(tmp_path / "python_w2_e255_p.npz")
+    assert a["points"].shape == b["points"].shape and a["points"].shape[0] > 10000
+
+    def canon(d):
+        rows = np.concatenate([d["points"], d["colours"], d["normals"]], axis=1)
+        return rows[np.lexsort(rows.T[::-1])]
+    assert np.array_equal(canon(a), canon(b))
 
 
 @pytest.mark.parametrize("ncam", [5, 19])
