@@ -96,6 +96,15 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_py(Cam cam_val, const Cam* 
     // mm != nullptr: the depth keys go to the bucket sort (prims.hip), whose first pass -- the range of the keys -- is folded
     // in here: every block leaves (max ~key, max key) in slot blockIdx.x % mm_slots of the (zeroed) header.
     __shared__ uint32_t s_mm[2];
+    // The tile intervals of both axes, staged in LDS (<= 256 per axis, rect packs 8-bit tile coordinates): interval_range runs two
+    // binary searches per axis, ~20 DEPENDENT loads per Gaussian -- from global memory each was a round trip to the L2, and
+    // beside the blends of the other cameras (one or two waves of this kernel resident per SIMD, nothing to hide behind) those
+    // round trips were the kernel's duration: 148 us per camera under load against 44 alone (round 4).
+    __shared__ int32_t s_xs[256], s_ws[256], s_ys[256], s_hs[256];
+    for (int k = threadIdx.x; k < 256; k += blockDim.x) {
+        s_xs[k] = k < lay.nx ? lay.xs[k] : 0; s_ws[k] = k < lay.nx ? lay.ws[k] : 0;
+        s_ys[k] = k < lay.ny ? lay.ys[k] : 0; s_hs[k] = k < lay.ny ? lay.hs[k] : 0;
+    }
     depth_key_rev = seg(depth_key_rev, cs); index_rev = seg(index_rev, cs); tiles_touched = seg(tiles_touched, cs);
     rec = seg(rec, cs); rect = seg(rect, cs); mm = seg(mm, cs);
     if (threadIdx.x == 0) { s_mm[0] = 0u; s_mm[1] = 0u; }
@@ -115,7 +124,7 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_py(Cam cam_val, const Cam* 
         const G2pcCameraJob* jb = (const G2pcCameraJob*)((const char*)cam_dev + (size_t)blockIdx.y * sizeof(G2pcCameraJob));
         alive = (const uint8_t*)(((unsigned long long)jb->alive_hi << 32) | jb->alive_lo);
     }
-    if (mm) __syncthreads();
+    __syncthreads();
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // (block size: RA_T, or g_head_threads in the camera pipeline)
     const Cam& cam = cam_s;
     uint32_t key = 0xFFFFFFFFu, touched = 0, rc = 0;
@@ -141,8 +150,8 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_py(Cam cam_val, const Cam* 
         float rminx = fminf(fmaxf(mx - radius, 0.0f), wmax), rmaxx = fminf(fmaxf(mx + radius, 0.0f), wmax);
         float rminy = fminf(fmaxf(my - radius, 0.0f), hmax), rmaxy = fminf(fmaxf(my + radius, 0.0f), hmax);
         int ix0, ix1, iy0, iy1;
-        interval_range(lay.xs, lay.ws, lay.nx, rminx, rmaxx, ix0, ix1);
-        interval_range(lay.ys, lay.hs, lay.ny, rminy, rmaxy, iy0, iy1);
+        interval_range(s_xs, s_ws, lay.nx, rminx, rmaxx, ix0, ix1);
+        interval_range(s_ys, s_hs, lay.ny, rminy, rmaxy, iy0, iy1);
         // conic = inverse(cov2d) (:349); exponent pre-scaled for exp2:  w = exp(-0.5 q) = exp2(A dx^2 + C dy^2 + B dx dy)
         float idet = 1.0f / det;
         float k00 = c11 * idet, k11 = c00 * idet, k01 = -c01 * idet, k10 = -c10 * idet;
