@@ -288,6 +288,17 @@ __global__ __launch_bounds__(RS_T) void k_radix_scatter(const uint32_t* __restri
         if ((long)blockIdx.x * TILE >= n) return;                        // idle tail block of a capacity-sized launch
     }
     const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // the tile's keys first: their loads are in flight while the digit bases are put together (two more dependent rounds of
+    // loads and a barrier) -- beside other kernels a block of this one has little else to hide a round trip behind
+    const long wbase = (long)blockIdx.x * TILE + (long)w * (TILE / RS_W);
+    uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const long idx = wbase + (long)r * 64 + lane;
+        const bool valid = idx < n;
+        key[r] = valid ? keys_in[idx] : 0xFFFFFFFFu;
+        val[r] = (valid && vals_in) ? vals_in[idx] : 0u;          // vals_in == nullptr: keys only
+    }
     for (int i = threadIdx.x; i < RS_W * BINS; i += RS_T) (&whist[0][0])[i] = 0;
     {   // gbase[d] = (number of keys with a smaller digit) + (keys with digit d in the tiles before this one):
         // exclusive scan of the row totals, BINS / RS_T digits per thread
@@ -315,15 +326,11 @@ __global__ __launch_bounds__(RS_T) void k_radix_scatter(const uint32_t* __restri
     }
     __syncthreads();
 
-    const long wbase = (long)blockIdx.x * TILE + (long)w * (TILE / RS_W);
-    uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
     const unsigned long long lt = lanemask_lt();
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
         long idx = wbase + (long)r * 64 + lane;
         bool valid = idx < n;
-        key[r] = valid ? keys_in[idx] : 0xFFFFFFFFu;
-        val[r] = (valid && vals_in) ? vals_in[idx] : 0u;          // vals_in == nullptr: keys only
         unsigned d = (key[r] >> shift) & mask;
         // match-any: lanes holding the same digit
         unsigned long long peers = __ballot(valid);
