@@ -474,6 +474,7 @@ int sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* k
 // on 2 K addresses: 0.66 ms per camera, and every co-running kernel slowed 4x) and cleared its header with a
 // hipMemsetAsync, whose graph node this runtime did not order against the kernels around it (replays faulted).
 // ------------------------------------------------------------------------------------------------
+constexpr int BK_UNROLL = 8;      // keys a lane of k_bk_hist / k_bk_scatter requests before it uses the first
 constexpr int BK_MIN = 1024, BK_AVG = 256, BK_CAP_SMALL = 1024, BK_CAP_LARGE = 4096, BK_T = 256, BK_MAXCHUNKS = 512, BK_TAILBLOCKS = 256;
 BucketPlan bucket_plan(long n) {
     BucketPlan p;
@@ -543,9 +544,19 @@ __global__ __launch_bounds__(BK_T) void k_bk_hist(const uint32_t* __restrict__ k
     for (uint32_t i = threadIdx.x; i <= nbk; i += BK_T) lh[i] = 0;
     const BucketMap m = bucket_map_from_partials(h, plan.nminmax, red);   // (its barriers also publish the zeroed histogram)
     const long base = (long)blockIdx.x * plan.kpb;
-    for (uint32_t j = threadIdx.x; j < plan.kpb; j += BK_T) {
-        const long i = base + j;
-        if (i < n) atomicAdd(&lh[m.of(keys[i])], 1u);
+    for (uint32_t j0 = threadIdx.x; j0 < plan.kpb; j0 += BK_T * BK_UNROLL) {      // BK_UNROLL loads in flight per lane
+        uint32_t k[BK_UNROLL];
+        bool ok[BK_UNROLL];
+#pragma unroll
+        for (int u = 0; u < BK_UNROLL; ++u) {
+            const uint32_t j = j0 + (uint32_t)u * BK_T;
+            const long i = base + j;
+            ok[u] = j < plan.kpb && i < n;
+            k[u] = ok[u] ? keys[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < BK_UNROLL; ++u)
+            if (ok[u]) atomicAdd(&lh[m.of(k[u])], 1u);
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i <= nbk; i += BK_T) table[(size_t)i * plan.nchunks + blockIdx.x] = lh[i];
@@ -601,12 +612,22 @@ __global__ __launch_bounds__(BK_T) void k_bk_scatter(const uint32_t* __restrict_
     for (uint32_t i = threadIdx.x; i <= nbk; i += BK_T) cur[i] = h->start[i] + table[(size_t)i * plan.nchunks + blockIdx.x];
     const BucketMap m = bucket_map_from_partials(h, plan.nminmax, red);   // (its barriers also publish the cursors)
     const long base = (long)blockIdx.x * plan.kpb;
-    for (uint32_t j = threadIdx.x; j < plan.kpb; j += BK_T) {
-        const long i = base + j;
-        if (i < n) {
-            const uint32_t k = keys[i];
-            const uint32_t pos = atomicAdd(&cur[m.of(k)], 1u);
-            items[pos] = ((unsigned long long)k << 32) | (unsigned long long)(uint32_t)i;
+    for (uint32_t j0 = threadIdx.x; j0 < plan.kpb; j0 += BK_T * BK_UNROLL) {
+        uint32_t k[BK_UNROLL];
+        bool ok[BK_UNROLL];
+#pragma unroll
+        for (int u = 0; u < BK_UNROLL; ++u) {
+            const uint32_t j = j0 + (uint32_t)u * BK_T;
+            const long i = base + j;
+            ok[u] = j < plan.kpb && i < n;
+            k[u] = ok[u] ? keys[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < BK_UNROLL; ++u) {
+            if (!ok[u]) continue;
+            const long i = base + j0 + (uint32_t)u * BK_T;
+            const uint32_t pos = atomicAdd(&cur[m.of(k[u])], 1u);
+            items[pos] = ((unsigned long long)k[u] << 32) | (unsigned long long)(uint32_t)i;
         }
     }
 }

@@ -129,14 +129,22 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_py(Cam cam_val, const Cam* 
     const Cam& cam = cam_s;
     uint32_t key = 0xFFFFFFFFu, touched = 0, rc = 0;
     if (i < n) {
+    // ALL of the Gaussian's inputs are requested at once (17 loads in one round): behind the in-front-of-the-camera test the
+    // covariance, opacity and colour were a second round trip, which a wave with one or two neighbours on its SIMD (the rest
+    // of the registers belong to another camera's blend) sits out in full
     const float x = means3D[3 * i], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
+    float S9[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) S9[k] = cov9[9 * i + k];
+    const float op_in = opacity[i];
+    const float col_r = colours[3 * i], col_g = colours[3 * i + 1], col_b = colours[3 * i + 2];
     const float* V = cam.V;
     float pv[4];
     py_view(V, x, y, z, pv);                                         // p_view = [x,1] @ V  (gauss_render.py:163)
     const bool in_mask = pv[2] <= -0.000001f;                       // :167
     if (in_mask) {
         float cv[4];                                                 // cov2d (:101-148), torch's evaluation order: py_project.inl
-        py_cov2d(V, pv, cam.lim_x, cam.lim_y, cam.focal_x, cam.focal_y, cov9 + 9 * i, cv);
+        py_cov2d(V, pv, cam.lim_x, cam.lim_y, cam.focal_x, cam.focal_y, S9, cv);
         const float c00 = cv[0], c01 = cv[1], c10 = cv[2], c11 = cv[3];
         float ph[4];
         py_hom(cam.P, pv, ph);                                       // projection (:160-163)
@@ -185,8 +193,8 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_py(Cam cam_val, const Cam* 
         // every pixel of it.
         const float qa = sc * k00, qb = sc * (k01 + k10), qc = sc * k11;
         rec[4 * i + 0] = make_float4(mx, my, qa, qb);
-        rec[4 * i + 1] = make_float4(qc, opacity[i], -qb / (2.0f * qc), -qb / (2.0f * qa));
-        rec[4 * i + 2] = make_float4(colours[3 * i], colours[3 * i + 1], colours[3 * i + 2], -25.5f - log2f(opacity[i]));
+        rec[4 * i + 1] = make_float4(qc, op_in, -qb / (2.0f * qc), -qb / (2.0f * qa));
+        rec[4 * i + 2] = make_float4(col_r, col_g, col_b, -25.5f - log2f(op_in));
     }
     const long r = n - 1 - i;
     depth_key_rev[r] = key;
