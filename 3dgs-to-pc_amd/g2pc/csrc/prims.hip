@@ -65,6 +65,10 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_add_self(uint32_t* __restrict__
                                                          const uint32_t* __restrict__ block_sums, size_t cs) {
     __shared__ uint32_t wsum[SCAN_T / kWave];
     out = seg(out, cs); block_sums = seg(block_sums, cs);
+    const long base = (long)blockIdx.x * SCAN_TILE + (long)threadIdx.x * SCAN_I;
+    uint32_t v[SCAN_I];                      // (requested before the block totals are summed: one round of loads, not two)
+#pragma unroll
+    for (int i = 0; i < SCAN_I; ++i) v[i] = (base + i < n) ? out[base + i] : 0u;
     uint32_t acc = 0;
     for (unsigned i = threadIdx.x; i < blockIdx.x; i += SCAN_T) acc += block_sums[i];
     acc = wave_sum(acc);
@@ -73,10 +77,9 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_add_self(uint32_t* __restrict__
     uint32_t off = 0;
 #pragma unroll
     for (int i = 0; i < SCAN_T / kWave; ++i) off += wsum[i];
-    const long base = (long)blockIdx.x * SCAN_TILE + (long)threadIdx.x * SCAN_I;
 #pragma unroll
     for (int i = 0; i < SCAN_I; ++i)
-        if (base + i < n) out[base + i] += off;
+        if (base + i < n) out[base + i] = v[i] + off;
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = off + block_sums[blockIdx.x];
 }
 
@@ -246,6 +249,31 @@ __global__ __launch_bounds__(SCAN_T) void k_radix_rowscan(uint32_t* __restrict__
     __shared__ uint32_t carry;
     ghist = seg(ghist, cs); gtot = seg(gtot, cs);
     uint32_t* row = ghist + (size_t)blockIdx.x * nb;
+    constexpr unsigned RSC_PER = 24;          // rows of up to SCAN_T * RSC_PER tiles: every thread takes `per` consecutive entries,
+    if (nb <= SCAN_T * RSC_PER) {             // all requested at once -- one barrier instead of two per 256 entries
+        const unsigned per = (nb + SCAN_T - 1) / SCAN_T, first = threadIdx.x * per;
+        uint32_t v[RSC_PER], tsum = 0;
+#pragma unroll
+        for (unsigned k = 0; k < RSC_PER; ++k) {
+            v[k] = (k < per && first + k < nb) ? row[first + k] : 0u;
+            tsum += v[k];
+        }
+        const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const uint32_t incl = wave_incl_scan_u32(tsum);
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        uint32_t woff = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_T / kWave; ++k) { const uint32_t t = wsum[k]; if (k < (int)w) woff += t; total += t; }
+        uint32_t run = woff + incl - tsum;
+#pragma unroll
+        for (unsigned k = 0; k < RSC_PER; ++k) {
+            if (k < per && first + k < nb) row[first + k] = run;
+            run += v[k];
+        }
+        if (threadIdx.x == 0) gtot[blockIdx.x] = total;
+        return;
+    }
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     for (unsigned base = 0; base < nb; base += SCAN_T) {
