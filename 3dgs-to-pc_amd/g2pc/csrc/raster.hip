@@ -47,9 +47,18 @@ struct Layout {         // device pointers of G2pcTileLayout
     const int32_t *inner_x, *inner_y; // [(1 << depth) - 1][2] inclusive pixel extents of the interior nodes per axis
     const int32_t* tile_stick;        // [ny*nx] bit k: the leaf reaches beyond its level-k ancestor (nullptr = none does)
     const uint8_t* tile_force;        // [ny*nx] non-zero: always split when it holds a Gaussian (nullptr = none); 2 = children follow statically
-    const int32_t* tile_parent;       // [ny*nx] child level of another layout: the parent tile there (-1 none), with G2pcCameraJob.alive
+    const int32_t* tile_parent;       // [ny*nx][G2PC_TILE_PARENTS] child level of another layout: the parent tiles there (-1 none), with G2pcCameraJob.alive
     int walk_cap;                     // DIAGNOSTIC (g2pc_debug_set_walk_cap): the dual-list blend stops a walk after this many batches (0 = never; results are then WRONG)
 };
+
+// Child level of another layout (G2pcTileLayout.tile_parent, G2PC_TILE_PARENTS entries per tile, -1 = none): does this tile exist
+// for the camera whose first pass left `alive` (one byte per parent tile: "split")?  A tile can be the child of several parents:
+// a child reaches one pixel beyond an odd-sized parent, and the neighbouring parent may have the very same rectangle among its own.
+__device__ __forceinline__ bool child_exists(const int32_t* __restrict__ tile_parent, const uint8_t* __restrict__ alive, int t) {
+    const int32_t* p = tile_parent + (size_t)G2PC_TILE_PARENTS * t;
+    const int a = p[0], b = p[1], c = p[2], d = p[3];           // (one 16-byte load)
+    return (a >= 0 && alive[a]) || (b >= 0 && alive[b]) || (c >= 0 && alive[c]) || (d >= 0 && alive[d]);
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // K1 (PY): per Gaussian projection, EWA covariance, conic, radius, pixel rect -> tile index ranges.
@@ -171,8 +180,7 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_py(Cam cam_val, const Cam* 
             uint32_t cnt = 0;
             for (int iy = iy0; iy <= iy1; ++iy)
                 for (int ix = ix0; ix <= ix1; ++ix) {
-                    const int p = lay.tile_parent[iy * lay.nx + ix];
-                    cnt += (p >= 0 && alive[p]) ? 1u : 0u;
+                    cnt += child_exists(lay.tile_parent, alive, iy * lay.nx + ix) ? 1u : 0u;
                 }
             ok = cnt > 0;
             touched = cnt;
@@ -255,7 +263,7 @@ __global__ __launch_bounds__(RA_T) void k_duplicate(const uint32_t* __restrict__
     }
     for (int iy = iy0; iy <= iy1; ++iy)
         for (int ix = ix0; ix <= ix1; ++ix) {
-            if (alive) { const int p = tile_parent[iy * nx + ix]; if (p < 0 || !alive[p]) continue; }
+            if (alive && !child_exists(tile_parent, alive, iy * nx + ix)) continue;
             if (gshift) {
                 inst_tile[off] = ((uint32_t)(iy * nx + ix) << gshift) | g;
             } else {
@@ -1940,10 +1948,7 @@ __global__ __launch_bounds__(RA_T) void k_tile_gate(Layout lay, Cam cam_val, con
         alive = (uint8_t*)(((unsigned long long)jb->alive_hi << 32) | jb->alive_lo);
     }
     if (alive) {
-        if (lay.tile_parent) {
-            const int p = lay.tile_parent[t];
-            if (p >= 0 && !alive[p]) in_tree = false;
-        }
+        if (lay.tile_parent && in_tree && !child_exists(lay.tile_parent, alive, t)) in_tree = false;
     }
     // ... and a node the size rule has not finished with (tile_force) is split whenever it holds a Gaussian (:319: `or` of the two)
     const uint8_t force = lay.tile_force ? lay.tile_force[t] : (uint8_t)0;

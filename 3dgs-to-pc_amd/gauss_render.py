@@ -285,22 +285,29 @@ class _ChildPass:
                 else:
                     pa = lay
                 is_child = np.zeros((level.num_tiles,), bool)
-                parent = np.full((level.num_tiles,), -1, dtype=np.int32)
+                parent = np.full((level.num_tiles, 4), -1, dtype=np.int32)       # G2PC_TILE_PARENTS entries per tile
                 still = np.zeros((level.num_tiles,), dtype=np.uint8)
-                # children come four per parent, in the parents' FIFO order (tiles.child_layout): order[:-1] names the parent
+                # children come four per parent, in the parents' FIFO order (tiles.child_layout): order[:-1] names the parent.
+                # Two neighbouring parents can have the SAME rectangle among their children (a child reaches one pixel beyond
+                # an odd-sized parent): one tile of the level, up to two parents per axis
                 by_order = {p[4]: tile_of[(p[0], p[1])] for p in parents}
                 for (t, x0, y0, w, hh, order) in children:
                     is_child[t] = True
-                    parent[t] = by_order[tuple(order[:-1])]
+                    pt = by_order[tuple(order[:-1])]
+                    if pt not in parent[t]:
+                        free = np.nonzero(parent[t] < 0)[0]
+                        if not len(free):
+                            return None                                          # (cannot happen: at most 2 x 2 parents)
+                        parent[t, free[0]] = pt
                     still[t] = 1 if (w > self.max_tile_size or hh > self.max_tile_size) else 0
                 pb = level.only(is_child)
-                pb.t["tile_parent"] = torch.from_numpy(parent).to(lay.device)
+                pb.t["tile_parent"] = torch.from_numpy(np.ascontiguousarray(parent)).to(lay.device)
                 pb.c.tile_parent = pb.t["tile_parent"].data_ptr()
                 if still.any():
                     pb.t["tile_force"] = torch.from_numpy(still).to(lay.device)
                     pb.c.tile_force = pb.t["tile_force"].data_ptr()
                 pb.children = len(children)
-                self.children_of = np.bincount(parent[parent >= 0], minlength=lay.num_tiles)     # children per parent tile
+                self.children_of = np.bincount([by_order[tuple(c[5][:-1])] for c in children], minlength=lay.num_tiles)  # per parent tile
                 self._built = (pa, pb)
         return self._built or None
 

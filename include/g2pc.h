@@ -23,6 +23,7 @@ extern "C" {
 #endif
 
 #define G2PC_ABI_VERSION 5
+#define G2PC_TILE_PARENTS 4       /* entries per tile of G2pcTileLayout.tile_parent */
 
 #define G2PC_OK 0
 #define G2PC_ERR_ARG (-1)
@@ -310,10 +311,12 @@ typedef struct G2pcTileLayout {      /* HOST struct of DEVICE pointers: tiles = 
                                       * holds a Gaussian -- empty range, state 1, its children rendered in further passes.
                                       * Value 2: the same, but the children follow as a STATIC pass of the same launch plan
                                       * (tile_parent below): state 3, not reported through count_host */
-    const int32_t* tile_parent;      /* ABI 5, optional [ny*nx]: this layout is the child level of another one; entry = the tile of
-                                      * that layout this tile is a child of (-1: none).  With G2pcCameraJob.alive (see there): the
-                                      * child pass of a camera -- static (the children of tile_force nodes, every camera) or on
-                                      * demand (the children of the leaves a camera overloaded) */
+    const int32_t* tile_parent;      /* ABI 5, optional [ny*nx][G2PC_TILE_PARENTS] (16-byte aligned): this layout is the child level of
+                                      * another one; entries = the tiles of that layout this tile is a child of, -1 = none (a child
+                                      * reaches one pixel beyond an odd-sized parent, so neighbouring parents can have the SAME
+                                      * rectangle among their children: up to two per axis).  With G2pcCameraJob.alive (see there):
+                                      * the child pass of a camera -- static (the children of tile_force nodes, every camera) or on
+                                      * demand (the children of the leaves a camera overloaded); a tile exists if ANY parent is split */
 } G2pcTileLayout;
 
 size_t g2pc_raster_front_workspace(int64_t n);

@@ -319,3 +319,25 @@ def test_on_demand_child_pass_of_overloaded_leaves(emu, monkeypatch, w, h, n, cr
     assert res["child_pass_cameras"] >= 5 and res["split_leaves"] > 0, res
     assert (res["host_driven"] > 0) == deeper, res
     assert res["contribution"] < 1e-5 and res["flips"] == 0 and res["colour_off_gaussians"] <= 3, res
+
+
+def test_child_pass_children_shared_by_two_parents(emu, monkeypatch):
+    """A child reaches one pixel beyond an odd-sized parent, so two neighbouring leaves can have the SAME rectangle among their
+    children (92 x 38 at max_tile_size 9: leaves of 6 x 3 and 6 x 2 pixels, children of 3 x 2): one tile of the child level
+    with two parents (G2pcTileLayout.tile_parent holds up to four).  It exists for a camera if ANY of them is split -- the
+    first version looked at one parent only, left such a tile out of pass B, and the deferred colour resolve then painted the
+    Gaussians the host levels had blended there white (found by tools/experiments/quadtree_fuzz.py 11 50 pipelined, case 43)."""
+    import gauss_render
+    from render_checks import run_vs_oracle
+    gauss_render.clear_context_pool()
+    monkeypatch.setattr(gauss_render, "BLEND_SUBBLOCKS", 2)
+    monkeypatch.setattr(gauss_render, "PIPELINE_IN_EMULATOR", True)
+    res = run_vs_oracle(1395, 1043, 92, 38, 0.9 * 92, 4, scale=(0.004, 0.02), t_floor=1e-6, max_tile_size=9,
+                        max_gaussians_per_tile=60, xyz_scale=0.4, pipelined=True)
+    lay = gauss_render._LAYOUT_CACHE and next(l for l in gauss_render._LAYOUT_CACHE.values() if getattr(l, "num_tiles", 0) == 256)
+    cp = lay.child_pass(9, 60)
+    children = cp.runs()[0][1]
+    assert len(children) > len({c[0] for c in children})          # the layout really has children with two parents
+    gauss_render.clear_context_pool()
+    assert res["child_pass_cameras"] == 3 and res["contribution"] < 1e-5 and res["flips"] == 0, res
+    assert res["colour_off_gaussians"] == 0 and res["colour"] < 1e-4, res
