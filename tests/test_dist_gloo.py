@@ -36,8 +36,10 @@ def _run(rank, world, port, out_dir, renderer="python", epoch=255, ncam=3, warm_
     import gauss_to_pc
     from gauss_to_pc import convert_gaussians_to_pc
     gauss_to_pc.CAMERA_EPOCH = epoch
+    import gauss_render
+    saved = (gauss_render.PIPELINE_IN_EMULATOR, gauss_render.PIPELINE_STREAMS, gauss_render.CAMERA_BATCH,
+             gauss_render.GaussHipRenderer.MAX_GAUSSIANS_PER_TILE, gauss_render.GaussHipRenderer.MAX_TILE_SIZE)
     if pipelined or tile_limit:
-        import gauss_render
         gauss_render.PIPELINE_IN_EMULATOR = bool(pipelined)          # the capture-and-replay camera pipeline, through the emulator
         gauss_render.PIPELINE_STREAMS, gauss_render.CAMERA_BATCH = 2, 2
         if tile_limit:
@@ -67,6 +69,10 @@ def _run(rank, world, port, out_dir, renderer="python", epoch=255, ncam=3, warm_
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    # (world 1 runs inside the pytest process: leave the module as it was found)
+    (gauss_render.PIPELINE_IN_EMULATOR, gauss_render.PIPELINE_STREAMS, gauss_render.CAMERA_BATCH,
+     gauss_render.GaussHipRenderer.MAX_GAUSSIANS_PER_TILE, gauss_render.GaussHipRenderer.MAX_TILE_SIZE) = saved
+    gauss_render.clear_context_pool()
 
 
 def test_two_rank_pipeline_equals_single_process(tmp_path):
