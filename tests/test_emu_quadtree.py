@@ -334,9 +334,12 @@ def test_child_pass_children_shared_by_two_parents(emu, monkeypatch):
     monkeypatch.setattr(gauss_render, "PIPELINE_IN_EMULATOR", True)
     res = run_vs_oracle(1395, 1043, 92, 38, 0.9 * 92, 4, scale=(0.004, 0.02), t_floor=1e-6, max_tile_size=9,
                         max_gaussians_per_tile=60, xyz_scale=0.4, pipelined=True)
-    lay = gauss_render._LAYOUT_CACHE and next(l for l in gauss_render._LAYOUT_CACHE.values() if getattr(l, "num_tiles", 0) == 256)
-    cp = lay.child_pass(9, 60)
-    children = cp.runs()[0][1]
+    from g2pc import tiles
+    h = tiles.python_quadtree_layout(92, 38, 9, 2)
+    nx = h["nx"]
+    leaves = [(int(h["xs"][t % nx]), int(h["ys"][t // nx]), int(h["ws"][t % nx]), int(h["hs"][t // nx]), (int(h["tile_seq"][t]),))
+              for t in range(nx * h["ny"])]
+    (_, children), = tiles.child_layout(92, 38, leaves, 2)
     assert len(children) > len({c[0] for c in children})          # the layout really has children with two parents
     gauss_render.clear_context_pool()
     assert res["child_pass_cameras"] == 3 and res["contribution"] < 1e-5 and res["flips"] == 0, res
