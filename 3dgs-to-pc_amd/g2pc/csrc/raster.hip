@@ -24,6 +24,10 @@ constexpr int RA_T = 256;
 // single-wave blocks of another camera's blend hold 5 x 92 of every SIMD's 512 VGPRs; a 64-thread block goes wherever one
 // wave fits (the reason k_bk_sort is one wave per block).  g2pc_debug_set_head_threads, 64 / 128 / 256.
 static int g_head_threads = RA_T;
+// DIAGNOSTIC (g2pc_debug_set_extra_launches): this many empty one-wave kernels are launched after the preprocess of every camera
+// batch -- what does one more kernel boundary in a head chain cost the JOB?
+static int g_extra_launches = 0;
+__global__ void k_nothing(uint32_t* __restrict__ p) { if (p && threadIdx.x == 1000) p[0] = 0; }
 __global__ void k_tile_ranges(const uint32_t* __restrict__ tile_sorted, long L, int T, uint32_t* __restrict__ tile_start,
                               const uint32_t* __restrict__ l_dev, int gshift, size_t cs);
 constexpr float LOG2E = 1.4426950408889634f;
@@ -2192,6 +2196,7 @@ static int py_front(const Cam& cam_val, const Cam* cam_dev, const G2pcTileLayout
         hipLaunchKernelGGL(k_preprocess_py<false>, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, cam_val, cam_dev, to_layout(layout),
                            means3D, cov9, opacity, n, key_rev, idx_rev, touched, colours, fb.rec, fb.rect, (size_t)0,
                            (BucketHdr*)nullptr, 1u);
+    for (int k = 0; k < g_extra_launches; ++k) hipLaunchKernelGGL(k_nothing, dim3(1), dim3(64), 0, s, (uint32_t*)nullptr);
     int rc = depth_overflow ? bucket_sort_u32(key_rev, fold ? nullptr : idx_rev, fb.sorted_idx, nullptr, n, bucket_ws, bucket_bytes,
                                               depth_overflow, s, bt, fold, fold)
                             : sort_pairs_u32(key_rev, idx_rev, key_sorted, fb.sorted_idx, ktmp, vtmp, n, 0, 32, sort_ws, sort_bytes, s, nullptr, bt);
@@ -2463,6 +2468,7 @@ int g2pc_raster_repack_keys(unsigned long long* best_key, int64_t n, int32_t old
 
 /* diagnostics: see g2pc.h */
 int g2pc_raster_debug_chunk_work(uint32_t* buf) { g2pc::g_chunk_work = buf; return G2PC_OK; }
+int g2pc_debug_set_extra_launches(int n) { g2pc::g_extra_launches = n > 0 ? n : 0; return G2PC_OK; }
 int g2pc_debug_set_head_threads(int threads) {
     if (threads != 64 && threads != 128 && threads != 256) return G2PC_ERR_ARG;
     g2pc::g_head_threads = threads;

@@ -49,6 +49,8 @@ def parse():
                          "weak = every GPU brings its own 50 cameras and 10M-point budget (50N cameras, 10M*N points)")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity block (reference fixtures at the benchmark's scale)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_workloads lines (configs[1] sampling job)")
+    ap.add_argument("--extra-launches", type=int, default=0,
+                    help="DIAGNOSTIC: empty kernels added to every camera batch's head chain (the cost of a kernel boundary)")
     ap.add_argument("--head-threads", type=int, default=0, choices=[0, 64, 128, 256],
                     help="tuning aid: block size of the head kernels without block-level cooperation (default 256)")
     ap.add_argument("--sort-bits", type=int, default=0, help="tuning aid: wide radix digit bits (8, 10 = one pass for 9-10 bit fields, or 11)")
@@ -503,6 +505,8 @@ def main():
         nv.lib().g2pc_set_sort_tuning(a.sort_bits, a.sort_small)
     if a.head_threads:
         nv.lib().g2pc_debug_set_head_threads(a.head_threads)
+    if a.extra_launches:
+        nv.lib().g2pc_debug_set_extra_launches(a.extra_launches)
     if a.blend_variant is not None:
         nv.lib().g2pc_set_blend_variant(a.blend_variant)
     if a.walk_cap:

@@ -444,6 +444,8 @@ int g2pc_debug_set_walk_cap(int batches);
 /* tuning: threads per block (64, 128 or 256 = default) of the python-semantics head kernels that need no block-level
  * cooperation (preprocess, duplicate, tile ranges); set before the first camera of a process (captured graphs keep theirs) */
 int g2pc_debug_set_head_threads(int threads);
+/* diagnostic: n empty kernels after the preprocess of every python-semantics camera batch (what a kernel boundary costs a job) */
+int g2pc_debug_set_extra_launches(int n);
 /* --- native-rasteriser ("cuda") semantics: _C.rasterize_gaussians (rasterize_points.h:18-41) ----------------------
  * Deterministic spec of SURVEY.md §8(a.5): 16x16 tiles, near cull z_view <= 0.2, radius ceil(3 sqrt(lambda_max)),
  * stable (tile, depth) order, alpha rules (power > 0 skip, min(0.99, .), alpha < 1/255 skip, T(1-alpha) < 1e-4 stop),
