@@ -156,6 +156,14 @@ def python_quadtree_layout(width: int, height: int, max_tile_size: int = 60, sub
     lay = _finish([x for x, _ in xs], [w for _, w in xs], [y for y, _ in ys], [h for _, h in ys], seq_of, subblocks,
                   tile_shard)
     lay.update(_tree_tables(width, height, lay))
+    if len(nodes) > 1 and (min(w for _, w in xs) <= 1 or min(h for _, h in ys) <= 1):
+        # A leaf the image border clips to ONE pixel can have no member (the reference's test is strict on inclusive pixel
+        # bounds, gauss_render.py:306-309) -- but a Gaussian whose clipped rectangle ends in that pixel IS a member of the
+        # ancestors.  The rasteriser's gate derives "this ancestor holds no Gaussian" (:311-314) from the members of the leaves
+        # and would call such an ancestor empty (tools/experiments/quadtree_fuzz.py 101, case 52: 272 x 48 at max_tile_size 14,
+        # leaves of 9 x 2 and 9 x 1 pixels).  Only trees with leaves one or two pixels thin have such leaves; the renderer then
+        # takes the "which nodes are empty" decision on the host, with the reference's own count (GaussHipRenderer._static_plan).
+        lay["thin_leaves"] = True
     force = np.array([force_of[(x, y)] for (y, _) in ys for (x, _) in xs], dtype=np.uint8)
     if force.any():
         lay["tile_force"] = force                 # [ny*nx]: 1 = larger than max_tile_size, always split (G2pcTileLayout.tile_force)

@@ -196,6 +196,9 @@ class _DeviceLayout:
         self.device = device
         names = ["xs", "ws", "ys", "hs", "tile_seq", "seq_tile", "tile_pix_off", "chunk_tile", "chunk_pix0"]
         self.has_tree = int(lay.get("depth", 0)) > 0
+        # leaves one pixel thin (tiles.python_quadtree_layout): the empty-node rule is decided on the HOST for this layout -- the
+        # device gate gets no tree (depth 0), every camera takes the two-call path
+        self.host_vacancy = self.has_tree and bool(lay.get("thin_leaves"))
         if self.has_tree:
             names += ["inner_x", "inner_y", "tile_stick"]
         self.forced = lay.get("tile_force")            # nodes still larger than max_tile_size: split for every camera
@@ -211,7 +214,7 @@ class _DeviceLayout:
         self.seq_bits = min(14, max(12, int(np.ceil(np.log2(max(T + reserve, 2))))))
         self.c = _Layout(nx=lay["nx"], ny=lay["ny"], num_chunks=len(lay["chunk_tile"]),
                          chunk_subblocks=lay["chunk_subblocks"], seq_bits=self.seq_bits, seq_base=int(seq_base),
-                         seq_count=int(seq_count), depth=int(lay.get("depth", 0)) if self.has_tree else 0,
+                         seq_count=int(seq_count), depth=int(lay.get("depth", 0)) if (self.has_tree and not self.host_vacancy) else 0,
                          **{k: v.data_ptr() for k, v in self.t.items()})
         self.num_tiles = lay["nx"] * lay["ny"]
         self.total_pixels = lay["total_pixels"]
@@ -785,7 +788,7 @@ class GaussHipRenderer():
         self._back(sc, cam, lay, slot, num_inst, image, 1, "raster_bin")
         counts, states = self._tile_states(sc, lay, num_inst)
         plan = None
-        if states.any() or (return_image and lay.has_tree and not counts.all()):
+        if states.any() or ((return_image or getattr(lay, "host_vacancy", False)) and lay.has_tree and not counts.all()):
             plan = self._static_plan(cam, lay, counts, states)
         if plan is not None and (plan["overloaded"].any() or plan["dead"].any()):
             self._render_tree(sc, cam, lay, slot, num_inst, image, plan, static_done)
@@ -855,7 +858,11 @@ class GaussHipRenderer():
             over = over & ~dead
         # the gate (k_tile_gate) took the same decisions for every leaf with members, by other means
         has = counts > 0
-        if not (np.array_equal(states == 1, over) and np.array_equal(((states & 0xFF) == 2) & has, dead & has)):
+        if getattr(lay, "host_vacancy", False):
+            dev_dead = dead                        # (the device took no such decision: depth 0 in its copy of the layout)
+        else:
+            dev_dead = (states & 0xFF) == 2
+        if not (np.array_equal(states == 1, over) and np.array_equal(dev_dead & has, dead & has)):
             raise RuntimeError("quad-tree plan: the device gate and the host disagree on %d leaves"
                                % int(((states == 1) != over).sum() + ((((states & 0xFF) == 2) & has) != (dead & has)).sum()))
         return dict(overloaded=over, dead=dead, fills=fills)
@@ -1294,7 +1301,8 @@ class GaussHipRenderer():
         slot = self.camera_slot
 
         on_gpu = self.device.type == "cuda" and not nv.emulated()
-        if (not return_image) and PIPELINE_STREAMS > 1 and (on_gpu or (nv.emulated() and PIPELINE_IN_EMULATOR)):
+        if ((not return_image) and PIPELINE_STREAMS > 1 and (on_gpu or (nv.emulated() and PIPELINE_IN_EMULATOR))
+                and not getattr(lay, "host_vacancy", False)):
             self._render_pipelined(camera, lay, slot)
             return None, None, None, None
 

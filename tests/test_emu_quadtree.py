@@ -344,3 +344,28 @@ def test_child_pass_children_shared_by_two_parents(emu, monkeypatch):
     gauss_render.clear_context_pool()
     assert res["child_pass_cameras"] == 3 and res["contribution"] < 1e-5 and res["flips"] == 0, res
     assert res["colour_off_gaussians"] == 0 and res["colour"] < 1e-4, res
+
+
+def test_leaves_one_pixel_thin_take_the_empty_node_rule_on_the_host(emu, monkeypatch):
+    """272 x 48 at max_tile_size 14: leaves of 9 x 2 pixels and, at the bottom border, 9 x 1.  A one-pixel leaf can have no
+    member (the reference's test is strict on inclusive bounds) but a Gaussian whose clipped rectangle ends in that pixel row
+    is a member of the ANCESTORS: the fourth camera of this scene has one, and the device gate -- which derives "this ancestor
+    is empty" from the leaves' members -- called a non-empty ancestor empty (the two-call path noticed: RuntimeError "the
+    device gate and the host disagree"; the pipeline would have left a leaf unblended).  Such layouts (tiles: thin_leaves) now
+    take that decision on the host with the reference's own count, and every camera takes the two-call path.
+    Found by tools/experiments/quadtree_fuzz.py 101 70 pipelined, case 52 (present since round 3)."""
+    import gauss_render
+    from g2pc import tiles
+    from render_checks import run_vs_oracle
+    assert tiles.python_quadtree_layout(272, 48, 14, 2).get("thin_leaves")
+    assert not tiles.python_quadtree_layout(1280, 720, 60, 2).get("thin_leaves")
+    monkeypatch.setattr(gauss_render, "BLEND_SUBBLOCKS", 2)
+    for pipelined in (False, True):
+        gauss_render.clear_context_pool()
+        monkeypatch.setattr(gauss_render, "PIPELINE_IN_EMULATOR", pipelined)
+        res = run_vs_oracle(2322, 1052, 272, 48, 0.9 * 272, 4, scale=(0.004, 0.02), t_floor=1e-6 if pipelined else 0.0, max_tile_size=14,
+                            max_gaussians_per_tile=1000, pipelined=pipelined)
+        assert res["contribution"] < 1e-5 and res["flips"] == 0 and res["colour_off_gaussians"] <= 2, (pipelined, res)
+        if not pipelined:
+            assert res["image"] < 1e-5, res
+    gauss_render.clear_context_pool()
