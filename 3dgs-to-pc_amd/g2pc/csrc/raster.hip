@@ -1960,8 +1960,10 @@ __global__ __launch_bounds__(RA_T) void k_tile_gate(Layout lay, Cam cam_val, con
     // "this node is split for this camera": its children exist (tile_mask does not matter here: the static pass A masks the
     // very nodes whose children follow)
     if (alive && !lay.tile_parent) alive[t] = (!state && (over || forced)) ? 1 : 0;
-    if (!state && (over || forced) && in_tree) {
-        const bool follows = force == 2 && !over;          // its children come with the camera's static child pass
+    // (a node whose children follow statically, force == 2, is masked out of pass A's tile_mask -- its chunks are not in the work
+    // list --, so it is recognised by its force byte, not by in_tree: it gets state 3 and an empty range as include/g2pc.h says)
+    const bool follows = force == 2 && !over && cnt > 0;   // its children come with the camera's static child pass
+    if (!state && (over || forced) && (in_tree || follows)) {
         state = follows ? 3u : 1u;
         if (flag && over) atomicMax(flag, cnt);
         if (count_host && !follows) count_host[4 * blockIdx.y + 2] = cnt;   // pinned, through its device mapping: "some leaf of this camera"

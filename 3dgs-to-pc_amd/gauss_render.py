@@ -371,6 +371,7 @@ PIPELINE_SLOTS_PER_STREAM = 1     # batch slots (pinned jobs, arena, captured gr
 PIPELINE_BLEND_STREAMS = 1        # split modes: blend streams the batches alternate over (2: two blends in flight -- the
                                   # throughput phase of one beside the draining tail of the other)
 PIPELINE_IN_EMULATOR = False      # tests: drive the capture / replay path through the CPU emulator too
+MAX_GRAPHS_PER_SLOT = 12          # executable graphs a slot keeps (one per layout / pass / batch size met): bounded, ADVICE r04
 CAPACITY_HEADROOM = 1.25          # instance capacity of the captured graphs relative to the largest count seen so far
 MIN_CAPACITY = 1 << 16
 _LAYOUT_CACHE = {}
@@ -984,7 +985,10 @@ class GaussHipRenderer():
                 sl.ws_bytes = int(need)
                 sl.ws = nv.workspace(sl.ws_bytes, self.device)
             if sl.tilebuf is None or sl.tilebuf.numel() < lay.total_pixels * 3:
+                sl.release()                       # ... and the slot's fallback colour buffer's
                 sl.tilebuf = torch.empty((lay.total_pixels * 3,), dtype=torch.float32, device=self.device)
+        if len(sl.graphs) >= MAX_GRAPHS_PER_SLOT:
+            sl.release()                           # a job over many image sizes / passes: start the slot's cache afresh
         # run the state-free half once outside the capture: kernels that are launched for the first time INSIDE a stream
         # capture (k_preprocess_py<true>, k_resolve_count, ...) leave a graph that replays ~25 % slower for good
         nv.check(self._camera_call(sl, lay, capacity, 1, batch), "raster_cameras_py (warm-up)")
@@ -1129,9 +1133,25 @@ class GaussHipRenderer():
         # staged at flush() for the cameras whose pass A reported an overloaded leaf (_retire).  The packed-key atomicMax makes
         # the order of the passes irrelevant.
         # One row of a persistent [256, tiles] byte array per pending camera (written by pass A's gate -- every entry --, read by
-        # pass B): allocated once per renderer context, so no block of the caching allocator changes streams under it
+        # pass B).  _stage takes the row, AFTER every flush it can trigger itself (retiring the slot's previous batch grows
+        # pass_b, which can reach the deferred-buffer limit): flush() hands all rows back, and a row taken before it would be
+        # given to a later camera whose pass-A gate overwrites the bytes this camera's pass B still has to read (ADVICE r04:
+        # jobs longer than the limit whose overloaded leaves vary between cameras lost maxima of up to 0.28).
+        if cp.static:
+            pa, pb = cp.build()
+            pa.c.seq_bits = self.seq_bits
+            alive = self._stage(camera, pa, slot, lay, take_alive=True)
+            self.pass_b.append((self._camera_struct(camera), cp, slot, lay, alive))
+        else:
+            alive = self._stage(camera, lay, slot, lay, take_alive=True)
+            self.on_demand[slot] = (cp, alive)
+
+    def _take_alive_row(self, lay):
+        """The next free row of the context's `alive` pool ([256, tiles] bytes, allocated once per renderer context, so no block
+        of the caching allocator changes streams under it).  May flush (all rows in use): call it after any other flush."""
         pool = getattr(self.ctx, "alive_pool", None)
         if pool is None or pool.shape[1] < lay.num_tiles:
+            self.flush()                           # (rows of the old pool may be pending)
             if self.device.type == "cuda" and not nv.emulated():
                 torch.cuda.synchronize(self.device)
             pool = self.ctx.alive_pool = torch.zeros((256, lay.num_tiles), dtype=torch.uint8, device=self.device)
@@ -1141,18 +1161,22 @@ class GaussHipRenderer():
             self.flush()
         alive = pool[self.alive_rows]
         self.alive_rows += 1
-        if cp.static:
-            pa, pb = cp.build()
-            pa.c.seq_bits = self.seq_bits
-            self._stage(camera, pa, slot, lay, alive=alive)
-            self.pass_b.append((self._camera_struct(camera), cp, slot, lay, alive))
-        else:
-            self._stage(camera, lay, slot, lay, alive=alive)
-            self.on_demand[slot] = (cp, alive)
+        return alive
 
-    def _stage(self, camera, lay, slot, orig, alive=None, second=False):
+    def _make_deferred_room(self, lay):
+        """The deferred colour buffers are bounded (DEFERRED_*): once the cameras waiting for their colours reach the limit of
+        this image size, resolve them (flush) and recycle the ring.  True if it flushed."""
+        limit = max(DEFERRED_MIN, min(DEFERRED_MAX, DEFERRED_BUDGET_BYTES // (lay.total_pixels * 12)))
+        if len(self.deferred) + len(self.pass_b) < limit:
+            return False
+        self.flush()                               # resolve the colours of the cameras so far; their buffers are free again
+        del self.ctx.cam_tilebufs[limit:]          # a smaller image earlier in the job may have grown the ring past this limit
+        return True
+
+    def _stage(self, camera, lay, slot, orig, alive=None, second=False, take_alive=False):
         """Write one camera into the next free job of the pipeline (launching the batch when it is full).  lay: the layout this
-        pass blends; orig: the camera's own layout (what a re-render through the two-call path uses); alive: see _DeviceLayout.child_pass;
+        pass blends; orig: the camera's own layout (what a re-render through the two-call path uses); alive: see _DeviceLayout.child_pass
+        (take_alive: a fresh row of the pool, taken here behind the last flush this call can trigger; returned);
         second: a child pass staged from inside flush() (never flushes itself)."""
         on_gpu = self.device.type == "cuda" and not nv.emulated()
         sl = self.slots[self.slot_next]
@@ -1165,11 +1189,11 @@ class GaussHipRenderer():
         # winners' colours are then resolved in one pass at flush() instead of one update per camera chained in camera
         # order across the streams
         ring = self.ctx.cam_tilebufs
-        limit = max(DEFERRED_MIN, min(DEFERRED_MAX, DEFERRED_BUDGET_BYTES // (lay.total_pixels * 12)))
-        if not second and len(self.deferred) + len(self.pass_b) >= limit:
-            self.flush()                           # resolve the colours of the cameras so far; their buffers are free again
-            del ring[limit:]                       # a smaller image earlier in the job may have grown the ring past this limit
+        if not second and self._make_deferred_room(lay):
             sl = self.slots[self.slot_next]
+        if take_alive:
+            alive = self._take_alive_row(orig)
+            sl = self.slots[self.slot_next]        # (it may have flushed: every slot is then retired and empty)
         idx = len(self.deferred)
         if idx >= len(ring) or ring[idx].numel() < lay.total_pixels * 3:
             import contextlib
@@ -1195,6 +1219,7 @@ class GaussHipRenderer():
         sl.fill_lay = lay
         if sl.fill == sl.batch:
             self._launch_batch(sl)
+        return alive
 
     def flush(self):
         """Complete every camera staged or in flight and make the running state visible to the current stream."""

@@ -369,3 +369,56 @@ def test_leaves_one_pixel_thin_take_the_empty_node_rule_on_the_host(emu, monkeyp
         if not pipelined:
             assert res["image"] < 1e-5, res
     gauss_render.clear_context_pool()
+
+
+def _rig_two_radii(n_far, n_near, width, height, focal, far=3.5, near=1.3):
+    """n_far cameras on a sphere of radius `far` followed by n_near on one of radius `near` (same intrinsics)."""
+    from g2pc.synth import make_cameras
+    t1, i1 = make_cameras(n_far, radius=far, width=width, height=height, focal=focal)
+    t2, i2 = make_cameras(n_near, radius=near, width=width, height=height, focal=focal)
+    names = ["a%03d" % k for k in range(n_far)] + ["b%03d" % k for k in range(n_near)]
+    tr = dict(zip(names, list(t1.values()) + list(t2.values())))
+    return tr, {k: next(iter(i1.values())) for k in names}
+
+
+def test_pipelined_job_longer_than_the_deferred_limit_with_uneven_overloads(emu, monkeypatch):
+    """a pipelined camera took its row of the `alive` pool BEFORE _stage could flush for the deferred-buffer
+    limit; the flush handed every row back, a later camera got the same row and its pass-A gate overwrote the bytes the first
+    camera's pass B reads.  A job with more cameras than the limit, the first ones overloading leaves (far cameras: the scene
+    crowded into a few tiles) and the rest not (near cameras), must equal the two-call path Gaussian for Gaussian."""
+    import camera_handler
+    import gauss_render
+    import ref_gauss as RG
+    from gauss_handler import Gaussians
+    from render_checks import unpack_keys
+    from g2pc.synth import make_scene
+    monkeypatch.setattr(gauss_render, "BLEND_SUBBLOCKS", 2)
+    monkeypatch.setattr(gauss_render, "DEFERRED_MIN", 14)     # (with 12 overloading cameras first and 16 that do not, the code before
+    monkeypatch.setattr(gauss_render, "DEFERRED_MAX", 14)     # the fix left 18 Gaussians with a wrong maximum, up to 0.21)
+    w, h, n = 128, 64, 1500
+    sc = make_scene(n, 1800, scale_lo=0.004, scale_hi=0.05)
+    sc = sc._replace(xyz=sc.xyz * 0.5)
+    tr, intr = _rig_two_radii(12, 16, w, h, 0.9 * w)
+    cov = RG.covariances(sc.scales, sc.rots)
+    out = {}
+    for pipelined in (True, False):
+        gauss_render.clear_context_pool()
+        monkeypatch.setattr(gauss_render, "PIPELINE_IN_EMULATOR", pipelined)
+        G = Gaussians(sc.xyz, sc.scales, sc.rots, sc.colours, sc.opacities)
+        R = gauss_render.get_renderer("python", G.xyz, G.opacities.unsqueeze(1), G.colours, cov, visible_gaussian_threshold=0.05)
+        R.t_floor, R.MAX_TILE_SIZE, R.MAX_GAUSSIANS_PER_TILE = 1e-6, 16, 500
+        for name in tr:
+            R(camera_handler.get_camera("python", torch.tensor(tr[name]), intr[name]), return_image=False)
+        c = R.gaussian_max_contribution.clone()
+        out[pipelined] = (unpack_keys(R.best_key.numpy().copy(), R.seq_bits), c.numpy(), R.get_gaussian_colours().numpy().copy(),
+                          R.child_pass_cameras, R.split_leaves)
+        R.close()
+    gauss_render.clear_context_pool()
+    (kp, cp_, colp, passes, split_p), (ks, cs_, cols, _, split_s) = out[True], out[False]
+    assert 0 < passes < len(tr), passes                     # some cameras overloaded a leaf, some did not
+    assert split_p == split_s and split_p > 0
+    assert np.array_equal(cp_, cs_), int((cp_ != cs_).sum())
+    # the same camera holds every maximum (the children's sequence numbers are order-isomorphic, not equal: pass B numbers the
+    # children of ALL leaves, the two-call path those of the leaves it splits) and it resolved to the same pixel colour
+    assert np.array_equal(kp[:, 1], ks[:, 1])
+    assert np.array_equal(colp, cols)
