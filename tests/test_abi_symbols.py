@@ -41,3 +41,17 @@ def test_no_cpu_fallback():
                                       torch.eye(3).repeat(4, 1, 1))
         import camera_handler
         R(camera_handler.get_camera("python", torch.eye(4), [64, 64, 50.0, 50.0]))
+
+
+def test_kernel_meta_names_the_timed_template_instance():
+    """bench.py's roofline block quotes the registers of the kernel it TIMES: `k_blend_py_dl<4>`, not whichever instance of the
+    template comes first in the code object (the line said 74 VGPRs / 6 waves, the <2> instance's)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import __graft_entry__ as ge
+    ge.build()
+    from kernel_meta import kernel_meta
+    k4 = kernel_meta("k_blend_py_dl<4>")
+    assert k4 is not None and ("dl<4>" in k4["name"] or "dlILi4E" in k4["name"]), k4
+    assert k4["vgpr_spill_count"] == 0 and k4["group_segment_fixed_size"] > 0
+    assert k4["max_waves_per_simd"] == min(8, 512 // ((k4["vgpr_count"] + k4["agpr_count"] + 7) // 8 * 8))

@@ -53,12 +53,25 @@ def all_kernels(path=LIB):
 
 
 def demangle(names):
-    try:
-        p = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"] + list(names), capture_output=True, text=True)
-        d = p.stdout.split("\n")[:len(names)]
-        return dict(zip(names, d)) if len(d) == len(names) else {n: n for n in names}
-    except Exception:
-        return {n: n for n in names}
+    """mangled -> demangled (llvm-cxxfilt where the image has it, else binutils' c++filt; the mangled name itself if neither)."""
+    for tool in ("/opt/rocm/lib/llvm/bin/llvm-cxxfilt", "c++filt"):
+        try:
+            p = subprocess.run([tool] + list(names), capture_output=True, text=True)
+            d = p.stdout.split("\n")[:len(names)]
+            if p.returncode == 0 and len(d) == len(names):
+                return dict(zip(names, d))
+        except Exception:
+            pass
+    return {n: n for n in names}
+
+
+def _matches(substring, mangled, demangled):
+    """`k_blend_py_dl<4>` names ONE template instance: matched in the demangled name, or -- no demangler -- as the Itanium
+    encoding of an integer template argument (k_blend_py_dlILi4E)."""
+    if substring in demangled:
+        return True
+    m = re.fullmatch(r"(.*?)<(\d+)>", substring.split("::")[-1])
+    return bool(m) and ("%sILi%sE" % (m.group(1), m.group(2))) in mangled
 
 
 def occupancy(rec, block_threads=None):
@@ -77,11 +90,12 @@ def occupancy(rec, block_threads=None):
 
 
 def kernel_meta(substring, path=LIB):
-    """First kernel whose demangled name contains `substring`: {name, vgpr_count, ..., max_waves_per_simd} or None."""
+    """First kernel whose demangled name contains `substring`: {name, vgpr_count, ..., max_waves_per_simd} or None.  Name a
+    template instance with its arguments ("k_blend_py_dl<4>"): a bare "k_blend_py_dl" returns whichever instance comes first."""
     ks = all_kernels(path)
     dm = demangle(list(ks))
-    for mangled, rec in ks.items():
-        if substring in dm[mangled]:
+    for mangled, rec in sorted(ks.items(), key=lambda kv: dm[kv[0]]):
+        if _matches(substring, mangled, dm[mangled]):
             r = dict(rec, name=dm[mangled].split("(")[0])
             r.update(occupancy(rec, rec.get("max_flat_workgroup_size")))
             return r
@@ -93,7 +107,7 @@ if __name__ == "__main__":
     dm = demangle(list(ks))
     want = sys.argv[1:]
     for mangled, rec in sorted(ks.items(), key=lambda kv: dm[kv[0]]):
-        if not want or any(w in dm[mangled] for w in want):
+        if not want or any(_matches(w, mangled, dm[mangled]) for w in want):
             r = dict(rec, name=dm[mangled].split("(")[0])
             r.update(occupancy(rec, rec.get("max_flat_workgroup_size")))
             print(json.dumps(r))

@@ -15,6 +15,8 @@ SURVEY.md §8(d) asks to be reported with every number:
   ppg_mismatch_given_ref_contrib       points-per-Gaussian differences when OUR magnitudes / distribute_points are fed
                                        the reference's contributions (isolates the allocation: expected 0)
   ppg_mismatch_end_to_end              the same from our own render (contributions differ by ~1e-6 -> a few +-1)
+  colour_off_gaussians                 sampled Gaussians (every 16th above the floor) whose colour differs by > 1e-4: an arg-max
+                                       that fell on another pixel of a tie (colour_compared_gaussians = how many were compared)
   sample_*                             the 10 M-point cloud sampled from the reference's kept set with the same keyed
                                        noise: point count, rows compared (every 64th), max |xyz| and |rgb| difference of the
                                        MATCHED rows (same position, or the row a few places off that holds the same point when an
@@ -197,6 +199,10 @@ def run(device="cuda:0", t_floor=None, sampler=True, tag="1m"):
     seen = (ref_c[::16 // cs] if 16 % cs == 0 else c[::16]) > max(R.t_floor, 1e-12)
     dcol = np.abs(cols - ref_cols)[seen]
     out["colour_max"], out["colour_frac_gt_1e-4"] = float(dcol.max()), float((dcol.max(axis=1) > 1e-4).mean())
+    # Gaussians whose colour is another pixel's: a Gaussian's colour IS the rendered colour of its arg-max pixel, and two pixels
+    # whose contributions tie to ~1e-6 may swap under the floor mode's expanded exponent (contributions and image unaffected)
+    out["colour_off_gaussians"] = int((dcol.max(axis=1) > 1e-4).sum())
+    out["colour_compared_gaussians"] = int(seen.sum())
 
     # allocation: cull -> validate -> magnitudes -> distribute, from our own render
     ref_ppg = g["ppg_u16"].astype(np.int64)
