@@ -182,4 +182,13 @@ __device__ __forceinline__ void sym3_eigvals(double a00, double a01, double a02,
     e[0] = lo; e[1] = mid; e[2] = hi;
 }
 
+// Child level of another layout (G2pcTileLayout.tile_parent, G2PC_TILE_PARENTS entries per tile, -1 = none): does this tile exist
+// for the camera whose first pass left `alive` (one byte per parent tile: "split")?  A tile can be the child of several parents:
+// a child reaches one pixel beyond an odd-sized parent, and the neighbouring parent may have the very same rectangle among its own.
+__device__ __forceinline__ bool child_exists(const int32_t* __restrict__ tile_parent, const uint8_t* __restrict__ alive, int t) {
+    const int32_t* p = tile_parent + (size_t)G2PC_TILE_PARENTS * t;
+    const int a = p[0], b = p[1], c = p[2], d = p[3];           // (one 16-byte load)
+    return (a >= 0 && alive[a]) || (b >= 0 && alive[b]) || (c >= 0 && alive[c]) || (d >= 0 && alive[d]);
+}
+
 }  // namespace g2pc

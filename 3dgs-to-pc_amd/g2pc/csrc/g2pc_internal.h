@@ -109,8 +109,27 @@ struct BucketHdr {
     uint32_t overflow, nbk, nchunks, cap;
     uint32_t partial[2 * BK_PARTIALS];              // per minmax slot: max(~key), max(key)
     uint32_t count[BK_MAX + 2], start[BK_MAX + 2];
+    uint32_t wstart[BK_MAX + 2];                    // fused emission (BucketEmit): exclusive scan of the buckets' weight sums
 };
 struct BucketPlan { uint32_t nbk, kpb, nchunks, nminmax, cap; };
+// Fused emission (the rasteriser's captured camera path): every key carries a weight -- the tiles its Gaussian touches -- and
+// the sort's last kernel, one wave per bucket, turns its sorted bucket straight into (tile, Gaussian) instances at
+// [exclusive scan of the weights in sorted order).  The weight sums per bucket ride in the histogram pass (one 64-bit LDS
+// add per key: count << 32 | weight), their scan and the capacity test in k_bk_scan: no separate scan over the n weights,
+// no duplication kernel, no count kernel (four launches and ~25 MB of traffic per camera less).  Keys must be fed in
+// REVERSED index order (value of position r = n - 1 - r), weights / rects are indexed by the value.
+struct BucketEmit {
+    const uint32_t* weight;       // [n] instances per Gaussian (0 for keys 0xFFFFFFFF)
+    const uint32_t* rect;         // [n] ix0 | ix1 << 8 | iy0 << 16 | iy1 << 24 tile-interval ranges
+    uint32_t* inst_tile;          // out: tile << gshift | Gaussian (gshift > 0), else the tile id ...
+    uint32_t* inst_g;             // ... with the Gaussian here
+    int gshift, nx;
+    uint32_t capacity;            // room of the instance arrays
+    uint32_t* l_eff;              // out (device): the instance count, or 0 when it exceeds the capacity / a bucket overflowed
+    uint32_t* count_host;         // out (pinned, optional): [camera][instances, unsorted, 0, -]
+    const int32_t* tile_parent;   // child pass of a camera: only the children of split nodes take instances ...
+    const G2pcCameraJob* jobs;    // ... per the camera's `alive` bytes (weight counted them the same way)
+};
 BucketPlan bucket_plan(long n);
 size_t bucket_sort_workspace(long n);
 bool bucket_sort_pays(long n);          // measured on MI355X: 90 vs 101 us (radix) at 1 M keys, 533 vs 278 us at 5 M
@@ -125,7 +144,8 @@ __device__ __forceinline__ void bucket_hdr_init(BucketHdr* h, const BucketPlan& 
 // vals == nullptr: the values are the input positions r themselves, or n - 1 - r when `reversed` (keys fed in reversed index order)
 int bucket_sort_u32(const uint32_t* keys, const uint32_t* vals, uint32_t* vals_out, uint32_t* keys_out, long n, void* ws,
                     size_t ws_bytes, uint32_t** overflow_flag, hipStream_t s, Batch b = Batch(), bool minmax_done = false,
-                    bool reversed = false);
+                    bool reversed = false, const BucketEmit* emit = nullptr);
+bool bucket_emit_supported(long n);     // the fused emission exists for the register-sorted buckets (cap 1024) only
 
 // Philox4x32-10 keyed standard normals (see oracle/np_philox.py for the definition)
 struct Normal3 { float x, y, z; };

@@ -589,46 +589,115 @@ __global__ __launch_bounds__(BK_T) void k_bk_hist(const uint32_t* __restrict__ k
     __syncthreads();
     for (uint32_t i = threadIdx.x; i <= nbk; i += BK_T) table[(size_t)i * plan.nchunks + blockIdx.x] = lh[i];
 }
+// Fused emission (BucketEmit): the same histogram with the keys' WEIGHTS summed per bucket beside the counts -- one 64-bit LDS
+// add per key (count << 32 | weight: a chunk holds at most 2^16 keys and its weights sum to less than 2^32, the capacity
+// test in k_bk_scan sees to the rest) --, the weight sums written row-wise (wtable[chunk][bucket], coalesced; they are only
+// ever summed over the chunks).  Keys are in reversed index order: position j carries Gaussian n - 1 - j.  NBK sizes the LDS
+// table (8 bytes per bucket: 32 KB at the 4 096 buckets of a 1 M-key sort, what the plain histogram takes).
+template <int NBK>
+__global__ __launch_bounds__(BK_T) void k_bk_hist_w(const uint32_t* __restrict__ keys, long n, const BucketHdr* __restrict__ h,
+                                                   uint32_t* __restrict__ table, uint32_t* __restrict__ wtable,
+                                                   const uint32_t* __restrict__ weight, BucketPlan plan, size_t cs) {
+    __shared__ unsigned long long lh[NBK + 1];
+    __shared__ uint32_t red[2];
+    keys = seg(keys, cs); h = seg(h, cs); table = seg(table, cs); wtable = seg(wtable, cs); weight = seg(weight, cs);
+    const uint32_t nbk = plan.nbk;
+    for (uint32_t i = threadIdx.x; i <= nbk; i += BK_T) lh[i] = 0ull;
+    const BucketMap m = bucket_map_from_partials(h, plan.nminmax, red);   // (its barriers also publish the zeroed histogram)
+    const long base = (long)blockIdx.x * plan.kpb;
+    for (uint32_t j0 = threadIdx.x; j0 < plan.kpb; j0 += BK_T * BK_UNROLL) {      // BK_UNROLL loads in flight per lane
+        uint32_t k[BK_UNROLL], wt[BK_UNROLL];
+        bool ok[BK_UNROLL];
+#pragma unroll
+        for (int u = 0; u < BK_UNROLL; ++u) {
+            const uint32_t j = j0 + (uint32_t)u * BK_T;
+            const long i = base + j;
+            ok[u] = j < plan.kpb && i < n;
+            k[u] = ok[u] ? keys[i] : 0u;
+            wt[u] = ok[u] ? weight[n - 1 - i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < BK_UNROLL; ++u)
+            if (ok[u]) atomicAdd(&lh[m.of(k[u])], (1ull << 32) | (unsigned long long)wt[u]);
+    }
+    __syncthreads();
+    uint32_t* wrow = wtable + (size_t)blockIdx.x * (nbk + 1);
+    for (uint32_t i = threadIdx.x; i <= nbk; i += BK_T) {
+        const unsigned long long v = lh[i];
+        table[(size_t)i * plan.nchunks + blockIdx.x] = (uint32_t)(v >> 32);
+        wrow[i] = (uint32_t)v;
+    }
+}
 // one wave per bucket (4 per block): table row -> exclusive prefix over the chunks, row total -> count[bucket]
+// wtable != nullptr (fused emission): the bucket's weight sum over the chunks -> wstart[bucket] (scanned by k_bk_scan)
 __global__ __launch_bounds__(BK_T) void k_bk_colscan(BucketHdr* __restrict__ h, uint32_t* __restrict__ table, BucketPlan plan,
-                                                    size_t cs) {
-    h = seg(h, cs); table = seg(table, cs);
+                                                    size_t cs, const uint32_t* __restrict__ wtable) {
+    h = seg(h, cs); table = seg(table, cs); wtable = seg(wtable, cs);
     const uint32_t b = blockIdx.x * (BK_T / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (b > plan.nbk) return;
     uint32_t* row = table + (size_t)b * plan.nchunks;
-    uint32_t carry = 0;
+    uint32_t carry = 0, wsum = 0;
     for (uint32_t j0 = 0; j0 < plan.nchunks; j0 += 64) {
         const uint32_t j = j0 + lane;
         const uint32_t v = j < plan.nchunks ? row[j] : 0u;
+        if (wtable && j < plan.nchunks) wsum += wtable[(size_t)j * (plan.nbk + 1) + b];
         const uint32_t incl = wave_incl_scan_u32(v);
         if (j < plan.nchunks) row[j] = carry + incl - v;
         carry += (uint32_t)__shfl((int)incl, 63);
     }
-    if (lane == 0) h->count[b] = carry;
+    if (wtable) wsum = wave_sum(wsum);
+    if (lane == 0) { h->count[b] = carry; if (wtable) h->wstart[b] = wsum; }
 }
-__global__ __launch_bounds__(1024) void k_bk_scan(BucketHdr* __restrict__ h, size_t cs) {
-    __shared__ uint32_t wsum[16];
-    h = seg(h, cs);
+// emit (fused emission): the weight sums are scanned as well (wstart), and the block settles what k_resolve_count settles on the
+// unfused path: l_eff = the instance count if it fits the capacity and no bucket overflowed, else 0 (camera skipped as a
+// whole); the pinned counts go to the host through their device mapping.
+__global__ __launch_bounds__(1024) void k_bk_scan(BucketHdr* __restrict__ h, size_t cs, bool emit, uint32_t capacity,
+                                                 uint32_t* __restrict__ l_eff, uint32_t* __restrict__ count_host) {
+    __shared__ uint32_t wsum[16], wsum2[16], s_worst;
+    h = seg(h, cs); l_eff = seg(l_eff, cs);
     const unsigned t = threadIdx.x, lane = t & 63, w = t >> 6;
     const uint32_t nbk = h->nbk, per = nbk >> 10;                     // nbk is a multiple of 1024: `per` buckets per thread
-    uint32_t c[BK_MAX / 1024], mine = 0, worst = 0;
+    uint32_t c[BK_MAX / 1024], wv[BK_MAX / 1024], mine = 0, worst = 0, mine_w = 0;
+    if (t == 0) s_worst = 0u;
 #pragma unroll
     for (uint32_t k = 0; k < (uint32_t)(BK_MAX / 1024); ++k) {
         c[k] = k < per ? h->count[t * per + k] : 0u;
+        wv[k] = (emit && k < per) ? h->wstart[t * per + k] : 0u;
         mine += c[k];
+        mine_w += wv[k];
         worst = umax_(worst, c[k]);
     }
     const uint32_t incl = wave_incl_scan_u32(mine);
-    if (lane == 63) wsum[w] = incl;
+    const uint32_t incl_w = emit ? wave_incl_scan_u32(mine_w) : 0u;
+    if (lane == 63) { wsum[w] = incl; wsum2[w] = incl_w; }
     __syncthreads();
-    uint32_t woff = 0, total = 0;
-    for (int k = 0; k < 16; ++k) { const uint32_t v = wsum[k]; if (k < (int)w) woff += v; total += v; }
-    uint32_t run = woff + incl - mine;
+    uint32_t woff = 0, total = 0, woff_w = 0, total_w = 0;
+    for (int k = 0; k < 16; ++k) {
+        const uint32_t v = wsum[k], v2 = wsum2[k];
+        if (k < (int)w) { woff += v; woff_w += v2; }
+        total += v; total_w += v2;
+    }
+    uint32_t run = woff + incl - mine, run_w = woff_w + incl_w - mine_w;
 #pragma unroll
     for (uint32_t k = 0; k < (uint32_t)(BK_MAX / 1024); ++k)
-        if (k < per) { h->start[t * per + k] = run; run += c[k]; }
-    if (worst > h->cap) atomicMax(&h->overflow, worst);
+        if (k < per) {
+            h->start[t * per + k] = run; run += c[k];
+            if (emit) { h->wstart[t * per + k] = run_w; run_w += wv[k]; }
+        }
+    if (worst > h->cap) { atomicMax(&h->overflow, worst); atomicMax(&s_worst, worst); }
     if (t == 0) { h->start[nbk] = total; h->start[nbk + 1] = total + h->count[nbk]; }   // the tail bucket
+    if (emit) {
+        __syncthreads();
+        if (t == 0) {
+            const uint32_t unsorted = s_worst;                    // a bucket beyond its room: the camera is not sorted
+            h->wstart[nbk] = total_w;
+            l_eff[0] = (total_w <= capacity && !unsorted) ? total_w : 0u;
+            if (count_host) {
+                count_host += 4 * blockIdx.y;
+                count_host[0] = total_w; count_host[1] = unsorted; count_host[2] = 0u;   // ([2] is raised by k_tile_gate later)
+            }
+        }
+    }
 }
 __global__ __launch_bounds__(BK_T) void k_bk_scatter(const uint32_t* __restrict__ keys, long n, const BucketHdr* __restrict__ h,
                                                     const uint32_t* __restrict__ table, unsigned long long* __restrict__ items,
@@ -771,19 +840,85 @@ __global__ __launch_bounds__(64) void k_bk_sort(const BucketHdr* __restrict__ h,
     }
 }
 
+// Fused emission: bucket b sorted in registers as above, then -- in sorted order -- the exclusive scan of its Gaussians' weights
+// on top of wstart[b] and the (tile, Gaussian) instances themselves (what k_duplicate writes from offsets[] on the unfused
+// path: the same words at the same places).  The rect gathers of all R registers are requested together.
+template <int R>
+__device__ __forceinline__ void bucket_sort_emit_in_registers(const unsigned long long* __restrict__ items, uint32_t s0, uint32_t cnt,
+                                                              unsigned lane, uint32_t rev, uint32_t base, const BucketEmit& em,
+                                                              const uint8_t* __restrict__ alive) {
+    unsigned long long v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { const uint32_t e = (uint32_t)r * 64u + lane; v[r] = e < cnt ? items[s0 + e] : ~0ull; }
+    wave_bitonic_sort<R>(v, lane);
+    uint32_t g[R], rc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const bool valid = (uint32_t)r * 64u + lane < cnt;
+        g[r] = valid ? rev - 1u - (uint32_t)v[r] : 0u;
+        rc[r] = valid ? em.rect[g[r]] : 0u;
+    }
+    uint32_t run = base;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const bool valid = (uint32_t)r * 64u + lane < cnt;
+        const int ix0 = rc[r] & 255, ix1 = (rc[r] >> 8) & 255, iy0 = (rc[r] >> 16) & 255, iy1 = rc[r] >> 24;
+        // the weight the histogram summed: the rect's area, or (child pass) the children that exist for this camera
+        uint32_t wgt = 0u;
+        if (valid) wgt = alive ? em.weight[g[r]] : (uint32_t)((ix1 - ix0 + 1) * (iy1 - iy0 + 1));
+        const uint32_t incl = wave_incl_scan_u32(wgt);
+        uint32_t off = run + incl - wgt;
+        run += (uint32_t)__shfl((int)incl, 63);
+        if (!valid || wgt == 0u) continue;
+        for (int iy = iy0; iy <= iy1; ++iy)
+            for (int ix = ix0; ix <= ix1; ++ix) {
+                if (alive && !child_exists(em.tile_parent, alive, iy * em.nx + ix)) continue;
+                if (em.gshift) {
+                    em.inst_tile[off] = ((uint32_t)(iy * em.nx + ix) << em.gshift) | g[r];
+                } else {
+                    em.inst_tile[off] = (uint32_t)(iy * em.nx + ix);
+                    em.inst_g[off] = g[r];
+                }
+                ++off;
+            }
+    }
+}
+__global__ __launch_bounds__(64) void k_bk_sort_emit(const BucketHdr* __restrict__ h, const unsigned long long* __restrict__ items,
+                                                     size_t cs, uint32_t rev, BucketEmit em) {
+    h = seg(h, cs); items = seg(items, cs);
+    em.weight = seg(em.weight, cs); em.rect = seg(em.rect, cs); em.inst_tile = seg(em.inst_tile, cs); em.inst_g = seg(em.inst_g, cs);
+    em.l_eff = seg(em.l_eff, cs);
+    if (*em.l_eff == 0u) return;                  // nothing to emit, more than fits, or a bucket beyond its room: camera skipped
+    const uint8_t* alive = nullptr;
+    if (em.tile_parent && em.jobs) {
+        const G2pcCameraJob* jb = em.jobs + blockIdx.y;
+        alive = (const uint8_t*)(((unsigned long long)jb->alive_hi << 32) | jb->alive_lo);
+    }
+    const unsigned lane = threadIdx.x, b = blockIdx.x;         // (the tail bucket -- keys 0xFFFFFFFF, weight 0 -- emits nothing)
+    const uint32_t s0 = h->start[b], cnt = h->start[b + 1] - s0, base = h->wstart[b];
+    if (cnt == 0) return;
+    if (cnt <= 64) bucket_sort_emit_in_registers<1>(items, s0, cnt, lane, rev, base, em, alive);
+    else if (cnt <= 128) bucket_sort_emit_in_registers<2>(items, s0, cnt, lane, rev, base, em, alive);
+    else if (cnt <= 256) bucket_sort_emit_in_registers<4>(items, s0, cnt, lane, rev, base, em, alive);
+    else if (cnt <= 512) bucket_sort_emit_in_registers<8>(items, s0, cnt, lane, rev, base, em, alive);
+    else bucket_sort_emit_in_registers<16>(items, s0, cnt, lane, rev, base, em, alive);
+}
+
 // the per-bucket sort is one wave per bucket: it pays while buckets stay small (the 8 KB footprint)
 bool bucket_sort_pays(long n) { return n > 0 && bucket_plan(n).cap == (uint32_t)BK_CAP_SMALL; }
+bool bucket_emit_supported(long n) { return bucket_sort_pays(n) && n < (1l << 31); }
 
 size_t bucket_sort_workspace(long n) {
     const BucketPlan p = bucket_plan(n > 0 ? n : 1);
-    return align_up(sizeof(BucketHdr)) + align_up((size_t)(n > 0 ? n : 1) * 8) + align_up((size_t)(p.nbk + 1) * p.nchunks * 4) + 1024;
+    return align_up(sizeof(BucketHdr)) + align_up((size_t)(n > 0 ? n : 1) * 8) + 2 * align_up((size_t)(p.nbk + 1) * p.nchunks * 4) + 1024;
 }
 
 // vals_out[p] = vals[r_p] (and keys_out[p] = keys[r_p] when given) for the positions r sorted by (keys[r], r) ascending,
 // keys 0xFFFFFFFF last.  *overflow_flag (device u32, optional) receives the size of the largest bucket when one exceeds
 // the room of a bucket (BucketPlan::cap) -- the output is then a permutation in bucket order only and the caller must sort again with sort_pairs_u32.
 int bucket_sort_u32(const uint32_t* keys, const uint32_t* vals, uint32_t* vals_out, uint32_t* keys_out, long n, void* ws,
-                    size_t ws_bytes, uint32_t** overflow_flag, hipStream_t s, Batch b, bool minmax_done, bool reversed) {
+                    size_t ws_bytes, uint32_t** overflow_flag, hipStream_t s, Batch b, bool minmax_done, bool reversed,
+                    const BucketEmit* emit) {
     if (n <= 0) return G2PC_OK;
     const BucketPlan plan = bucket_plan(n);
     const unsigned by = (unsigned)b.n;
@@ -792,12 +927,31 @@ int bucket_sort_u32(const uint32_t* keys, const uint32_t* vals, uint32_t* vals_o
     BucketHdr* h = ar.get<BucketHdr>(1);
     unsigned long long* items = ar.get<unsigned long long>((size_t)n);
     uint32_t* table = ar.get<uint32_t>((size_t)(plan.nbk + 1) * plan.nchunks);
+    uint32_t* wtable = ar.get<uint32_t>((size_t)(plan.nbk + 1) * plan.nchunks);
     if (!ar.ok()) { set_error("bucket_sort", "workspace too small"); return G2PC_ERR_WORKSPACE; }
+    if (emit && (!rev || plan.cap != (uint32_t)BK_CAP_SMALL || !emit->weight || !emit->rect || !emit->inst_tile || !emit->l_eff)) {
+        set_error("bucket_sort", "fused emission needs reversed position values, register-sized buckets and its arrays");
+        return G2PC_ERR_ARG;
+    }
     if (!minmax_done) hipLaunchKernelGGL(k_bk_minmax, dim3(plan.nminmax, by), dim3(BK_T), 0, s, keys, n, h, plan, b.cs);
-    hipLaunchKernelGGL(k_bk_hist, dim3(plan.nchunks, by), dim3(BK_T), 0, s, keys, n, (const BucketHdr*)h, table, plan, b.cs);
-    hipLaunchKernelGGL(k_bk_colscan, dim3(cdiv(plan.nbk + 1, BK_T / 64), by), dim3(BK_T), 0, s, h, table, plan, b.cs);
-    hipLaunchKernelGGL(k_bk_scan, dim3(1, by), dim3(1024), 0, s, h, b.cs);
+    if (emit) {
+        if (plan.nbk <= 4096)
+            hipLaunchKernelGGL(k_bk_hist_w<4096>, dim3(plan.nchunks, by), dim3(BK_T), 0, s, keys, n, (const BucketHdr*)h, table, wtable, emit->weight, plan, b.cs);
+        else
+            hipLaunchKernelGGL(k_bk_hist_w<BK_MAX>, dim3(plan.nchunks, by), dim3(BK_T), 0, s, keys, n, (const BucketHdr*)h, table, wtable, emit->weight, plan, b.cs);
+    } else {
+        hipLaunchKernelGGL(k_bk_hist, dim3(plan.nchunks, by), dim3(BK_T), 0, s, keys, n, (const BucketHdr*)h, table, plan, b.cs);
+    }
+    hipLaunchKernelGGL(k_bk_colscan, dim3(cdiv(plan.nbk + 1, BK_T / 64), by), dim3(BK_T), 0, s, h, table, plan, b.cs,
+                       emit ? (const uint32_t*)wtable : (const uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_bk_scan, dim3(1, by), dim3(1024), 0, s, h, b.cs, emit != nullptr, emit ? emit->capacity : 0u,
+                       emit ? emit->l_eff : (uint32_t*)nullptr, emit ? emit->count_host : (uint32_t*)nullptr);
     hipLaunchKernelGGL(k_bk_scatter, dim3(plan.nchunks, by), dim3(BK_T), 0, s, keys, n, (const BucketHdr*)h, (const uint32_t*)table, items, plan, b.cs);
+    if (emit) {
+        hipLaunchKernelGGL(k_bk_sort_emit, dim3(plan.nbk, by), dim3(64), 0, s, (const BucketHdr*)h, (const unsigned long long*)items, b.cs, rev, *emit);
+        if (overflow_flag) *overflow_flag = &h->overflow;
+        return check_launch("bucket_sort");
+    }
     if (plan.cap == (uint32_t)BK_CAP_SMALL)
         hipLaunchKernelGGL(k_bk_sort<BK_CAP_SMALL>, dim3(plan.nbk + BK_TAILBLOCKS, by), dim3(64), 0, s, (const BucketHdr*)h,
                            (const unsigned long long*)items, vals, vals_out, keys_out, b.cs, rev);

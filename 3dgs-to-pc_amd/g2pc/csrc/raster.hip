@@ -55,15 +55,6 @@ struct Layout {         // device pointers of G2pcTileLayout
     int walk_cap;                     // DIAGNOSTIC (g2pc_debug_set_walk_cap): the dual-list blend stops a walk after this many batches (0 = never; results are then WRONG)
 };
 
-// Child level of another layout (G2pcTileLayout.tile_parent, G2PC_TILE_PARENTS entries per tile, -1 = none): does this tile exist
-// for the camera whose first pass left `alive` (one byte per parent tile: "split")?  A tile can be the child of several parents:
-// a child reaches one pixel beyond an odd-sized parent, and the neighbouring parent may have the very same rectangle among its own.
-__device__ __forceinline__ bool child_exists(const int32_t* __restrict__ tile_parent, const uint8_t* __restrict__ alive, int t) {
-    const int32_t* p = tile_parent + (size_t)G2PC_TILE_PARENTS * t;
-    const int a = p[0], b = p[1], c = p[2], d = p[3];           // (one 16-byte load)
-    return (a >= 0 && alive[a]) || (b >= 0 && alive[b]) || (c >= 0 && alive[c]) || (d >= 0 && alive[d]);
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // K1 (PY): per Gaussian projection, EWA covariance, conic, radius, pixel rect -> tile index ranges.
 // Writes the depth-sort input in REVERSED index order so that the stable ascending radix sort leaves equal
@@ -2128,6 +2119,10 @@ static size_t py_front_ws(long n) {
 }
 static int g_blend_variant = 1;               // 2 sub-blocks per chunk: 2 = two-wave dual-list kernel (k_blend_py_2w, one wave per sub-block), 1 = dual-list kernel (k_blend_py_dl), 0 = packed kernel (k_blend_py_pk)
 static int g_depth_bucket_sort = 1;           // captured camera path: 1 = bucket sort of the depth keys, 0 = radix (g2pc_set_depth_sort)
+#ifndef G2PC_FUSED_EMIT
+#define G2PC_FUSED_EMIT 1
+#endif
+static const int g_fused_emit = G2PC_FUSED_EMIT;   // build-time A/B switch: 0 = scan + k_duplicate + k_resolve_count as until round 4
 // Packed tile-sort instances: when the tile id and the Gaussian index share one 32-bit word (tile << gshift | index) the
 // stable sort by tile moves keys only -- half the traffic of the two passes -- and the blend masks the index out.
 // Returns gshift (0: they do not fit, separate arrays as before).
@@ -2166,10 +2161,13 @@ struct PyBackArena {
 
 // depth_overflow != nullptr: the depth order comes from the bucket sort (prims.hip) and *depth_overflow points at its
 // overflow word afterwards (non-zero = NOT sorted: the caller must discard the camera and repeat it with the radix path)
+// emit != nullptr (captured path, bucket sort): the depth sort's last kernel writes the (tile, Gaussian) instances itself and
+// the instance count is settled inside the sort (BucketEmit, prims.hip) -- no tiles-touched scan here, no k_duplicate and no
+// k_resolve_count afterwards; fb.sorted_idx / fb.offsets are then NOT written.
 static int py_front(const Cam& cam_val, const Cam* cam_dev, const G2pcTileLayout* layout, const float* means3D,
                     const float* cov9, const float* opacity, const float* colours, long n, const PyFrontBuffers& fb,
                     void* ws, size_t ws_bytes, hipStream_t s, uint32_t** depth_overflow = nullptr, Batch bt = Batch(),
-                    const G2pcCameraJob* jobs_host = nullptr, G2pcCameraJob* jobs_dev = nullptr) {
+                    const G2pcCameraJob* jobs_host = nullptr, G2pcCameraJob* jobs_dev = nullptr, BucketEmit* emit = nullptr) {
     Arena ar(ws, ws_bytes);
     uint32_t* key_rev = ar.get<uint32_t>((size_t)n);
     uint32_t* idx_rev = ar.get<uint32_t>((size_t)n);
@@ -2199,10 +2197,13 @@ static int py_front(const Cam& cam_val, const Cam* cam_dev, const G2pcTileLayout
                            means3D, cov9, opacity, n, key_rev, idx_rev, touched, colours, fb.rec, fb.rect, (size_t)0,
                            (BucketHdr*)nullptr, 1u);
     for (int k = 0; k < g_extra_launches; ++k) hipLaunchKernelGGL(k_nothing, dim3(1), dim3(64), 0, s, (uint32_t*)nullptr);
+    if (emit && !(fold && depth_overflow)) { set_error("raster_front_py", "fused emission without the folded bucket sort"); return G2PC_ERR_ARG; }
+    if (emit) { emit->weight = touched; emit->rect = fb.rect; }
     int rc = depth_overflow ? bucket_sort_u32(key_rev, fold ? nullptr : idx_rev, fb.sorted_idx, nullptr, n, bucket_ws, bucket_bytes,
-                                              depth_overflow, s, bt, fold, fold)
+                                              depth_overflow, s, bt, fold, fold, emit)
                             : sort_pairs_u32(key_rev, idx_rev, key_sorted, fb.sorted_idx, ktmp, vtmp, n, 0, 32, sort_ws, sort_bytes, s, nullptr, bt);
     if (rc) return rc;
+    if (emit) return G2PC_OK;
     // exclusive scan of the tiles touched, taken in depth order (the gather rides in the scan's first kernel)
     return scan_exclusive_u32(touched, fb.offsets, n, scan_ws, scan_bytes, s, fb.sorted_idx, bt);
 }
@@ -2219,7 +2220,7 @@ static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t*
                    const PyBlendArgs& ba, int W, int H, const PyFrontBuffers& fb, unsigned long long* best_key,
                    float* colours_out, float* tilebuf, float* image, int phases, uint32_t max_per_tile,
                    uint32_t* overflow_flag, void* ws, size_t ws_bytes, hipStream_t s, Batch bt = Batch(),
-                   const PyScene& sc = PyScene{}) {
+                   const PyScene& sc = PyScene{}, bool emitted = false) {      // emitted: the instances are there already (BucketEmit)
     const int T = layout->nx * layout->ny;
     PyBackArena A(ws, ws_bytes, L, T);
     if (!A.ok) { set_error("raster_back_py", "workspace too small"); return G2PC_ERR_WORKSPACE; }
@@ -2233,9 +2234,10 @@ static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t*
     const uint32_t* blend_list = gshift ? tile_sorted : g_sorted;
     if (phases & 1) {
         if (L > 0) {
-            hipLaunchKernelGGL(k_duplicate<false>, dim3(cdiv(n, g_head_threads), (unsigned)bt.n), dim3(g_head_threads), 0, s, fb.sorted_idx, fb.offsets, fb.rect, n, lay.nx,
-                               inst_tile, inst_g, l_eff, gshift, bt.cs, sc.cam_dev ? lay.tile_parent : (const int32_t*)nullptr,
-                               (const G2pcCameraJob*)sc.cam_dev);
+            if (!emitted)
+                hipLaunchKernelGGL(k_duplicate<false>, dim3(cdiv(n, g_head_threads), (unsigned)bt.n), dim3(g_head_threads), 0, s, fb.sorted_idx, fb.offsets, fb.rect, n, lay.nx,
+                                   inst_tile, inst_g, l_eff, gshift, bt.cs, sc.cam_dev ? lay.tile_parent : (const int32_t*)nullptr,
+                                   (const G2pcCameraJob*)sc.cam_dev);
             int rc = gshift ? sort_pairs_u32(inst_tile, nullptr, tile_sorted, nullptr, tile_tmp, nullptr, L, gshift,
                                              gshift + bits_for_tiles((unsigned)T), sort_ws, sort_bytes, s, l_eff, bt)
                             : sort_pairs_u32(inst_tile, inst_g, tile_sorted, g_sorted, tile_tmp, g_tmp, L, 0,
@@ -2385,22 +2387,36 @@ int g2pc_raster_cameras_py(const G2pcCameraJob* jobs_dev, const G2pcCameraJob* j
     char* back_ws = ar.get<char>(back_bytes);
     G2PC_REQUIRE(ar.ok(), G2PC_ERR_WORKSPACE, "workspace too small");
     int rc;
+    // Bucket-sorted cameras emit their instances from inside the sort (BucketEmit): the depth sort's last kernel, one wave per
+    // depth bucket, writes what k_duplicate would write, the count is settled by the sort's own scan kernel.
+    const bool bucket = g_depth_bucket_sort && bucket_sort_pays((long)n);
+    const bool fused = bucket && g_fused_emit && bucket_emit_supported((long)n);
     if (phases & 1) {
         // Both hand-overs with the host go through kernels that touch the PINNED buffers via their device mapping, not
         // through copy nodes: a graph whose first node is a host-to-device copy replayed with ~0.1 ms of extra latency
         // per camera for the lifetime of the first buffers a process pinned (25.9 -> 29 ms per 50-camera job).
         uint32_t* depth_overflow = nullptr;
+        BucketEmit em{};
+        if (fused) {
+            PyBackArena A(back_ws, back_bytes, (long)capacity, T);
+            G2PC_REQUIRE(A.ok, G2PC_ERR_WORKSPACE, "workspace too small");
+            em.inst_tile = A.inst_tile; em.inst_g = A.inst_g;
+            em.gshift = packed_instance_shift((long)n, T); em.nx = layout->nx;
+            em.capacity = (uint32_t)capacity; em.l_eff = l_eff; em.count_host = count_host;
+            em.tile_parent = layout->tile_parent; em.jobs = jobs_dev;
+        }
         rc = py_front(Cam{}, (const Cam*)&jobs_dev->cam, layout, means3D, cov9, opacity, colours, (long)n, fb, front_ws,
-                      front_bytes, s, (g_depth_bucket_sort && bucket_sort_pays((long)n)) ? &depth_overflow : nullptr, bt, jobs_host,
-                      (G2pcCameraJob*)jobs_dev);
+                      front_bytes, s, bucket ? &depth_overflow : nullptr, bt, jobs_host,
+                      (G2pcCameraJob*)jobs_dev, fused ? &em : nullptr);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_resolve_count, dim3(1, (unsigned)batch), dim3(64), 0, s, fb.offsets + n, (uint32_t)capacity, l_eff,
-                           count_host, (const uint32_t*)depth_overflow, bt.cs);
+        if (!fused)
+            hipLaunchKernelGGL(k_resolve_count, dim3(1, (unsigned)batch), dim3(64), 0, s, fb.offsets + n, (uint32_t)capacity, l_eff,
+                               count_host, (const uint32_t*)depth_overflow, bt.cs);
     }
     PyBlendArgs ba{0u, 0.0f, 0.0f, jobs_dev};
     PyScene scene{Cam{}, (const Cam*)&jobs_dev->cam, means3D, cov9, count_host};
     rc = py_back(layout, (long)n, (long)capacity, l_eff, ba, 0, 0, fb, best_key, nullptr, tilebuf, nullptr,
-                 phases & (3 | 8), max_per_tile, overflow_flag, back_ws, back_bytes, s, bt, scene);
+                 phases & (3 | 8), max_per_tile, overflow_flag, back_ws, back_bytes, s, bt, scene, fused);
     if (rc) return rc;
     return check_launch("g2pc_raster_cameras_py");
 }
