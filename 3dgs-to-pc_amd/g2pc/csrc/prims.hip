@@ -502,6 +502,9 @@ int sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* k
 // on 2 K addresses: 0.66 ms per camera, and every co-running kernel slowed 4x) and cleared its header with a
 // hipMemsetAsync, whose graph node this runtime did not order against the kernels around it (replays faulted).
 // ------------------------------------------------------------------------------------------------
+#ifndef G2PC_BK_EMIT_RMAX
+#define G2PC_BK_EMIT_RMAX 16      // build-time A/B switch (k_bk_sort_emit): 8 = buckets beyond 512 items through LDS, half the VGPRs
+#endif
 constexpr int BK_UNROLL = 8;      // keys a lane of k_bk_hist / k_bk_scatter requests before it uses the first
 constexpr int BK_MIN = 1024, BK_AVG = 256, BK_CAP_SMALL = 1024, BK_CAP_LARGE = 4096, BK_T = 256, BK_MAXCHUNKS = 512, BK_TAILBLOCKS = 256;
 BucketPlan bucket_plan(long n) {
@@ -843,6 +846,28 @@ __global__ __launch_bounds__(64) void k_bk_sort(const BucketHdr* __restrict__ h,
 // Fused emission: bucket b sorted in registers as above, then -- in sorted order -- the exclusive scan of its Gaussians' weights
 // on top of wstart[b] and the (tile, Gaussian) instances themselves (what k_duplicate writes from offsets[] on the unfused
 // path: the same words at the same places).  The rect gathers of all R registers are requested together.
+__device__ __forceinline__ void emit_instances(const BucketEmit& em, const uint8_t* __restrict__ alive, bool valid, uint32_t g,
+                                               uint32_t rc, uint32_t& run) {
+    const int ix0 = rc & 255, ix1 = (rc >> 8) & 255, iy0 = (rc >> 16) & 255, iy1 = rc >> 24;
+    // the weight the histogram summed: the rect's area, or (child pass) the children that exist for this camera
+    uint32_t wgt = 0u;
+    if (valid) wgt = alive ? em.weight[g] : (uint32_t)((ix1 - ix0 + 1) * (iy1 - iy0 + 1));
+    const uint32_t incl = wave_incl_scan_u32(wgt);
+    uint32_t off = run + incl - wgt;
+    run += (uint32_t)__shfl((int)incl, 63);
+    if (!valid || wgt == 0u) return;
+    for (int iy = iy0; iy <= iy1; ++iy)
+        for (int ix = ix0; ix <= ix1; ++ix) {
+            if (alive && !child_exists(em.tile_parent, alive, iy * em.nx + ix)) continue;
+            if (em.gshift) {
+                em.inst_tile[off] = ((uint32_t)(iy * em.nx + ix) << em.gshift) | g;
+            } else {
+                em.inst_tile[off] = (uint32_t)(iy * em.nx + ix);
+                em.inst_g[off] = g;
+            }
+            ++off;
+        }
+}
 template <int R>
 __device__ __forceinline__ void bucket_sort_emit_in_registers(const unsigned long long* __restrict__ items, uint32_t s0, uint32_t cnt,
                                                               unsigned lane, uint32_t rev, uint32_t base, const BucketEmit& em,
@@ -860,31 +885,15 @@ __device__ __forceinline__ void bucket_sort_emit_in_registers(const unsigned lon
     }
     uint32_t run = base;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const bool valid = (uint32_t)r * 64u + lane < cnt;
-        const int ix0 = rc[r] & 255, ix1 = (rc[r] >> 8) & 255, iy0 = (rc[r] >> 16) & 255, iy1 = rc[r] >> 24;
-        // the weight the histogram summed: the rect's area, or (child pass) the children that exist for this camera
-        uint32_t wgt = 0u;
-        if (valid) wgt = alive ? em.weight[g[r]] : (uint32_t)((ix1 - ix0 + 1) * (iy1 - iy0 + 1));
-        const uint32_t incl = wave_incl_scan_u32(wgt);
-        uint32_t off = run + incl - wgt;
-        run += (uint32_t)__shfl((int)incl, 63);
-        if (!valid || wgt == 0u) continue;
-        for (int iy = iy0; iy <= iy1; ++iy)
-            for (int ix = ix0; ix <= ix1; ++ix) {
-                if (alive && !child_exists(em.tile_parent, alive, iy * em.nx + ix)) continue;
-                if (em.gshift) {
-                    em.inst_tile[off] = ((uint32_t)(iy * em.nx + ix) << em.gshift) | g[r];
-                } else {
-                    em.inst_tile[off] = (uint32_t)(iy * em.nx + ix);
-                    em.inst_g[off] = g[r];
-                }
-                ++off;
-            }
-    }
+    for (int r = 0; r < R; ++r) emit_instances(em, alive, (uint32_t)r * 64u + lane < cnt, g[r], rc[r], run);
 }
+// RMAX: buckets of up to 64 * RMAX items are sorted in registers, larger ones (up to the 1 024 of the room) through an 8 KB LDS
+// network.  RMAX = 16 is the whole room in registers at 86 VGPRs; RMAX = 8 halves the registers of the kernel -- beside the
+// blends of the other streams (5 waves x 96 VGPRs allocated per SIMD) what a head wave needs decides when it can start.
+template <int RMAX>
 __global__ __launch_bounds__(64) void k_bk_sort_emit(const BucketHdr* __restrict__ h, const unsigned long long* __restrict__ items,
                                                      size_t cs, uint32_t rev, BucketEmit em) {
+    __shared__ unsigned long long s_it[RMAX < 16 ? 1024 : 1];
     h = seg(h, cs); items = seg(items, cs);
     em.weight = seg(em.weight, cs); em.rect = seg(em.rect, cs); em.inst_tile = seg(em.inst_tile, cs); em.inst_g = seg(em.inst_g, cs);
     em.l_eff = seg(em.l_eff, cs);
@@ -901,7 +910,32 @@ __global__ __launch_bounds__(64) void k_bk_sort_emit(const BucketHdr* __restrict
     else if (cnt <= 128) bucket_sort_emit_in_registers<2>(items, s0, cnt, lane, rev, base, em, alive);
     else if (cnt <= 256) bucket_sort_emit_in_registers<4>(items, s0, cnt, lane, rev, base, em, alive);
     else if (cnt <= 512) bucket_sort_emit_in_registers<8>(items, s0, cnt, lane, rev, base, em, alive);
-    else bucket_sort_emit_in_registers<16>(items, s0, cnt, lane, rev, base, em, alive);
+    else if (RMAX >= 16) bucket_sort_emit_in_registers<(RMAX >= 16 ? 16 : 1)>(items, s0, cnt, lane, rev, base, em, alive);
+    else {
+        // (rare: a bucket of more than twice the mean) bitonic network in LDS: pair p of step jj is (i, i + jj), i = 2 jj (p / jj) + p % jj
+        uint32_t np = 2;
+        while (np < cnt) np <<= 1;
+        for (uint32_t j = lane; j < np; j += 64) s_it[j] = j < cnt ? items[s0 + j] : ~0ull;
+        wave_sync();
+        const uint32_t half = np >> 1;
+        for (uint32_t k = 2; k <= np; k <<= 1)
+            for (uint32_t jj = k >> 1; jj > 0; jj >>= 1) {
+                for (uint32_t p = lane; p < half; p += 64) {
+                    const uint32_t i = ((p & ~(jj - 1)) << 1) | (p & (jj - 1)), l = i + jj;
+                    const unsigned long long x = s_it[i], y = s_it[l];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) { s_it[i] = y; s_it[l] = x; }
+                }
+                wave_sync();
+            }
+        uint32_t run = base;
+        for (uint32_t e0 = 0; e0 < cnt; e0 += 64) {
+            const bool valid = e0 + lane < cnt;
+            const uint32_t g = valid ? rev - 1u - (uint32_t)s_it[e0 + lane] : 0u;
+            const uint32_t rc = valid ? em.rect[g] : 0u;
+            emit_instances(em, alive, valid, g, rc, run);
+        }
+    }
 }
 
 // the per-bucket sort is one wave per bucket: it pays while buckets stay small (the 8 KB footprint)
@@ -948,7 +982,7 @@ int bucket_sort_u32(const uint32_t* keys, const uint32_t* vals, uint32_t* vals_o
                        emit ? emit->l_eff : (uint32_t*)nullptr, emit ? emit->count_host : (uint32_t*)nullptr);
     hipLaunchKernelGGL(k_bk_scatter, dim3(plan.nchunks, by), dim3(BK_T), 0, s, keys, n, (const BucketHdr*)h, (const uint32_t*)table, items, plan, b.cs);
     if (emit) {
-        hipLaunchKernelGGL(k_bk_sort_emit, dim3(plan.nbk, by), dim3(64), 0, s, (const BucketHdr*)h, (const unsigned long long*)items, b.cs, rev, *emit);
+        hipLaunchKernelGGL(k_bk_sort_emit<G2PC_BK_EMIT_RMAX>, dim3(plan.nbk, by), dim3(64), 0, s, (const BucketHdr*)h, (const unsigned long long*)items, b.cs, rev, *emit);
         if (overflow_flag) *overflow_flag = &h->overflow;
         return check_launch("bucket_sort");
     }

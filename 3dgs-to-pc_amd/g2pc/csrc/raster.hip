@@ -84,22 +84,26 @@ __device__ __forceinline__ void interval_range(const int32_t* __restrict__ start
     if (first <= last) { i0 = first; i1 = last; } else { i0 = n; i1 = -1; }
 }
 
-template <bool CAM_ON_DEVICE>
+// MULTI (round 5): ONE thread per Gaussian for ALL cameras of the batch (grid.y = 1, `ncam` cameras in a loop) instead of one
+// per (Gaussian, camera): the Gaussian's 17 input words, the tile-interval stage and the block's barriers are paid once per
+// batch -- beside the blends of the other streams a wave of this kernel is a chain of round trips (stage, inputs, stores),
+// and half as many waves walk it.  The arithmetic per camera is the same instruction sequence: bit-identical outputs.
+template <bool CAM_ON_DEVICE, bool MULTI>
 __global__ __launch_bounds__(RA_T) void k_preprocess_py(Cam cam_val, const Cam* __restrict__ cam_dev, Layout lay,
                                                        const float* __restrict__ means3D,
                                                        const float* __restrict__ cov9,
                                                        const float* __restrict__ opacity, long n,
-                                                       uint32_t* __restrict__ depth_key_rev,
-                                                       uint32_t* __restrict__ index_rev,
-                                                       uint32_t* __restrict__ tiles_touched,
+                                                       uint32_t* __restrict__ depth_key_rev0,
+                                                       uint32_t* __restrict__ index_rev0,
+                                                       uint32_t* __restrict__ tiles_touched0,
                                                        const float* __restrict__ colours,
-                                                       float4* __restrict__ rec, uint32_t* __restrict__ rect, size_t cs,
-                                                       BucketHdr* __restrict__ mm, uint32_t mm_slots) {
+                                                       float4* __restrict__ rec0, uint32_t* __restrict__ rect0, size_t cs,
+                                                       BucketHdr* __restrict__ mm0, uint32_t mm_slots, int ncam) {
     // device-resident camera: lets ONE captured launch sequence serve every camera (scalar loads, see below).
-    // Batched launch (grid.y cameras): camera c's job is the c-th G2pcCameraJob, its outputs live in the c-th arena.
+    // Batched launch (grid.y cameras, or MULTI): camera c's job is the c-th G2pcCameraJob, its outputs live in the c-th arena.
     // mm != nullptr: the depth keys go to the bucket sort (prims.hip), whose first pass -- the range of the keys -- is folded
     // in here: every block leaves (max ~key, max key) in slot blockIdx.x % mm_slots of the (zeroed) header.
-    __shared__ uint32_t s_mm[2];
+    __shared__ uint32_t s_mm[2 * G2PC_MAX_CAMERA_BATCH];
     // The tile intervals of both axes, staged in LDS (<= 256 per axis, rect packs 8-bit tile coordinates): interval_range runs two
     // binary searches per axis, ~20 DEPENDENT loads per Gaussian -- from global memory each was a round trip to the L2, and
     // beside the blends of the other cameras (one or two waves of this kernel resident per SIMD, nothing to hide behind) those
@@ -109,39 +113,46 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_py(Cam cam_val, const Cam* 
         s_xs[k] = k < lay.nx ? lay.xs[k] : 0; s_ws[k] = k < lay.nx ? lay.ws[k] : 0;
         s_ys[k] = k < lay.ny ? lay.ys[k] : 0; s_hs[k] = k < lay.ny ? lay.hs[k] : 0;
     }
-    depth_key_rev = seg(depth_key_rev, cs); index_rev = seg(index_rev, cs); tiles_touched = seg(tiles_touched, cs);
-    rec = seg(rec, cs); rect = seg(rect, cs); mm = seg(mm, cs);
-    if (threadIdx.x == 0) { s_mm[0] = 0u; s_mm[1] = 0u; }
+    if (threadIdx.x < 2 * G2PC_MAX_CAMERA_BATCH) s_mm[threadIdx.x] = 0u;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // (block size: RA_T, or g_head_threads in the camera pipeline)
+    // ALL of the Gaussian's inputs are requested at once (17 loads in one round): behind the in-front-of-the-camera test the
+    // covariance, opacity and colour were a second round trip, which a wave with one or two neighbours on its SIMD (the rest
+    // of the registers belong to another camera's blend) sits out in full
+    float x = 0.f, y = 0.f, z = 0.f, S9[9], op_in = 0.f, col_r = 0.f, col_g = 0.f, col_b = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) S9[k] = 0.f;
+    if (i < n) {
+        x = means3D[3 * i]; y = means3D[3 * i + 1]; z = means3D[3 * i + 2];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) S9[k] = cov9[9 * i + k];
+        op_in = opacity[i];
+        col_r = colours[3 * i]; col_g = colours[3 * i + 1]; col_b = colours[3 * i + 2];
+    }
+    __syncthreads();
+    const unsigned c_first = MULTI ? 0u : blockIdx.y, c_end = MULTI ? (unsigned)ncam : blockIdx.y + 1u;
+    for (unsigned c = c_first; c < c_end; ++c) {
+    uint32_t* depth_key_rev = seg_at(depth_key_rev0, cs, c); uint32_t* index_rev = seg_at(index_rev0, cs, c);
+    uint32_t* tiles_touched = seg_at(tiles_touched0, cs, c);
+    float4* rec = seg_at(rec0, cs, c); uint32_t* rect = seg_at(rect0, cs, c);
     // Device-resident camera (round 4): read through the constant address space -- the job was written before the launch
     // sequence started and no kernel modifies it -- so the 43 words arrive by SCALAR loads and live in SGPRs.  (Until round 4
     // they were staged through LDS: every matrix element then sat in a VGPR, 50 VGPRs against 36 for the by-value variant.)
     Cam cam_s = cam_val;
     if (CAM_ON_DEVICE) {
         const uint32_t G2PC_CONSTANT* cw =
-            (const uint32_t G2PC_CONSTANT*)((const char*)cam_dev + (size_t)blockIdx.y * sizeof(G2pcCameraJob));
+            (const uint32_t G2PC_CONSTANT*)((const char*)cam_dev + (size_t)c * sizeof(G2pcCameraJob));
         uint32_t* dst = (uint32_t*)&cam_s;
 #pragma unroll
         for (int k = 0; k < (int)(sizeof(Cam) / 4); ++k) dst[k] = cw[k];
     }
     const uint8_t* alive = nullptr;          // child pass of a camera (G2pcCameraJob.alive + G2pcTileLayout.tile_parent)
     if (CAM_ON_DEVICE && lay.tile_parent) {
-        const G2pcCameraJob* jb = (const G2pcCameraJob*)((const char*)cam_dev + (size_t)blockIdx.y * sizeof(G2pcCameraJob));
+        const G2pcCameraJob* jb = (const G2pcCameraJob*)((const char*)cam_dev + (size_t)c * sizeof(G2pcCameraJob));
         alive = (const uint8_t*)(((unsigned long long)jb->alive_hi << 32) | jb->alive_lo);
     }
-    __syncthreads();
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // (block size: RA_T, or g_head_threads in the camera pipeline)
     const Cam& cam = cam_s;
     uint32_t key = 0xFFFFFFFFu, touched = 0, rc = 0;
     if (i < n) {
-    // ALL of the Gaussian's inputs are requested at once (17 loads in one round): behind the in-front-of-the-camera test the
-    // covariance, opacity and colour were a second round trip, which a wave with one or two neighbours on its SIMD (the rest
-    // of the registers belong to another camera's blend) sits out in full
-    const float x = means3D[3 * i], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
-    float S9[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) S9[k] = cov9[9 * i + k];
-    const float op_in = opacity[i];
-    const float col_r = colours[3 * i], col_g = colours[3 * i + 1], col_b = colours[3 * i + 2];
     const float* V = cam.V;
     float pv[4];
     py_view(V, x, y, z, pv);                                         // p_view = [x,1] @ V  (gauss_render.py:163)
@@ -205,15 +216,21 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_py(Cam cam_val, const Cam* 
     tiles_touched[i] = touched;
     rect[i] = rc;
     }
-    if (mm) {
+    if (mm0) {
         uint32_t a = key != 0xFFFFFFFFu ? ~key : 0u, b = key != 0xFFFFFFFFu ? key : 0u;
         a = wave_max_u32(a); b = wave_max_u32(b);
-        if ((threadIdx.x & 63) == 0) { atomicMax(&s_mm[0], a); atomicMax(&s_mm[1], b); }
+        const unsigned cl = MULTI ? c : 0u;
+        if ((threadIdx.x & 63) == 0) { atomicMax(&s_mm[2 * cl], a); atomicMax(&s_mm[2 * cl + 1], b); }
+    }
+    }
+    if (mm0) {
         __syncthreads();
-        if (threadIdx.x == 0) {
+        const unsigned nslots = 2u * (MULTI ? (unsigned)ncam : 1u);
+        if (threadIdx.x < nslots) {
+            const unsigned cl = threadIdx.x >> 1, c = MULTI ? cl : blockIdx.y;
+            BucketHdr* mm = seg_at(mm0, cs, c);
             const uint32_t slot = blockIdx.x % mm_slots;
-            atomicMax(&mm->partial[2 * slot], s_mm[0]);
-            atomicMax(&mm->partial[2 * slot + 1], s_mm[1]);
+            atomicMax(&mm->partial[2 * slot + (threadIdx.x & 1u)], s_mm[threadIdx.x]);
         }
     }
 }
@@ -2119,6 +2136,10 @@ static size_t py_front_ws(long n) {
 }
 static int g_blend_variant = 1;               // 2 sub-blocks per chunk: 2 = two-wave dual-list kernel (k_blend_py_2w, one wave per sub-block), 1 = dual-list kernel (k_blend_py_dl), 0 = packed kernel (k_blend_py_pk)
 static int g_depth_bucket_sort = 1;           // captured camera path: 1 = bucket sort of the depth keys, 0 = radix (g2pc_set_depth_sort)
+#ifndef G2PC_PREPROCESS_MULTI
+#define G2PC_PREPROCESS_MULTI 1
+#endif
+static const int g_preprocess_multi = G2PC_PREPROCESS_MULTI;   // build-time A/B switch: one thread per Gaussian for all cameras of a batch
 #ifndef G2PC_FUSED_EMIT
 #define G2PC_FUSED_EMIT 1
 #endif
@@ -2188,14 +2209,18 @@ static int py_front(const Cam& cam_val, const Cam* cam_dev, const G2pcTileLayout
     const BucketPlan plan = bucket_plan(n);
     if (cam_dev && (jobs_host || hdr))
         hipLaunchKernelGGL(k_fetch_job, dim3((unsigned)bt.n), dim3(64), 0, s, (const uint32_t*)jobs_host, (uint32_t*)jobs_dev, hdr, bt.cs, plan);
-    if (cam_dev)
-        hipLaunchKernelGGL(k_preprocess_py<true>, dim3(cdiv(n, g_head_threads), (unsigned)bt.n), dim3(g_head_threads), 0, s, cam_val, cam_dev, to_layout(layout),
+    if (cam_dev && bt.n > 1 && g_preprocess_multi)
+        hipLaunchKernelGGL((k_preprocess_py<true, true>), dim3(cdiv(n, g_head_threads), 1u), dim3(g_head_threads), 0, s, cam_val, cam_dev, to_layout(layout),
                            means3D, cov9, opacity, n, key_rev, fold ? (uint32_t*)nullptr : idx_rev, touched, colours, fb.rec, fb.rect,
-                           bt.cs, hdr, plan.nminmax);
+                           bt.cs, hdr, plan.nminmax, bt.n);
+    else if (cam_dev)
+        hipLaunchKernelGGL((k_preprocess_py<true, false>), dim3(cdiv(n, g_head_threads), (unsigned)bt.n), dim3(g_head_threads), 0, s, cam_val, cam_dev, to_layout(layout),
+                           means3D, cov9, opacity, n, key_rev, fold ? (uint32_t*)nullptr : idx_rev, touched, colours, fb.rec, fb.rect,
+                           bt.cs, hdr, plan.nminmax, 1);
     else
-        hipLaunchKernelGGL(k_preprocess_py<false>, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, cam_val, cam_dev, to_layout(layout),
+        hipLaunchKernelGGL((k_preprocess_py<false, false>), dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, cam_val, cam_dev, to_layout(layout),
                            means3D, cov9, opacity, n, key_rev, idx_rev, touched, colours, fb.rec, fb.rect, (size_t)0,
-                           (BucketHdr*)nullptr, 1u);
+                           (BucketHdr*)nullptr, 1u, 1);
     for (int k = 0; k < g_extra_launches; ++k) hipLaunchKernelGGL(k_nothing, dim3(1), dim3(64), 0, s, (uint32_t*)nullptr);
     if (emit && !(fold && depth_overflow)) { set_error("raster_front_py", "fused emission without the folded bucket sort"); return G2PC_ERR_ARG; }
     if (emit) { emit->weight = touched; emit->rect = fb.rect; }

@@ -8,13 +8,15 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def build_emu() -> str:
-    if os.environ.get("G2PC_EMU_LIB"):          # a prebuilt variant, e.g. the AddressSanitizer build of tools/emu_asan.sh
+def build_emu(tag: str = "", defs: str = "") -> str:
+    """tag / defs: a second emulator library built with other build-time switches (-D...), e.g. ("_r8", "-DG2PC_BK_EMIT_RMAX=8")."""
+    if os.environ.get("G2PC_EMU_LIB") and not tag:          # a prebuilt variant, e.g. the AddressSanitizer build of tools/emu_asan.sh
         return os.environ["G2PC_EMU_LIB"]
-    out = subprocess.run(["bash", os.path.join(HERE, "hipemu", "build_emu.sh")], capture_output=True, text=True)
+    env = dict(os.environ, EMU_TAG=tag, EMU_DEFS=defs)
+    out = subprocess.run(["bash", os.path.join(HERE, "hipemu", "build_emu.sh")], capture_output=True, text=True, env=env)
     if out.returncode != 0:
         raise RuntimeError("emulator build failed:\n" + out.stdout + out.stderr)
-    return os.path.join(HERE, "hipemu", "libg2pc_emu.so")
+    return os.path.join(HERE, "hipemu", "libg2pc_emu%s.so" % tag)
 
 
 @pytest.fixture(scope="module")

@@ -5,17 +5,20 @@ set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 ROOT="$(cd "$HERE/../.." && pwd)"
 SRC="$ROOT/3dgs-to-pc_amd/g2pc/csrc"
-OUT="$HERE/libg2pc_emu.so"
+# EMU_TAG / EMU_DEFS: a second build with other build-time switches (e.g. EMU_TAG=_r8 EMU_DEFS=-DG2PC_BK_EMIT_RMAX=8), its own objects
+TAG="${EMU_TAG:-}"
+OUT="$HERE/libg2pc_emu$TAG.so"
 OBJS=""
 for f in prims geom alloc sampler raster clean project; do
   [ -f "$SRC/$f.hip" ] || continue
-  if [ ! -f "$HERE/$f.emu.o" ] || [ "$SRC/$f.hip" -nt "$HERE/$f.emu.o" ] || [ "$SRC/g2pc_internal.h" -nt "$HERE/$f.emu.o" ] \
-     || [ "$SRC/g2pc_device.inl" -nt "$HERE/$f.emu.o" ] || [ "$HERE/hip/hip_runtime.h" -nt "$HERE/$f.emu.o" ] \
-     || [ "$ROOT/include/g2pc.h" -nt "$HERE/$f.emu.o" ]; then
+  O="$HERE/$f$TAG.emu.o"
+  if [ ! -f "$O" ] || [ "$SRC/$f.hip" -nt "$O" ] || [ "$SRC/g2pc_internal.h" -nt "$O" ] \
+     || [ "$SRC/g2pc_device.inl" -nt "$O" ] || [ "$SRC/py_project.inl" -nt "$O" ] || [ "$HERE/hip/hip_runtime.h" -nt "$O" ] \
+     || [ "$ROOT/include/g2pc.h" -nt "$O" ]; then
     g++ -O1 -g -std=c++17 -fPIC -ffp-contract=off -x c++ -I"$HERE" -I"$ROOT/include" -Wno-attributes -Wno-unknown-pragmas \
-        -c "$SRC/$f.hip" -o "$HERE/$f.emu.o"
+        ${EMU_DEFS:-} -c "$SRC/$f.hip" -o "$O"
   fi
-  OBJS="$OBJS $HERE/$f.emu.o"
+  OBJS="$OBJS $O"
 done
 g++ -shared -fPIC $OBJS -o "$OUT"
 echo "$OUT"

@@ -135,3 +135,51 @@ def test_deferred_colour_buffers_are_bounded(emu, monkeypatch):
     k1, c1, _, R = _render_all(True, monkeypatch, ncam=7)
     assert np.array_equal(k0, k1) and np.array_equal(c0, c1)
     assert len(R.ctx.cam_tilebufs) <= 2 and not R.deferred
+
+
+@pytest.mark.parametrize("variant", ["default", "unfused", "regs8"])
+def test_crowded_depth_bucket_within_its_room(emu, monkeypatch, variant):
+    """700 of 2 500 Gaussians on a sheet facing the camera: one depth bucket holds 513 .. 1 024 keys -- within its room, so the
+    captured graph keeps the camera, but beyond what most buckets hold: the fused sort-and-emit kernel takes its largest
+    register path (16 items per lane) or, in the build with half the registers (-DG2PC_BK_EMIT_RMAX=8), its LDS network.
+    All builds (and the round-4 chain: scan + k_duplicate + k_resolve_count, -DG2PC_FUSED_EMIT=0) must leave the state of the
+    two-call path bit for bit, without a re-render."""
+    import gauss_render
+    import camera_handler
+    from emu_util import build_emu
+    from gauss_handler import Gaussians
+    from g2pc import _native as nv
+    defs = {"default": ("", ""), "unfused": ("_unfused", "-DG2PC_FUSED_EMIT=0 -DG2PC_PREPROCESS_MULTI=0"),
+            "regs8": ("_r8", "-DG2PC_BK_EMIT_RMAX=8")}[variant]
+    saved = (nv._LIB, nv._EMULATED)
+    if defs[0]:
+        nv._inject_for_tests(build_emu(*defs))
+    try:
+        gauss_render.clear_context_pool()
+        monkeypatch.setattr(gauss_render, "BLEND_SUBBLOCKS", 2)
+        monkeypatch.setattr(gauss_render, "PIPELINE_STREAMS", 2)
+        sc = make_scene(2500, 81, scale_lo=0.01, scale_hi=0.05)
+        xyz = sc.xyz.clone()
+        xyz[:700, 2] = 0.0                                       # the sheet z = 0: one depth for 700 Gaussians seen head on
+        transforms, intr = make_cameras(3, width=128, height=72, focal=112.0)
+        eye = torch.eye(4)
+        eye[2, 3] = 3.5
+        cams = [eye.clone(), eye.clone(), torch.tensor(transforms[sorted(transforms)[1]]), eye.clone()]
+        cams[1][0, 3] = 0.2
+        cams[3][1, 3] = -0.1
+        G = Gaussians(xyz, sc.scales, sc.rots, sc.colours, sc.opacities)
+        res = []
+        for pipelined in (False, True):
+            monkeypatch.setattr(gauss_render, "PIPELINE_IN_EMULATOR", pipelined)
+            R = gauss_render.get_renderer("python", G.xyz, G.opacities.unsqueeze(1), G.colours, G.covariances,
+                                          visible_gaussian_threshold=0.05)
+            for c2w in cams:
+                R(camera_handler.get_camera("python", c2w, intr[sorted(intr)[0]]), return_image=not pipelined)
+            cols = R.get_gaussian_colours().numpy().copy()
+            res.append((R.best_key.numpy().copy(), cols, R.rerendered))
+            R.close()
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+        assert res[1][2] == 0                                    # no bucket beyond its room: every camera stayed in its graph
+    finally:
+        gauss_render.clear_context_pool()
+        nv._LIB, nv._EMULATED = saved
