@@ -511,7 +511,10 @@ BucketPlan bucket_plan(long n) {
     BucketPlan p;
     p.nbk = BK_MIN;
     while (p.nbk < (uint32_t)BK_MAX && (long)p.nbk * BK_AVG < n) p.nbk <<= 1;
-    long kpb = 8192;                                // keys per chunk: at most BK_MAXCHUNKS chunks (the table is nbk x nchunks)
+#ifndef G2PC_BK_KPB
+#define G2PC_BK_KPB 8192
+#endif
+    long kpb = G2PC_BK_KPB;                         // keys per chunk: at most BK_MAXCHUNKS chunks (the table is nbk x nchunks)
     while (kpb * BK_MAXCHUNKS < n) kpb += 1024;
     // room of one bucket in the in-LDS sort: 4x the mean while that fits the small footprint (8 KB per wave, which
     // squeezes in beside the blend waves of the other cameras), else the large one
@@ -654,39 +657,40 @@ __global__ __launch_bounds__(BK_T) void k_bk_colscan(BucketHdr* __restrict__ h, 
 // emit (fused emission): the weight sums are scanned as well (wstart), and the block settles what k_resolve_count settles on the
 // unfused path: l_eff = the instance count if it fits the capacity and no bucket overflowed, else 0 (camera skipped as a
 // whole); the pinned counts go to the host through their device mapping.
-__global__ __launch_bounds__(1024) void k_bk_scan(BucketHdr* __restrict__ h, size_t cs, bool emit, uint32_t capacity,
-                                                 uint32_t* __restrict__ l_eff, uint32_t* __restrict__ count_host) {
-    __shared__ uint32_t wsum[16], wsum2[16], s_worst;
+// ONE block of 256 threads with a handful of registers: beside the blends of the other streams (5 waves x 96 VGPRs allocated
+// on every SIMD) a 1 024-thread block needs four free wave slots on all four SIMDs of ONE CU at the same moment -- the first
+// fused version (68 VGPRs) waited 40 - 120 us for that, every camera batch, in the middle of the head chain.
+constexpr int BKS_T = 256;
+__global__ __launch_bounds__(BKS_T) void k_bk_scan(BucketHdr* __restrict__ h, size_t cs, bool emit, uint32_t capacity,
+                                                  uint32_t* __restrict__ l_eff, uint32_t* __restrict__ count_host) {
+    __shared__ uint32_t wsum[BKS_T / 64], wsum2[BKS_T / 64], s_worst;
     h = seg(h, cs); l_eff = seg(l_eff, cs);
     const unsigned t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const uint32_t nbk = h->nbk, per = nbk >> 10;                     // nbk is a multiple of 1024: `per` buckets per thread
-    uint32_t c[BK_MAX / 1024], wv[BK_MAX / 1024], mine = 0, worst = 0, mine_w = 0;
+    const uint32_t nbk = h->nbk, per = nbk / BKS_T;                   // nbk is a multiple of 1024: `per` consecutive buckets per thread
+    uint32_t mine = 0, worst = 0, mine_w = 0;
     if (t == 0) s_worst = 0u;
-#pragma unroll
-    for (uint32_t k = 0; k < (uint32_t)(BK_MAX / 1024); ++k) {
-        c[k] = k < per ? h->count[t * per + k] : 0u;
-        wv[k] = (emit && k < per) ? h->wstart[t * per + k] : 0u;
-        mine += c[k];
-        mine_w += wv[k];
-        worst = umax_(worst, c[k]);
+    for (uint32_t k = 0; k < per; ++k) {
+        const uint32_t c = h->count[t * per + k];
+        mine += c;
+        worst = umax_(worst, c);
+        if (emit) mine_w += h->wstart[t * per + k];
     }
     const uint32_t incl = wave_incl_scan_u32(mine);
     const uint32_t incl_w = emit ? wave_incl_scan_u32(mine_w) : 0u;
     if (lane == 63) { wsum[w] = incl; wsum2[w] = incl_w; }
     __syncthreads();
     uint32_t woff = 0, total = 0, woff_w = 0, total_w = 0;
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < BKS_T / 64; ++k) {
         const uint32_t v = wsum[k], v2 = wsum2[k];
         if (k < (int)w) { woff += v; woff_w += v2; }
         total += v; total_w += v2;
     }
     uint32_t run = woff + incl - mine, run_w = woff_w + incl_w - mine_w;
-#pragma unroll
-    for (uint32_t k = 0; k < (uint32_t)(BK_MAX / 1024); ++k)
-        if (k < per) {
-            h->start[t * per + k] = run; run += c[k];
-            if (emit) { h->wstart[t * per + k] = run_w; run_w += wv[k]; }
-        }
+    for (uint32_t k = 0; k < per; ++k) {
+        const uint32_t c = h->count[t * per + k];
+        h->start[t * per + k] = run; run += c;
+        if (emit) { const uint32_t wv = h->wstart[t * per + k]; h->wstart[t * per + k] = run_w; run_w += wv; }
+    }
     if (worst > h->cap) { atomicMax(&h->overflow, worst); atomicMax(&s_worst, worst); }
     if (t == 0) { h->start[nbk] = total; h->start[nbk + 1] = total + h->count[nbk]; }   // the tail bucket
     if (emit) {
@@ -978,7 +982,7 @@ int bucket_sort_u32(const uint32_t* keys, const uint32_t* vals, uint32_t* vals_o
     }
     hipLaunchKernelGGL(k_bk_colscan, dim3(cdiv(plan.nbk + 1, BK_T / 64), by), dim3(BK_T), 0, s, h, table, plan, b.cs,
                        emit ? (const uint32_t*)wtable : (const uint32_t*)nullptr);
-    hipLaunchKernelGGL(k_bk_scan, dim3(1, by), dim3(1024), 0, s, h, b.cs, emit != nullptr, emit ? emit->capacity : 0u,
+    hipLaunchKernelGGL(k_bk_scan, dim3(1, by), dim3(BKS_T), 0, s, h, b.cs, emit != nullptr, emit ? emit->capacity : 0u,
                        emit ? emit->l_eff : (uint32_t*)nullptr, emit ? emit->count_host : (uint32_t*)nullptr);
     hipLaunchKernelGGL(k_bk_scatter, dim3(plan.nchunks, by), dim3(BK_T), 0, s, keys, n, (const BucketHdr*)h, (const uint32_t*)table, items, plan, b.cs);
     if (emit) {

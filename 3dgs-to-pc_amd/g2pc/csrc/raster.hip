@@ -724,8 +724,16 @@ __global__ __launch_bounds__(BL_T) void k_blend_py_pk(Layout lay, const int32_t*
 // -- five FMAs per pixel instead of seven operations, and the opacity multiply rides in K.  Rounding differs from the
 // reference's order of operations by ~eps * (|exponent| + |A| 50): <= 2e-5 relative in alpha for the sharpest Gaussians
 // the 0.3-pixel dilation admits, ~3e-6 typically (the reference's own dx = pixel - mean carries eps * |mean| already).
+#ifndef G2PC_BLEND_VGPRS
+#define G2PC_BLEND_VGPRS 0
+#endif
+#if G2PC_BLEND_VGPRS
+#define G2PC_BLEND_ATTR __attribute__((amdgpu_num_vgpr(G2PC_BLEND_VGPRS)))
+#else
+#define G2PC_BLEND_ATTR
+#endif
 template <int U>
-__global__ __launch_bounds__(BL_T) void k_blend_py_dl(Layout lay, const int32_t* __restrict__ chunk_tile,
+__global__ __launch_bounds__(BL_T) G2PC_BLEND_ATTR void k_blend_py_dl(Layout lay, const int32_t* __restrict__ chunk_tile,
                                                      const int32_t* __restrict__ chunk_pix0,
                                                      const uint2* __restrict__ tile_range,
                                                      const uint32_t* __restrict__ inst_g, uint32_t gmask,
@@ -1898,14 +1906,16 @@ __device__ __forceinline__ bool rect_in_node(const float r[4], int x0, int x1, i
 // (Cost beside the blends of the other streams: 16 us per launch against 6 for the count check it replaces -- not its loads,
 // which go out in one round, but its 94 VGPRs: five blend waves leave 32 of a SIMD's 512 free, so its waves start when a
 // blend wave retires.  The job time does not see it, profiles/r03zo_*.)
-__global__ __launch_bounds__(RA_T) void k_tile_gate(Layout lay, Cam cam_val, const Cam* __restrict__ cam_dev,
+constexpr int GATE_T = 64;    // one wave per block: its 94 VGPRs find a slot wherever ONE blend wave retires (a 256-thread block
+                              // waits for a free slot on all four SIMDs of one CU at once: 44 - 83 us beside the blends)
+__global__ __launch_bounds__(GATE_T) void k_tile_gate(Layout lay, Cam cam_val, const Cam* __restrict__ cam_dev,
                                                    const float* __restrict__ means3D, const float* __restrict__ cov9,
                                                    const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ inst_g,
                                                    uint32_t gmask, int T, uint32_t limit, uint2* __restrict__ tile_range,
                                                    uint32_t* __restrict__ tile_state, uint32_t* __restrict__ flag,
                                                    uint32_t* __restrict__ count_host, size_t cs) {
     tile_start = seg(tile_start, cs); inst_g = seg(inst_g, cs); tile_range = seg(tile_range, cs); tile_state = seg(tile_state, cs);
-    const int t = blockIdx.x * RA_T + threadIdx.x;
+    const int t = blockIdx.x * GATE_T + threadIdx.x;
     if (t >= T) return;
     // the usual answer with ONE round of independent loads: the first leaf of an ancestor's block lies inside that ancestor,
     // so its having members settles the level (bit k of `vacant`: it has none)
@@ -2273,7 +2283,7 @@ static int py_back(const G2pcTileLayout* layout, long n, long L, const uint32_t*
         Layout glay = lay;
         // no scene / no tree tables: leaves under empty nodes are not looked for (depth 0; the kernel's loads stay unconditional)
         if (!sc.means3D || !lay.tile_stick) { glay.depth = 0; glay.tile_stick = lay.tile_seq; }
-        hipLaunchKernelGGL(k_tile_gate, dim3(cdiv(T, RA_T), (unsigned)bt.n), dim3(RA_T), 0, s, glay, sc.cam_val, sc.cam_dev, sc.means3D,
+        hipLaunchKernelGGL(k_tile_gate, dim3(cdiv(T, GATE_T), (unsigned)bt.n), dim3(GATE_T), 0, s, glay, sc.cam_val, sc.cam_dev, sc.means3D,
                            sc.cov9, tile_start, blend_list, gmask, T, max_per_tile, A.tile_range, A.tile_state, overflow_flag,
                            sc.count_host, bt.cs);
     }
