@@ -17,7 +17,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libg2pc.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _LIB: Optional[C.CDLL] = None
 _EMULATED = False
@@ -31,8 +31,6 @@ _PROTOS = {
     "g2pc_scan_workspace": (_sz, [_i64]),
     "g2pc_scan_exclusive_u32": (C.c_int, [_vp, _vp, _i64, _vp, _sz, _vp]),
     "g2pc_sort_workspace": (_sz, [_i64]),
-    "g2pc_debug_set_head_threads": (C.c_int, [C.c_int]),
-    "g2pc_set_sort_tuning": (C.c_int, [C.c_int, _i64]),
     "g2pc_bucket_sort_workspace": (_sz, [_i64]),
     "g2pc_bucket_sort_u32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
     "g2pc_sort_pairs_u32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, _vp, _sz, _vp]),
@@ -72,6 +70,17 @@ _PROTOS["g2pc_mahalanobis"] = (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp])
 _PROTOS["g2pc_sample_mvn"] = (C.c_int, [_vp, _vp, _i64, _i32, _u64, _u64, _i32, _vp, _vp])
 # rasteriser prototypes are appended by g2pc/_native_raster.py style additions below
 _RASTER_PROTOS = {}
+# Entry points of -DG2PC_EXPERIMENTS builds only (csrc/experiments/knobs.inl: tuning and diagnostic knobs of rounds 2-4).  The
+# product library exports none of them; tools/ and bench.py's tuning flags reach them through experiments().
+_EXPERIMENT_PROTOS = {
+    "g2pc_debug_set_head_threads": (C.c_int, [C.c_int]),
+    "g2pc_set_sort_tuning": (C.c_int, [C.c_int, _i64]),
+    "g2pc_raster_debug_chunk_work": (C.c_int, [C.c_void_p]),
+    "g2pc_debug_set_extra_launches": (C.c_int, [C.c_int]),
+    "g2pc_set_depth_sort": (C.c_int, [C.c_int]),
+    "g2pc_set_blend_variant": (C.c_int, [C.c_int]),
+    "g2pc_debug_set_walk_cap": (C.c_int, [C.c_int]),
+}
 
 
 class G2pcError(RuntimeError):
@@ -103,6 +112,30 @@ def lib() -> C.CDLL:
         if v != ABI_VERSION:
             raise G2pcError("libg2pc.so ABI %d != binding ABI %d" % (v, ABI_VERSION))
     return _LIB
+
+
+def experiments() -> C.CDLL:
+    """The loaded library IF it is an experiments build (libg2pc_exp.so through LIB_PATH, or the test suite's "_exp" emulator
+    build): binds the knobs of csrc/experiments/knobs.inl.  Raises for the product library, which has none."""
+    L = lib()
+    for name, (res, args) in _EXPERIMENT_PROTOS.items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError:
+            raise G2pcError("%s is not in this library: tuning / diagnostic knobs exist in -DG2PC_EXPERIMENTS builds only "
+                            "(tools/experiments/build_variant.sh exp -DG2PC_EXPERIMENTS, then run through "
+                            "tools/experiments/ab_lib.py 3dgs-to-pc_amd/g2pc/libg2pc_exp.so)" % name)
+        fn.restype = res
+        fn.argtypes = args
+    return L
+
+
+def has_experiments() -> bool:
+    try:
+        experiments()
+        return True
+    except G2pcError:
+        return False
 
 
 def _inject_for_tests(path: str):

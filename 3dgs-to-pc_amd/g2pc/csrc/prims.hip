@@ -394,11 +394,17 @@ __global__ __launch_bounds__(RS_T) void k_radix_scatter(const uint32_t* __restri
     }
 }
 
-// pass geometry: digits of up to 11 bits (2048 LDS bins) when more than 8 bits have to be sorted, 4 keys per
-// thread for inputs that would otherwise leave CUs idle (<= 2M keys), else 8
-static int g_radix_wide_bits = 8;          // 8 or 11: digit width used when more than 8 bits are sorted (tuning knob); 10: ONE
+// pass geometry: digits of up to 8 bits, 4 keys per thread for inputs that would otherwise leave CUs idle (<= 2M keys), else 8.
+// (Wider digits -- 11 bits, or ONE 10-bit pass for the tile sort of up to 1 024 leaves -- were measured in rounds 2-4 and lost:
+// they exist in -DG2PC_EXPERIMENTS builds only, behind g2pc_set_sort_tuning.)
+#ifdef G2PC_EXPERIMENTS
+static int g_radix_wide_bits = 8;          // 8 or 11: digit width used when more than 8 bits are sorted; 10: ONE
                                            // 10-bit pass for 9 - 10 bits (the tile sort of up to 1 024 leaves), else as 8
 static long g_radix_small_n = 2L << 20;    // inputs up to this size use 4 keys per thread
+#else
+constexpr int g_radix_wide_bits = 8;
+constexpr long g_radix_small_n = 2L << 20;
+#endif
 static inline int radix_items(long n) { return n <= g_radix_small_n ? 4 : 8; }
 static inline int radix_maxbits(int total_bits) {
     if (total_bits <= 8) return 8;
@@ -468,13 +474,16 @@ int sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* k
         if (maxbits == 8) {
             if (items == 4) radix_pass<8, 4>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc, n_dev, b);
             else radix_pass<8, 8>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc, n_dev, b);
-        } else if (maxbits == 10) {
+        }
+#ifdef G2PC_EXPERIMENTS
+        else if (maxbits == 10) {
             if (items == 4) radix_pass<10, 4>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc, n_dev, b);
             else radix_pass<10, 8>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc, n_dev, b);
         } else {
             if (items == 4) radix_pass<11, 4>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc, n_dev, b);
             else radix_pass<11, 8>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc, n_dev, b);
         }
+#endif
         if (rc) return rc;
         kin = kout; vin = vout;
         bit += nbits;
@@ -1014,12 +1023,16 @@ extern "C" {
 const char* g2pc_last_error(void) { return g2pc::g_err.c_str(); }
 int g2pc_abi_version(void) { return G2PC_ABI_VERSION; }
 
+#ifdef G2PC_EXPERIMENTS
+/* EXPERIMENTS ONLY: digit width (8 or 11 bits) for sorts of more than 8 bits -- 10: one 10-bit pass for fields of 9 - 10 bits --;
+ * inputs up to small_input_keys use 4 keys per thread */
 int g2pc_set_sort_tuning(int wide_digit_bits, int64_t small_input_keys) {
     if (wide_digit_bits != 8 && wide_digit_bits != 10 && wide_digit_bits != 11) return G2PC_ERR_ARG;
     g2pc::g_radix_wide_bits = wide_digit_bits;
     g2pc::g_radix_small_n = small_input_keys;
     return G2PC_OK;
 }
+#endif
 #define G2PC_HIP_CALL(expr, where)                                                  \
     do {                                                                            \
         hipError_t e_ = (expr);                                                     \

@@ -87,11 +87,7 @@ nv._RASTER_PROTOS.update({
     "g2pc_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
     "g2pc_graph_destroy": (C.c_int, [C.c_void_p]),
     "g2pc_raster_rebase_keys": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
-    "g2pc_raster_debug_chunk_work": (C.c_int, [C.c_void_p]),
     "g2pc_raster_resolve_colours_py": (C.c_int, [C.POINTER(_Layout), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "g2pc_set_depth_sort": (C.c_int, [C.c_int]),
-    "g2pc_set_blend_variant": (C.c_int, [C.c_int]),
-    "g2pc_debug_set_walk_cap": (C.c_int, [C.c_int]),
     "g2pc_raster_key_owner": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "g2pc_raster_keep_winner_colours": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "g2pc_raster_contributions": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

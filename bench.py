@@ -501,18 +501,22 @@ def main():
     import gauss_render
     if a.t_floor is not None:
         gauss_render.DEFAULT_T_FLOOR = a.t_floor
-    if a.sort_bits:
-        nv.lib().g2pc_set_sort_tuning(a.sort_bits, a.sort_small)
+    # tuning / diagnostic knobs: entry points of -DG2PC_EXPERIMENTS builds only (run through tools/experiments/ab_lib.py with
+    # 3dgs-to-pc_amd/g2pc/libg2pc_exp.so); the product library has no process-global state and nv.experiments() raises for it
+    if a.sort_bits or a.sort_small != (2 << 20):
+        nv.experiments().g2pc_set_sort_tuning(a.sort_bits or 8, a.sort_small)
     if a.head_threads:
-        nv.lib().g2pc_debug_set_head_threads(a.head_threads)
+        nv.experiments().g2pc_debug_set_head_threads(a.head_threads)
     if a.extra_launches:
-        nv.lib().g2pc_debug_set_extra_launches(a.extra_launches)
+        nv.experiments().g2pc_debug_set_extra_launches(a.extra_launches)
     if a.blend_variant is not None:
-        nv.lib().g2pc_set_blend_variant(a.blend_variant)
+        nv.experiments().g2pc_set_blend_variant(a.blend_variant)
     if a.walk_cap:
-        nv.lib().g2pc_debug_set_walk_cap(a.walk_cap)
+        nv.experiments().g2pc_debug_set_walk_cap(a.walk_cap)
     if a.depth_sort:
-        nv.lib().g2pc_set_depth_sort(1 if a.depth_sort == "bucket" else 0)
+        nv.experiments().g2pc_set_depth_sort(1 if a.depth_sort == "bucket" else 0)
+    if a.blend_subblocks and a.blend_subblocks != 2:
+        nv.experiments()                           # (1 or 4 sub-blocks per wave: the scalar blend of experiments builds)
     if a.blend_subblocks:
         gauss_render.BLEND_SUBBLOCKS = a.blend_subblocks
     if a.streams:

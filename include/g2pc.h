@@ -21,8 +21,12 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: the entry points below are ALL it exports */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
-#define G2PC_ABI_VERSION 5
+#define G2PC_ABI_VERSION 6
 #define G2PC_TILE_PARENTS 4       /* entries per tile of G2pcTileLayout.tile_parent */
 
 #define G2PC_OK 0
@@ -45,9 +49,6 @@ size_t g2pc_scan_workspace(int64_t n);
 /* out[0..n] = exclusive prefix sums of in[0..n-1]; out[n] = total.  in may alias out. */
 int g2pc_scan_exclusive_u32(const uint32_t* in, uint32_t* out, int64_t n, void* ws, size_t ws_bytes, void* stream);
 size_t g2pc_sort_workspace(int64_t n);
-/* tuning: digit width (8 or 11 bits) for sorts of more than 8 bits -- 10: one 10-bit pass for fields of 9 - 10 bits, passes of
- * up to 8 bits otherwise --; inputs up to small_input_keys use 4 keys/thread */
-int g2pc_set_sort_tuning(int wide_digit_bits, int64_t small_input_keys);
 /* --- hipGraph capture of a sequence of g2pc_* calls --------------------------------------------------------------------
  * Every g2pc_* entry point only queues work on `stream` (no allocation, no synchronisation), so whatever is called
  * between g2pc_graph_capture_begin(stream) and g2pc_graph_capture_end(stream, &graph) -- on that stream, with fixed
@@ -285,7 +286,7 @@ typedef struct G2pcTileLayout {      /* HOST struct of DEVICE pointers: tiles = 
     int32_t num_chunks;              /* blend work list: one wave64 per chunk = chunk_subblocks consecutive 8x8 pixel */
     const int32_t* chunk_tile;       /* [num_chunks]    sub-blocks of a tile (sub-blocks row-major inside the tile)   */
     const int32_t* chunk_pix0;       /* [num_chunks] first sub-block of the chunk; chunk_subblocks = 2: a | b << 16, two adjacent sub-blocks (b = 0xFFFF: none) */
-    int32_t chunk_subblocks;         /* 1, 2 or 4 (pixels per lane) */
+    int32_t chunk_subblocks;         /* 2 (sub-blocks per wave; 1 and 4 exist in -DG2PC_EXPERIMENTS builds only) */
     int32_t seq_bits;                /* ABI 3: width of the tile-sequence field of the packed visibility keys, 12 .. 14 (0 = 12):
                                       * key = contribution bits << 32 | ~(camera_slot << (12 + seq_bits) | tile_seq << 12 | pixel).
                                       * ny*nx <= 1 << seq_bits tiles, camera slots 1 .. (1 << (20 - seq_bits)) - 1 (255 / 127 / 63).
@@ -427,25 +428,15 @@ int g2pc_raster_camera_update_py(const G2pcTileLayout* layout, int64_t n, uint32
  * cameras share `layout`.  Replaces the per-camera update and its camera-order chaining across streams. */
 int g2pc_raster_resolve_colours_py(const G2pcTileLayout* layout, int64_t n, const unsigned long long* best_key,
                                    const unsigned long long* tilebufs, float* colours_out, void* stream);
-/* depth order inside g2pc_raster_camera_py: 1 = range-normalised bucket sort + in-LDS bitonic sort (default; five
- * launches), 0 = four-pass radix sort.  Same order bit for bit.  count_host holds FOUR words per camera: [0] = instance count,
- * [1] != 0 = the bucket sort overflowed (depths piled up in 1/1024 of their range), the camera was skipped as a whole
- * and has to be rendered again through the two-call path (which always sorts by radix). */
-int g2pc_set_depth_sort(int bucket);
-/* tuning aid: blend kernel of the python-semantics rasteriser for 2 sub-blocks per wave: 1 = dual-list (default), 0 = packed */
-int g2pc_set_blend_variant(int variant);
+/* Depth order inside g2pc_raster_cameras_py: a range-normalised bucket sort whose last kernel also emits the (tile, Gaussian)
+ * instances (up to ~2 M Gaussians; a four-pass radix sort beyond).  count_host holds FOUR words per camera: [0] = instance
+ * count, [1] != 0 = the bucket sort met a pile-up of equal depths (more than 1 024 keys in 1 / 4 096 of the depth range): the
+ * camera was skipped as a whole and has to be rendered again through the two-call path (which always sorts by radix).
+ * ABI 6: the library has no process-global state.  The tuning and diagnostic entry points of ABI <= 5 (g2pc_set_sort_tuning,
+ * g2pc_set_depth_sort, g2pc_set_blend_variant, g2pc_debug_set_walk_cap / _head_threads / _extra_launches,
+ * g2pc_raster_debug_chunk_work) and the blend kernels nothing selects exist only in -DG2PC_EXPERIMENTS builds
+ * (csrc/experiments/, tools/experiments/build_variant.sh); G2pcTileLayout.chunk_subblocks must be 2. */
 int g2pc_raster_rebase_keys(unsigned long long* best_key, int64_t n, void* stream);
-/* diagnostics: when non-NULL, the PY blend records per chunk, in u32[8*num_chunks] (batch 1): [0] tile list length, [1] entries
- * walked; the dual-list kernel also [2] start and [3] duration on the 100 MHz wall clock, [4] HW_ID, [5] XCC_ID of its wave, [6] (Gaussian, sub-block) visits after the cull */
-int g2pc_raster_debug_chunk_work(uint32_t* buf);
-/* diagnostics: the dual-list PY blend stops every tile walk after `batches` 64-entry batches (0 = off).  The results are
- * WRONG; the knob exists to measure what the long walks cost a pipelined job (bench.py --walk-cap). */
-int g2pc_debug_set_walk_cap(int batches);
-/* tuning: threads per block (64, 128 or 256 = default) of the python-semantics head kernels that need no block-level
- * cooperation (preprocess, duplicate, tile ranges); set before the first camera of a process (captured graphs keep theirs) */
-int g2pc_debug_set_head_threads(int threads);
-/* diagnostic: n empty kernels after the preprocess of every python-semantics camera batch (what a kernel boundary costs a job) */
-int g2pc_debug_set_extra_launches(int n);
 /* --- native-rasteriser ("cuda") semantics: _C.rasterize_gaussians (rasterize_points.h:18-41) ----------------------
  * Deterministic spec of SURVEY.md §8(a.5): 16x16 tiles, near cull z_view <= 0.2, radius ceil(3 sqrt(lambda_max)),
  * stable (tile, depth) order, alpha rules (power > 0 skip, min(0.99, .), alpha < 1/255 skip, T(1-alpha) < 1e-4 stop),
@@ -509,6 +500,9 @@ int g2pc_mark_visible(const float* means3D, int64_t n, const float* viewmatrix, 
 /* gaussian_max_contribution f32[n] out of the packed keys (gauss_render.py:243-264 getters read this) */
 int g2pc_raster_contributions(const unsigned long long* best_key, int64_t n, float* out, void* stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

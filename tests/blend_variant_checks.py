@@ -1,4 +1,4 @@
-"""The blend kernel variants of the python-semantics renderer (g2pc_set_blend_variant) must agree: 1 = dual-list single-wave
+"""EXPERIMENTS build only (csrc/experiments/): the blend kernel variants of the python-semantics renderer (g2pc_set_blend_variant) must agree: 1 = dual-list single-wave
 kernel (default), 2 / 3 = two-wave form (one wave per 8x8 sub-block, 128-entry batches; unroll 4 / 2), 4 / 5 = scalar-gather form
 (A, B, C and colour of a list entry through scalar loads of its record, unroll 4 / 2).  Same loads, tests and
 floating-point operations per (pixel, Gaussian) visit, so every contribution at or above the transmittance floor, every
@@ -14,13 +14,13 @@ def run_variants(device, golden_dir, variants=(1, 2, 3, 4, 5, 6), t_floor=1e-6, 
     out = {}
     try:
         for v in variants:
-            nv.lib().g2pc_set_blend_variant(v)
+            nv.experiments().g2pc_set_blend_variant(v)
             gauss_render.clear_context_pool()
             g, R, images, contribs = run_render_case(golden_dir, device=device, t_floor=t_floor)
             assert_render_matches(g, R, images, contribs, max_colour_flips=1)      # (expanded exponent: one swapped arg-max tie in 6 000)
             out[v] = (images, contribs, R.get_gaussian_colours().cpu().numpy(), R.best_key.cpu().numpy().copy())
     finally:
-        nv.lib().g2pc_set_blend_variant(1)
+        nv.experiments().g2pc_set_blend_variant(1)
         gauss_render.clear_context_pool()
     return out
 

@@ -26,3 +26,18 @@ def emu():
     nv._inject_for_tests(build_emu())
     yield nv
     nv._LIB, nv._EMULATED = saved
+
+
+@pytest.fixture()
+def emu_exp():
+    """The EXPERIMENTS build of the emulator (-DG2PC_EXPERIMENTS: csrc/experiments/ -- blend kernel variants, 1 / 4 sub-blocks per
+    wave, wide radix digits, the process-global knobs) for one test; the library routed before it is restored afterwards."""
+    from g2pc import _native as nv
+    import gauss_render
+    saved = (nv._LIB, nv._EMULATED)
+    gauss_render.clear_context_pool()
+    nv._inject_for_tests(build_emu("_exp", "-DG2PC_EXPERIMENTS"))
+    nv.experiments()
+    yield nv
+    gauss_render.clear_context_pool()
+    nv._LIB, nv._EMULATED = saved

@@ -9,11 +9,11 @@ SRC="$ROOT/3dgs-to-pc_amd/g2pc/csrc"
 TAG="${EMU_TAG:-}"
 OUT="$HERE/libg2pc_emu$TAG.so"
 OBJS=""
-for f in prims geom alloc sampler raster clean project; do
+for f in prims geom alloc sampler raster raster_cu clean project; do
   [ -f "$SRC/$f.hip" ] || continue
   O="$HERE/$f$TAG.emu.o"
   if [ ! -f "$O" ] || [ "$SRC/$f.hip" -nt "$O" ] || [ "$SRC/g2pc_internal.h" -nt "$O" ] \
-     || [ "$SRC/g2pc_device.inl" -nt "$O" ] || [ "$SRC/py_project.inl" -nt "$O" ] || [ "$HERE/hip/hip_runtime.h" -nt "$O" ] \
+     || [ "$SRC/g2pc_device.inl" -nt "$O" ] || [ "$SRC/py_project.inl" -nt "$O" ] || [ "$SRC/raster_common.h" -nt "$O" ] || [ -n "$(find "$SRC/experiments" -newer "$O" 2>/dev/null)" ] || [ "$HERE/hip/hip_runtime.h" -nt "$O" ] \
      || [ "$ROOT/include/g2pc.h" -nt "$O" ]; then
     g++ -O1 -g -std=c++17 -fPIC -ffp-contract=off -x c++ -I"$HERE" -I"$ROOT/include" -Wno-attributes -Wno-unknown-pragmas \
         ${EMU_DEFS:-} -c "$SRC/$f.hip" -o "$O"

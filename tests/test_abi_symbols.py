@@ -26,7 +26,21 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     lib.g2pc_abi_version.restype = ctypes.c_int
     from g2pc import _native as nv
-    assert lib.g2pc_abi_version() == nv.ABI_VERSION == 5
+    assert lib.g2pc_abi_version() == nv.ABI_VERSION == 6
+
+
+def test_library_exports_its_abi_and_nothing_else():
+    """ABI 6: no process-global tuning / diagnostic state in the product library ("thread-safe, no globals") -- the
+    g2pc_set_* / g2pc_debug_* entry points of earlier rounds live in -DG2PC_EXPERIMENTS builds only --, and (built with
+    -fvisibility=hidden) it exports the entry points of include/g2pc.h and nothing else."""
+    import subprocess
+    import __graft_entry__ as ge
+    ge.build()
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "3dgs-to-pc_amd", "g2pc", "libg2pc.so")],
+                         capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if " T " in ln})
+    assert not [s for s in exported if "set_" in s or "debug_" in s], exported
+    assert set(exported) == set(_declared()), (sorted(set(exported) - set(_declared())), sorted(set(_declared()) - set(exported)))
 
 
 def test_no_cpu_fallback():

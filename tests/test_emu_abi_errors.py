@@ -42,7 +42,7 @@ def test_raster_argument_checks(emu):
     import gauss_render
     from g2pc import _native as nv
     L = nv.lib()
-    lay_host = gauss_render.tiles.python_quadtree_layout(64, 48, 60, 1)
+    lay_host = gauss_render.tiles.python_quadtree_layout(64, 48, 60, 2)
     lay = gauss_render._DeviceLayout(lay_host, torch.device("cpu"))
     cam = gauss_render._Camera()
     n = 16
@@ -56,6 +56,10 @@ def test_raster_argument_checks(emu):
     assert L.g2pc_raster_back_py(*args(0)) == -1 and b"camera_slot" in L.g2pc_last_error()       # slots are 1..255
     assert L.g2pc_raster_back_py(*args(256)) == -1
     assert L.g2pc_raster_back_py(*args(1)) == 0                                                    # empty camera: fine
+    # the product library blends layouts of 2 sub-blocks per wave only (ABI 6; 1 / 4 exist in experiments builds)
+    lay.c.chunk_subblocks = 4
+    assert L.g2pc_raster_back_py(*args(1)) == -4 and b"chunk_subblocks must be 2" in L.g2pc_last_error()
+    lay.c.chunk_subblocks = 2
     # capture needs a real (non-default) stream
     assert L.g2pc_graph_capture_begin(None) == -1
     assert L.g2pc_graph_launch(None, None) == -1

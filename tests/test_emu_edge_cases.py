@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from emu_util import emu  # noqa: F401
+from emu_util import emu, emu_exp  # noqa: F401
 import ref_gauss as RG
 from np_philox import keyed_normals
 from g2pc import ops
@@ -94,25 +94,25 @@ def test_nan_covariance_rows_follow_the_reference(emu):
     assert keep.tolist() == ref_keep.tolist()               # eigvals(NaN) <= eps is False -> kept, as in the reference
 
 
-def test_wide_radix_digits_and_zero_budget(emu):
+def test_wide_radix_digits_and_zero_budget(emu_exp):
     from g2pc import _native as nv
     rng = np.random.default_rng(4)
     keys = rng.integers(0, 2 ** 32, size=9000, dtype=np.uint64).astype(np.uint32)
     vals = np.arange(9000, dtype=np.uint32)
     try:
-        assert nv.lib().g2pc_set_sort_tuning(11, 1 << 21) == 0
+        assert nv.experiments().g2pc_set_sort_tuning(11, 1 << 21) == 0
         ko, vo = ops.sort_pairs_u32(torch.from_numpy(keys.view(np.int32)), torch.from_numpy(vals.view(np.int32)), 0, 32)
     finally:
-        nv.lib().g2pc_set_sort_tuning(8, 1 << 21)
+        nv.experiments().g2pc_set_sort_tuning(8, 1 << 21)
     order = np.argsort(keys, kind="stable")
     assert np.array_equal(vo.numpy().view(np.uint32), vals[order])
     # wide_digit_bits = 10: ONE pass for a 9- or 10-bit field (the tile sort of 257 - 1 024 leaves), passes of up to 8 otherwise
     for lo, hi in ((20, 29), (3, 13), (0, 32), (5, 12)):
         try:
-            assert nv.lib().g2pc_set_sort_tuning(10, 1 << 21) == 0
+            assert nv.experiments().g2pc_set_sort_tuning(10, 1 << 21) == 0
             ko, vo = ops.sort_pairs_u32(torch.from_numpy(keys.view(np.int32)), torch.from_numpy(vals.view(np.int32)), lo, hi)
         finally:
-            nv.lib().g2pc_set_sort_tuning(8, 1 << 21)
+            nv.experiments().g2pc_set_sort_tuning(8, 1 << 21)
         field = (keys >> np.uint32(lo)) & np.uint32((1 << (hi - lo)) - 1 if hi - lo < 32 else 0xFFFFFFFF)
         order = np.argsort(field, kind="stable")
         assert np.array_equal(vo.numpy().view(np.uint32), vals[order]), (lo, hi)

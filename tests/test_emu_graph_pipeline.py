@@ -8,7 +8,7 @@ from emu_util import emu  # noqa: F401
 from g2pc.synth import make_scene, make_cameras
 
 
-def _render_all(pipelined, monkeypatch, headroom=None, ncam=6, subblocks=4, batch=4):
+def _render_all(pipelined, monkeypatch, headroom=None, ncam=6, subblocks=2, batch=4):
     import gauss_render
     import camera_handler
     from gauss_handler import Gaussians
@@ -70,7 +70,7 @@ def test_replayed_graph_with_an_empty_camera(emu, monkeypatch):
     import gauss_render
     import camera_handler
     from gauss_handler import Gaussians
-    monkeypatch.setattr(gauss_render, "BLEND_SUBBLOCKS", 4)
+    monkeypatch.setattr(gauss_render, "BLEND_SUBBLOCKS", 2)
     monkeypatch.setattr(gauss_render, "PIPELINE_STREAMS", 2)
     sc = make_scene(500, 78, scale_lo=0.01, scale_hi=0.07)
     transforms, intr = make_cameras(4, width=160, height=90, focal=140.0)
@@ -100,7 +100,7 @@ def test_depth_pile_up_falls_back_to_the_radix_sort(emu, monkeypatch):
     import gauss_render
     import camera_handler
     from gauss_handler import Gaussians
-    monkeypatch.setattr(gauss_render, "BLEND_SUBBLOCKS", 4)
+    monkeypatch.setattr(gauss_render, "BLEND_SUBBLOCKS", 2)
     monkeypatch.setattr(gauss_render, "PIPELINE_STREAMS", 2)
     sc = make_scene(2500, 79, scale_lo=0.01, scale_hi=0.05)
     xyz = sc.xyz.clone()

@@ -5,14 +5,14 @@ import numpy as np
 import pytest
 import torch
 
-from emu_util import emu  # noqa: F401
+from emu_util import emu, emu_exp  # noqa: F401
 
 
 @pytest.mark.parametrize("n,w,h,scale,sub,floor", [
     (1, 64, 48, (0.05, 0.06), 2, 0.0),            # one Gaussian
-    (7, 17, 9, (0.02, 0.2), 1, 0.0),              # tiny image, sub-blocks mostly padding
+    (7, 17, 9, (0.02, 0.2), 2, 0.0),              # tiny image, sub-blocks mostly padding
     (120, 61, 61, (0.3, 0.6), 2, 1e-6),           # one pixel over the 60-pixel tile limit; splats larger than the image
-    (300, 123, 77, (0.005, 0.05), 4, 1e-6),       # odd sizes, 4 pixels per lane
+    (300, 123, 77, (0.005, 0.05), 2, 1e-6),       # odd sizes
     (300, 200, 50, (0.005, 0.05), 2, 0.0),        # wide image, packed kernel, exact mode
 ])
 def test_shapes_vs_oracle(emu, monkeypatch, n, w, h, scale, sub, floor):
@@ -62,7 +62,7 @@ def test_nothing_in_front_of_the_camera(emu):
 
 
 @pytest.mark.parametrize("sub", [1, 2])
-def test_floor_mode_keeps_contributions_bit_identical(emu, monkeypatch, sub):
+def test_floor_mode_keeps_contributions_bit_identical(emu, request, monkeypatch, sub):
     """The documented guarantee of the transmittance floor: the floor only stops walks whose remaining contributions are all
     below it.  With one 8x8 sub-block per wave both modes run the same kernel and every contribution above the floor equals
     the exact mode's bit for bit, as do the winners.  With two (the default) the exact mode runs k_blend_py_pk -- the
@@ -73,6 +73,8 @@ def test_floor_mode_keeps_contributions_bit_identical(emu, monkeypatch, sub):
     import camera_handler
     from gauss_handler import Gaussians
     from g2pc.synth import make_scene, make_cameras
+    if sub == 1:
+        request.getfixturevalue("emu_exp")         # (one sub-block per wave: the scalar blend of the experiments build)
     monkeypatch.setattr(gauss_render, "BLEND_SUBBLOCKS", sub)
     sc = make_scene(1500, 41, scale_lo=0.004, scale_hi=0.03)
     tr, intr = make_cameras(2, width=160, height=90, focal=140.0)

@@ -153,9 +153,3 @@ def test_threshold_at_or_below_the_floor_takes_the_exact_blend():
     from render_checks import assert_hidden_behind_wall
     assert_hidden_behind_wall("cuda:0")
 
-
-def test_two_wave_blend_equals_single_wave_blend(golden_dir):
-    """k_blend_py_2w (one wave per 8x8 sub-block, shared 128-entry batches) vs k_blend_py_dl on the MI355X: bit-identical
-    images, contributions at or above the floor, packed keys and colours; both against the reference's golden vectors."""
-    from blend_variant_checks import run_variants, assert_variants_agree
-    assert_variants_agree(run_variants("cuda:0", golden_dir))

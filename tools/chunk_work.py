@@ -33,7 +33,7 @@ for rep in range(2):                                  # the first pass warms the
         lay = R._layout(cam.image_width, cam.image_height)
         nchunks = lay.c.num_chunks
         buf = torch.zeros(8 * nchunks, dtype=torch.int32, device=dev)
-        nv.lib().g2pc_raster_debug_chunk_work(nv.ptr(buf))
+        nv.experiments().g2pc_raster_debug_chunk_work(nv.ptr(buf))
         torch.cuda.synchronize()
         nv.PROFILE = {}
         R(cam, return_image=False)
@@ -82,6 +82,6 @@ for rep in range(2):                                  # the first pass warms the
                "blend_region_ms": prof.get("raster_blend")}
         print(json.dumps(rec))
         out.append(rec)
-nv.lib().g2pc_raster_debug_chunk_work(None)
+nv.experiments().g2pc_raster_debug_chunk_work(None)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", os.environ.get("CHUNK_WORK_OUT", "chunk_clocks.json")), "w"), indent=1)

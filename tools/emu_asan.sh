@@ -12,7 +12,7 @@ ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT=${G2PC_ASAN_DIR:-/tmp/g2pc_asan}
 mkdir -p "$OUT"
 SRC="$ROOT/3dgs-to-pc_amd/g2pc/csrc"
-for f in prims geom alloc sampler raster clean project; do
+for f in prims geom alloc sampler raster raster_cu clean project; do
   if [ ! -f "$OUT/$f.o" ] || [ "$SRC/$f.hip" -nt "$OUT/$f.o" ] || [ "$ROOT/tests/hipemu/hip/hip_runtime.h" -nt "$OUT/$f.o" ] || [ "$ROOT/include/g2pc.h" -nt "$OUT/$f.o" ]; then
     # (asan-stack=0: the kernels run on the emulator's own fibre stacks, which ASan's stack instrumentation does not know)
     g++ -O1 -g -std=c++17 -fPIC -ffp-contract=off -fsanitize=address --param asan-stack=0 -fno-omit-frame-pointer -x c++ \

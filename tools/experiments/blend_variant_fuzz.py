@@ -26,7 +26,7 @@ for it in range(int(sys.argv[2])):
     out = {}
     t = time.time()
     for v in (1, 2, 3, 4, 5, 6):
-        nv.lib().g2pc_set_blend_variant(v)
+        nv.experiments().g2pc_set_blend_variant(v)
         gauss_render.clear_context_pool()
         G = Gaussians(xyz, sc.scales, sc.rots, sc.colours, sc.opacities)
         R = gauss_render.get_renderer("python", G.xyz, G.opacities.unsqueeze(1), G.colours, G.covariances, visible_gaussian_threshold=0.05)
@@ -34,7 +34,7 @@ for it in range(int(sys.argv[2])):
         imgs = [R(camera_handler.get_camera("python", torch.tensor(tr[k]), intr[k]))[0].numpy().copy() for k in tr]
         out[v] = (np.stack(imgs), R.gaussian_max_contribution.numpy().copy(), R.best_key.numpy().copy(), R.get_gaussian_colours().numpy().copy())
         del R
-    nv.lib().g2pc_set_blend_variant(1)
+    nv.experiments().g2pc_set_blend_variant(1)
     base = out[1]
     above = base[1] >= FLOOR
     ok = True

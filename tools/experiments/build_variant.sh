@@ -7,10 +7,10 @@ set -e
 cd "$(dirname "$0")/../../3dgs-to-pc_amd/g2pc/csrc"
 tag=$1; shift
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-value -I../../../include"
+FLAGS="-O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-value -I../../../include"
 mkdir -p ../../../_ab_old/$tag
 objs=""
-for f in prims geom alloc sampler raster clean project; do
+for f in prims geom alloc sampler raster raster_cu clean project; do
   $HIPCC $FLAGS "$@" -c $f.hip -o ../../../_ab_old/$tag/$f.o &
   objs="$objs ../../../_ab_old/$tag/$f.o"
 done

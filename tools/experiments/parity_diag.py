@@ -17,7 +17,7 @@ names = sorted(tr)
 res = {}
 for variant in (0, 1):
     for floor in (1e-6, 0.0):
-        nv.lib().g2pc_set_blend_variant(variant)
+        nv.experiments().g2pc_set_blend_variant(variant)
         G = Gaussians(sc.xyz.to(dev), sc.scales.to(dev), sc.rots.to(dev), sc.colours.to(dev), sc.opacities.to(dev))
         R = gauss_render.get_renderer("python", G.xyz, G.opacities.unsqueeze(1), G.colours, G.covariances, visible_gaussian_threshold=0.05)
         R.t_floor = floor
