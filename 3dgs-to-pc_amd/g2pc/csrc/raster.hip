@@ -73,7 +73,7 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_py(Cam cam_val, const Cam* 
                                                        uint32_t* __restrict__ tiles_touched0,
                                                        const float* __restrict__ colours,
                                                        float4* __restrict__ rec0, uint32_t* __restrict__ rect0, size_t cs,
-                                                       BucketHdr* __restrict__ mm0, uint32_t mm_slots, int ncam) {
+                                                       BucketHdr* __restrict__ mm0, uint32_t mm_slots, int ncam, long reload) {
     // device-resident camera: lets ONE captured launch sequence serve every camera (scalar loads, see below).
     // Batched launch (grid.y cameras, or MULTI): camera c's job is the c-th G2pcCameraJob, its outputs live in the c-th arena.
     // mm != nullptr: the depth keys go to the bucket sort (prims.hip), whose first pass -- the range of the keys -- is folded
@@ -94,19 +94,24 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_py(Cam cam_val, const Cam* 
     // ALL of the Gaussian's inputs are requested at once (17 loads in one round): behind the in-front-of-the-camera test the
     // covariance, opacity and colour were a second round trip, which a wave with one or two neighbours on its SIMD (the rest
     // of the registers belong to another camera's blend) sits out in full
+    // MULTI: the inputs are read again for every camera -- from the L1 / L2, where the first camera's reads left them -- rather
+    // than held across the loop: 17 live registers more put the kernel at 70 VGPRs, and beside the blends of the other streams
+    // (5 waves x 96 VGPRs allocated per SIMD) a wave's register count decides how many of them a retiring blend wave makes
+    // room for (40: three; 72: one).  `reload` is 0: an offset the compiler cannot see through (it would hoist the loads).
+    __syncthreads();
+    const unsigned c_first = MULTI ? 0u : blockIdx.y, c_end = MULTI ? (unsigned)ncam : blockIdx.y + 1u;
+    for (unsigned c = c_first; c < c_end; ++c) {
     float x = 0.f, y = 0.f, z = 0.f, S9[9], op_in = 0.f, col_r = 0.f, col_g = 0.f, col_b = 0.f;
 #pragma unroll
     for (int k = 0; k < 9; ++k) S9[k] = 0.f;
     if (i < n) {
-        x = means3D[3 * i]; y = means3D[3 * i + 1]; z = means3D[3 * i + 2];
+        const long ii = i + (long)c * reload;
+        x = means3D[3 * ii]; y = means3D[3 * ii + 1]; z = means3D[3 * ii + 2];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) S9[k] = cov9[9 * i + k];
-        op_in = opacity[i];
-        col_r = colours[3 * i]; col_g = colours[3 * i + 1]; col_b = colours[3 * i + 2];
+        for (int k = 0; k < 9; ++k) S9[k] = cov9[9 * ii + k];
+        op_in = opacity[ii];
+        col_r = colours[3 * ii]; col_g = colours[3 * ii + 1]; col_b = colours[3 * ii + 2];
     }
-    __syncthreads();
-    const unsigned c_first = MULTI ? 0u : blockIdx.y, c_end = MULTI ? (unsigned)ncam : blockIdx.y + 1u;
-    for (unsigned c = c_first; c < c_end; ++c) {
     uint32_t* depth_key_rev = seg_at(depth_key_rev0, cs, c); uint32_t* index_rev = seg_at(index_rev0, cs, c);
     uint32_t* tiles_touched = seg_at(tiles_touched0, cs, c);
     float4* rec = seg_at(rec0, cs, c); uint32_t* rect = seg_at(rect0, cs, c);
@@ -1033,15 +1038,15 @@ static int py_front(const Cam& cam_val, const Cam* cam_dev, const G2pcTileLayout
     if (cam_dev && bt.n > 1 && g_preprocess_multi)
         hipLaunchKernelGGL((k_preprocess_py<true, true>), dim3(cdiv(n, G2PC_KNOB(head_threads, RA_T)), 1u), dim3(G2PC_KNOB(head_threads, RA_T)), 0, s, cam_val, cam_dev, to_layout(layout),
                            means3D, cov9, opacity, n, key_rev, fold ? (uint32_t*)nullptr : idx_rev, touched, colours, fb.rec, fb.rect,
-                           bt.cs, hdr, plan.nminmax, bt.n);
+                           bt.cs, hdr, plan.nminmax, bt.n, 0l);
     else if (cam_dev)
         hipLaunchKernelGGL((k_preprocess_py<true, false>), dim3(cdiv(n, G2PC_KNOB(head_threads, RA_T)), (unsigned)bt.n), dim3(G2PC_KNOB(head_threads, RA_T)), 0, s, cam_val, cam_dev, to_layout(layout),
                            means3D, cov9, opacity, n, key_rev, fold ? (uint32_t*)nullptr : idx_rev, touched, colours, fb.rec, fb.rect,
-                           bt.cs, hdr, plan.nminmax, 1);
+                           bt.cs, hdr, plan.nminmax, 1, 0l);
     else
         hipLaunchKernelGGL((k_preprocess_py<false, false>), dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, cam_val, cam_dev, to_layout(layout),
                            means3D, cov9, opacity, n, key_rev, idx_rev, touched, colours, fb.rec, fb.rect, (size_t)0,
-                           (BucketHdr*)nullptr, 1u, 1);
+                           (BucketHdr*)nullptr, 1u, 1, 0l);
 #ifdef G2PC_EXPERIMENTS
     for (int k = 0; k < g_knobs.extra_launches; ++k) hipLaunchKernelGGL(k_nothing, dim3(1), dim3(64), 0, s, (uint32_t*)nullptr);
 #endif

@@ -12,9 +12,9 @@ import ref_gauss as RG
 from g2pc.synth import make_scene, make_cameras
 
 
-def run_golden_case(name, device="cpu"):
+def run_golden_case(name, device="cpu", keep=False):
     """Drives the drop-in exactly like oracle/make_golden_cu.run_case drives the reference; returns (per-camera reports,
-    state report, Case)."""
+    state report, Case) -- and, with keep, the renderer, the Gaussians and the scene for the rest of the conversion."""
     import camera_handler
     import gauss_render
     import cu_golden
@@ -68,6 +68,8 @@ def run_golden_case(name, device="cpu"):
     if r["surf"]:
         st["low_surface_distance"] = R.get_gaussians_with_low_surface_distance().cpu().numpy()
         st["predicted_surface"] = R.get_predicted_surface_gaussians(0.5).cpu().numpy()
+    if keep:
+        return reps, cu_golden.compare_state(case, st), case, R, G, sc
     return reps, cu_golden.compare_state(case, st), case
 
 
@@ -145,3 +147,66 @@ def assert_cuda_matches(rep, n):
     if "surface_mask_flips" in rep:
         assert rep["surf_frac_off"] < 2e-3, rep
         assert rep["surface_mask_flips"] <= max(2, n // 2000), rep
+
+
+def run_configs4_end_to_end(device, golden_dir):
+    """BASELINE configs[4] END TO END at its own size against tests/golden/pipeline_cu_cfg4_1m.npz (oracle/make_golden_cu.py
+    --e2e: the reference's own rasteriser for cameras 0 and 17, then the reference's own conversion tail -- surface cull,
+    unrendered cull, filter, validate, generate_pointcloud(exact_num_points=True, 100 attempts) with keyed noise).
+    Returns the gates; tests/test_gpu_cuda_semantics.py asserts them."""
+    import os
+    import sys
+    import gauss_to_pc as g2p
+    from gauss_handler import Gaussians
+    from g2pc import ops
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from parity_cfg2 import match_rows
+    f = np.load(os.path.join(golden_dir, "pipeline_cu_cfg4_1m.npz"))
+    n = int(f["n"])
+    bits = lambda k, m=n: np.unpackbits(f[k])[:m].astype(bool)
+    reps, st, case, R, G, sc = run_golden_case(str(f["case"]), device, keep=True)
+    dev = torch.device(device)
+    out = dict(gaussians=n, kept_ref=int(f["kept"]), points_ref=int(f["m"]))
+    # ---- the cull chain from OUR render (gauss_to_pc.py:478-546 order) ----
+    G.colours = R.get_gaussian_colours()
+    low, vis = R.get_gaussians_with_low_surface_distance(), R.get_visible_gaussians()
+    out["low_surface_flips"] = int((low.cpu().numpy() != bits("low_surface_bits")).sum())
+    out["visible_flips"] = int((vis.cpu().numpy() != bits("visible_bits")).sum())
+    G.add_gaussians_to_cull(low)
+    G.add_gaussians_to_cull(vis)
+    G.apply_min_opacity(0.0)
+    G.apply_bounding_box(None, None)
+    G.cull_large_gaussians(0.0)
+    culled = G.filter_gaussians()
+    out["culled_equal"] = bool(np.array_equal(culled.cpu().numpy(), bits("culled_bits")))
+    contrib = R.get_total_gaussian_contributions()[culled]
+    keep = G.validate_covariances()
+    kb = bits("keep_bits", int(keep.numel()))
+    out["keep_equal"] = bool(np.array_equal(keep.cpu().numpy().astype(bool), kb)) if keep.numel() == kb.shape[0] else False
+    ref_ppg = f["ppg"].astype(np.int64)
+    if out["culled_equal"] and out["keep_equal"]:
+        contrib = contrib[keep]
+        out["contrib_max"] = float((contrib.cpu() - torch.from_numpy(f["kept_contrib"])).abs().max())
+        mags = G.get_gaussian_magnitudes(contributions=contrib)
+        ppg = ops.distribute_points(mags, int(f["num_points"]))[1].cpu().numpy().astype(np.int64)
+        out["ppg_mismatch_end_to_end"] = int((ppg != ref_ppg).sum())
+        out["ppg_max_abs_diff_end_to_end"] = int(np.abs(ppg - ref_ppg).max())
+    del R
+    # ---- quotas and the exact-points sampler on the REFERENCE's kept set (isolates distribute_points and the 100-attempt sampler) ----
+    rc = torch.from_numpy(bits("culled_bits"))
+    G2 = Gaussians(sc.xyz[rc].to(dev), sc.scales[rc].to(dev), sc.rots[rc].to(dev), torch.from_numpy(f["kept_colours"]).to(dev),
+                   sc.opacities[rc].to(dev))
+    keep2 = G2.validate_covariances()
+    out["keep_all_of_ref_kept"] = bool(keep2.all()) and int(keep2.numel()) == int(bits("keep_bits", int(keep2.numel())).sum())
+    kc = torch.from_numpy(f["kept_contrib"]).to(dev)
+    mags2 = G2.get_gaussian_magnitudes(contributions=kc)
+    ppg2 = ops.distribute_points(mags2, int(f["num_points"]))[1].cpu().numpy().astype(np.int64)
+    out["ppg_mismatch_given_ref_contrib"] = int((ppg2 != ref_ppg).sum())
+    out["ppg_max_abs_diff_given_ref_contrib"] = int(np.abs(ppg2 - ref_ppg).max())
+    pts, cols, _ = g2p.generate_pointcloud(G2, int(f["num_points"]), exact_num_points=True, mahalanobis_distance_std=2.0,
+                                           calculate_normals=False, num_sample_attempts=100, contributions=kc, device=str(dev),
+                                           quiet=True, seed=int(f["noise_seed"]))
+    out["sample_points"] = int(pts.shape[0])
+    rs = int(f["row_stride"])
+    out.update(match_rows(pts.cpu().numpy(), cols.cpu().numpy(), f["points_s256"], f["colours_s256"], np.arange(0, int(f["m"]), rs)))
+    return reps, st, case, out

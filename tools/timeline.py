@@ -80,3 +80,21 @@ if delays:
                 if any(bs < ready < be and (bs, be) != (s, e) for bs, be in bl2):
                     held += 1
     print("blends that became ready while another blend was running: %d of %d" % (held, len(delays)))
+    # per stream: how long does it sit idle between the end of a blend and the start of its next head chain (the host notices,
+    # stages the next cameras and launches), and what do the gaps between consecutive head kernels of a chain add up to?
+    idle, inner = [], []
+    for key, ks in by_stream.items():
+        gap_sum = 0.0
+        for i in range(1, len(ks)):
+            g = (ks[i][0] - ks[i - 1][1]) / 1e3
+            if "blend" in ks[i - 1][2]:
+                idle.append(g)
+                gap_sum = 0.0
+            elif "blend" in ks[i][2]:
+                inner.append(gap_sum + max(g, 0.0))
+            else:
+                gap_sum += max(g, 0.0)
+    if idle:
+        print("stream idle between a blend's end and the next head chain's start us: n=%d mean %.1f p50 %.1f p90 %.1f" % (len(idle), st_.mean(idle), q(idle, .5), q(idle, .9)))
+    if inner:
+        print("sum of the gaps between the kernels of one head chain us: mean %.1f p50 %.1f p90 %.1f" % (st_.mean(inner), q(inner, .5), q(inner, .9)))
