@@ -1,5 +1,6 @@
 // EXPERIMENTS ONLY (-DG2PC_EXPERIMENTS; not part of libg2pc.so): the process-global tuning and diagnostic entry points of
 // rounds 2-4.  tools/ and bench.py's tuning flags bind them from libg2pc_exp.so; the product ABI (include/g2pc.h) has none.
+#pragma GCC visibility push(default)
 extern "C" {
 /* per-chunk walk statistics of the PY blends: u32[8 * num_chunks] (batch 1): [0] tile list length, [1] entries walked; the dual-list
  * kernel also [2] start and [3] duration on the 100 MHz wall clock, [4] HW_ID, [5] XCC_ID, [6] visits after the cull */
@@ -19,3 +20,4 @@ int g2pc_set_blend_variant(int variant) { g2pc::g_knobs.blend_variant = variant;
 /* depth order of the capture-safe camera call: 1 = bucket sort (the product's), 0 = 4-pass radix.  Identical results. */
 int g2pc_set_depth_sort(int bucket) { g2pc::g_knobs.depth_bucket_sort = bucket ? 1 : 0; return G2PC_OK; }
 }
+#pragma GCC visibility pop

@@ -116,8 +116,8 @@ struct BucketPlan { uint32_t nbk, kpb, nchunks, nminmax, cap; };
 // the sort's last kernel, one wave per bucket, turns its sorted bucket straight into (tile, Gaussian) instances at
 // [exclusive scan of the weights in sorted order).  The weight sums per bucket ride in the histogram pass (one 64-bit LDS
 // add per key: count << 32 | weight), their scan and the capacity test in k_bk_scan: no separate scan over the n weights,
-// no duplication kernel, no count kernel (four launches and ~25 MB of traffic per camera less).  Keys must be fed in
-// REVERSED index order (value of position r = n - 1 - r), weights / rects are indexed by the value.
+// no duplication kernel, no count kernel (four launches and ~25 MB of traffic per camera less).  The values are the input
+// positions (vals == NULL; n - 1 - position when the keys are fed in reversed index order); weights / rects are indexed by the value.
 struct BucketEmit {
     const uint32_t* weight;       // [n] instances per Gaussian (0 for keys 0xFFFFFFFF)
     const uint32_t* rect;         // [n] ix0 | ix1 << 8 | iy0 << 16 | iy1 << 24 tile-interval ranges

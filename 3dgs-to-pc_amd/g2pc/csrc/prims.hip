@@ -607,12 +607,12 @@ __global__ __launch_bounds__(BK_T) void k_bk_hist(const uint32_t* __restrict__ k
 // Fused emission (BucketEmit): the same histogram with the keys' WEIGHTS summed per bucket beside the counts -- one 64-bit LDS
 // add per key (count << 32 | weight: a chunk holds at most 2^16 keys and its weights sum to less than 2^32, the capacity
 // test in k_bk_scan sees to the rest) --, the weight sums written row-wise (wtable[chunk][bucket], coalesced; they are only
-// ever summed over the chunks).  Keys are in reversed index order: position j carries Gaussian n - 1 - j.  NBK sizes the LDS
+// ever summed over the chunks).  reversed: the keys are in reversed index order, position j carries Gaussian n - 1 - j.  NBK sizes the LDS
 // table (8 bytes per bucket: 32 KB at the 4 096 buckets of a 1 M-key sort, what the plain histogram takes).
 template <int NBK>
 __global__ __launch_bounds__(BK_T) void k_bk_hist_w(const uint32_t* __restrict__ keys, long n, const BucketHdr* __restrict__ h,
                                                    uint32_t* __restrict__ table, uint32_t* __restrict__ wtable,
-                                                   const uint32_t* __restrict__ weight, BucketPlan plan, size_t cs) {
+                                                   const uint32_t* __restrict__ weight, BucketPlan plan, size_t cs, bool reversed) {
     __shared__ unsigned long long lh[NBK + 1];
     __shared__ uint32_t red[2];
     keys = seg(keys, cs); h = seg(h, cs); table = seg(table, cs); wtable = seg(wtable, cs); weight = seg(weight, cs);
@@ -629,7 +629,7 @@ __global__ __launch_bounds__(BK_T) void k_bk_hist_w(const uint32_t* __restrict__
             const long i = base + j;
             ok[u] = j < plan.kpb && i < n;
             k[u] = ok[u] ? keys[i] : 0u;
-            wt[u] = ok[u] ? weight[n - 1 - i] : 0u;
+            wt[u] = ok[u] ? weight[reversed ? n - 1 - i : i] : 0u;
         }
 #pragma unroll
         for (int u = 0; u < BK_UNROLL; ++u)
@@ -893,7 +893,7 @@ __device__ __forceinline__ void bucket_sort_emit_in_registers(const unsigned lon
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const bool valid = (uint32_t)r * 64u + lane < cnt;
-        g[r] = valid ? rev - 1u - (uint32_t)v[r] : 0u;
+        g[r] = valid ? bk_value(nullptr, (uint32_t)v[r], rev) : 0u;
         rc[r] = valid ? em.rect[g[r]] : 0u;
     }
     uint32_t run = base;
@@ -944,7 +944,7 @@ __global__ __launch_bounds__(64) void k_bk_sort_emit(const BucketHdr* __restrict
         uint32_t run = base;
         for (uint32_t e0 = 0; e0 < cnt; e0 += 64) {
             const bool valid = e0 + lane < cnt;
-            const uint32_t g = valid ? rev - 1u - (uint32_t)s_it[e0 + lane] : 0u;
+            const uint32_t g = valid ? bk_value(nullptr, (uint32_t)s_it[e0 + lane], rev) : 0u;
             const uint32_t rc = valid ? em.rect[g] : 0u;
             emit_instances(em, alive, valid, g, rc, run);
         }
@@ -976,16 +976,16 @@ int bucket_sort_u32(const uint32_t* keys, const uint32_t* vals, uint32_t* vals_o
     uint32_t* table = ar.get<uint32_t>((size_t)(plan.nbk + 1) * plan.nchunks);
     uint32_t* wtable = ar.get<uint32_t>((size_t)(plan.nbk + 1) * plan.nchunks);
     if (!ar.ok()) { set_error("bucket_sort", "workspace too small"); return G2PC_ERR_WORKSPACE; }
-    if (emit && (!rev || plan.cap != (uint32_t)BK_CAP_SMALL || !emit->weight || !emit->rect || !emit->inst_tile || !emit->l_eff)) {
-        set_error("bucket_sort", "fused emission needs reversed position values, register-sized buckets and its arrays");
+    if (emit && (vals || plan.cap != (uint32_t)BK_CAP_SMALL || !emit->weight || !emit->rect || !emit->inst_tile || !emit->l_eff)) {
+        set_error("bucket_sort", "fused emission needs position values (vals == NULL), register-sized buckets and its arrays");
         return G2PC_ERR_ARG;
     }
     if (!minmax_done) hipLaunchKernelGGL(k_bk_minmax, dim3(plan.nminmax, by), dim3(BK_T), 0, s, keys, n, h, plan, b.cs);
     if (emit) {
         if (plan.nbk <= 4096)
-            hipLaunchKernelGGL(k_bk_hist_w<4096>, dim3(plan.nchunks, by), dim3(BK_T), 0, s, keys, n, (const BucketHdr*)h, table, wtable, emit->weight, plan, b.cs);
+            hipLaunchKernelGGL(k_bk_hist_w<4096>, dim3(plan.nchunks, by), dim3(BK_T), 0, s, keys, n, (const BucketHdr*)h, table, wtable, emit->weight, plan, b.cs, rev != 0u);
         else
-            hipLaunchKernelGGL(k_bk_hist_w<BK_MAX>, dim3(plan.nchunks, by), dim3(BK_T), 0, s, keys, n, (const BucketHdr*)h, table, wtable, emit->weight, plan, b.cs);
+            hipLaunchKernelGGL(k_bk_hist_w<BK_MAX>, dim3(plan.nchunks, by), dim3(BK_T), 0, s, keys, n, (const BucketHdr*)h, table, wtable, emit->weight, plan, b.cs, rev != 0u);
     } else {
         hipLaunchKernelGGL(k_bk_hist, dim3(plan.nchunks, by), dim3(BK_T), 0, s, keys, n, (const BucketHdr*)h, table, plan, b.cs);
     }
@@ -1024,6 +1024,7 @@ const char* g2pc_last_error(void) { return g2pc::g_err.c_str(); }
 int g2pc_abi_version(void) { return G2PC_ABI_VERSION; }
 
 #ifdef G2PC_EXPERIMENTS
+#pragma GCC visibility push(default)
 /* EXPERIMENTS ONLY: digit width (8 or 11 bits) for sorts of more than 8 bits -- 10: one 10-bit pass for fields of 9 - 10 bits --;
  * inputs up to small_input_keys use 4 keys per thread */
 int g2pc_set_sort_tuning(int wide_digit_bits, int64_t small_input_keys) {
@@ -1032,6 +1033,7 @@ int g2pc_set_sort_tuning(int wide_digit_bits, int64_t small_input_keys) {
     g2pc::g_radix_small_n = small_input_keys;
     return G2PC_OK;
 }
+#pragma GCC visibility pop
 #endif
 #define G2PC_HIP_CALL(expr, where)                                                  \
     do {                                                                            \

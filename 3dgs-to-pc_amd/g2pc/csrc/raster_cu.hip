@@ -576,6 +576,86 @@ int g2pc_raster_back_cu_dev(const G2pcCamera* cam, const int32_t* mask, int64_t 
     return check_launch("g2pc_raster_back_cu_dev");
 }
 
+// CU semantics, ONE camera without the host in the loop and without a separate duplication: preprocess -> depth bucket sort whose
+// last kernel emits the (tile, Gaussian) instances (BucketEmit, prims.hip: what g2pc_raster_front_cu's radix sort + scan and
+// g2pc_raster_back_cu_dev's k_duplicate + k_resolve_count do in 17 launches) -> tile sort -> ranges -> blend.  Same results bit for
+// bit: the bucket sort leaves THE stable ascending order (equal depths in ascending Gaussian index, as the reference's radix
+// sort of (tile << 32 | depth bits) does).  count_host (pinned, optional) = [instances, unsorted, -, -]: a camera with more
+// instances than `capacity`, or whose depths piled up in one bucket (unsorted != 0), is skipped as a whole -- render it again with
+// g2pc_raster_front_cu / _back_cu.  G2PC_ERR_UNSUPPORTED: grids beyond 256 tiles per axis, or more Gaussians than the bucket sort
+// pays for (~2 M): use the two-call path.  Follow with g2pc_raster_back_cu_tiles(phases = 4, num_instances = capacity).
+size_t g2pc_raster_camera_cu_workspace(int64_t n, int64_t capacity, int32_t num_tiles) {
+    using namespace g2pc;
+    return align_up((size_t)n * 4) * 3 + bucket_sort_workspace((long)n) + g2pc_raster_back_workspace(capacity, num_tiles) + 4096;
+}
+int g2pc_raster_camera_cu(const G2pcCamera* cam, const float* means3D, const float* cov6, const float* opacity,
+                          const float* colours_precomp, const float* shs, int32_t sh_degree, int32_t sh_coeffs,
+                          const float* campos, const int32_t* mask, int64_t n, int64_t capacity, float* rec, uint32_t* rect,
+                          int32_t* radii, int calculate_surface_distance, unsigned long long* cam_key, uint32_t* cam_surf,
+                          float* out_color, float* out_depth, float* out_invdepth, uint32_t* count_host, int32_t tile_first,
+                          int32_t tile_step, void* ws, size_t ws_bytes, void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(cam && means3D && cov6 && opacity && campos && rec && rect && radii && cam_key && cam_surf && out_color &&
+                     out_depth && out_invdepth && ws && n > 0 && capacity > 0, G2PC_ERR_ARG, "bad arguments");
+    G2PC_REQUIRE((colours_precomp != nullptr) != (shs != nullptr), G2PC_ERR_ARG, "provide exactly one of precomputed colours or SHs");
+    G2PC_REQUIRE(!shs || (sh_degree >= 0 && sh_degree <= 3 && sh_coeffs >= (sh_degree + 1) * (sh_degree + 1)), G2PC_ERR_ARG,
+                 "SH degree / coefficient count mismatch");
+    const int W = cam->width, H = cam->height;
+    const int gx = (W + 15) / 16, gy = (H + 15) / 16, T = gx * gy;
+    G2PC_REQUIRE(!cu_wide_grid(gx, gy) && bucket_emit_supported((long)n) && capacity < (1ll << 31), G2PC_ERR_UNSUPPORTED,
+                 "the fused camera call takes grids of up to 256 x 256 tiles and as many Gaussians as the bucket sort pays for");
+    G2PC_REQUIRE(tile_step >= 1 && tile_first >= 0 && tile_first < tile_step, G2PC_ERR_ARG, "bad tile shard");
+    const bool sharded = tile_step > 1;
+    hipStream_t s = (hipStream_t)stream;
+    const long L = capacity;
+    Arena ar(ws, ws_bytes);
+    uint32_t* key = ar.get<uint32_t>((size_t)n);
+    uint32_t* idx = ar.get<uint32_t>((size_t)n);            // (the identity index the radix path sorts along: unused here)
+    uint32_t* touched = ar.get<uint32_t>((size_t)n);
+    const size_t bucket_bytes = bucket_sort_workspace((long)n);
+    char* bucket_ws = ar.get<char>(bucket_bytes);
+    uint32_t* inst_tile = ar.get<uint32_t>((size_t)L + 1);
+    uint32_t* inst_g = ar.get<uint32_t>((size_t)L + 1);
+    uint32_t* tile_sorted = ar.get<uint32_t>((size_t)L + 1);
+    uint32_t* g_sorted = ar.get<uint32_t>((size_t)L + 1);
+    uint32_t* tile_tmp = ar.get<uint32_t>((size_t)L + 1);
+    uint32_t* g_tmp = ar.get<uint32_t>((size_t)L + 1);
+    uint32_t* tile_start = ar.get<uint32_t>((size_t)T + 2);
+    size_t sort_bytes = sort_workspace(L);
+    char* sort_ws = ar.get<char>(sort_bytes);
+    uint32_t* l_eff = ar.get<uint32_t>(1);
+    G2PC_REQUIRE(ar.ok(), G2PC_ERR_WORKSPACE, "workspace too small");
+    const int gshift = packed_instance_shift((long)n, T);
+    const uint32_t gmask = gshift ? ((1u << gshift) - 1u) : 0xFFFFFFFFu;
+    hipLaunchKernelGGL(k_preprocess_cu, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, to_cam(cam), gx, gy, means3D, cov6, opacity,
+                       colours_precomp, shs, (int)sh_degree, (int)sh_coeffs, make_float3(campos[0], campos[1], campos[2]),
+                       (long)n, key, idx, touched, (float4*)rec, rect, radii, 0);
+    BucketEmit em{};
+    em.weight = touched; em.rect = rect; em.inst_tile = inst_tile; em.inst_g = inst_g; em.gshift = gshift; em.nx = gx;
+    em.capacity = (uint32_t)capacity; em.l_eff = l_eff; em.count_host = count_host;
+    uint32_t* depth_overflow = nullptr;
+    int rc = bucket_sort_u32(key, nullptr, nullptr, nullptr, (long)n, bucket_ws, bucket_bytes, &depth_overflow, s, Batch(), false, false, &em);
+    if (rc) return rc;
+    if (mask || sharded) {                        // without a mask every pixel is written by the blend kernel
+        hipMemsetAsync(out_color, 0, (size_t)3 * W * H * 4, s);
+        hipMemsetAsync(out_depth, 0, (size_t)W * H * 4, s);
+        hipMemsetAsync(out_invdepth, 0, (size_t)W * H * 4, s);
+    }
+    hipLaunchKernelGGL(k_init_camera_state_cu, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, (unsigned long long*)cam_key, (uint32_t*)cam_surf, (long)n);
+    rc = gshift ? sort_pairs_u32(inst_tile, nullptr, tile_sorted, nullptr, tile_tmp, nullptr, L, gshift,
+                                 gshift + bits_for_tiles((unsigned)T), sort_ws, sort_bytes, s, l_eff)
+                : sort_pairs_u32(inst_tile, inst_g, tile_sorted, g_sorted, tile_tmp, g_tmp, L, 0, bits_for_tiles((unsigned)T),
+                                 sort_ws, sort_bytes, s, l_eff);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(L + 1, RA_T)), dim3(RA_T), 0, s, tile_sorted, L, T, tile_start, (const uint32_t*)l_eff, gshift, (size_t)0);
+    if (tile_first < T)
+        hipLaunchKernelGGL(k_blend_cu, dim3((unsigned)((T - tile_first + tile_step - 1) / tile_step)), dim3(CU_T), 0, s, W, H, gx,
+                           (int)tile_first, (int)tile_step, tile_start, gshift ? tile_sorted : g_sorted, gmask, (const float4*)rec, mask,
+                           make_float3(cam->bg[0], cam->bg[1], cam->bg[2]), calculate_surface_distance, cam_key, cam_surf,
+                           out_color, out_depth, out_invdepth);
+    return check_launch("g2pc_raster_camera_cu");
+}
+
 int g2pc_raster_back_cu(const G2pcCamera* cam, const int32_t* mask, int64_t n, int64_t num_instances, const float* rec,
                         const uint32_t* rect, const uint32_t* sorted_idx, const uint32_t* offsets, int calculate_surface_distance,
                         unsigned long long* cam_key, uint32_t* cam_surf, float* out_color, float* out_depth, float* out_invdepth,

@@ -55,12 +55,16 @@ nv._RASTER_PROTOS.update({
     "g2pc_raster_back_cu_dev": (C.c_int, [C.POINTER(_Camera), _vp, C.c_int64, C.c_int64] + [_vp] * 4 + [C.c_int] + [_vp] * 6 +
                                 [C.c_int32, C.c_int32, _vp, C.c_size_t, _vp]),
     "g2pc_mark_visible": (C.c_int, [_vp, C.c_int64, C.POINTER(C.c_float * 16), _vp, _vp]),
+    "g2pc_raster_camera_cu_workspace": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32]),
+    "g2pc_raster_camera_cu": (C.c_int, [C.POINTER(_Camera)] + [_vp] * 5 + [C.c_int32, C.c_int32, _vp, _vp, C.c_int64, C.c_int64] +
+                              [_vp] * 3 + [C.c_int] + [_vp] * 6 + [C.c_int32, C.c_int32, _vp, C.c_size_t, _vp]),
 })
 if nv._LIB is not None:
     nv._bind(nv._LIB)
 
 
 PIPELINE_STREAMS = 4
+FUSED_CAMERA_CALL = True          # pipelined cameras through g2pc_raster_camera_cu (False: front + device-side back half, as until round 4)
 PIPELINE_IN_EMULATOR = False      # tests: drive the no-read-back camera path through the CPU emulator too
 CAPACITY_HEADROOM = 1.25          # instance capacity of the pipelined cameras relative to the largest count seen so far
 MIN_CAPACITY = 1 << 16
@@ -230,7 +234,11 @@ class GaussianRasterizer(nn.Module):
         L = nv.lib()
         W, H = cam.width, cam.height
         tiles_n = ((W + 15) // 16) * ((H + 15) // 16)
-        need = L.g2pc_raster_back_workspace(capacity, tiles_n)
+        # ONE call per camera (g2pc_raster_camera_cu: the depth bucket sort emits the instances itself) where the library offers
+        # it -- up to 256 x 256 tiles and ~2 M Gaussians --, else the front half + the device-side back half
+        fused = FUSED_CAMERA_CALL and getattr(self, "_fused_ok", True) and max((W + 15) // 16, (H + 15) // 16) <= 256
+        need = max(L.g2pc_raster_back_workspace(capacity, tiles_n),
+                   L.g2pc_raster_camera_cu_workspace(self.n, capacity, tiles_n) if fused else 0)
         with (torch.cuda.stream(sc.stream) if sc.stream is not None else contextlib.nullcontext()):
             if need > sc.back_bytes:
                 sc.back_bytes = int(need)
@@ -240,14 +248,30 @@ class GaussianRasterizer(nn.Module):
                 sc.colour = torch.empty((3, H, W), dtype=torch.float32, device=self.device)
                 sc.depths = torch.empty((1, H, W), dtype=torch.float32, device=self.device)
                 sc.invdepths = torch.empty((1, H, W), dtype=torch.float32, device=self.device)
-        self._front(sc, cam, campos, sh_degree, count_host=False)
         first, step = self.tile_shard if self.tile_shard is not None else (0, 1)
-        with nv.region("raster_bin+blend_cu", self.device, sc.stream):
-            nv.check(L.g2pc_raster_back_cu_dev(
-                C.byref(cam), nv.ptr(mask), self.n, capacity, nv.ptr(sc.rec), nv.ptr(sc.rect), nv.ptr(sc.sorted),
-                nv.ptr(sc.offsets), 1 if self.calculate_surface_distance else 0, nv.ptr(sc.cam_key), nv.ptr(sc.cam_surf),
-                nv.ptr(sc.colour), nv.ptr(sc.depths), nv.ptr(sc.invdepths), C.c_void_p(sc.count_host.data_ptr()),
-                int(first), int(step), nv.ptr(sc.back_ws), sc.back_bytes, self._stream_ptr(sc)), "raster_back_cu_dev")
+        if fused:
+            shs = self.shs
+            with nv.region("raster_camera_cu", self.device, sc.stream):
+                rc = L.g2pc_raster_camera_cu(
+                    C.byref(cam), nv.ptr(self.means3D), nv.ptr(self.cov3D_precomp), nv.ptr(self.opacities),
+                    nv.ptr(self.colors_precomp), nv.ptr(shs), int(sh_degree) if shs is not None else 0,
+                    int(shs.shape[1]) if shs is not None else 0, C.cast(campos, C.c_void_p), nv.ptr(mask), self.n, capacity,
+                    nv.ptr(sc.rec), nv.ptr(sc.rect), nv.ptr(sc.radii), 1 if self.calculate_surface_distance else 0,
+                    nv.ptr(sc.cam_key), nv.ptr(sc.cam_surf), nv.ptr(sc.colour), nv.ptr(sc.depths), nv.ptr(sc.invdepths),
+                    C.c_void_p(sc.count_host.data_ptr()), int(first), int(step), nv.ptr(sc.back_ws), sc.back_bytes,
+                    self._stream_ptr(sc))
+            if rc == -4:                               # G2PC_ERR_UNSUPPORTED: a scene the bucket sort does not pay for
+                self._fused_ok = fused = False
+            else:
+                nv.check(rc, "raster_camera_cu")
+        if not fused:
+            self._front(sc, cam, campos, sh_degree, count_host=False)
+            with nv.region("raster_bin+blend_cu", self.device, sc.stream):
+                nv.check(L.g2pc_raster_back_cu_dev(
+                    C.byref(cam), nv.ptr(mask), self.n, capacity, nv.ptr(sc.rec), nv.ptr(sc.rect), nv.ptr(sc.sorted),
+                    nv.ptr(sc.offsets), 1 if self.calculate_surface_distance else 0, nv.ptr(sc.cam_key), nv.ptr(sc.cam_surf),
+                    nv.ptr(sc.colour), nv.ptr(sc.depths), nv.ptr(sc.invdepths), C.c_void_p(sc.count_host.data_ptr()),
+                    int(first), int(step), nv.ptr(sc.back_ws), sc.back_bytes, self._stream_ptr(sc)), "raster_back_cu_dev")
         if self._last_update is not None and sc.stream is not None:
             sc.stream.wait_event(self._last_update)
         self._back(sc, cam, mask, capacity, cam_index, 4, "raster_update_cu")
@@ -263,7 +287,7 @@ class GaussianRasterizer(nn.Module):
             sc.update_done.synchronize()
         num_rendered = int(sc.count_host[0])
         self.last = dict(num_rendered=num_rendered)
-        if num_rendered > capacity:
+        if num_rendered > capacity or int(sc.count_host[1]) != 0:     # too many instances, or depths piled up in one sort bucket
             self._capacity = max(self._capacity, int(num_rendered * CAPACITY_HEADROOM))
             self.rerendered += 1
             self._render_two_call(sc, cam, campos, mask, sh_degree, cam_index)

@@ -476,6 +476,22 @@ int g2pc_raster_back_cu_tiles(const G2pcCamera* cam, const int32_t* mask, int64_
                               float* total_contrib, float* colours, float* min_surf, int32_t* winner_cam, int32_t cam_index,
                               float* cur_contrib, int32_t* cur_pixels, float* cur_surf, int phases, int32_t tile_first,
                               int32_t tile_step, void* ws, size_t ws_bytes, void* stream);
+/* ABI 6: ONE pipelined camera of the native-rasteriser semantics in one call, without the host in the loop and without a separate
+ * duplication: preprocess (forward.cu:153-271) -> depth bucket sort whose last kernel emits the (tile, Gaussian) instances (what
+ * rasterizer_impl.cu:285-316 does with an InclusiveSum, duplicateWithKeys and a 64-bit SortPairs) -> stable tile sort -> ranges
+ * (rasterizer_impl.cu:322-331) -> blend (forward.cu:303-497).  Results bit for bit those of g2pc_raster_front_cu +
+ * g2pc_raster_back_cu_dev.  count_host (PINNED, optional): [0] instances, [1] != 0: the depths piled up beyond a bucket's room;
+ * a camera with [0] > capacity or [1] != 0 was skipped as a whole: render it again with g2pc_raster_front_cu / _back_cu.
+ * Returns G2PC_ERR_UNSUPPORTED for grids beyond 256 x 256 tiles or more than ~2 M Gaussians (use the two calls).
+ * Follow with g2pc_raster_back_cu_tiles(phases = 4, num_instances = capacity, ws = this ws) for the running-state update -- it
+ * reads none of rect / sorted_idx / offsets. */
+size_t g2pc_raster_camera_cu_workspace(int64_t n, int64_t capacity, int32_t num_tiles);
+int g2pc_raster_camera_cu(const G2pcCamera* cam, const float* means3D, const float* cov6, const float* opacity,
+                          const float* colours_precomp, const float* shs, int32_t sh_degree, int32_t sh_coeffs,
+                          const float* campos, const int32_t* mask, int64_t n, int64_t capacity, float* rec, uint32_t* rect,
+                          int32_t* radii, int calculate_surface_distance, unsigned long long* cam_key, uint32_t* cam_surf,
+                          float* out_color, float* out_depth, float* out_invdepth, uint32_t* count_host, int32_t tile_first,
+                          int32_t tile_step, void* ws, size_t ws_bytes, void* stream);
 /* Bin + blend of one camera with the instance count kept on the device: launches sized for `capacity`, the count goes to
  * the pinned count_host[0] (count_host[1] = 0) asynchronously; a camera with more instances is skipped as a whole and
  * must be rendered again through g2pc_raster_back_cu[_tiles].  Removes the host read-back between the halves of a camera

@@ -59,10 +59,13 @@ def test_generate_mesh_surface_point_cloud(emu):
     print(check_surface_cloud())
 
 
-def test_cameras_without_read_back_equal_one_at_a_time(emu, monkeypatch):
-    """The pipelined native-semantics path (instance count kept on the device, launches sized for a capacity,
-    g2pc_raster_back_cu_dev) leaves the same running state as one camera at a time -- including cameras that outgrow the
-    capacity learned from the first one, which are skipped on the device and rendered again through the two-call path."""
+@pytest.mark.parametrize("fused", [True, False])
+def test_cameras_without_read_back_equal_one_at_a_time(emu, monkeypatch, fused):
+    """The pipelined native-semantics path (instance count kept on the device, launches sized for a capacity) leaves the same
+    running state as one camera at a time -- including cameras that outgrow the capacity learned from the first one, which are
+    skipped on the device and rendered again through the two-call path.  fused: ONE call per camera, g2pc_raster_camera_cu (the
+    depth bucket sort emits the instances itself); else g2pc_raster_front_cu + g2pc_raster_back_cu_dev (radix sort, scan,
+    k_duplicate, k_resolve_count) as until round 4."""
     import torch
     import camera_handler
     import gaussian_pointcloud_rasterization as gpr
@@ -73,6 +76,7 @@ def test_cameras_without_read_back_equal_one_at_a_time(emu, monkeypatch):
 
     def run(pipelined, shrink):
         monkeypatch.setattr(gpr, "PIPELINE_IN_EMULATOR", pipelined)
+        monkeypatch.setattr(gpr, "FUSED_CAMERA_CALL", fused)
         monkeypatch.setattr(gpr, "MIN_CAPACITY", 16)
         monkeypatch.setattr(gpr, "PIPELINE_STREAMS", 2)        # retire early: the capacity grows while cameras are still coming
         R = gpr.GaussianRasterizer(sc.xyz, torch.zeros_like(sc.xyz), sc.opacities.unsqueeze(1), colors_precomp=sc.colours,
@@ -122,3 +126,44 @@ def test_pipelined_path_on_an_image_wider_than_4096_pixels(emu, monkeypatch):
     assert float(a[0].max()) > 0.05                      # something was really rendered
     for x, z in zip(a, b):
         assert torch.equal(x, z)
+
+
+def test_fused_camera_call_with_a_depth_pile_up_and_sh(emu, monkeypatch):
+    """g2pc_raster_camera_cu on a sheet of Gaussians seen head on (one depth bucket beyond its room: the camera is skipped and
+    rendered again through the two-call path) and with SH colours + a mask: the running state of one camera at a time."""
+    import torch
+    import camera_handler
+    import gaussian_pointcloud_rasterization as gpr
+    from g2pc.synth import make_scene, make_cameras
+    sc = make_scene(2600, 13, with_sh=True, scale_lo=0.01, scale_hi=0.05)
+    xyz = sc.xyz.clone()
+    xyz[:1500, 2] = 0.0
+    tr, intr = make_cameras(3, width=160, height=96, focal=140.0)
+    eye = torch.eye(4)
+    eye[2, 3] = 3.5
+    cams = [torch.tensor(tr[sorted(tr)[0]]), eye.clone(), torch.tensor(tr[sorted(tr)[2]]), eye.clone()]
+    cams[3][0, 3] = 0.15
+    mask = torch.ones((96, 160), dtype=torch.int32)
+    mask[:, :48] = 0                                                    # whole 16-pixel tile columns: defined in the reference
+
+    def run(pipelined):
+        monkeypatch.setattr(gpr, "PIPELINE_IN_EMULATOR", pipelined)
+        monkeypatch.setattr(gpr, "PIPELINE_STREAMS", 2)
+        R = gpr.GaussianRasterizer(xyz, torch.zeros_like(xyz), sc.opacities.unsqueeze(1), shs=sc.shs,
+                                   scales=torch.exp(sc.scales), rotations=sc.rots, visible_gaussian_threshold=0.05,
+                                   surface_distance_std=2.0, calculate_surface_distance=True)
+        for c2w in cams:
+            R(camera_handler.get_camera("cuda", c2w, intr[sorted(intr)[0]], sh_degree=3, mask=mask), return_image=False)
+        R.flush()
+        return R, (R.gaussian_max_contribution.clone(), R.gaussian_total_contribution.clone(), R.gaussian_colours.clone(),
+                   R.gaussian_min_surface_distance.clone())
+
+    _, a = run(False)
+    R2, b = run(True)
+    assert R2.rerendered >= 1                                           # the pile-up really happened and was handled
+    assert float(a[0].max()) > 0.05
+    for i, (x, z) in enumerate(zip(a, b)):
+        if i == 1:
+            assert torch.allclose(x, z, rtol=1e-6, atol=1e-7)
+        else:
+            assert torch.equal(x, z)
