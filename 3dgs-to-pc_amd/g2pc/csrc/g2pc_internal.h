@@ -119,7 +119,7 @@ struct BucketPlan { uint32_t nbk, kpb, nchunks, nminmax, cap; };
 // no duplication kernel, no count kernel (four launches and ~25 MB of traffic per camera less).  The values are the input
 // positions (vals == NULL; n - 1 - position when the keys are fed in reversed index order); weights / rects are indexed by the value.
 struct BucketEmit {
-    const uint32_t* weight;       // [n] instances per Gaussian (0 for keys 0xFFFFFFFF)
+    const uint32_t* weight;       // [n] instances per Gaussian (0 for keys 0xFFFFFFFF); NULL: the area of the rect (no child pass)
     const uint32_t* rect;         // [n] ix0 | ix1 << 8 | iy0 << 16 | iy1 << 24 tile-interval ranges
     uint32_t* inst_tile;          // out: tile << gshift | Gaussian (gshift > 0), else the tile id ...
     uint32_t* inst_g;             // ... with the Gaussian here

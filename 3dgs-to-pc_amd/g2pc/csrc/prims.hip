@@ -405,7 +405,10 @@ static long g_radix_small_n = 2L << 20;    // inputs up to this size use 4 keys 
 constexpr int g_radix_wide_bits = 8;
 constexpr long g_radix_small_n = 2L << 20;
 #endif
-static inline int radix_items(long n) { return n <= g_radix_small_n ? 4 : 8; }
+#ifndef G2PC_RADIX10_ITEMS
+#define G2PC_RADIX10_ITEMS 8      // experiments: keys per thread of the ONE-pass 10-bit tile sort (16: 4 096 keys per block against its 1 024 bins)
+#endif
+static inline int radix_items(long n) { return n <= g_radix_small_n ? 4 : (g_radix_wide_bits == 10 ? G2PC_RADIX10_ITEMS : 8); }
 static inline int radix_maxbits(int total_bits) {
     if (total_bits <= 8) return 8;
     if (g_radix_wide_bits == 10) return total_bits <= 10 ? 10 : 8;
@@ -478,6 +481,7 @@ int sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* k
 #ifdef G2PC_EXPERIMENTS
         else if (maxbits == 10) {
             if (items == 4) radix_pass<10, 4>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc, n_dev, b);
+            else if (items == 16) radix_pass<10, 16>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc, n_dev, b);
             else radix_pass<10, 8>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc, n_dev, b);
         } else {
             if (items == 4) radix_pass<11, 4>(kin, vin, kout, vout, n, bit, nbits, ghist, nb, scan_ws, scan_bytes, s, rc, n_dev, b);
@@ -604,6 +608,9 @@ __global__ __launch_bounds__(BK_T) void k_bk_hist(const uint32_t* __restrict__ k
     __syncthreads();
     for (uint32_t i = threadIdx.x; i <= nbk; i += BK_T) table[(size_t)i * plan.nchunks + blockIdx.x] = lh[i];
 }
+__device__ __forceinline__ uint32_t rect_area(uint32_t rc) {       // tiles of ix0 | ix1 << 8 | iy0 << 16 | iy1 << 24 (inclusive)
+    return (((rc >> 8) & 255u) - (rc & 255u) + 1u) * ((rc >> 24) - ((rc >> 16) & 255u) + 1u);
+}
 // Fused emission (BucketEmit): the same histogram with the keys' WEIGHTS summed per bucket beside the counts -- one 64-bit LDS
 // add per key (count << 32 | weight: a chunk holds at most 2^16 keys and its weights sum to less than 2^32, the capacity
 // test in k_bk_scan sees to the rest) --, the weight sums written row-wise (wtable[chunk][bucket], coalesced; they are only
@@ -612,10 +619,11 @@ __global__ __launch_bounds__(BK_T) void k_bk_hist(const uint32_t* __restrict__ k
 template <int NBK>
 __global__ __launch_bounds__(BK_T) void k_bk_hist_w(const uint32_t* __restrict__ keys, long n, const BucketHdr* __restrict__ h,
                                                    uint32_t* __restrict__ table, uint32_t* __restrict__ wtable,
-                                                   const uint32_t* __restrict__ weight, BucketPlan plan, size_t cs, bool reversed) {
+                                                   const uint32_t* __restrict__ weight, const uint32_t* __restrict__ rect,
+                                                   BucketPlan plan, size_t cs, bool reversed) {
     __shared__ unsigned long long lh[NBK + 1];
     __shared__ uint32_t red[2];
-    keys = seg(keys, cs); h = seg(h, cs); table = seg(table, cs); wtable = seg(wtable, cs); weight = seg(weight, cs);
+    keys = seg(keys, cs); h = seg(h, cs); table = seg(table, cs); wtable = seg(wtable, cs); weight = seg(weight, cs); rect = seg(rect, cs);
     const uint32_t nbk = plan.nbk;
     for (uint32_t i = threadIdx.x; i <= nbk; i += BK_T) lh[i] = 0ull;
     const BucketMap m = bucket_map_from_partials(h, plan.nminmax, red);   // (its barriers also publish the zeroed histogram)
@@ -629,7 +637,9 @@ __global__ __launch_bounds__(BK_T) void k_bk_hist_w(const uint32_t* __restrict__
             const long i = base + j;
             ok[u] = j < plan.kpb && i < n;
             k[u] = ok[u] ? keys[i] : 0u;
-            wt[u] = ok[u] ? weight[reversed ? n - 1 - i : i] : 0u;
+            // weight == nullptr: the rect's area (every tile of the rectangle takes an instance; keys 0xFFFFFFFF carry rect 0 = one
+            // tile, but land in the tail bucket, whose weight sum nobody reads)
+            wt[u] = ok[u] ? (weight ? weight[reversed ? n - 1 - i : i] : rect_area(rect[reversed ? n - 1 - i : i])) : 0u;
         }
 #pragma unroll
         for (int u = 0; u < BK_UNROLL; ++u)
@@ -976,16 +986,17 @@ int bucket_sort_u32(const uint32_t* keys, const uint32_t* vals, uint32_t* vals_o
     uint32_t* table = ar.get<uint32_t>((size_t)(plan.nbk + 1) * plan.nchunks);
     uint32_t* wtable = ar.get<uint32_t>((size_t)(plan.nbk + 1) * plan.nchunks);
     if (!ar.ok()) { set_error("bucket_sort", "workspace too small"); return G2PC_ERR_WORKSPACE; }
-    if (emit && (vals || plan.cap != (uint32_t)BK_CAP_SMALL || !emit->weight || !emit->rect || !emit->inst_tile || !emit->l_eff)) {
+    if (emit && (vals || plan.cap != (uint32_t)BK_CAP_SMALL || !emit->rect || !emit->inst_tile || !emit->l_eff ||
+                 (emit->tile_parent && !emit->weight))) {
         set_error("bucket_sort", "fused emission needs position values (vals == NULL), register-sized buckets and its arrays");
         return G2PC_ERR_ARG;
     }
     if (!minmax_done) hipLaunchKernelGGL(k_bk_minmax, dim3(plan.nminmax, by), dim3(BK_T), 0, s, keys, n, h, plan, b.cs);
     if (emit) {
         if (plan.nbk <= 4096)
-            hipLaunchKernelGGL(k_bk_hist_w<4096>, dim3(plan.nchunks, by), dim3(BK_T), 0, s, keys, n, (const BucketHdr*)h, table, wtable, emit->weight, plan, b.cs, rev != 0u);
+            hipLaunchKernelGGL(k_bk_hist_w<4096>, dim3(plan.nchunks, by), dim3(BK_T), 0, s, keys, n, (const BucketHdr*)h, table, wtable, emit->weight, emit->rect, plan, b.cs, rev != 0u);
         else
-            hipLaunchKernelGGL(k_bk_hist_w<BK_MAX>, dim3(plan.nchunks, by), dim3(BK_T), 0, s, keys, n, (const BucketHdr*)h, table, wtable, emit->weight, plan, b.cs, rev != 0u);
+            hipLaunchKernelGGL(k_bk_hist_w<BK_MAX>, dim3(plan.nchunks, by), dim3(BK_T), 0, s, keys, n, (const BucketHdr*)h, table, wtable, emit->weight, emit->rect, plan, b.cs, rev != 0u);
     } else {
         hipLaunchKernelGGL(k_bk_hist, dim3(plan.nchunks, by), dim3(BK_T), 0, s, keys, n, (const BucketHdr*)h, table, plan, b.cs);
     }

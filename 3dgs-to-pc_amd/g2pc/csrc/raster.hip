@@ -194,7 +194,7 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_py(Cam cam_val, const Cam* 
     const long r = n - 1 - i;
     depth_key_rev[r] = key;
     if (index_rev) index_rev[r] = (uint32_t)i;       // nullptr: the sort returns n - 1 - position itself (bucket sort, reversed)
-    tiles_touched[i] = touched;
+    if (tiles_touched) tiles_touched[i] = touched;   // (nullptr: the fused emission derives it from the rect -- no child pass)
     rect[i] = rc;
     }
     if (mm0) {
@@ -1035,13 +1035,16 @@ static int py_front(const Cam& cam_val, const Cam* cam_dev, const G2pcTileLayout
     const BucketPlan plan = bucket_plan(n);
     if (cam_dev && (jobs_host || hdr))
         hipLaunchKernelGGL(k_fetch_job, dim3((unsigned)bt.n), dim3(64), 0, s, (const uint32_t*)jobs_host, (uint32_t*)jobs_dev, hdr, bt.cs, plan);
+    // (without a child pass a Gaussian's instance count IS its rect's area: the counts are then neither written nor read)
+    const bool need_counts = !emit || layout->tile_parent != nullptr;
+    if (emit) { emit->weight = need_counts ? touched : nullptr; emit->rect = fb.rect; }
     if (cam_dev && bt.n > 1 && g_preprocess_multi)
         hipLaunchKernelGGL((k_preprocess_py<true, true>), dim3(cdiv(n, G2PC_KNOB(head_threads, RA_T)), 1u), dim3(G2PC_KNOB(head_threads, RA_T)), 0, s, cam_val, cam_dev, to_layout(layout),
-                           means3D, cov9, opacity, n, key_rev, fold ? (uint32_t*)nullptr : idx_rev, touched, colours, fb.rec, fb.rect,
+                           means3D, cov9, opacity, n, key_rev, fold ? (uint32_t*)nullptr : idx_rev, need_counts ? touched : (uint32_t*)nullptr, colours, fb.rec, fb.rect,
                            bt.cs, hdr, plan.nminmax, bt.n, 0l);
     else if (cam_dev)
         hipLaunchKernelGGL((k_preprocess_py<true, false>), dim3(cdiv(n, G2PC_KNOB(head_threads, RA_T)), (unsigned)bt.n), dim3(G2PC_KNOB(head_threads, RA_T)), 0, s, cam_val, cam_dev, to_layout(layout),
-                           means3D, cov9, opacity, n, key_rev, fold ? (uint32_t*)nullptr : idx_rev, touched, colours, fb.rec, fb.rect,
+                           means3D, cov9, opacity, n, key_rev, fold ? (uint32_t*)nullptr : idx_rev, need_counts ? touched : (uint32_t*)nullptr, colours, fb.rec, fb.rect,
                            bt.cs, hdr, plan.nminmax, 1, 0l);
     else
         hipLaunchKernelGGL((k_preprocess_py<false, false>), dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, cam_val, cam_dev, to_layout(layout),
@@ -1051,7 +1054,6 @@ static int py_front(const Cam& cam_val, const Cam* cam_dev, const G2pcTileLayout
     for (int k = 0; k < g_knobs.extra_launches; ++k) hipLaunchKernelGGL(k_nothing, dim3(1), dim3(64), 0, s, (uint32_t*)nullptr);
 #endif
     if (emit && !(fold && depth_overflow)) { set_error("raster_front_py", "fused emission without the folded bucket sort"); return G2PC_ERR_ARG; }
-    if (emit) { emit->weight = touched; emit->rect = fb.rect; }
     int rc = depth_overflow ? bucket_sort_u32(key_rev, fold ? nullptr : idx_rev, fb.sorted_idx, nullptr, n, bucket_ws, bucket_bytes,
                                               depth_overflow, s, bt, fold, fold, emit)
                             : sort_pairs_u32(key_rev, idx_rev, key_sorted, fb.sorted_idx, ktmp, vtmp, n, 0, 32, sort_ws, sort_bytes, s, nullptr, bt);

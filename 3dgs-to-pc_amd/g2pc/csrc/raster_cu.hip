@@ -146,7 +146,7 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_cu(Cam cam, int grid_x, int
     }
     depth_key[i] = key;
     index[i] = (uint32_t)i;
-    tiles_touched[i] = touched;
+    if (tiles_touched) tiles_touched[i] = touched;
     if (wide) { rect[2 * i] = rc; rect[2 * i + 1] = rc_hi; } else rect[i] = rc;
     radii[i] = rad;
 }
@@ -586,7 +586,7 @@ int g2pc_raster_back_cu_dev(const G2pcCamera* cam, const int32_t* mask, int64_t 
 // pays for (~2 M): use the two-call path.  Follow with g2pc_raster_back_cu_tiles(phases = 4, num_instances = capacity).
 size_t g2pc_raster_camera_cu_workspace(int64_t n, int64_t capacity, int32_t num_tiles) {
     using namespace g2pc;
-    return align_up((size_t)n * 4) * 3 + bucket_sort_workspace((long)n) + g2pc_raster_back_workspace(capacity, num_tiles) + 4096;
+    return align_up((size_t)n * 4) * 2 + bucket_sort_workspace((long)n) + g2pc_raster_back_workspace(capacity, num_tiles) + 4096;
 }
 int g2pc_raster_camera_cu(const G2pcCamera* cam, const float* means3D, const float* cov6, const float* opacity,
                           const float* colours_precomp, const float* shs, int32_t sh_degree, int32_t sh_coeffs,
@@ -611,7 +611,6 @@ int g2pc_raster_camera_cu(const G2pcCamera* cam, const float* means3D, const flo
     Arena ar(ws, ws_bytes);
     uint32_t* key = ar.get<uint32_t>((size_t)n);
     uint32_t* idx = ar.get<uint32_t>((size_t)n);            // (the identity index the radix path sorts along: unused here)
-    uint32_t* touched = ar.get<uint32_t>((size_t)n);
     const size_t bucket_bytes = bucket_sort_workspace((long)n);
     char* bucket_ws = ar.get<char>(bucket_bytes);
     uint32_t* inst_tile = ar.get<uint32_t>((size_t)L + 1);
@@ -629,9 +628,9 @@ int g2pc_raster_camera_cu(const G2pcCamera* cam, const float* means3D, const flo
     const uint32_t gmask = gshift ? ((1u << gshift) - 1u) : 0xFFFFFFFFu;
     hipLaunchKernelGGL(k_preprocess_cu, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, to_cam(cam), gx, gy, means3D, cov6, opacity,
                        colours_precomp, shs, (int)sh_degree, (int)sh_coeffs, make_float3(campos[0], campos[1], campos[2]),
-                       (long)n, key, idx, touched, (float4*)rec, rect, radii, 0);
+                       (long)n, key, idx, (uint32_t*)nullptr /* counts = rect areas */, (float4*)rec, rect, radii, 0);
     BucketEmit em{};
-    em.weight = touched; em.rect = rect; em.inst_tile = inst_tile; em.inst_g = inst_g; em.gshift = gshift; em.nx = gx;
+    em.weight = nullptr; em.rect = rect; em.inst_tile = inst_tile; em.inst_g = inst_g; em.gshift = gshift; em.nx = gx;
     em.capacity = (uint32_t)capacity; em.l_eff = l_eff; em.count_host = count_host;
     uint32_t* depth_overflow = nullptr;
     int rc = bucket_sort_u32(key, nullptr, nullptr, nullptr, (long)n, bucket_ws, bucket_bytes, &depth_overflow, s, Batch(), false, false, &em);

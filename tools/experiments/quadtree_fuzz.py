@@ -17,6 +17,7 @@ if not GPU:
 from render_checks import run_vs_oracle
 rng = np.random.default_rng(int(sys.argv[1]))
 PIPE = "pipelined" in sys.argv[3:]
+ONLY = next((int(a.split("=")[1]) for a in sys.argv[3:] if a.startswith("only=")), None)      # replay ONE case of the stream
 if PIPE:
     import gauss_render
     gauss_render.PIPELINE_IN_EMULATOR = True
@@ -27,6 +28,8 @@ for it in range(int(sys.argv[2])):
     mt = int(rng.choice([6, 9, 14, 25, 60])); mg = int(rng.choice([15, 60, 250, 1000]))
     n = int(rng.integers(300, 2500)); crowd = float(rng.choice([0.15, 0.4, 1.0]))
     sc = (0.004, float(rng.choice([0.02, 0.06])))
+    if ONLY is not None and it != ONLY:
+        continue
     t = time.time()
     try:
         if PIPE:
@@ -52,5 +55,5 @@ for it in range(int(sys.argv[2])):
         print(it, W, H, mt, mg, n, crowd, "Refused:", str(e)[:70]); continue
     ok = res["image"] < 2e-5 and res["contribution"] < 2e-5 and res["flips"] == 0 and res["colour_off_gaussians"] <= (8 if PIPE else 2)
     bad += (not ok)
-    print(it, W, H, mt, mg, n, crowd, "split", res["split_leaves"], "childpass", res.get("child_pass_cameras"), "host", res.get("host_driven"), "img %.1e c %.1e col %.1e" % (res["image"], res["contribution"], res["colour"]), "OK" if ok else "MISMATCH", "%.1fs" % (time.time() - t), flush=True)
+    print(it, W, H, mt, mg, n, crowd, "split", res["split_leaves"], "childpass", res.get("child_pass_cameras"), "host", res.get("host_driven"), "img %.1e c %.1e col %.1e off %d flips %d" % (res["image"], res["contribution"], res["colour"], res["colour_off_gaussians"], res["flips"]), "OK" if ok else "MISMATCH", "%.1fs" % (time.time() - t), flush=True)
 print("mismatches", bad)
