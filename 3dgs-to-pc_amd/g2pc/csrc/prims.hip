@@ -683,11 +683,12 @@ constexpr int BKS_T = 256;
 __global__ __launch_bounds__(BKS_T) void k_bk_scan(BucketHdr* __restrict__ h, size_t cs, bool emit, uint32_t capacity,
                                                   uint32_t* __restrict__ l_eff, uint32_t* __restrict__ count_host) {
     __shared__ uint32_t wsum[BKS_T / 64], wsum2[BKS_T / 64], s_worst;
+    __shared__ unsigned long long s_total64;      // the instance count in 64 bits: a 32-bit total that wrapped must not pass the capacity test
     h = seg(h, cs); l_eff = seg(l_eff, cs);
     const unsigned t = threadIdx.x, lane = t & 63, w = t >> 6;
     const uint32_t nbk = h->nbk, per = nbk / BKS_T;                   // nbk is a multiple of 1024: `per` consecutive buckets per thread
     uint32_t mine = 0, worst = 0, mine_w = 0;
-    if (t == 0) s_worst = 0u;
+    if (t == 0) { s_worst = 0u; s_total64 = 0ull; }
     for (uint32_t k = 0; k < per; ++k) {
         const uint32_t c = h->count[t * per + k];
         mine += c;
@@ -696,6 +697,13 @@ __global__ __launch_bounds__(BKS_T) void k_bk_scan(BucketHdr* __restrict__ h, si
     }
     const uint32_t incl = wave_incl_scan_u32(mine);
     const uint32_t incl_w = emit ? wave_incl_scan_u32(mine_w) : 0u;
+    __syncthreads();                                              // (s_total64 zeroed)
+    if (emit) {
+        unsigned long long m64 = 0ull;
+        for (uint32_t k = 0; k < per; ++k) m64 += h->wstart[t * per + k];
+        m64 = wave_sum(m64);
+        if (lane == 0) atomicAdd(&s_total64, m64);
+    }
     if (lane == 63) { wsum[w] = incl; wsum2[w] = incl_w; }
     __syncthreads();
     uint32_t woff = 0, total = 0, woff_w = 0, total_w = 0;
@@ -717,10 +725,12 @@ __global__ __launch_bounds__(BKS_T) void k_bk_scan(BucketHdr* __restrict__ h, si
         if (t == 0) {
             const uint32_t unsorted = s_worst;                    // a bucket beyond its room: the camera is not sorted
             h->wstart[nbk] = total_w;
-            l_eff[0] = (total_w <= capacity && !unsorted) ? total_w : 0u;
+            const unsigned long long total64 = s_total64;
+            l_eff[0] = (total64 <= (unsigned long long)capacity && !unsorted) ? total_w : 0u;
             if (count_host) {
                 count_host += 4 * blockIdx.y;
-                count_host[0] = total_w; count_host[1] = unsorted; count_host[2] = 0u;   // ([2] is raised by k_tile_gate later)
+                count_host[0] = total64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : total_w;      // (saturated: "does not fit", whatever the capacity)
+                count_host[1] = unsorted; count_host[2] = 0u;                          // ([2] is raised by k_tile_gate later)
             }
         }
     }
