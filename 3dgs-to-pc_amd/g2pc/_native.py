@@ -80,6 +80,7 @@ _EXPERIMENT_PROTOS = {
     "g2pc_set_depth_sort": (C.c_int, [C.c_int]),
     "g2pc_set_blend_variant": (C.c_int, [C.c_int]),
     "g2pc_debug_set_walk_cap": (C.c_int, [C.c_int]),
+    "g2pc_debug_stream_create_cu_mask": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
 }
 
 

@@ -19,5 +19,15 @@ int g2pc_debug_set_walk_cap(int batches) { g2pc::g_knobs.walk_cap = batches > 0 
 int g2pc_set_blend_variant(int variant) { g2pc::g_knobs.blend_variant = variant; return G2PC_OK; }
 /* depth order of the capture-safe camera call: 1 = bucket sort (the product's), 0 = 4-pass radix.  Identical results. */
 int g2pc_set_depth_sort(int bucket) { g2pc::g_knobs.depth_bucket_sort = bucket ? 1 : 0; return G2PC_OK; }
+/* a HIP stream restricted to the CUs of `mask` (bit i of word i / 32 = CU i; hipExtStreamCreateWithCUMask): the experiment
+ * "heads and blends on disjoint CUs" of DESIGN.md §5.3 (the emulator has no such thing: a plain handle) */
+int g2pc_debug_stream_create_cu_mask(const uint32_t* mask, uint32_t words, void** stream) {
+    if (!mask || !words || !stream) return G2PC_ERR_ARG;
+    hipStream_t s = nullptr;
+    hipError_t e = hipExtStreamCreateWithCUMask(&s, words, mask);
+    if (e != hipSuccess) { g2pc::set_error("stream_create_cu_mask", hipGetErrorString(e)); return G2PC_ERR_LAUNCH; }
+    *stream = (void*)s;
+    return G2PC_OK;
+}
 }
 #pragma GCC visibility pop

@@ -399,6 +399,15 @@ def _child_levels(W, H, parents, seq_next, device):
     return hit
 
 
+STREAM_FACTORY = None             # experiments only (bench.py --cu-mask-heads): callable(device, kind) -> torch stream, kind "head" / "blend"
+
+
+def _new_stream(device, kind, priority=0):
+    if STREAM_FACTORY is not None:
+        return STREAM_FACTORY(device, kind)
+    return torch.cuda.Stream(device, priority=priority)
+
+
 class _GraphSlot:
     """One in-flight camera of the capture-and-replay pipeline."""
 
@@ -407,7 +416,7 @@ class _GraphSlot:
         self.batch = int(batch)
         # (slots may share a stream: PIPELINE_SLOTS_PER_STREAM)
         self.stream = stream if stream is not None else (
-            torch.cuda.Stream(device, priority=-1 if PIPELINE_MODE.startswith("split") else 0) if on_gpu else None)
+            _new_stream(device, "head", priority=-1 if PIPELINE_MODE.startswith("split") else 0) if on_gpu else None)
         self.stream_ptr = C.c_void_p(self.stream.cuda_stream) if on_gpu else C.c_void_p(1)   # the emulator ignores streams
         nbytes = C.sizeof(_Job) * self.batch
         self.job_host = torch.zeros((nbytes,), dtype=torch.uint8)
@@ -465,7 +474,7 @@ class _RenderContext:
 
     def blend_stream(self, device, index=0):
         while len(self._blend_streams) <= index:
-            self._blend_streams.append(torch.cuda.Stream(device))
+            self._blend_streams.append(_new_stream(device, "blend"))
         return self._blend_streams[index]
 
     def release(self):

@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--blend-variant", type=int, default=None, choices=[None, 0, 1, 2, 3, 4, 5, 6], help="tuning aid: 2 / 3 = two-wave (unroll 4 / 2) dual-list kernel (one wave per sub-block), 1 = dual-list blend kernel, 0 = packed kernel")
     ap.add_argument("--depth-sort", default=None, choices=[None, "bucket", "radix"], help="tuning aid: depth order of the captured camera path")
     ap.add_argument("--streams", type=int, default=0, help="tuning aid: camera batches in flight (HIP streams) of the renderer")
+    ap.add_argument("--cu-mask-heads", type=int, default=0, help="EXPERIMENT (libg2pc_exp.so, split pipeline modes): head streams on the first K CUs, blend streams on the other 256 - K")
     ap.add_argument("--cu-unfused", action="store_true", help="A/B aid (render_cuda): pipelined cameras through g2pc_raster_front_cu + g2pc_raster_back_cu_dev (round 4) instead of g2pc_raster_camera_cu")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the untimed region / kernel profile passes after the timed loop")
     ap.add_argument("--pipeline-mode", default=None, choices=[None, "chain", "split", "split_multi"], help="tuning aid: see gauss_render.PIPELINE_MODE")
@@ -524,6 +525,18 @@ def main():
         gauss_render.PIPELINE_STREAMS = a.streams
         import gaussian_pointcloud_rasterization as _gpr
         _gpr.PIPELINE_STREAMS = a.streams
+    if a.cu_mask_heads:
+        import ctypes as _C
+        import torch as _t
+        K, _L = int(a.cu_mask_heads), nv.experiments()
+
+        def _masked(device, kind, K=K):
+            bits = [(i < K) if kind == "head" else (i >= K) for i in range(256)]
+            words = (_C.c_uint32 * 8)(*[sum(1 << b for b in range(32) if bits[32 * w + b]) for w in range(8)])
+            st = _C.c_void_p(None)
+            nv.check(_L.g2pc_debug_stream_create_cu_mask(words, 8, _C.byref(st)), "stream_create_cu_mask")
+            return _t.cuda.ExternalStream(st.value, device=device)
+        gauss_render.STREAM_FACTORY = _masked
     if a.cu_unfused:
         import gaussian_pointcloud_rasterization as _gpr2
         _gpr2.FUSED_CAMERA_CALL = False

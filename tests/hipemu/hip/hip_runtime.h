@@ -76,6 +76,7 @@ enum hipStreamCaptureStatus { hipStreamCaptureStatusNone = 0, hipStreamCaptureSt
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { hipemu::submit([=]() { memset(p, v, n); }); return 0; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { hipemu::submit([=]() { memcpy(d, s, n); }); return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+static inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s, uint32_t, const uint32_t*) { *s = nullptr; return 0; }   // (no CUs to mask here)
 static inline hipError_t hipStreamBeginCapture(hipStream_t, int) { hipemu::capturing() = new hipemu::Graph(); return 0; }
 static inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = hipemu::capturing(); hipemu::capturing() = nullptr; return 0; }
 static inline hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* st) { *st = hipemu::capturing() ? hipStreamCaptureStatusActive : hipStreamCaptureStatusNone; return 0; }
