@@ -8,8 +8,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path[:0] = [os.path.join(ROOT, 'tests'), os.path.join(ROOT, '3dgs-to-pc_amd'), os.path.join(ROOT, 'oracle')]
 import numpy as np, torch
 from g2pc import _native as nv
-from emu_util import build_emu
-nv._inject_for_tests(build_emu())
+GPU = "gpu" in sys.argv[3:]                   # gpu: the real library on cuda:0 (GPU box), the oracle on the host
+if not GPU:
+    from emu_util import build_emu
+    nv._inject_for_tests(build_emu())
 import mesh_handler, ref_clean
 rng = np.random.default_rng(int(sys.argv[1]))
 bad = 0
@@ -25,7 +27,7 @@ for it in range(int(sys.argv[2])):
     pts = pts.astype(np.float32)
     t = time.time()
     try:
-        avg = mesh_handler.knn_mean_distance(torch.from_numpy(pts), k).numpy()
+        avg = mesh_handler.knn_mean_distance(torch.from_numpy(pts).to('cuda:0' if GPU else 'cpu'), k).cpu().numpy()
         ref = ref_clean.knn_mean_distance(pts, k)
         ok = avg.shape == ref.shape and np.allclose(avg, ref, rtol=1e-12, atol=1e-300, equal_nan=True)
     except Exception as e:
