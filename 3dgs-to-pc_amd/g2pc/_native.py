@@ -17,7 +17,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libg2pc.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _LIB: Optional[C.CDLL] = None
 _EMULATED = False

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_cu(Cam cam, int grid_x, int
                                                        float3 campos, long n, uint32_t* __restrict__ depth_key,
                                                        uint32_t* __restrict__ index, uint32_t* __restrict__ tiles_touched,
                                                        float4* __restrict__ rec, uint32_t* __restrict__ rect,
-                                                       int32_t* __restrict__ radii, int wide) {
+                                                       int32_t* __restrict__ radii, int wide, int antialiasing) {
 #pragma clang fp contract(off)
     long i = (long)blockIdx.x * RA_T + threadIdx.x;
     if (i >= n) return;
@@ -71,10 +71,15 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_cu(Cam cam, int grid_x, int
             a0[k] = T0[0] * S[k][0] + T0[1] * S[k][1] + T0[2] * S[k][2];
             a1[k] = T1[0] * S[k][0] + T1[1] * S[k][1] + T1[2] * S[k][2];
         }
-        float cxx = a0[0] * T0[0] + a0[1] * T0[1] + a0[2] * T0[2] + 0.3f;
+        float cxx = a0[0] * T0[0] + a0[1] * T0[1] + a0[2] * T0[2];
         float cxy = a1[0] * T0[0] + a1[1] * T0[1] + a1[2] * T0[2];
-        float cyy = a1[0] * T1[0] + a1[1] * T1[1] + a1[2] * T1[2] + 0.3f;
+        float cyy = a1[0] * T1[0] + a1[1] * T1[1] + a1[2] * T1[2];
+        const float det_cov = cxx * cyy - cxy * cxy;                    // forward.cu:217-225: before the 0.3-pixel dilation
+        cxx += 0.3f;
+        cyy += 0.3f;
         float det = cxx * cyy - cxy * cxy;
+        // antialiasing (forward.cu:224-225,264): the opacity is scaled by sqrt(max(0.000025, det(cov) / det(cov + 0.3 I)))
+        const float h_scale = antialiasing ? sqrtf(fmaxf(0.000025f, det_cov / det)) : 1.0f;
         if (det != 0.0f) {
             float di = 1.0f / det;
             float kx = cyy * di, ky = -cxy * di, kz = cxx * di;
@@ -102,10 +107,11 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_cu(Cam cam, int grid_x, int
                 const float sc = LOG2E;
                 const float qa = -0.5f * sc * kx, qb = -sc * ky, qc = -0.5f * sc * kz;
                 rec[4 * i + 0] = make_float4(px, py, qa, qb);                           // one 64-byte record per Gaussian,
-                rec[4 * i + 1] = make_float4(qc, opacity[i], tz0, my_radius);           // as on the PY path
+                const float op = antialiasing ? opacity[i] * h_scale : opacity[i];
+                rec[4 * i + 1] = make_float4(qc, op, tz0, my_radius);                    // as on the PY path
                 // per-wave cull of k_blend_cu (rect_may_touch): slopes of the exponent's edge maxima and the exponent below
                 // which alpha < 1/255 (with a 0.7 % margin for the different rounding of the bound)
-                rec[4 * i + 3] = make_float4(-qb / (2.0f * qc), -qb / (2.0f * qa), -8.00435f - log2f(opacity[i]), 0.0f);
+                rec[4 * i + 3] = make_float4(-qb / (2.0f * qc), -qb / (2.0f * qa), -8.00435f - log2f(op), 0.0f);
                 float cr, cg, cb;
                 if (colours_precomp) {
                     cr = colours_precomp[3 * i]; cg = colours_precomp[3 * i + 1]; cb = colours_precomp[3 * i + 2];
@@ -388,6 +394,43 @@ __global__ __launch_bounds__(RA_T) void k_mark_visible(View16 V, const float* __
     present[i] = (V.m[2] * x + V.m[6] * y + V.m[10] * z + V.m[14]) > 0.2f ? 1 : 0;
 }
 
+// computeCov3D (forward.cu:115-150) for g2pc_rasterize_gaussians: Sigma = (S R)^T (S R) with glm's column-major constructors, ACTIVATED
+// scales times scale_modifier, the quaternion as given (its normalisation is commented out there); every operation rounded on
+// its own, sums over k = 0, 1, 2 in order as glm's operator* writes them.
+__global__ __launch_bounds__(RA_T) void k_cov3d_cu(const float* __restrict__ scales, const float* __restrict__ rots, float mod,
+                                                  long n, float* __restrict__ cov6) {
+#pragma clang fp contract(off)
+    long i = (long)blockIdx.x * RA_T + threadIdx.x;
+    if (i >= n) return;
+    const float s[3] = {mod * scales[3 * i], mod * scales[3 * i + 1], mod * scales[3 * i + 2]};
+    const float r = rots[4 * i], x = rots[4 * i + 1], y = rots[4 * i + 2], z = rots[4 * i + 3];
+    const float R[3][3] = {{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},     // R[column][row]
+                           {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
+                           {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}};
+    float M[3][3];                                                          // M = S R: M[column][row] = s[row] R[column][row]
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) M[c][k] = s[k] * R[c][k];
+    auto dot = [&](int a, int b) { return M[a][0] * M[b][0] + M[a][1] * M[b][1] + M[a][2] * M[b][2]; };
+    float* o = cov6 + 6 * i;
+    o[0] = dot(0, 0); o[1] = dot(0, 1); o[2] = dot(0, 2); o[3] = dot(1, 1); o[4] = dot(1, 2); o[5] = dot(2, 2);
+}
+
+// results 9-11 of _C.rasterize_gaussians out of the camera's packed (contribution, ~pixel) keys and surface distances
+__global__ __launch_bounds__(RA_T) void k_unpack_camera_cu(const unsigned long long* __restrict__ cam_key,
+                                                          const uint32_t* __restrict__ cam_surf, long n,
+                                                          float* __restrict__ contrib, float* __restrict__ surf,
+                                                          int32_t* __restrict__ pixels) {
+    long i = (long)blockIdx.x * RA_T + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long key = cam_key[i];
+    const float c = __uint_as_float((uint32_t)(key >> 32));
+    contrib[i] = c;
+    pixels[i] = c > 0.0f ? (int32_t)(~(uint32_t)key) : 0;
+    surf[i] = __uint_as_float(cam_surf[i]);
+}
+
 // per-camera state of the native-semantics blend in one launch: packed (contribution, ~pixel) keys = 0, surface distance = FLT_MAX
 __global__ __launch_bounds__(RA_T) void k_init_camera_state_cu(unsigned long long* __restrict__ cam_key, uint32_t* __restrict__ cam_surf,
                                                               long n) {
@@ -409,11 +452,11 @@ int g2pc_mark_visible(const float* means3D, int64_t n, const float* viewmatrix, 
 }
 
 // CU semantics, front half: preprocess (+SH) -> depth sort (ascending index on ties) -> tiles-touched scan.
-int g2pc_raster_front_cu(const G2pcCamera* cam, const float* means3D, const float* cov6, const float* opacity,
+static int front_cu_impl(const G2pcCamera* cam, const float* means3D, const float* cov6, const float* opacity,
                          const float* colours_precomp, const float* shs, int32_t sh_degree, int32_t sh_coeffs,
                          const float* campos, int64_t n, float* rec, uint32_t* rect, int32_t* radii,
                          uint32_t* sorted_idx, uint32_t* offsets, uint32_t* count_host, void* ws, size_t ws_bytes,
-                         void* stream) {
+                         void* stream, int antialiasing) {
     using namespace g2pc;
     G2PC_REQUIRE(cam && means3D && cov6 && opacity && campos && rec && rect && radii && sorted_idx && offsets && ws && n > 0,
                  G2PC_ERR_ARG, "bad arguments");
@@ -437,13 +480,21 @@ int g2pc_raster_front_cu(const G2pcCamera* cam, const float* means3D, const floa
     G2PC_REQUIRE(ar.ok(), G2PC_ERR_WORKSPACE, "workspace too small");
     hipLaunchKernelGGL(k_preprocess_cu, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, to_cam(cam), gx, gy, means3D, cov6, opacity,
                        colours_precomp, shs, (int)sh_degree, (int)sh_coeffs, make_float3(campos[0], campos[1], campos[2]),
-                       (long)n, key, idx, touched, (float4*)rec, rect, radii, cu_wide_grid(gx, gy) ? 1 : 0);
+                       (long)n, key, idx, touched, (float4*)rec, rect, radii, cu_wide_grid(gx, gy) ? 1 : 0, antialiasing);
     int rc = sort_pairs_u32(key, idx, key_sorted, sorted_idx, ktmp, vtmp, n, 0, 32, sort_ws, sort_bytes, s);
     if (rc) return rc;
     rc = scan_exclusive_u32(touched, offsets, n, scan_ws, scan_bytes, s, sorted_idx);
     if (rc) return rc;
     if (count_host) hipMemcpyAsync(count_host, offsets + n, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
     return check_launch("g2pc_raster_front_cu");
+}
+int g2pc_raster_front_cu(const G2pcCamera* cam, const float* means3D, const float* cov6, const float* opacity,
+                         const float* colours_precomp, const float* shs, int32_t sh_degree, int32_t sh_coeffs,
+                         const float* campos, int64_t n, float* rec, uint32_t* rect, int32_t* radii,
+                         uint32_t* sorted_idx, uint32_t* offsets, uint32_t* count_host, void* ws, size_t ws_bytes,
+                         void* stream) {
+    return front_cu_impl(cam, means3D, cov6, opacity, colours_precomp, shs, sh_degree, sh_coeffs, campos, n, rec, rect, radii,
+                         sorted_idx, offsets, count_host, ws, ws_bytes, stream, 0);
 }
 
 // CU semantics, back half: duplicate -> tile sort -> ranges -> blend -> running-state update.
@@ -457,7 +508,8 @@ int g2pc_raster_back_cu_tiles(const G2pcCamera* cam, const int32_t* mask, int64_
                         int phases, int32_t tile_first, int32_t tile_step, void* ws, size_t ws_bytes, void* stream) {
     using namespace g2pc;
     G2PC_REQUIRE(cam && rec && rect && sorted_idx && offsets && cam_key && cam_surf && out_color &&
-                     out_depth && out_invdepth && max_contrib && total_contrib && colours && min_surf && ws && n > 0,
+                     out_depth && out_invdepth && ws && n > 0 &&
+                     (!(phases & 4) || (max_contrib && total_contrib && colours && min_surf)),
                  G2PC_ERR_ARG, "bad arguments");
     const int W = cam->width, H = cam->height;
     const int gx = (W + 15) / 16, gy = (H + 15) / 16, T = gx * gy;
@@ -628,7 +680,7 @@ int g2pc_raster_camera_cu(const G2pcCamera* cam, const float* means3D, const flo
     const uint32_t gmask = gshift ? ((1u << gshift) - 1u) : 0xFFFFFFFFu;
     hipLaunchKernelGGL(k_preprocess_cu, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, to_cam(cam), gx, gy, means3D, cov6, opacity,
                        colours_precomp, shs, (int)sh_degree, (int)sh_coeffs, make_float3(campos[0], campos[1], campos[2]),
-                       (long)n, key, idx, (uint32_t*)nullptr /* counts = rect areas */, (float4*)rec, rect, radii, 0);
+                       (long)n, key, idx, (uint32_t*)nullptr /* counts = rect areas */, (float4*)rec, rect, radii, 0, 0 /* antialiasing: g2pc_rasterize_gaussians only */);
     BucketEmit em{};
     em.weight = nullptr; em.rect = rect; em.inst_tile = inst_tile; em.inst_g = inst_g; em.gshift = gshift; em.nx = gx;
     em.capacity = (uint32_t)capacity; em.l_eff = l_eff; em.count_host = count_host;
@@ -665,5 +717,86 @@ int g2pc_raster_back_cu(const G2pcCamera* cam, const int32_t* mask, int64_t n, i
                                      cam_key, cam_surf, out_color, out_depth, out_invdepth, max_contrib, total_contrib, colours,
                                      min_surf, winner_cam, cam_index, cur_contrib, cur_pixels, cur_surf, phases, 0, 1, ws,
                                      ws_bytes, stream);
+}
+// _C.rasterize_gaussians (rasterize_points.h:18-41, rasterize_points.cu:36-145 -> CudaRasterizer::Rasterizer::forward,
+// rasterizer_impl.cu:197-352): include/g2pc.h, ABI 7.
+int g2pc_rasterize_gaussians(const G2pcRasterizeArgs* a, const G2pcRasterizeOut* o, int32_t* num_rendered,
+                             G2pcResizeFn geometry_buffer, void* geometry_user, G2pcResizeFn binning_buffer, void* binning_user,
+                             G2pcResizeFn image_buffer, void* image_user, void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(a && o && num_rendered && geometry_buffer && binning_buffer && image_buffer, G2PC_ERR_ARG, "bad arguments");
+    const int64_t P = a->P;
+    const int W = a->image_width, H = a->image_height;
+    G2PC_REQUIRE(P >= 0 && W > 0 && H > 0, G2PC_ERR_ARG, "bad sizes");
+    G2PC_REQUIRE(o->out_color && o->out_depth && o->out_invdepth, G2PC_ERR_ARG, "missing image outputs");
+    hipStream_t s = (hipStream_t)stream;
+    *num_rendered = 0;
+    if (P == 0) {                                  // rasterize_points.cu:101: nothing is launched, the images stay zero
+        hipMemsetAsync(o->out_color, 0, (size_t)3 * W * H * 4, s);
+        hipMemsetAsync(o->out_depth, 0, (size_t)W * H * 4, s);
+        hipMemsetAsync(o->out_invdepth, 0, (size_t)W * H * 4, s);
+        return check_launch("g2pc_rasterize_gaussians");
+    }
+    G2PC_REQUIRE(a->background && a->means3D && a->opacity && a->viewmatrix && a->projmatrix && a->campos && o->radii &&
+                     o->gauss_contributions && o->gauss_surface_distances && o->gauss_pixels,
+                 G2PC_ERR_ARG, "bad arguments");
+    // rasterizer_impl.cu:249-252 ("For non-RGB, provide precomputed Gaussian colors!") and the binding's exactly-one-of rules
+    G2PC_REQUIRE((a->colors != nullptr) != (a->sh != nullptr), G2PC_ERR_ARG, "provide exactly one of precomputed colours or SHs");
+    const bool own_cov = a->cov3D_precomp == nullptr;
+    G2PC_REQUIRE(own_cov ? (a->scales && a->rotations) : (!a->scales && !a->rotations), G2PC_ERR_ARG,
+                 "provide exactly one of a scale / rotation pair or precomputed 3D covariances");
+    G2pcCamera cam{};
+    for (int i = 0; i < 16; ++i) { cam.view[i] = a->viewmatrix[i]; cam.proj[i] = a->projmatrix[i]; }
+    cam.tan_fovx = a->tan_fovx; cam.tan_fovy = a->tan_fovy; cam.width = W; cam.height = H;
+    cam.bg[0] = a->background[0]; cam.bg[1] = a->background[1]; cam.bg[2] = a->background[2];
+    const int gx = (W + 15) / 16, gy = (H + 15) / 16, T = gx * gy;
+    // geometry buffer: blend records, tile rectangles, depth order, instance offsets, own covariances, the front half's scratch
+    const size_t front_bytes = g2pc_raster_front_workspace(P);
+    const size_t geom_bytes = align_up((size_t)P * 64) + align_up((size_t)P * 8) + align_up((size_t)P * 4) + align_up((size_t)(P + 1) * 4) +
+                              (own_cov ? align_up((size_t)P * 24) : 0) + align_up(front_bytes) + 256;
+    void* geom = geometry_buffer(geometry_user, geom_bytes);
+    G2PC_REQUIRE(geom, G2PC_ERR_WORKSPACE, "the geometry buffer callback returned no memory");
+    Arena ga(geom, geom_bytes);
+    float* rec = ga.get<float>((size_t)P * 16);
+    uint32_t* rect = ga.get<uint32_t>((size_t)P * 2);
+    uint32_t* sorted_idx = ga.get<uint32_t>((size_t)P);
+    uint32_t* offsets = ga.get<uint32_t>((size_t)P + 1);
+    float* cov6 = own_cov ? ga.get<float>((size_t)P * 6) : nullptr;
+    char* front_ws = ga.get<char>(front_bytes);
+    G2PC_REQUIRE(ga.ok(), G2PC_ERR_WORKSPACE, "geometry buffer too small");
+    // image buffer: this camera's per-Gaussian visibility state (packed (contribution, ~pixel) keys, surface distances)
+    const size_t img_bytes = align_up((size_t)P * 8) + align_up((size_t)P * 4) + 256;
+    void* img = image_buffer(image_user, img_bytes);
+    G2PC_REQUIRE(img, G2PC_ERR_WORKSPACE, "the image buffer callback returned no memory");
+    Arena ia(img, img_bytes);
+    unsigned long long* cam_key = ia.get<unsigned long long>((size_t)P);
+    uint32_t* cam_surf = ia.get<uint32_t>((size_t)P);
+    if (own_cov)
+        hipLaunchKernelGGL(k_cov3d_cu, dim3(cdiv(P, RA_T)), dim3(RA_T), 0, s, a->scales, a->rotations, a->scale_modifier, (long)P, cov6);
+    int rc = front_cu_impl(&cam, a->means3D, own_cov ? cov6 : a->cov3D_precomp, a->opacity, a->colors, a->sh, a->sh ? a->degree : 0,
+                           a->sh ? a->M : 0, a->campos, P, rec, rect, o->radii, sorted_idx, offsets, nullptr, front_ws, front_bytes,
+                           stream, a->antialiasing ? 1 : 0);
+    if (rc) return rc;
+    uint32_t L = 0;                                    // rasterizer_impl.cu:289: the one blocking read-back
+    if (hipMemcpyAsync(&L, offsets + P, sizeof(uint32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) {
+        set_error(__func__, "reading the instance count back failed");
+        return G2PC_ERR_LAUNCH;
+    }
+    *num_rendered = (int32_t)L;
+    const size_t bin_bytes = g2pc_raster_back_workspace((int64_t)L, T);
+    void* bin = binning_buffer(binning_user, bin_bytes);
+    G2PC_REQUIRE(bin, G2PC_ERR_WORKSPACE, "the binning buffer callback returned no memory");
+    rc = g2pc_raster_back_cu_tiles(&cam, a->mask, P, (int64_t)L, rec, rect, sorted_idx, offsets, a->calculate_surface_distance ? 1 : 0,
+                                   cam_key, cam_surf, o->out_color, o->out_depth, o->out_invdepth, nullptr, nullptr, nullptr, nullptr,
+                                   nullptr, 0, nullptr, nullptr, nullptr, 3, 0, 1, bin, bin_bytes, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_unpack_camera_cu, dim3(cdiv(P, RA_T)), dim3(RA_T), 0, s, cam_key, cam_surf, (long)P, o->gauss_contributions,
+                       o->gauss_surface_distances, o->gauss_pixels);
+    if (a->debug && hipStreamSynchronize(s) != hipSuccess) {           // CHECK_CUDA(..., debug), auxiliary.h:178-185
+        set_error(__func__, "a kernel of the rasterisation failed (debug)");
+        return G2PC_ERR_LAUNCH;
+    }
+    return check_launch("g2pc_rasterize_gaussians");
 }
 }

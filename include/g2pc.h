@@ -26,7 +26,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define G2PC_ABI_VERSION 6
+#define G2PC_ABI_VERSION 7
 #define G2PC_TILE_PARENTS 4       /* entries per tile of G2pcTileLayout.tile_parent */
 
 #define G2PC_OK 0
@@ -501,6 +501,64 @@ int g2pc_raster_back_cu_dev(const G2pcCamera* cam, const int32_t* mask, int64_t 
                             int calculate_surface_distance, unsigned long long* cam_key, uint32_t* cam_surf, float* out_color,
                             float* out_depth, float* out_invdepth, uint32_t* count_host, int32_t tile_first, int32_t tile_step,
                             void* ws, size_t ws_bytes, void* stream);
+
+/* --- ABI 7: the reference's native entry point itself ---------------------------------------------------------------------
+ * _C.rasterize_gaussians (gaussian-pointcloud-rasterization/rasterize_points.h:18-41, rasterize_points.cu:36-145, bound at
+ * ext.cpp:15-18): the same 22 arguments in the same order, the same 11 results.  The reference's UNMODIFIED binding
+ * gaussian_pointcloud_rasterization/__init__.py:90-158 runs on it through the ctypes module
+ * 3dgs-to-pc_amd/gaussian_pointcloud_rasterization/_C.py.
+ *   - tensors the reference signals as absent by an EMPTY tensor (colors, scales, rotations, cov3D_precomp, sh; forward.cu:204,251
+ *     test their data pointers) are NULL here; exactly one of (colors, sh) and of (cov3D_precomp, scales + rotations);
+ *   - background f32[3], viewmatrix f32[16], projmatrix f32[16] (the FULL projection, view @ proj), campos f32[3] are HOST
+ *     arrays (16 + 16 + 6 floats that become kernel arguments); everything else is a device pointer;
+ *   - scales are ACTIVATED (not log-space) and the quaternion is used as given: computeCov3D, forward.cu:115-150, evaluated
+ *     operation by operation (no contraction) -- bit for bit what oracle/_ref computes from the same inputs;
+ *   - antialiasing multiplies the opacity by sqrt(max(0.000025, det(cov) / det(cov + 0.3 I))) (forward.cu:217-225,264);
+ *   - prefiltered is accepted and ignored: the reference traps the DEVICE when a Gaussian fails the frustum test although
+ *     `prefiltered` was set (auxiliary.h:168-172); this library culls such a Gaussian as it does without the flag;
+ *   - debug != 0: the stream is synchronised before returning and a failed launch is reported (the reference's CHECK_CUDA,
+ *     auxiliary.h:178-185);
+ *   - scratch: the reference grows three byte tensors through std::function<char*(size_t)> callbacks (rasterizer.h:32-34,
+ *     rasterize_points.cu:25-34) and returns them; here the three G2pcResizeFn play that role -- each is called exactly once per
+ *     rasterisation with the bytes needed (geometry: per-Gaussian state incl. the per-camera visibility keys; binning: instances
+ *     and sort space, sized from num_rendered; image: tile ranges) and must return device memory of at least that size that
+ *     stays valid until the work queued on `stream` has run;
+ *   - like the reference (rasterizer_impl.cu:289) the call blocks ONCE on the host, to read the instance count between its
+ *     halves -- the only entry point of this header that synchronises (the pipelined production path is g2pc_raster_camera_cu).
+ * Outputs (device, caller-allocated; rasterize_points.cu:73-93 gives their shapes and initial values, which are written here):
+ * out_color f32[3,H,W], out_depth f32[1,H,W], radii i32[P], out_invdepth f32[1,H,W], gauss_contributions f32[P] (0 where never
+ * blended), gauss_surface_distances f32[P] (FLT_MAX where not measured), gauss_pixels i32[P] (0 where never blended);
+ * *num_rendered = number of (tile, Gaussian) instances.  P == 0: the images are zero-filled, nothing else happens. */
+typedef void* (*G2pcResizeFn)(void* user, size_t bytes);
+typedef struct G2pcRasterizeArgs {      /* rasterize_points.h:18-41, argument for argument */
+    const float* background;            /* HOST f32[3] */
+    const float* means3D;               /* f32[P,3] */
+    const float* colors;                /* f32[P,3] or NULL */
+    const float* opacity;               /* f32[P] (the reference passes [P,1]) */
+    const float* scales;                /* f32[P,3] or NULL */
+    const float* rotations;             /* f32[P,4] or NULL */
+    float scale_modifier;
+    const float* cov3D_precomp;         /* f32[P,6] or NULL */
+    const float* viewmatrix;            /* HOST f32[16], as torch stores the [4,4] tensor (row-major = glm column-major) */
+    const float* projmatrix;            /* HOST f32[16] */
+    float tan_fovx, tan_fovy;
+    int32_t image_height, image_width;
+    const float* sh;                    /* f32[P,M,3] or NULL */
+    int32_t degree;
+    const float* campos;                /* HOST f32[3] */
+    const int32_t* mask;                /* i32[H*W], 0 = skip the pixel; NULL = all ones (the binding's default, __init__.py:95-98) */
+    int32_t prefiltered, antialiasing, calculate_surface_distance, debug;
+    /* sizes torch tensors carry themselves */
+    int64_t P;                          /* means3D.size(0) */
+    int32_t M;                          /* sh.size(1), 0 without SHs */
+} G2pcRasterizeArgs;
+typedef struct G2pcRasterizeOut {       /* results 2-4 and 8-11 of the reference's tuple (1 = *num_rendered, 5-7 = the buffers) */
+    float* out_color; float* out_depth; int32_t* radii; float* out_invdepth;
+    float* gauss_contributions; float* gauss_surface_distances; int32_t* gauss_pixels;
+} G2pcRasterizeOut;
+int g2pc_rasterize_gaussians(const G2pcRasterizeArgs* args, const G2pcRasterizeOut* out, int32_t* num_rendered,
+                             G2pcResizeFn geometry_buffer, void* geometry_user, G2pcResizeFn binning_buffer, void* binning_user,
+                             G2pcResizeFn image_buffer, void* image_user, void* stream);
 
 /* Multi-GPU exchange of the python-semantics state (cameras sharded over ranks): all-reduce MAX of best_key, then
  * g2pc_raster_key_owner (owner[i] = rank where this rank holds the winning key, INT32_MAX elsewhere), all-reduce MIN of

@@ -5,7 +5,7 @@ Runs the UNTOUCHED reference (/root/reference, python renderer + sampler) on CPU
 oracle/ref_shim.py on seeded synthetic inputs and stores inputs' seeds + the reference's outputs.
 /root/reference only exists in the authoring container; the fixtures travel, this script is the
 committed provenance.  Usage:   python oracle/make_golden.py [geom] [sampler] [render] [pipeline]
-                                                         [helpers] [render_big] [render_mini] [render_split]
+                                                         [helpers] [render_big] [render_mini] [render_split] [render_all]
 (render_split: scenes whose leaves exceed max_gaussians_per_tile -- the reference's count-driven quad-tree split.)
 """
 import json
@@ -456,6 +456,99 @@ def gen_render_big(ref, tag="1m", n=1_000_000, num_points=10_000_000, width=1280
           "s/camera", secs)
 
 
+def gen_render_all(ref, tag="1m_all50", n=1_000_000, num_points=10_000_000, width=1280, height=720, focal=1100.0, rig=50):
+    """BASELINE configs[2] IN FULL: the bench scene, ALL `rig` cameras of the rig in the order convert_3dgs_to_pc walks them
+    (gauss_to_pc.py:437-454), untouched reference python renderer on CPU under the stable tie rule, then the reference's own
+    tail (gauss_to_pc.py:481-513): colours -> visible cull -> filter -> validate -> magnitudes(contributions) ->
+    distribute_points -> generate_pointcloud with keyed noise.  ~1 h of container CPU.  Everything is first dumped raw into the
+    git-ignored oracle/_build/ (so the compact fixture can be re-cut without another hour), then cut by `cut_render_all`."""
+    import time
+    gh, gr, ch, g2p = (ref[k] for k in ("gauss_handler", "gauss_render", "camera_handler", "gauss_to_pc"))
+    seed = 1234 + 3
+    sc = make_scene(n, seed)
+    transforms, intr = make_cameras(rig, width=width, height=height, focal=focal)
+    names = sorted(transforms)
+    raw = dict(n=n, seed=seed, rig=rig, width=width, height=height, focal=focal, num_points=num_points)
+    with CudaToCpu():
+        G = gh.Gaussians(sc.xyz.clone(), sc.scales.clone(), sc.rots.clone(), sc.colours.double(), sc.opacities.clone())
+        with stable_depth_ties():
+            R = gr.get_renderer("python", G.xyz, torch.unsqueeze(torch.clone(G.opacities), 1), G.colours, G.covariances,
+                                visible_gaussian_threshold=0.05)
+            secs = []
+            prev = np.zeros(n, dtype=np.float32)
+            winner = np.full(n, 255, dtype=np.uint8)
+            for ci, name in enumerate(names):
+                cam = ch.get_camera("python", torch.tensor(transforms[name]), intr[name], colour_resolution=width)
+                t0 = time.perf_counter()
+                img, _, _, _ = R(cam)
+                secs.append(time.perf_counter() - t0)
+                cur = _np(R.gaussian_max_contribution).copy()
+                winner[cur > prev] = ci                  # strict > : the camera whose render last raised the running maximum
+                prev = cur
+                raw["cam%d_view" % ci] = _np(cam.world_view_transform).astype(np.float32)
+                raw["cam%d_proj" % ci] = _np(cam.projection_matrix).astype(np.float32)
+                raw["cam%d_fov_focal" % ci] = np.array([cam.FoVx, cam.FoVy, cam.focal_x, cam.focal_y], dtype=np.float64)
+                raw["cam%d_image_s8" % ci] = _np(img).astype(np.float32)[::8, ::8].copy()
+                raw["cam%d_contrib_s16" % ci] = cur[::16].copy()
+                print("render_all: camera %d in %.1f s" % (ci, secs[-1]), flush=True)
+        colours = _np(R.get_gaussian_colours())
+        visible = _np(R.get_visible_gaussians())
+        c9 = _np(G.covariances).reshape(n, 9)
+        raw.update(contrib_final=prev, winner_cam=winner, colours=colours.astype(np.float32), visible=visible,
+                   cov3d_hash8=k1_hash8(*[c9[:, j] for j in (0, 1, 2, 4, 5, 8)]), seconds_per_camera=np.array(secs),
+                   threads=torch.get_num_threads())
+        G.colours = R.get_gaussian_colours()
+        G.add_gaussians_to_cull(R.get_visible_gaussians())
+        G.apply_min_opacity(0.0)
+        G.apply_bounding_box(None, None)
+        culled = G.filter_gaussians()
+        contrib = R.get_total_gaussian_contributions()[culled]
+        keep = G.validate_covariances()
+        contrib = contrib[keep]
+        mags = G.get_gaussian_magnitudes(contrib)
+        ppg = g2p.distribute_points(mags, num_points)
+        noise_seed = 4242
+        t0 = time.perf_counter()
+        with KeyedNoise(g2p, G.xyz, noise_seed):
+            pts, cols, nrms = g2p.generate_pointcloud(
+                G, num_points, exact_num_points=False, mahalanobis_distance_std=2.0, calculate_normals=False,
+                num_sample_attempts=5, contributions=contrib, device="cpu", quiet=True)
+        raw.update(culled=_np(culled), keep=_np(keep), kept_contrib=_np(contrib).astype(np.float32),
+                   kept_colours=_np(G.colours).astype(np.float32), kept_mags=_np(mags).astype(np.float64),
+                   ppg=_np(ppg).astype(np.float64), noise_seed=noise_seed, m=pts.shape[0],
+                   sample_seconds=time.perf_counter() - t0, points_s64=_np(pts)[::64].copy(),
+                   colours_s64=_np(cols)[::64].astype(np.float32))
+        print("render_all: sampler %d points in %.1f s" % (pts.shape[0], raw["sample_seconds"]), flush=True)
+    os.makedirs(os.path.join(HERE, "_build"), exist_ok=True)
+    np.savez(os.path.join(HERE, "_build", "raw_render_%s.npz" % tag), **raw)
+    cut_render_all(tag)
+
+
+def cut_render_all(tag="1m_all50"):
+    """Cuts tests/golden/render_py_cfg2_<tag>.npz from the raw dump of gen_render_all: masks, winner camera and point quotas for
+    every Gaussian; final contributions at every 4th, colours at every 16th; per camera the reference's matrices, every 16th pixel
+    (x and y) of its image and the running maximum after it at every 64th Gaussian; every 256th row of the cloud."""
+    raw = np.load(os.path.join(HERE, "_build", "raw_render_%s.npz" % tag))
+    n, rig = int(raw["n"]), int(raw["rig"])
+    assert float(raw["ppg"].max()) < 65535
+    out = {k: raw[k] for k in ("n", "seed", "rig", "width", "height", "focal", "num_points", "seconds_per_camera", "threads",
+                               "noise_seed", "m", "sample_seconds", "winner_cam", "cov3d_hash8", "kept_contrib")}
+    out.update(tie_rule="stable", contrib_stride=4, contrib_final=raw["contrib_final"][::4].copy(),
+               colours_s16=raw["colours"][::16].copy(), visible_bits=np.packbits(raw["visible"]),
+               culled_bits=np.packbits(raw["culled"]), keep_bits=np.packbits(raw["keep"]),
+               ppg_u16=raw["ppg"].astype(np.uint16), ppg_sum=float(raw["ppg"].sum()),
+               kept_colours_u8x=np.round(raw["kept_colours"]).astype(np.float32)[::16].copy(),
+               row_stride=256, points_s256=raw["points_s64"][::4].copy(), colours_s256=raw["colours_s64"][::4].copy(),
+               cam_view=np.stack([raw["cam%d_view" % c] for c in range(rig)]),
+               cam_proj=np.stack([raw["cam%d_proj" % c] for c in range(rig)]),
+               cam_fov_focal=np.stack([raw["cam%d_fov_focal" % c] for c in range(rig)]),
+               images_s16=np.stack([raw["cam%d_image_s8" % c][::2, ::2] for c in range(rig)]),
+               contrib_after_cam_s64=np.stack([raw["cam%d_contrib_s16" % c][::4] for c in range(rig)]))
+    np.savez_compressed(os.path.join(GOLD, "render_py_cfg2_%s.npz" % tag), **out)
+    print("render_all: visible", int(raw["visible"].sum()), "kept", int(raw["keep"].sum()), "ppg sum", float(raw["ppg"].sum()),
+          "points", int(raw["m"]), "fixture bytes", os.path.getsize(os.path.join(GOLD, "render_py_cfg2_%s.npz" % tag)))
+
+
 def gen_helpers(ref):
     """The reference's public helper functions on seeded inputs: eval_sh (degrees 0..4), build_covariance_2d,
     projection_ndc, get_radius, get_rect (gauss_render.py:43-193); mahalanobis (gauss_to_pc.py:92-103); and a
@@ -522,7 +615,10 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["geom", "sampler", "render", "pipeline"]
     for w in which:
         {"geom": gen_geom, "sampler": gen_sampler, "render": gen_render, "pipeline": gen_pipeline,
-         "render_big": gen_render_big, "helpers": gen_helpers, "render_split": gen_render_split,
+         "render_big": gen_render_big, "helpers": gen_helpers, "render_all": gen_render_all,
+         "cut_render_all": lambda r: cut_render_all(),
+         # a rehearsal of render_all at a size that takes a minute (checks the generator and the checker)
+         "render_all_mini": lambda r: gen_render_all(r, "mini_all6", 4000, 40_000, 320, 180, 275.0, rig=6), "render_split": gen_render_split,
          # BASELINE configs[3] at its own size: 5 M Gaussians, one camera of the 200-camera rig, distribute_points(50 M) + sampler
          "render_5m": lambda r: gen_render_big(r, "5m", 5_000_000, 50_000_000, rig=200, cam_ids=(17,), compact=True),
          # the same job at a size the CPU emulator can follow: checks the checker (tools/parity_cfg2.py) without a GPU
