@@ -623,6 +623,9 @@ __global__ __launch_bounds__(BK_T) void k_bk_hist_w(const uint32_t* __restrict__
                                                    BucketPlan plan, size_t cs, bool reversed) {
     __shared__ unsigned long long lh[NBK + 1];
     __shared__ uint32_t red[2];
+    // the <BK_MAX> instance (1 048 576 < n <= 2 097 152 keys) holds 64 KB + 16 B of LDS: a gfx950 size (160 KB per CU; two blocks
+    // per CU either way, 3 x 64 KB would not fit) -- this library is built for gfx950 only
+    static_assert(sizeof(unsigned long long) * (NBK + 1) + 8 <= 160 * 1024 / 2, "k_bk_hist_w: two blocks per CU must fit gfx950's LDS");
     keys = seg(keys, cs); h = seg(h, cs); table = seg(table, cs); wtable = seg(wtable, cs); weight = seg(weight, cs); rect = seg(rect, cs);
     const uint32_t nbk = plan.nbk;
     for (uint32_t i = threadIdx.x; i <= nbk; i += BK_T) lh[i] = 0ull;

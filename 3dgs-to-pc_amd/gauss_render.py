@@ -1021,11 +1021,14 @@ class GaussHipRenderer():
         if sl.on_gpu:
             sl.update_done.synchronize()
         for i, (cam, lay, slot, capacity, orig, second) in enumerate(batch):
-            num_inst, unsorted, overloaded = (int(sl.count_host[4 * i + j]) for j in range(3))
+            # (the pinned counts are u32 words in an int32 tensor: read them unsigned -- a count >= 2^31, or k_bk_scan's
+            # 0xFFFFFFFF "the instance count does not fit 32 bits" sentinel, must not read as negative and pass for a fit)
+            num_inst, unsorted, overloaded = (int(sl.count_host[4 * i + j]) & 0xFFFFFFFF for j in range(3))
             if num_inst > capacity or unsorted:
                 # did not fit the graph's buffers, or the depth bucket sort met a pile-up of equal depths: the graph skipped
                 # the camera as a whole; render it again through the two-call path (radix depth sort, exact instance count)
-                if num_inst > capacity:
+                if num_inst > capacity and not unsorted and num_inst != 0xFFFFFFFF:
+                    # (with a pile-up the per-bucket weight sums may have wrapped: the count is not one to size buffers from)
                     self.capacity = max(self.capacity, int(num_inst * CAPACITY_HEADROOM))
                 self.redo.append((cam, orig, slot))            # (the camera's OWN layout: leaves and children, idempotent)
                 # a pass A that did not fit takes its pass B with it: the two-call path numbers the children as IT meets them

@@ -285,12 +285,17 @@ class GaussianRasterizer(nn.Module):
         sc, cam, campos, mask, sh_degree, cam_index, capacity = entry
         if sc.stream is not None:
             sc.update_done.synchronize()
-        num_rendered = int(sc.count_host[0])
+        # (u32 words in an int32 tensor: read unsigned -- 0xFFFFFFFF is k_bk_scan's "does not fit 32 bits" sentinel)
+        num_rendered, unsorted = int(sc.count_host[0]) & 0xFFFFFFFF, int(sc.count_host[1]) & 0xFFFFFFFF
         self.last = dict(num_rendered=num_rendered)
-        if num_rendered > capacity or int(sc.count_host[1]) != 0:     # too many instances, or depths piled up in one sort bucket
-            self._capacity = max(self._capacity, int(num_rendered * CAPACITY_HEADROOM))
+        if num_rendered > capacity or unsorted != 0:     # too many instances, or depths piled up in one sort bucket
             self.rerendered += 1
-            self._render_two_call(sc, cam, campos, mask, sh_degree, cam_index)
+            exact = self._render_two_call(sc, cam, campos, mask, sh_degree, cam_index)
+            # the capacity grows from the two-call path's EXACT count: after a pile-up the fused call's per-bucket weight sums may
+            # have wrapped, and a garbage count would push the capacity past what g2pc_raster_camera_cu accepts
+            if exact > capacity:
+                self._capacity = max(self._capacity, int(exact * CAPACITY_HEADROOM))
+            self.last = dict(num_rendered=exact)
 
     def _render_two_call(self, sc, cam, campos, mask, sh_degree, cam_index):
         """front -> host reads the instance count -> bin + blend -> ordered update, on the scratch's stream."""

@@ -45,3 +45,30 @@ def test_row_matching_survives_shifted_order():
     # a reference row with no counterpart at all is reported, not silently dropped
     gone = np.delete(ours, 2047, axis=0)
     assert parity_cfg2.match_rows(gone, np.delete(ours_rgb, 2047, axis=0), ref[::64], rgb[::64], rr)["sample_rows_unmatched"] == 1
+
+
+def test_all_camera_production_checker_on_mini_job(emu, monkeypatch):
+    """tools/parity_all50.py (the 50-camera production-path checker behind bench.py's `parity` block) on a rehearsal of the same
+    generator at a size the emulator follows: 4 000 Gaussians, all 6 cameras of a 6-camera rig at 320x180, 40 000 points
+    (tests/golden/render_py_cfg2_mini_all6.npz, oracle/make_golden.py render_all_mini), pipelined cameras included."""
+    import gauss_render
+    import parity_all50
+    gauss_render.clear_context_pool()
+    monkeypatch.setattr(gauss_render, "PIPELINE_IN_EMULATOR", True)
+    monkeypatch.setattr(gauss_render, "PIPELINE_STREAMS", 2)
+    assert parity_all50.available("mini_all6")
+    r = parity_all50.run("cpu", tag="mini_all6")
+    print(r)
+    gauss_render.clear_context_pool()
+    assert r["mask_flips"] == 0 and r["culled_equal"] and r["keep_equal"]
+    assert r["contrib_max"] < 1e-5 and r["winner_camera_mismatch"] == 0
+    # a Gaussian's colour is the colour of its arg-max PIXEL: where two pixels tie to ~1e-6 the floor mode's expanded exponent may
+    # pick the other one (contributions unaffected) -- counted, and absent in the to-the-letter mode below
+    assert r["colour_off_gaussians"] <= 2
+    assert r["ppg_mismatch_given_ref_contrib"] == 0 and r["ppg_mismatch_end_to_end"] == r["ppg_flips_explained"]
+    assert r["sample_points"] == r["sample_points_ref"] and r["sample_rows_unmatched"] == 0
+    assert r["sample_xyz_max"] < 1e-4 and r["sample_rgb_max"] < 1e-4
+    e = parity_all50.run("cpu", tag="mini_all6", sampler=False, t_floor=0.0)
+    gauss_render.clear_context_pool()
+    assert e["mask_flips"] == 0 and e["contrib_max"] < 1e-5 and e["winner_camera_mismatch"] == 0
+    assert e["colour_off_gaussians"] == 0 and e["colour_max"] < 1e-5, e
