@@ -61,6 +61,13 @@ _PROTOS["g2pc_sampler_scan_counts"] = (C.c_int, [_vp, _vp, _i64, _i32, _vp, _sz,
 _PROTOS["g2pc_sampler_sections"] = (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i64, C.c_int, _vp, _vp, _vp, _vp])
 _PROTOS["g2pc_sampler_emit_rows"] = (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _u64, _u64, _vp, _vp,
                                                _i64, _vp, _vp, _vp, _vp, _vp])
+_PROTOS["g2pc_validate_covariances_area"] = (C.c_int, [_vp, _i64, C.c_int, _f32, _f32, _f32, C.c_int, _vp, _vp, _vp, _vp])
+_PROTOS["g2pc_gaussian_magnitudes_from_area"] = (C.c_int, [_vp, _vp, _i64, _vp, _vp])
+_PROTOS["g2pc_sampler_stage_plan"] = (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp])
+_PROTOS["g2pc_sampler_count_staged"] = (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _i32, _i32, _u64, _u64, _vp,
+                                                  _vp, _vp, _vp, _vp, _vp])
+_PROTOS["g2pc_sampler_emit_rows_staged"] = (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _vp, _vp, _vp,
+                                                      _i64, _vp, _vp, _vp, _vp, _vp, _vp])
 _PROTOS["g2pc_eval_sh"] = (C.c_int, [_i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp])
 _PROTOS["g2pc_build_covariance_2d"] = (C.c_int, [_vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _vp, _vp])
 _PROTOS["g2pc_projection_ndc"] = (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp])

@@ -169,9 +169,19 @@ __device__ __forceinline__ void sym3_clamp(double A[6], const double e[3], doubl
 // validate_covariances (gauss_handler.py:142-166) incl. regularise (:129-140), the eigen test (:108-112)
 // and clamp (:114-127).  The reference tests eigvals(cov).real <= eps with a general (non-symmetric)
 // LAPACK solver on the float32 matrix; here: closed-form fp64 eigenvalues of the symmetrised matrix.
+// sqrt of the Knud-Thomsen ellipsoid area (p = 1.6075) from the eigenvalues, in fp32 as the reference evaluates it
+__device__ __forceinline__ float sqrt_ellipsoid_area(const double e[3]) {
+    const float p = 1.6075f;
+    float a = sqrtf((float)e[0]), b = sqrtf((float)e[1]), cc = sqrtf((float)e[2]);
+    float radicand = (powf(a * b, p) + powf(a * cc, p) + powf(b * cc, p)) / 3.0f;
+    float area = 12.566370614359172f * powf(radicand, (float)(1.0 / 1.6075));
+    return sqrtf(area);
+}
+
 __global__ __launch_bounds__(GEO_T) void k_validate_cov(float* __restrict__ cov9, long n, int regularise,
                                                        float reg_eps, float eps, float min_eps, int iters,
-                                                       uint8_t* __restrict__ keep, uint32_t* __restrict__ culled_count) {
+                                                       uint8_t* __restrict__ keep, uint32_t* __restrict__ culled_count,
+                                                       float* __restrict__ sqrt_area) {
     long i = (long)blockIdx.x * GEO_T + threadIdx.x;
     if (i >= n) return;
     float* c = cov9 + 9 * i;
@@ -198,6 +208,9 @@ __global__ __launch_bounds__(GEO_T) void k_validate_cov(float* __restrict__ cov9
     const bool cull = sym3_min_eig(Af, e, (double)min_eps) <= (double)min_eps;    // NaN compares false -> kept, as in the reference
     keep[i] = cull ? 0 : 1;
     if (cull && culled_count) atomicAdd(culled_count, 1u);                        // rare: no contention in practice
+    // the eigenvalues of the matrix as it is stored below are exactly what get_gaussian_magnitudes derives from it: keep
+    // sqrt(ellipsoid area) so that the magnitudes are one multiply per Gaussian instead of a second eigen-decomposition
+    if (sqrt_area) sqrt_area[i] = sqrt_ellipsoid_area(e);
     if (dirty) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) c[k] = m[k];
@@ -215,12 +228,14 @@ __global__ __launch_bounds__(GEO_T) void k_magnitudes(const float* __restrict__ 
     double e[3];
     sym3_eigvals((double)c[0], 0.5 * ((double)c[1] + (double)c[3]), 0.5 * ((double)c[2] + (double)c[6]),
                  (double)c[4], 0.5 * ((double)c[5] + (double)c[7]), (double)c[8], e);
-    const float p = 1.6075f;
-    float a = sqrtf((float)e[0]), b = sqrtf((float)e[1]), cc = sqrtf((float)e[2]);
-    float radicand = (powf(a * b, p) + powf(a * cc, p) + powf(b * cc, p)) / 3.0f;
-    float area = 12.566370614359172f * powf(radicand, (float)(1.0 / 1.6075));
-    float mag = sqrtf(area) * weights[i];
+    float mag = sqrt_ellipsoid_area(e) * weights[i];
     sizes[i] = (double)mag;
+}
+// the same from the sqrt(area) the validation pass kept (k_validate_cov): one multiply per Gaussian
+__global__ __launch_bounds__(GEO_T) void k_magnitudes_area(const float* __restrict__ sqrt_area, const float* __restrict__ weights,
+                                                          long n, double* __restrict__ sizes) {
+    long i = (long)blockIdx.x * GEO_T + threadIdx.x;
+    if (i < n) sizes[i] = (double)(sqrt_area[i] * weights[i]);
 }
 
 
@@ -326,14 +341,25 @@ int g2pc_build_covariances(const float* log_scales, const float* rots, float sca
     return check_launch("g2pc_build_covariances");
 }
 
-int g2pc_validate_covariances_counted(float* cov9, int64_t n, int regularise, float reg_eps, float eps, float min_eps,
-                                      int iters, uint8_t* keep, uint32_t* culled_count, void* stream) {
+int g2pc_validate_covariances_area(float* cov9, int64_t n, int regularise, float reg_eps, float eps, float min_eps,
+                                   int iters, uint8_t* keep, uint32_t* culled_count, float* sqrt_area, void* stream) {
     using namespace g2pc;
     G2PC_REQUIRE(n >= 0 && (n == 0 || (cov9 && keep)), G2PC_ERR_ARG, "null input");
     if (n == 0) return G2PC_OK;
     hipLaunchKernelGGL(k_validate_cov, dim3(cdiv(n, GEO_T)), dim3(GEO_T), 0, (hipStream_t)stream, cov9, (long)n,
-                       regularise, reg_eps, eps, min_eps, iters, keep, culled_count);
+                       regularise, reg_eps, eps, min_eps, iters, keep, culled_count, sqrt_area);
     return check_launch("g2pc_validate_covariances");
+}
+int g2pc_validate_covariances_counted(float* cov9, int64_t n, int regularise, float reg_eps, float eps, float min_eps,
+                                      int iters, uint8_t* keep, uint32_t* culled_count, void* stream) {
+    return g2pc_validate_covariances_area(cov9, n, regularise, reg_eps, eps, min_eps, iters, keep, culled_count, nullptr, stream);
+}
+int g2pc_gaussian_magnitudes_from_area(const float* sqrt_area, const float* weights, int64_t n, double* sizes, void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(n >= 0 && (n == 0 || (sqrt_area && weights && sizes)), G2PC_ERR_ARG, "null input");
+    if (n == 0) return G2PC_OK;
+    hipLaunchKernelGGL(k_magnitudes_area, dim3(cdiv(n, GEO_T)), dim3(GEO_T), 0, (hipStream_t)stream, sqrt_area, weights, (long)n, sizes);
+    return check_launch("g2pc_gaussian_magnitudes_from_area");
 }
 
 int g2pc_validate_covariances(float* cov9, int64_t n, int regularise, float reg_eps, float eps, float min_eps,

@@ -25,14 +25,23 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_cu(Cam cam, int grid_x, int
                                                        float3 campos, long n, uint32_t* __restrict__ depth_key,
                                                        uint32_t* __restrict__ index, uint32_t* __restrict__ tiles_touched,
                                                        float4* __restrict__ rec, uint32_t* __restrict__ rect,
-                                                       int32_t* __restrict__ radii, int wide, int antialiasing) {
+                                                       int32_t* __restrict__ radii, int wide, int antialiasing,
+                                                       unsigned long long* __restrict__ cam_key, uint32_t* __restrict__ cam_surf,
+                                                       BucketHdr* __restrict__ mm, uint32_t mm_slots) {
+    // cam_key / cam_surf (optional): the camera's per-Gaussian visibility state is initialised here (packed key 0, surface
+    // distance FLT_MAX) instead of by a launch of its own; mm (optional): the depth bucket sort's header -- the range of the
+    // keys is noted here (one atomic pair per block) instead of by a pass over the keys (k_bk_minmax), as on the PY path
 #pragma clang fp contract(off)
+    __shared__ uint32_t s_mm[2];
+    if (mm && threadIdx.x < 2) s_mm[threadIdx.x] = 0u;
+    if (mm) __syncthreads();
     long i = (long)blockIdx.x * RA_T + threadIdx.x;
-    if (i >= n) return;
+    uint32_t key = 0xFFFFFFFFu;
+    if (i < n) {
     const float x = means3D[3 * i], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
     const float* V = cam.V;
     const float* P = cam.P;
-    uint32_t key = 0xFFFFFFFFu, touched = 0, rc = 0, rc_hi = 0;
+    uint32_t touched = 0, rc = 0, rc_hi = 0;
     int rad = 0;
     // Everything that decides an INTEGER of the reference (radius, tile rectangle, depth bits -> order) is evaluated
     // below with the reference's own expressions, operation by operation in source order, every operation rounded on its
@@ -155,7 +164,18 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_cu(Cam cam, int grid_x, int
     if (tiles_touched) tiles_touched[i] = touched;
     if (wide) { rect[2 * i] = rc; rect[2 * i + 1] = rc_hi; } else rect[i] = rc;
     radii[i] = rad;
+    if (cam_key) { cam_key[i] = 0ull; cam_surf[i] = 0x7F7FFFFFu; }             // (k_init_camera_state_cu's values)
+    }
+    if (mm) {
+        uint32_t a = key != 0xFFFFFFFFu ? ~key : 0u, b = key != 0xFFFFFFFFu ? key : 0u;
+        a = wave_max_u32(a); b = wave_max_u32(b);
+        if ((threadIdx.x & 63) == 0) { atomicMax(&s_mm[0], a); atomicMax(&s_mm[1], b); }
+        __syncthreads();
+        if (threadIdx.x < 2) atomicMax(&mm->partial[2 * (blockIdx.x % mm_slots) + threadIdx.x], s_mm[threadIdx.x]);
+    }
 }
+// the depth bucket sort's header, cleared for the range notes of k_preprocess_cu
+__global__ void k_bucket_hdr_init_cu(BucketHdr* __restrict__ h, BucketPlan plan) { bucket_hdr_init(h, plan, threadIdx.x, blockDim.x); }
 
 // forward.cu:303-497 (renderCUDA).  One 256-thread block per 16x16 tile, one pixel per lane (thread rank t -> pixel
 // (t % 16, t / 16), as in the reference); the tile's list is staged 256 instances at a time (= the reference's batches:
@@ -480,7 +500,8 @@ static int front_cu_impl(const G2pcCamera* cam, const float* means3D, const floa
     G2PC_REQUIRE(ar.ok(), G2PC_ERR_WORKSPACE, "workspace too small");
     hipLaunchKernelGGL(k_preprocess_cu, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, to_cam(cam), gx, gy, means3D, cov6, opacity,
                        colours_precomp, shs, (int)sh_degree, (int)sh_coeffs, make_float3(campos[0], campos[1], campos[2]),
-                       (long)n, key, idx, touched, (float4*)rec, rect, radii, cu_wide_grid(gx, gy) ? 1 : 0, antialiasing);
+                       (long)n, key, idx, touched, (float4*)rec, rect, radii, cu_wide_grid(gx, gy) ? 1 : 0, antialiasing,
+                       (unsigned long long*)nullptr, (uint32_t*)nullptr, (BucketHdr*)nullptr, 0u);
     int rc = sort_pairs_u32(key, idx, key_sorted, sorted_idx, ktmp, vtmp, n, 0, 32, sort_ws, sort_bytes, s);
     if (rc) return rc;
     rc = scan_exclusive_u32(touched, offsets, n, scan_ws, scan_bytes, s, sorted_idx);
@@ -678,21 +699,27 @@ int g2pc_raster_camera_cu(const G2pcCamera* cam, const float* means3D, const flo
     G2PC_REQUIRE(ar.ok(), G2PC_ERR_WORKSPACE, "workspace too small");
     const int gshift = packed_instance_shift((long)n, T);
     const uint32_t gmask = gshift ? ((1u << gshift) - 1u) : 0xFFFFFFFFu;
+    // the preprocess also clears the camera's visibility state and notes the depth range in the bucket sort's header
+    // (until round 6: k_init_camera_state_cu, 68 us under load, and k_bk_minmax, 22 us, per camera)
+    const BucketPlan bplan = bucket_plan((long)n);
+    BucketHdr* hdr = bucket_sort_header(bucket_ws);
+    hipLaunchKernelGGL(k_bucket_hdr_init_cu, dim3(1), dim3(256), 0, s, hdr, bplan);
     hipLaunchKernelGGL(k_preprocess_cu, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, to_cam(cam), gx, gy, means3D, cov6, opacity,
                        colours_precomp, shs, (int)sh_degree, (int)sh_coeffs, make_float3(campos[0], campos[1], campos[2]),
-                       (long)n, key, idx, (uint32_t*)nullptr /* counts = rect areas */, (float4*)rec, rect, radii, 0, 0 /* antialiasing: g2pc_rasterize_gaussians only */);
+                       (long)n, key, idx, (uint32_t*)nullptr /* counts = rect areas */, (float4*)rec, rect, radii, 0, 0 /* antialiasing: g2pc_rasterize_gaussians only */,
+                       (unsigned long long*)cam_key, (uint32_t*)cam_surf, hdr, bplan.nminmax);
     BucketEmit em{};
     em.weight = nullptr; em.rect = rect; em.inst_tile = inst_tile; em.inst_g = inst_g; em.gshift = gshift; em.nx = gx;
     em.capacity = (uint32_t)capacity; em.l_eff = l_eff; em.count_host = count_host;
     uint32_t* depth_overflow = nullptr;
-    int rc = bucket_sort_u32(key, nullptr, nullptr, nullptr, (long)n, bucket_ws, bucket_bytes, &depth_overflow, s, Batch(), false, false, &em);
+    int rc = bucket_sort_u32(key, nullptr, nullptr, nullptr, (long)n, bucket_ws, bucket_bytes, &depth_overflow, s, Batch(), true, false, &em);
     if (rc) return rc;
     if (mask || sharded) {                        // without a mask every pixel is written by the blend kernel
         hipMemsetAsync(out_color, 0, (size_t)3 * W * H * 4, s);
         hipMemsetAsync(out_depth, 0, (size_t)W * H * 4, s);
         hipMemsetAsync(out_invdepth, 0, (size_t)W * H * 4, s);
     }
-    hipLaunchKernelGGL(k_init_camera_state_cu, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, (unsigned long long*)cam_key, (uint32_t*)cam_surf, (long)n);
+    // (cam_key / cam_surf were cleared by k_preprocess_cu)
     rc = gshift ? sort_pairs_u32(inst_tile, nullptr, tile_sorted, nullptr, tile_tmp, nullptr, L, gshift,
                                  gshift + bits_for_tiles((unsigned)T), sort_ws, sort_bytes, s, l_eff)
                 : sort_pairs_u32(inst_tile, inst_g, tile_sorted, g_sorted, tile_tmp, g_tmp, L, 0, bits_for_tiles((unsigned)T),

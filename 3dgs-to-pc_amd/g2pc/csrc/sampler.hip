@@ -96,7 +96,11 @@ __global__ __launch_bounds__(SM_T) void k_count_thread(const float* __restrict__
                                                       float std_limit, int attempt0, int num_attempts,
                                                       unsigned seed_lo, unsigned seed_hi, uint64_t gid_base,
                                                       uint32_t* __restrict__ added, uint32_t* __restrict__ dcount,
-                                                      uint32_t* __restrict__ remaining) {
+                                                      uint32_t* __restrict__ remaining, float* __restrict__ stage,
+                                                      uint32_t* __restrict__ hb) {
+    // stage (draw-once sampling, G2pcSampleStage): every draw that may be emitted -- k < room, the attempt emits its FIRST
+    // d <= room draws -- is kept at row have + k of its position, plane-major ([row][p_end][3]: the lanes of a wave write 768
+    // contiguous bytes per row); hb[attempt][p] = rows the position had before the attempt.  The emission then copies.
     long p = (long)blockIdx.x * SM_T + threadIdx.x;
     if (p >= p_end) return;
     const unsigned g = perm[p];
@@ -112,6 +116,7 @@ __global__ __launch_bounds__(SM_T) void k_count_thread(const float* __restrict__
     const unsigned gid_lo = (unsigned)gid, gid_hi = (unsigned)(gid >> 32);
     for (int a = 0; a < num_attempts; ++a) {
         unsigned d = 0;
+        if (hb) hb[(size_t)a * gv + p] = have;
         if (have < (unsigned)n) {
             unsigned acc = 0;
             const unsigned room = (unsigned)n - have;
@@ -120,6 +125,10 @@ __global__ __launch_bounds__(SM_T) void k_count_thread(const float* __restrict__
             for (int k = 0; k < n && acc < room; ++k) {
                 float x, y, z;
                 acc += draw(s, seed_lo, seed_hi, gid_lo, gid_hi, (unsigned)(attempt0 + a), (unsigned)k, std_limit, x, y, z) ? 1u : 0u;
+                if (stage && (unsigned)k < room) {
+                    float* dst = stage + ((size_t)(have + (unsigned)k) * (size_t)p_end + (size_t)p) * 3;
+                    dst[0] = x; dst[1] = y; dst[2] = z;
+                }
             }
             d = acc < room ? acc : room;
             have += d;
@@ -138,12 +147,17 @@ __global__ __launch_bounds__(SM_T) void k_count_wave(const float* __restrict__ m
                                                     float std_limit, int attempt0, int num_attempts,
                                                     unsigned seed_lo, unsigned seed_hi, uint64_t gid_base,
                                                     uint32_t* __restrict__ added, uint32_t* __restrict__ dcount,
-                                                    uint32_t* __restrict__ remaining) {
+                                                    uint32_t* __restrict__ remaining, float* __restrict__ stage,
+                                                    uint32_t* __restrict__ hb, const uint32_t* __restrict__ bin_start,
+                                                    const unsigned long long* __restrict__ wave_row_start) {
+    // stage: Gaussian-major rows ([wave_row_start[bin] + (p - bin_start[bin]) * (quota - 1) + row][3]); the lanes of the wave
+    // hold consecutive draws, i.e. consecutive rows
     const unsigned lane = threadIdx.x & 63;
     long p = p_begin + (long)blockIdx.x * (SM_T / kWave) + (threadIdx.x >> 6);
     if (p >= gv) return;                                   // whole wave leaves together
     const unsigned g = perm[p];
-    const int n = quota[pbin[p]] - 1;
+    const unsigned bin = pbin[p];
+    const int n = quota[bin] - 1;
     unsigned have = added[p];
     if (n <= 0 || have >= (unsigned)n) {
         if (lane == 0) for (int a = 0; a < num_attempts; ++a) dcount[(size_t)a * gv + p] = 0;
@@ -153,8 +167,10 @@ __global__ __launch_bounds__(SM_T) void k_count_wave(const float* __restrict__ m
     load_gauss(means, cov9, g, s);
     const uint64_t gid = gid_base + g;
     const unsigned gid_lo = (unsigned)gid, gid_hi = (unsigned)(gid >> 32);
+    float* rows = stage ? stage + 3 * (size_t)(wave_row_start[bin] + (unsigned long long)(p - (long)bin_start[bin]) * (unsigned long long)n) : nullptr;
     for (int a = 0; a < num_attempts; ++a) {
         unsigned d = 0;
+        if (hb && lane == 0) hb[(size_t)a * gv + p] = have;
         if (have < (unsigned)n) {
             unsigned acc = 0;
             const unsigned room = (unsigned)n - have;
@@ -163,7 +179,13 @@ __global__ __launch_bounds__(SM_T) void k_count_wave(const float* __restrict__ m
                 int k = k0 + (int)lane;
                 float x, y, z;
                 bool ok = false;
-                if (k < n) ok = draw(s, seed_lo, seed_hi, gid_lo, gid_hi, (unsigned)(attempt0 + a), (unsigned)k, std_limit, x, y, z);
+                if (k < n) {
+                    ok = draw(s, seed_lo, seed_hi, gid_lo, gid_hi, (unsigned)(attempt0 + a), (unsigned)k, std_limit, x, y, z);
+                    if (rows && (unsigned)k < room) {
+                        float* dst = rows + 3 * (size_t)(have + (unsigned)k);
+                        dst[0] = x; dst[1] = y; dst[2] = z;
+                    }
+                }
                 acc += (unsigned)__popcll(__ballot(ok));
             }
             d = acc < room ? acc : room;
@@ -188,6 +210,7 @@ __global__ __launch_bounds__(SM_T) void k_count_wave(const float* __restrict__ m
 constexpr int BT_T = 1024, BT_PER = 8, BT_MAX = BT_T * BT_PER;      // histograms of up to 8 192 entries
 struct BinPlan {            // what the host needs back (pinned memory), all int64
     int64_t num_bins, gv, p_wave, any_sampling, means_rows, rows_ub, error, start_bin, bin_size, distinct;
+    int64_t lane_planes, reserved;     // ABI 7: the largest quota - 1 of a lane-mode bin (rows of G2pcSampleStage.thread_rows)
 };
 // exclusive scan of one value per (thread, k) in thread-major order; returns the total.  s_w: BT_T / 64 + 1 words
 __device__ __forceinline__ uint32_t block_excl_scan8(const uint32_t v[BT_PER], uint32_t out[BT_PER], uint32_t* s_w) {
@@ -217,6 +240,7 @@ __global__ __launch_bounds__(BT_T) void k_bin_table(const uint32_t* __restrict__
     __shared__ uint32_t s_w[BT_T / kWave + 1];
     __shared__ int s_i[8];
     __shared__ unsigned long long s_rows[2];
+    __shared__ int s_planes;
     const int tid = (int)threadIdx.x;
     const long max_ppg = stats ? (long)stats[3] : (long)hist_len - 1;
     if (max_ppg >= hist_len || hist_len > BT_MAX) {                 // histogram too short for this job: the host takes over
@@ -292,7 +316,7 @@ __global__ __launch_bounds__(BT_T) void k_bin_table(const uint32_t* __restrict__
         const int i = tid * BT_PER + k;
         if (f[k]) pd[o[k]] = i < start_bin ? val[i] : (val[i] + bin_size - 1) / bin_size * bin_size;
     }
-    if (tid == 0) { s_i[1] = 0x7FFFFFFF; s_i[2] = 0; s_rows[0] = 0ull; s_rows[1] = 0ull; }
+    if (tid == 0) { s_i[1] = 0x7FFFFFFF; s_i[2] = 0; s_rows[0] = 0ull; s_rows[1] = 0ull; s_planes = 0; }
     __syncthreads();
     // (3) bins (start, end, quota), their members, the look-up table
     for (int b = tid; b < B; b += BT_T) {
@@ -323,6 +347,7 @@ __global__ __launch_bounds__(BT_T) void k_bin_table(const uint32_t* __restrict__
                 if (q > 0) means += mv[k];
                 if (q > 1) { rows += (unsigned long long)mv[k] * (unsigned long long)(q - 1); any_sampling = 1; }
                 if (q - 1 >= wave_min_draws && b < first_wave) first_wave = b;
+                if (q - 1 < wave_min_draws && q - 1 > 0) atomicMax(&s_planes, q - 1);
             }
         }
     }
@@ -338,6 +363,7 @@ __global__ __launch_bounds__(BT_T) void k_bin_table(const uint32_t* __restrict__
         p.means_rows = emit_means ? (int64_t)s_rows[0] : 0;
         p.rows_ub = p.means_rows + (int64_t)s_rows[1];
         p.start_bin = start_bin; p.bin_size = bin_size; p.distinct = D;
+        p.lane_planes = s_planes;
         *plan_host = p;                                            // p_wave below needs bin_start of another thread's bin
     }
     __syncthreads();
@@ -448,7 +474,9 @@ __global__ __launch_bounds__(ER_T) void k_emit_rows(
     const float* __restrict__ normals, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ bin_start, int B,
     int A, long gv, int attempt0, unsigned seed_lo, unsigned seed_hi, uint64_t gid_base,
     const uint32_t* __restrict__ dscan, const int64_t* __restrict__ sec_base, float* __restrict__ out_points,
-    float* __restrict__ out_colours, float* __restrict__ out_normals, int32_t* __restrict__ out_gauss, long rows_capacity) {
+    float* __restrict__ out_colours, float* __restrict__ out_normals, int32_t* __restrict__ out_gauss, long rows_capacity,
+    const float* __restrict__ stage_t, long p_wave, const float* __restrict__ stage_w,
+    const unsigned long long* __restrict__ wave_row_start, const uint32_t* __restrict__ hb, const int32_t* __restrict__ quota) {
     __shared__ uint32_t s_win[ER_WIN + 1];
     __shared__ float s_rows[ER_T / kWave][192];
     const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -516,14 +544,23 @@ __global__ __launch_bounds__(ER_T) void k_emit_rows(
                     // every per-Gaussian input is requested before the first is used: one round trip, not one per field
                     c0 = colours[3 * (size_t)g]; c1 = colours[3 * (size_t)g + 1]; c2 = colours[3 * (size_t)g + 2];
                     if (out_normals) { n0 = normals[3 * (size_t)g]; n1 = normals[3 * (size_t)g + 1]; n2 = normals[3 * (size_t)g + 2]; }
-                    GaussChol s;
-                    load_chol(means, cov9, g, s);
-                    const uint64_t gid = gid_base + g;
-                    const Normal3 e = keyed_normal3(seed_lo, seed_hi, (unsigned)gid, (unsigned)(gid >> 32),
-                                                    (unsigned)(attempt0 + sct - 1), k);
-                    x = s.mx + s.l00 * e.x;
-                    y = s.my + (s.l10 * e.x + s.l11 * e.y);
-                    z = s.mz + (s.l20 * e.x + s.l21 * e.y + s.l22 * e.z);
+                    if (hb) {
+                        // draw-once: the count pass kept the point (G2pcSampleStage) -- row hb + k of position p
+                        const uint32_t row = hb[(size_t)(sct - 1) * (size_t)gv + p] + k;
+                        const float* src = (long)p < p_wave
+                            ? stage_t + ((size_t)row * (size_t)p_wave + p) * 3
+                            : stage_w + 3 * (size_t)(wave_row_start[b] + (unsigned long long)(p - bs0) * (unsigned long long)(quota[b] - 1) + row);
+                        x = src[0]; y = src[1]; z = src[2];
+                    } else {
+                        GaussChol s;
+                        load_chol(means, cov9, g, s);
+                        const uint64_t gid = gid_base + g;
+                        const Normal3 e = keyed_normal3(seed_lo, seed_hi, (unsigned)gid, (unsigned)(gid >> 32),
+                                                        (unsigned)(attempt0 + sct - 1), k);
+                        x = s.mx + s.l00 * e.x;
+                        y = s.my + (s.l10 * e.x + s.l11 * e.y);
+                        z = s.mz + (s.l20 * e.x + s.l21 * e.y + s.l22 * e.z);
+                    }
                 }
             }
             wave_store_rows3(s_rows[w], x, y, z, valid, lane, cnt, out_points + 3 * (size_t)rb);
@@ -566,6 +603,20 @@ __global__ __launch_bounds__(SM_T) void k_sample_mvn(const float* __restrict__ m
         float* dst = out + 3 * ((size_t)k * g_count + g);
         dst[0] = x; dst[1] = y; dst[2] = z;
     }
+}
+
+// wave_row_start[b] = rows of the wave-mode bins before b (a bin is wave-mode when quota - 1 >= wave_min_draws; quotas ascend
+// with the bin index, so they are the last bins); [num_bins] = their total.  One thread: a few hundred bins at most.
+__global__ void k_stage_plan(const uint32_t* __restrict__ bin_start, const int32_t* __restrict__ quota, int B, int wave_min_draws,
+                             unsigned long long* __restrict__ wave_row_start) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    unsigned long long acc = 0ull;
+    for (int b = 0; b < B; ++b) {
+        wave_row_start[b] = acc;
+        const int q = quota[b] - 1;
+        if (q >= wave_min_draws) acc += (unsigned long long)(bin_start[b + 1] - bin_start[b]) * (unsigned long long)q;
+    }
+    wave_row_start[B] = acc;
 }
 
 static int bits_for(unsigned v) { int b = 0; while ((1u << b) <= v && b < 31) ++b; return b < 1 ? 1 : b; }
@@ -617,7 +668,7 @@ size_t g2pc_sampler_bin_table_workspace(int64_t hist_len) {
 /* The bin table on the device (see k_bin_table): hist u32[hist_len] = bincount of the points per Gaussian, stats = the
  * device-side result of g2pc_distribute_points ([3] = max points per Gaussian; NULL: hist_len - 1).  Out: lut i32[hist_len]
  * (bin of every point count, -1: none), quota i32[hist_len], bin_start u32[hist_len + 2], bin_lo i32[hist_len] (first
- * point count of every bin), plan_host (PINNED host memory, i64[10]: bins, Gaussians in bins, first wave-mode position,
+ * point count of every bin), plan_host (PINNED host memory, i64[12]: bins, Gaussians in bins, first wave-mode position,
  * any sampling, mean rows, row bound, error, start_bin, bin_size, distinct counts) written through its device mapping.
  * error 1: some Gaussian has hist_len or more points (build a longer histogram); 2: fewer than two distinct point counts in
  * binned mode (the reference's np.gradient raises). */
@@ -627,7 +678,7 @@ int g2pc_sampler_bin_table(const uint32_t* hist, int64_t hist_len, const int64_t
     using namespace g2pc;
     G2PC_REQUIRE(hist && hist_len > 0 && lut && quota && bin_start && bin_lo && plan_host && ws, G2PC_ERR_ARG, "bad arguments");
     G2PC_REQUIRE(hist_len <= BT_MAX, G2PC_ERR_UNSUPPORTED, "histograms of more than 8192 entries go through the host");
-    static_assert(sizeof(BinPlan) == 10 * sizeof(int64_t), "BinPlan is ten int64");
+    static_assert(sizeof(BinPlan) == 12 * sizeof(int64_t), "BinPlan is twelve int64");
     Arena ar(ws, ws_bytes);
     const size_t n = (size_t)hist_len + 2;
     int32_t* val = ar.get<int32_t>(n);
@@ -666,10 +717,11 @@ int g2pc_sampler_partition(const int32_t* ppg, int64_t g, const int32_t* bin_of_
     return check_launch("g2pc_sampler_partition");
 }
 
-int g2pc_sampler_count(const float* means, const float* cov9, const uint32_t* perm, const uint32_t* pbin,
-                       const int32_t* quota, int64_t gv, int64_t p_wave_begin, float std_limit, int32_t attempt0,
-                       int32_t num_attempts, uint64_t seed, uint64_t gid_base, uint32_t* added, uint32_t* dcount,
-                       uint32_t* remaining, void* stream) {
+static int sampler_count_impl(const float* means, const float* cov9, const uint32_t* perm, const uint32_t* pbin,
+                              const int32_t* quota, int64_t gv, int64_t p_wave_begin, float std_limit, int32_t attempt0,
+                              int32_t num_attempts, uint64_t seed, uint64_t gid_base, uint32_t* added, uint32_t* dcount,
+                              uint32_t* remaining, const G2pcSampleStage* st, uint32_t* hb, const uint32_t* bin_start,
+                              void* stream) {
     using namespace g2pc;
     G2PC_REQUIRE(gv >= 0 && means && cov9 && perm && pbin && quota && added && dcount && remaining, G2PC_ERR_ARG,
                  "bad arguments");
@@ -680,12 +732,41 @@ int g2pc_sampler_count(const float* means, const float* cov9, const uint32_t* pe
     if (p_wave_begin > 0)
         hipLaunchKernelGGL(k_count_thread, dim3(cdiv(p_wave_begin, SM_T)), dim3(SM_T), 0, s, means, cov9, perm, pbin,
                            quota, (long)p_wave_begin, (long)gv, std_limit, (int)attempt0, (int)num_attempts, slo, shi,
-                           gid_base, added, dcount, remaining);
+                           gid_base, added, dcount, remaining, st ? st->thread_rows : nullptr, hb);
     if (p_wave_begin < gv)
         hipLaunchKernelGGL(k_count_wave, dim3(cdiv(gv - p_wave_begin, SM_T / kWave)), dim3(SM_T), 0, s, means, cov9,
                            perm, pbin, quota, (long)p_wave_begin, (long)gv, std_limit, (int)attempt0,
-                           (int)num_attempts, slo, shi, gid_base, added, dcount, remaining);
+                           (int)num_attempts, slo, shi, gid_base, added, dcount, remaining, st ? st->wave_rows : nullptr, hb,
+                           bin_start, st ? (const unsigned long long*)st->wave_row_start : nullptr);
     return check_launch("g2pc_sampler_count");
+}
+int g2pc_sampler_count(const float* means, const float* cov9, const uint32_t* perm, const uint32_t* pbin,
+                       const int32_t* quota, int64_t gv, int64_t p_wave_begin, float std_limit, int32_t attempt0,
+                       int32_t num_attempts, uint64_t seed, uint64_t gid_base, uint32_t* added, uint32_t* dcount,
+                       uint32_t* remaining, void* stream) {
+    return sampler_count_impl(means, cov9, perm, pbin, quota, gv, p_wave_begin, std_limit, attempt0, num_attempts, seed, gid_base,
+                              added, dcount, remaining, nullptr, nullptr, nullptr, stream);
+}
+int g2pc_sampler_stage_plan(const uint32_t* bin_start, const int32_t* quota, int32_t num_bins, int32_t wave_min_draws,
+                            uint64_t* wave_row_start, void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(bin_start && quota && wave_row_start && num_bins >= 0, G2PC_ERR_ARG, "bad arguments");
+    hipLaunchKernelGGL(k_stage_plan, dim3(1), dim3(64), 0, (hipStream_t)stream, bin_start, quota, (int)num_bins,
+                       (int)wave_min_draws, (unsigned long long*)wave_row_start);
+    return check_launch("g2pc_sampler_stage_plan");
+}
+int g2pc_sampler_count_staged(const float* means, const float* cov9, const uint32_t* perm, const uint32_t* pbin,
+                              const int32_t* quota, const uint32_t* bin_start, int64_t gv, int64_t p_wave_begin, float std_limit,
+                              int32_t attempt0, int32_t num_attempts, uint64_t seed, uint64_t gid_base, uint32_t* added,
+                              uint32_t* dcount, uint32_t* have_before, uint32_t* remaining, const G2pcSampleStage* stage,
+                              void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(stage && have_before && bin_start, G2PC_ERR_ARG, "bad arguments");
+    if (p_wave_begin < 0 || p_wave_begin > gv) p_wave_begin = gv;
+    G2PC_REQUIRE((p_wave_begin == 0 || stage->thread_rows) && (p_wave_begin == gv || (stage->wave_rows && stage->wave_row_start)),
+                 G2PC_ERR_ARG, "missing staging arrays");
+    return sampler_count_impl(means, cov9, perm, pbin, quota, gv, p_wave_begin, std_limit, attempt0, num_attempts, seed, gid_base,
+                              added, dcount, remaining, stage, have_before, bin_start, stream);
 }
 }
 
@@ -726,11 +807,12 @@ int g2pc_sampler_sections(const uint32_t* bin_start, const int32_t* quota, int32
 
 /* Row-balanced emission of the whole cloud (means and every attempt's rows) in one launch: `rows_capacity` >= M is the
  * size the output arrays were allocated for (the launch covers it; blocks beyond the real M, read from sec_base, exit). */
-int g2pc_sampler_emit_rows(const float* means, const float* cov9, const float* colours, const float* normals,
-                           const uint32_t* perm, const uint32_t* bin_start, int32_t num_bins, int32_t attempt0,
-                           int32_t attempts, int64_t gv, uint64_t seed, uint64_t gid_base, const uint32_t* dscan,
-                           const int64_t* sec_base, int64_t rows_capacity, float* out_points, float* out_colours,
-                           float* out_normals, int32_t* out_gauss, void* stream) {
+static int sampler_emit_impl(const float* means, const float* cov9, const float* colours, const float* normals,
+                             const uint32_t* perm, const uint32_t* bin_start, int32_t num_bins, int32_t attempt0,
+                             int32_t attempts, int64_t gv, uint64_t seed, uint64_t gid_base, const uint32_t* dscan,
+                             const int64_t* sec_base, int64_t rows_capacity, float* out_points, float* out_colours,
+                             float* out_normals, int32_t* out_gauss, const G2pcSampleStage* st, int64_t p_wave,
+                             const uint32_t* hb, const int32_t* quota, void* stream) {
     using namespace g2pc;
     G2PC_REQUIRE(means && cov9 && colours && perm && bin_start && sec_base && out_points && out_colours, G2PC_ERR_ARG,
                  "bad arguments");
@@ -740,8 +822,32 @@ int g2pc_sampler_emit_rows(const float* means, const float* cov9, const float* c
     hipLaunchKernelGGL(k_emit_rows, dim3(cdiv(rows_capacity, ER_ROWS)), dim3(ER_T), 0, (hipStream_t)stream, means, cov9, colours,
                        normals, perm, bin_start, (int)num_bins, (int)attempts, (long)gv, (int)attempt0, (unsigned)seed,
                        (unsigned)(seed >> 32), gid_base, dscan, sec_base, out_points, out_colours, out_normals, out_gauss,
-                       (long)rows_capacity);
+                       (long)rows_capacity, st ? (const float*)st->thread_rows : nullptr, (long)p_wave,
+                       st ? (const float*)st->wave_rows : nullptr, st ? (const unsigned long long*)st->wave_row_start : nullptr,
+                       st ? hb : nullptr, quota);
     return check_launch("g2pc_sampler_emit_rows");
+}
+int g2pc_sampler_emit_rows(const float* means, const float* cov9, const float* colours, const float* normals,
+                           const uint32_t* perm, const uint32_t* bin_start, int32_t num_bins, int32_t attempt0,
+                           int32_t attempts, int64_t gv, uint64_t seed, uint64_t gid_base, const uint32_t* dscan,
+                           const int64_t* sec_base, int64_t rows_capacity, float* out_points, float* out_colours,
+                           float* out_normals, int32_t* out_gauss, void* stream) {
+    return sampler_emit_impl(means, cov9, colours, normals, perm, bin_start, num_bins, attempt0, attempts, gv, seed, gid_base, dscan,
+                             sec_base, rows_capacity, out_points, out_colours, out_normals, out_gauss, nullptr, 0, nullptr, nullptr,
+                             stream);
+}
+int g2pc_sampler_emit_rows_staged(const float* means, const float* cov9, const float* colours, const float* normals,
+                                  const uint32_t* perm, const uint32_t* bin_start, const int32_t* quota, int32_t num_bins,
+                                  int32_t attempts, int64_t gv, int64_t p_wave_begin, const uint32_t* dscan,
+                                  const uint32_t* have_before, const int64_t* sec_base, int64_t rows_capacity,
+                                  const G2pcSampleStage* stage, float* out_points, float* out_colours, float* out_normals,
+                                  int32_t* out_gauss, void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(stage && quota && (attempts == 0 || have_before), G2PC_ERR_ARG, "bad arguments");
+    if (p_wave_begin < 0 || p_wave_begin > gv) p_wave_begin = gv;
+    return sampler_emit_impl(means, cov9, colours, normals, perm, bin_start, num_bins, 0, attempts, gv, 0, 0, dscan, sec_base,
+                             rows_capacity, out_points, out_colours, out_normals, out_gauss, stage, p_wave_begin, have_before, quota,
+                             stream);
 }
 
 int g2pc_mahalanobis(const float* means, const float* samples, const float* cov9, int64_t n, float* out,

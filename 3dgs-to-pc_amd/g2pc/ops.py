@@ -157,20 +157,38 @@ def gather_rows_multi(srcs, index: torch.Tensor):
 
 
 def validate_covariances_(cov: torch.Tensor, regularise: bool = True, reg_eps: float = 5e-7, eps: float = 1e-7,
-                          min_eps: float = 1e-8, iters: int = 3, want_count: bool = False):
+                          min_eps: float = 1e-8, iters: int = 3, want_count: bool = False, want_area: bool = False,
+                          defer_count: bool = False):
     """In-place gauss_handler.py:142-166; returns the keep mask (bool[n]); want_count=True also returns the number of
-    culled rows as a python int (ONE 4-byte read-back -- the caller's `if anything was culled`)."""
+    culled rows as a python int (ONE 4-byte read-back -- the caller's `if anything was culled`), or with defer_count the
+    device tensor holding it (no read-back).  want_area=True appends sqrt(ellipsoid area) f32[n] of the validated matrices
+    (gaussian_magnitudes_from_area: the magnitudes without a second eigen-decomposition)."""
     assert cov.dtype == torch.float32 and cov.is_contiguous()
     n = cov.shape[0]
     keep = torch.empty((n,), dtype=torch.uint8, device=cov.device)
     count = torch.zeros((1,), dtype=torch.int32, device=cov.device) if want_count else None
-    nv.check(nv.lib().g2pc_validate_covariances_counted(nv.ptr(cov), n, int(regularise), reg_eps, eps, min_eps, iters,
-                                                        nv.ptr(keep), nv.ptr(count), nv.stream_handle(cov.device)),
+    area = torch.empty((n,), dtype=torch.float32, device=cov.device) if want_area else None
+    nv.check(nv.lib().g2pc_validate_covariances_area(nv.ptr(cov), n, int(regularise), reg_eps, eps, min_eps, iters,
+                                                     nv.ptr(keep), nv.ptr(count), nv.ptr(area), nv.stream_handle(cov.device)),
              "validate_covariances")
     keep = keep.view(torch.bool)                       # 0 / 1 bytes: a reinterpretation, not a conversion kernel
+    out = (keep,)
     if want_count:
-        return keep, int(count.item())
-    return keep
+        out += (count if defer_count else int(count.item()),)
+    if want_area:
+        out += (area,)
+    return out if len(out) > 1 else keep
+
+
+def gaussian_magnitudes_from_area(sqrt_area: torch.Tensor, weights: torch.Tensor) -> torch.Tensor:
+    """gauss_handler.py:278-279 on the sqrt(area) validate_covariances_ kept -> float64 [n]."""
+    a, w = _f32c(sqrt_area), _f32c(weights).reshape(-1)
+    n = a.shape[0]
+    assert w.shape[0] == n
+    out = torch.empty((n,), dtype=torch.float64, device=a.device)
+    nv.check(nv.lib().g2pc_gaussian_magnitudes_from_area(nv.ptr(a), nv.ptr(w), n, nv.ptr(out), nv.stream_handle(a.device)),
+             "gaussian_magnitudes_from_area")
+    return out
 
 
 def gaussian_magnitudes(cov: torch.Tensor, weights: torch.Tensor) -> torch.Tensor:
@@ -246,6 +264,15 @@ class SampledCloud(NamedTuple):
 WAVE_MODE_MIN_DRAWS = 32   # quota-1 at and above which one Gaussian is sampled by a whole wave64
 HIST_GUESS = 8192          # histogram length used before max(points per Gaussian) is known on the host
 ATTEMPT_CHUNK = 8
+DRAW_ONCE = True           # the count pass keeps the points it may have to emit, the emission copies (G2pcSampleStage)
+
+
+import ctypes as C  # noqa: E402
+
+
+class _SampleStage(C.Structure):
+    """G2pcSampleStage (include/g2pc.h)."""
+    _fields_ = [("thread_rows", C.c_void_p), ("wave_rows", C.c_void_p), ("wave_row_start", C.c_void_p)]
 
 
 def mahalanobis(means: torch.Tensor, samples: torch.Tensor, covs: torch.Tensor) -> torch.Tensor:
@@ -311,7 +338,7 @@ def sample_pointcloud(xyz: torch.Tensor, cov: torch.Tensor, colours: torch.Tenso
         quota_d = torch.empty((HIST_GUESS,), dtype=torch.int32, device=dev)
         bin_start = torch.empty((HIST_GUESS + 2,), dtype=torch.int32, device=dev)
         bin_lo = torch.empty((HIST_GUESS,), dtype=torch.int32, device=dev)
-        plan_host = _pinned_i64(dev, 10)
+        plan_host = _pinned_i64(dev, 12)
         tb = L.g2pc_sampler_bin_table_workspace(HIST_GUESS)
         tws = nv.workspace(tb, dev)
         stats64 = stats.to(torch.int64).contiguous()
@@ -329,6 +356,7 @@ def sample_pointcloud(xyz: torch.Tensor, cov: torch.Tensor, colours: torch.Tenso
             plan = None                                      # some Gaussian got >= HIST_GUESS points: the host path below
     if plan is not None:
         B, gv, p_wave, any_sampling, means_rows, rows_ub = plan[0], plan[1], plan[2], bool(plan[3]), plan[4], plan[5]
+        lane_planes = plan[10]
         lut_len = HIST_GUESS
         bins = _LazyBins(bin_lo, quota_d, B)
     else:
@@ -370,6 +398,7 @@ def sample_pointcloud(xyz: torch.Tensor, cov: torch.Tensor, colours: torch.Tenso
         any_sampling = bool(np.any((quota[:B] > 1) & (members[:B] > 0))) if B else False
         means_rows = int(sum(members[b] for b in range(B) if quota[b] > 0)) if emit_means else 0
         rows_ub = means_rows + int(sum(members[b] * max(int(quota[b]) - 1, 0) for b in range(B)))
+        lane_planes = max([int(quota[b]) - 1 for b in range(B) if members[b] > 0 and 0 < quota[b] - 1 < WAVE_MODE_MIN_DRAWS] or [0])
 
     perm = torch.empty((G,), dtype=torch.int32, device=dev)
     pbin = torch.empty((G,), dtype=torch.int32, device=dev)
@@ -393,7 +422,21 @@ def sample_pointcloud(xyz: torch.Tensor, cov: torch.Tensor, colours: torch.Tenso
             torch.cuda.current_stream(dev).synchronize()
 
     # ---- count pass: d[attempt][position]; exact mode loops over chunks of attempts until nothing is left unfinished ----
-    counts = []            # dcount chunks, each [na, gv]
+    # DRAW_ONCE: the count pass keeps every point it may have to emit (G2pcSampleStage, include/g2pc.h) and the emission copies
+    # -- each keyed draw (Philox + Box-Muller + Cholesky, ~250 instructions) is evaluated once instead of twice
+    stage = None
+    if DRAW_ONCE and any_sampling and gv > 0:
+        planes = max(int(lane_planes), 0)                         # the largest quota - 1 of a lane-mode bin (< WAVE_MODE_MIN_DRAWS)
+        wave_rows = max(rows_ub - means_rows, 0) if p_wave < gv else 0
+        stage = _SampleStage()
+        stage.keep = (torch.empty((planes * max(p_wave, 0) * 3 + 4,), dtype=torch.float32, device=dev),
+                      torch.empty((wave_rows * 3 + 4,), dtype=torch.float32, device=dev),
+                      torch.empty((B + 1,), dtype=torch.int64, device=dev))
+        stage.thread_rows, stage.wave_rows, stage.wave_row_start = (C_void(t) for t in stage.keep)
+        if p_wave < gv:
+            nv.check(L.g2pc_sampler_stage_plan(nv.ptr(bin_start), nv.ptr(quota_d), B, WAVE_MODE_MIN_DRAWS,
+                                               nv.ptr(stage.keep[2]), st), "sampler_stage_plan")
+    counts, befores = [], []            # dcount / have_before chunks, each [na, gv]
     a0 = 0
     while any_sampling and a0 < attempts:
         na = min(ATTEMPT_CHUNK, attempts - a0)
@@ -401,9 +444,17 @@ def sample_pointcloud(xyz: torch.Tensor, cov: torch.Tensor, colours: torch.Tenso
         if a0 > 0:
             remaining.zero_()
         with nv.region("sampler_count", dev):
-            nv.check(L.g2pc_sampler_count(nv.ptr(xyz), nv.ptr(cov), nv.ptr(perm), nv.ptr(pbin), nv.ptr(quota_d), gv,
-                                          p_wave, float(std), a0, na, int(seed), int(gid_base), nv.ptr(added),
-                                          nv.ptr(dcount), nv.ptr(remaining), st), "sampler_count")
+            if stage is not None:
+                hb = torch.empty((na, gv), dtype=torch.int32, device=dev)
+                befores.append(hb)
+                nv.check(L.g2pc_sampler_count_staged(nv.ptr(xyz), nv.ptr(cov), nv.ptr(perm), nv.ptr(pbin), nv.ptr(quota_d),
+                                                     nv.ptr(bin_start), gv, p_wave, float(std), a0, na, int(seed), int(gid_base),
+                                                     nv.ptr(added), nv.ptr(dcount), nv.ptr(hb), nv.ptr(remaining),
+                                                     C.byref(stage), st), "sampler_count_staged")
+            else:
+                nv.check(L.g2pc_sampler_count(nv.ptr(xyz), nv.ptr(cov), nv.ptr(perm), nv.ptr(pbin), nv.ptr(quota_d), gv,
+                                              p_wave, float(std), a0, na, int(seed), int(gid_base), nv.ptr(added),
+                                              nv.ptr(dcount), nv.ptr(remaining), st), "sampler_count")
         counts.append(dcount)
         a0 += na
         if a0 < attempts:                                        # only exact mode gets here: is anybody still short?
@@ -411,6 +462,7 @@ def sample_pointcloud(xyz: torch.Tensor, cov: torch.Tensor, colours: torch.Tenso
                 break
     A = a0 if counts else 0
     dcount = counts[0] if len(counts) == 1 else (torch.cat(counts, 0) if counts else None)
+    have_before = (befores[0] if len(befores) == 1 else torch.cat(befores, 0)) if befores else None
     dscan = torch.empty((A, gv + 1), dtype=torch.int32, device=dev) if A else None
     if A:
         sb = L.g2pc_sampler_scan_workspace(gv, A)
@@ -422,10 +474,17 @@ def sample_pointcloud(xyz: torch.Tensor, cov: torch.Tensor, colours: torch.Tenso
     pts, cols, nrm, gidx = outputs(rows_ub)
     if rows_ub > 0 and gv > 0 and B > 0:
         with nv.region("sampler_emit", dev):
-            nv.check(L.g2pc_sampler_emit_rows(nv.ptr(xyz), nv.ptr(cov), nv.ptr(colours), nv.ptr(normals), nv.ptr(perm),
-                                              nv.ptr(bin_start), B, 0, A, gv, int(seed), int(gid_base), nv.ptr(dscan),
-                                              nv.ptr(sec_base), rows_ub, nv.ptr(pts), nv.ptr(cols), nv.ptr(nrm),
-                                              nv.ptr(gidx), st), "sampler_emit_rows")
+            if stage is not None and A:
+                nv.check(L.g2pc_sampler_emit_rows_staged(nv.ptr(xyz), nv.ptr(cov), nv.ptr(colours), nv.ptr(normals), nv.ptr(perm),
+                                                         nv.ptr(bin_start), nv.ptr(quota_d), B, A, gv, p_wave, nv.ptr(dscan),
+                                                         nv.ptr(have_before), nv.ptr(sec_base), rows_ub, C.byref(stage),
+                                                         nv.ptr(pts), nv.ptr(cols), nv.ptr(nrm), nv.ptr(gidx), st),
+                         "sampler_emit_rows_staged")
+            else:
+                nv.check(L.g2pc_sampler_emit_rows(nv.ptr(xyz), nv.ptr(cov), nv.ptr(colours), nv.ptr(normals), nv.ptr(perm),
+                                                  nv.ptr(bin_start), B, 0, A, gv, int(seed), int(gid_base), nv.ptr(dscan),
+                                                  nv.ptr(sec_base), rows_ub, nv.ptr(pts), nv.ptr(cols), nv.ptr(nrm),
+                                                  nv.ptr(gidx), st), "sampler_emit_rows")
     sync()                                                        # round trip #2: how many points came out
     M = int(info[0]) if B > 0 else 0
     assert 0 <= M <= rows_ub, (M, rows_ub)

@@ -44,6 +44,18 @@ def build_covariance_from_scaling_rotation(scaling, scaling_modifier, rotation):
     return ops.build_covariances(scaling, rotation, scaling_modifier)[0]
 
 
+class _TensorKey:
+    def __init__(self, t):
+        import weakref
+        self.ref, self.version = weakref.ref(t), t._version
+
+    def __eq__(self, other):
+        return isinstance(other, _TensorKey) and self.ref() is not None and self.ref() is other.ref() and self.version == other.version
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+
 class Gaussians():
     """
     Manages all loaded gaussians in the renderer (gauss_handler.py:65-279)
@@ -110,18 +122,48 @@ class Gaussians():
             covariances[mask] += eye
         return covariances
 
-    def validate_covariances(self, regularise=True, epsilon=1e-7, min_ps_epsilon=1e-8, num_clamp_iters=3):
+    def validate_covariances(self, regularise=True, epsilon=1e-7, min_ps_epsilon=1e-8, num_clamp_iters=3, defer_cull=False):
         """gauss_handler.py:142-166 -- one fused kernel: regularise, up to num_clamp_iters clamp rounds,
         final test; culls what is still not positive definite and returns the keep mask."""
         cov = self.covariances.to(torch.float32).contiguous()
-        keep, culled = ops.validate_covariances_(cov, regularise=regularise, reg_eps=5e-7, eps=epsilon,
-                                                 min_eps=min_ps_epsilon, iters=num_clamp_iters, want_count=True)
+        keep, culled, area = ops.validate_covariances_(cov, regularise=regularise, reg_eps=5e-7, eps=epsilon,
+                                                       min_eps=min_ps_epsilon, iters=num_clamp_iters, want_count=True,
+                                                       want_area=True, defer_count=defer_cull)
         self.covariances = cov
+        # sqrt(ellipsoid area) of the validated matrices, from the pass's own eigenvalues: get_gaussian_magnitudes multiplies
+        # instead of decomposing again -- valid while self.covariances is this very tensor, unmodified
+        self._sqrt_area, self._sqrt_area_of = area, self._cov_key()
+        if defer_cull:
+            # the culled count stays on the device: the caller carries on as if nothing was culled (the common case) and asks
+            # resolve_deferred_cull() once its work is queued -- the host does not stall in the middle of the job
+            self._deferred_cull = (keep, culled)
+            self.last_validate_culled = False
+            return keep
         self.last_validate_culled = culled > 0
         if self.last_validate_culled:
             self.add_gaussians_to_cull(keep)
             self.filter_gaussians()
         return keep
+
+    def resolve_deferred_cull(self):
+        """After validate_covariances(defer_cull=True): were rows culled after all?  (One 4-byte read-back, meant to be asked
+        when the device has caught up anyway.)  If so the cull and the filter are applied now and True is returned -- whatever was
+        computed from the unfiltered Gaussians in between has to be computed again."""
+        pending, self._deferred_cull = getattr(self, "_deferred_cull", None), None
+        if pending is None:
+            return False
+        keep, count = pending
+        if int(count.item()) == 0:
+            return False
+        self.last_validate_culled = True
+        self.add_gaussians_to_cull(keep)
+        self.filter_gaussians()
+        return True
+
+    def _cov_key(self):
+        """Identity of the covariance tensor the kept sqrt(area) belongs to: the tensor OBJECT (held weakly) and its version
+        counter -- a reassigned or in-place modified self.covariances no longer matches."""
+        return _TensorKey(self.covariances)
 
     def add_gaussians_to_cull(self, indices_to_cull):
         self.filter_indices = indices_to_cull.clone() if self._filter is None else self._filter & indices_to_cull
@@ -133,10 +175,15 @@ class Gaussians():
         self.last_filter_index = index        # int32 positions of the survivors: select(per_gaussian_tensor) reuses it
 
         # every per-Gaussian array through ONE gather launch (they share the index)
+        area = getattr(self, "_sqrt_area", None)
+        if area is not None and getattr(self, "_sqrt_area_of", None) != self._cov_key():
+            area = None                                   # the covariances changed since the validation that kept it
         (self.xyz, self.scales, self.rots, self.colours, self.opacities, self.covariances, self.shs, self.normals) = \
             ops.gather_rows_multi([self.xyz, self.scales, self.rots, self.colours, self.opacities, self.covariances, self.shs,
                                    self.normals], index)
         self._normals_from_build = self.normals
+        self._sqrt_area = ops.gather_rows(area, index) if area is not None else None
+        self._sqrt_area_of = self._cov_key() if area is not None else None
 
         self.set_default_filter()
 
@@ -178,4 +225,7 @@ class Gaussians():
         """gauss_handler.py:252-279 -- sqrt(ellipsoid area) x (contributions or opacities), float64."""
         if contributions is None:
             contributions = self.opacities
+        area = getattr(self, "_sqrt_area", None)
+        if area is not None and getattr(self, "_sqrt_area_of", None) == self._cov_key():
+            return ops.gaussian_magnitudes_from_area(area, contributions)      # validate_covariances kept sqrt(area)
         return ops.gaussian_magnitudes(self.covariances, contributions)

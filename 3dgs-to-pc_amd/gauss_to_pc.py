@@ -160,6 +160,9 @@ def generate_pointcloud(gaussians, num_points, contributions=None, mahalanobis_d
     return _finish_dtypes(out.points, out.colours, out.normals)
 
 
+DEFER_VALIDATE_CULL = True      # validate_covariances' culled-row count is read after the sampling was queued, not before
+
+
 def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, pointcloud_settings, seed=None,
                             group=None, render_shs=False, keep_render_context=True, single_process=False,
                             stage_times=None):
@@ -332,7 +335,9 @@ def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, poin
         print()
         print("Ensuring Gaussians are Positive Semidefinite")
 
-    invalid_gaussian_indices = gaussians.validate_covariances()
+    # (the number of culled rows stays on the device: the sampling below is queued as if nothing was culled -- the usual case --
+    # and the host asks afterwards, when the device has caught up anyway, instead of stalling here in the middle of the job)
+    invalid_gaussian_indices = gaussians.validate_covariances(defer_cull=DEFER_VALIDATE_CULL)
 
     if total_gaussian_contributions is not None and gaussians.last_validate_culled:
         total_gaussian_contributions = gaussians.select(total_gaussian_contributions)      # [invalid_gaussian_indices]
@@ -345,13 +350,21 @@ def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, poin
         print("Starting Point Cloud Generation for All Gaussians")
         print()
 
-    points, colours, normals = generate_pointcloud(gaussians, s.num_points, exact_num_points=s.exact_num_points,
-                                                   mahalanobis_distance_std=s.mahalanobis_distance_std,
-                                                   calculate_normals=s.calculate_normals,
-                                                   num_sample_attempts=num_sample_attempts,
-                                                   contributions=total_gaussian_contributions,
-                                                   device=s.device, quiet=s.quiet, seed=seed,
-                                                   shard=(rank, world))
+    def _generate():
+        return generate_pointcloud(gaussians, s.num_points, exact_num_points=s.exact_num_points,
+                                   mahalanobis_distance_std=s.mahalanobis_distance_std,
+                                   calculate_normals=s.calculate_normals,
+                                   num_sample_attempts=num_sample_attempts,
+                                   contributions=total_gaussian_contributions,
+                                   device=s.device, quiet=s.quiet, seed=seed,
+                                   shard=(rank, world))
+
+    points, colours, normals = _generate()
+    if gaussians.resolve_deferred_cull():
+        # rows WERE culled (ill-conditioned covariances): the cloud above came from the unfiltered set -- sample again
+        if total_gaussian_contributions is not None:
+            total_gaussian_contributions = gaussians.select(total_gaussian_contributions)  # [invalid_gaussian_indices]
+        points, colours, normals = _generate()
 
     total_point_cloud = PointCloudData(points=points, colours=colours, normals=normals)
     _stage("sample_ms")

@@ -95,6 +95,14 @@ int g2pc_validate_covariances(float* cov9, int64_t n, int regularise, float reg_
 int g2pc_validate_covariances_counted(float* cov9, int64_t n, int regularise, float reg_eps, float eps, float min_eps,
                                       int iters, uint8_t* keep, uint32_t* culled_count, void* stream);
 
+/* ABI 7: validate_covariances and get_gaussian_magnitudes share ONE eigen-decomposition: sqrt_area (optional, f32[n] out) =
+ * sqrt of the Knud-Thomsen ellipsoid area of the matrix as the pass leaves it (gauss_handler.py:259-277) -- bit for bit the
+ * factor g2pc_gaussian_magnitudes derives from the stored matrix --, and g2pc_gaussian_magnitudes_from_area multiplies it
+ * with the weights (contributions or opacities, :278-279). */
+int g2pc_validate_covariances_area(float* cov9, int64_t n, int regularise, float reg_eps, float eps, float min_eps,
+                                   int iters, uint8_t* keep, uint32_t* culled_count, float* sqrt_area, void* stream);
+int g2pc_gaussian_magnitudes_from_area(const float* sqrt_area, const float* weights, int64_t n, double* sizes, void* stream);
+
 /* get_gaussian_magnitudes (gauss_handler.py:252-279): Knud-Thomsen ellipsoid area from the eigenvalues,
  * sqrt, times weights (contributions or opacities) -> f64[n]. */
 int g2pc_gaussian_magnitudes(const float* cov9, const float* weights, int64_t n, double* sizes, void* stream);
@@ -198,7 +206,7 @@ int g2pc_sampler_count(const float* means, const float* cov9, const uint32_t* pe
  * hist u32[hist_len <= 8192]; stats = g2pc_distribute_points' device result ([3] = max points per Gaussian; NULL: hist_len-1).
  * Out (device): lut i32[hist_len] (bin of a point count, -1 none), quota i32[hist_len], bin_start u32[hist_len + 2]
  * (exclusive scan of the bins' member counts), bin_lo i32[hist_len] (first point count of each bin).  plan_host: PINNED
- * host memory, i64[10], written through its device mapping: {bins, Gaussians in bins, first wave-mode position, any
+ * host memory, i64[12] (ABI 7; [10] = the largest quota - 1 of a lane-mode bin, [11] reserved), written through its device mapping: {bins, Gaussians in bins, first wave-mode position, any
  * sampling, mean rows, upper bound of output rows, error, start_bin, bin_size, distinct point counts}; error 1 = some
  * Gaussian has >= hist_len points (use a longer histogram on the host path), 2 = fewer than two distinct point counts in
  * binned mode (the reference's np.gradient raises there). */
@@ -226,6 +234,36 @@ int g2pc_sampler_emit_rows(const float* means, const float* cov9, const float* c
                            int32_t attempts, int64_t gv, uint64_t seed, uint64_t gid_base, const uint32_t* dscan,
                            const int64_t* sec_base, int64_t rows_capacity, float* out_points, float* out_colours,
                            float* out_normals, int32_t* out_gauss, void* stream);
+
+/* --- ABI 7: draw-once sampling ------------------------------------------------------------------------------------------------
+ * create_new_gaussian_points draws every sample once (gauss_to_pc.py:204-212) and emits the first d of them (:247-258).  The
+ * two-pass form above evaluates a draw twice (count, then emission: Philox + Box-Muller + Cholesky, ~250 instructions each time);
+ * here the count pass KEEPS every point it may have to emit -- draw k of an attempt with k < room, room = quota - 1 - rows so
+ * far -- and the emission copies.  Lane-mode positions (p < p_wave_begin: one Gaussian per lane) stage plane-major,
+ * thread_rows f32[planes][p_wave_begin][3] with planes >= the largest quota - 1 among them (< wave_min_draws): the lanes of
+ * a wave write one contiguous piece per row.  Wave-mode positions stage Gaussian-major, wave_rows f32[rows][3] with the
+ * rows of position p of bin b at wave_row_start[b] + (p - bin_start[b]) * (quota[b] - 1) (g2pc_sampler_stage_plan fills
+ * wave_row_start u64[num_bins + 1], [num_bins] = total): the lanes of a wave write consecutive rows.  have_before
+ * u32[num_attempts][gv] (same chunking as dcount) = rows a position had before the attempt.  Results are bit for bit those of
+ * g2pc_sampler_count + g2pc_sampler_emit_rows. */
+typedef struct G2pcSampleStage {
+    float* thread_rows;
+    float* wave_rows;
+    const uint64_t* wave_row_start;
+} G2pcSampleStage;
+int g2pc_sampler_stage_plan(const uint32_t* bin_start, const int32_t* quota, int32_t num_bins, int32_t wave_min_draws,
+                            uint64_t* wave_row_start, void* stream);
+int g2pc_sampler_count_staged(const float* means, const float* cov9, const uint32_t* perm, const uint32_t* pbin,
+                              const int32_t* quota, const uint32_t* bin_start, int64_t gv, int64_t p_wave_begin, float std_limit,
+                              int32_t attempt0, int32_t num_attempts, uint64_t seed, uint64_t gid_base, uint32_t* added,
+                              uint32_t* dcount, uint32_t* have_before, uint32_t* remaining, const G2pcSampleStage* stage,
+                              void* stream);
+int g2pc_sampler_emit_rows_staged(const float* means, const float* cov9, const float* colours, const float* normals,
+                                  const uint32_t* perm, const uint32_t* bin_start, const int32_t* quota, int32_t num_bins,
+                                  int32_t attempts, int64_t gv, int64_t p_wave_begin, const uint32_t* dscan,
+                                  const uint32_t* have_before, const int64_t* sec_base, int64_t rows_capacity,
+                                  const G2pcSampleStage* stage, float* out_points, float* out_colours, float* out_normals,
+                                  int32_t* out_gauss, void* stream);
 
 /* --- stand-alone helpers of the python renderer (the reference's public gauss_render functions) ------------------
  * eval_sh (gauss_render.py:43-99): sh f32[n, channels, coeffs] (coefficient index on the LAST axis, as the

@@ -28,6 +28,19 @@ def test_sampler_wave_mode_equals_thread_mode(emu, golden_dir, monkeypatch):
     assert torch.equal(out.points, out3.points)
 
 
+@pytest.mark.parametrize("name", ["sampler_binned_n3000.npz", "sampler_exact_n3000.npz"])
+@pytest.mark.parametrize("wave_min", [32, 4])
+def test_draw_once_equals_two_pass_sampling(emu, golden_dir, monkeypatch, name, wave_min):
+    """The count pass that keeps its points + the copying emission (G2pcSampleStage, the default) against the two-pass form that
+    evaluates every keyed draw twice: the same cloud bit for bit, lane-mode and wave-mode staging, 5 and 100 attempts."""
+    monkeypatch.setattr(ops, "WAVE_MODE_MIN_DRAWS", wave_min)
+    monkeypatch.setattr(ops, "DRAW_ONCE", True)
+    _, _, _, a = run_sampler_case(golden_dir, name)
+    monkeypatch.setattr(ops, "DRAW_ONCE", False)
+    _, _, _, b = run_sampler_case(golden_dir, name)
+    assert torch.equal(a.points, b.points) and torch.equal(a.colours, b.colours) and torch.equal(a.gauss_index, b.gauss_index)
+
+
 @pytest.mark.parametrize("seed,g,scale,exact", [(1, 5000, 30.0, False), (2, 20000, 300.0, False), (3, 3000, 3.0, False),
                                                 (4, 4000, 50.0, True), (5, 150, 800.0, False), (6, 9000, 1500.0, False)])
 def test_device_bin_table_equals_the_host_table(emu, seed, g, scale, exact):
@@ -47,7 +60,7 @@ def test_device_bin_table_equals_the_host_table(emu, seed, g, scale, exact):
     stats = torch.tensor([int(ppg.sum()), int((ppg == 0).sum()), 0, int(ppg.max())], dtype=torch.int64)
     lut, quota, bin_lo = (torch.empty((HL,), dtype=torch.int32) for _ in range(3))
     bin_start = torch.empty((HL + 2,), dtype=torch.int32)
-    plan = torch.zeros((10,), dtype=torch.int64)
+    plan = torch.zeros((12,), dtype=torch.int64)
     wb = L.g2pc_sampler_bin_table_workspace(HL)
     ws = emu.workspace(wb, "cpu")
     emu.check(L.g2pc_sampler_bin_table(emu.ptr(hist_dev), HL, emu.ptr(stats), int(exact), 1, ops.WAVE_MODE_MIN_DRAWS, emu.ptr(lut),
@@ -77,6 +90,8 @@ def test_device_bin_table_equals_the_host_table(emu, seed, g, scale, exact):
     assert bool(any_s) == bool(np.any((q > 1) & (members > 0)))
     assert means_rows == int(members[q > 0].sum())
     assert rows_ub == means_rows + int((members * np.maximum(q - 1, 0)).sum())
+    lane = [int(q[b]) - 1 for b in range(B) if members[b] > 0 and 0 < q[b] - 1 < ops.WAVE_MODE_MIN_DRAWS]
+    assert int(plan[10]) == (max(lane) if lane else 0)            # rows of the lane-mode staging planes (draw-once sampling)
 
 
 def test_point_counts_beyond_the_device_histogram_fall_back_to_the_host_table(emu, monkeypatch):
