@@ -701,25 +701,33 @@ int g2pc_raster_camera_cu(const G2pcCamera* cam, const float* means3D, const flo
     const uint32_t gmask = gshift ? ((1u << gshift) - 1u) : 0xFFFFFFFFu;
     // the preprocess also clears the camera's visibility state and notes the depth range in the bucket sort's header
     // (until round 6: k_init_camera_state_cu, 68 us under load, and k_bk_minmax, 22 us, per camera)
+#ifndef G2PC_CU_FOLD_INIT
+// build-time A/B switch.  1: k_preprocess_cu also clears the camera's visibility state and notes the depth range in the bucket
+// sort's header (k_init_camera_state_cu and k_bk_minmax leave the chain).  Measured on one box, alternating, configs[4]
+// (profiles/r06d_cmd1.log): 30.64 / 30.65 / 30.30 ms with the fold against 30.47 / 30.19 / 29.73 without -- the two launches it
+// removes cost less than the 12 bytes per Gaussian and the block-level atomics it adds to the SH-heavy preprocess.  Off.
+#define G2PC_CU_FOLD_INIT 0
+#endif
     const BucketPlan bplan = bucket_plan((long)n);
-    BucketHdr* hdr = bucket_sort_header(bucket_ws);
-    hipLaunchKernelGGL(k_bucket_hdr_init_cu, dim3(1), dim3(256), 0, s, hdr, bplan);
+    BucketHdr* hdr = G2PC_CU_FOLD_INIT ? bucket_sort_header(bucket_ws) : nullptr;
+    if (hdr) hipLaunchKernelGGL(k_bucket_hdr_init_cu, dim3(1), dim3(256), 0, s, hdr, bplan);
     hipLaunchKernelGGL(k_preprocess_cu, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, to_cam(cam), gx, gy, means3D, cov6, opacity,
                        colours_precomp, shs, (int)sh_degree, (int)sh_coeffs, make_float3(campos[0], campos[1], campos[2]),
                        (long)n, key, idx, (uint32_t*)nullptr /* counts = rect areas */, (float4*)rec, rect, radii, 0, 0 /* antialiasing: g2pc_rasterize_gaussians only */,
-                       (unsigned long long*)cam_key, (uint32_t*)cam_surf, hdr, bplan.nminmax);
+                       hdr ? (unsigned long long*)cam_key : (unsigned long long*)nullptr, hdr ? (uint32_t*)cam_surf : (uint32_t*)nullptr,
+                       hdr, bplan.nminmax);
     BucketEmit em{};
     em.weight = nullptr; em.rect = rect; em.inst_tile = inst_tile; em.inst_g = inst_g; em.gshift = gshift; em.nx = gx;
     em.capacity = (uint32_t)capacity; em.l_eff = l_eff; em.count_host = count_host;
     uint32_t* depth_overflow = nullptr;
-    int rc = bucket_sort_u32(key, nullptr, nullptr, nullptr, (long)n, bucket_ws, bucket_bytes, &depth_overflow, s, Batch(), true, false, &em);
+    int rc = bucket_sort_u32(key, nullptr, nullptr, nullptr, (long)n, bucket_ws, bucket_bytes, &depth_overflow, s, Batch(), hdr != nullptr, false, &em);
     if (rc) return rc;
     if (mask || sharded) {                        // without a mask every pixel is written by the blend kernel
         hipMemsetAsync(out_color, 0, (size_t)3 * W * H * 4, s);
         hipMemsetAsync(out_depth, 0, (size_t)W * H * 4, s);
         hipMemsetAsync(out_invdepth, 0, (size_t)W * H * 4, s);
     }
-    // (cam_key / cam_surf were cleared by k_preprocess_cu)
+    if (!hdr) hipLaunchKernelGGL(k_init_camera_state_cu, dim3(cdiv(n, RA_T)), dim3(RA_T), 0, s, (unsigned long long*)cam_key, (uint32_t*)cam_surf, (long)n);   // (else: cleared by k_preprocess_cu)
     rc = gshift ? sort_pairs_u32(inst_tile, nullptr, tile_sorted, nullptr, tile_tmp, nullptr, L, gshift,
                                  gshift + bits_for_tiles((unsigned)T), sort_ws, sort_bytes, s, l_eff)
                 : sort_pairs_u32(inst_tile, inst_g, tile_sorted, g_sorted, tile_tmp, g_tmp, L, 0, bits_for_tiles((unsigned)T),

@@ -136,7 +136,13 @@ class Gaussians():
         if defer_cull:
             # the culled count stays on the device: the caller carries on as if nothing was culled (the common case) and asks
             # resolve_deferred_cull() once its work is queued -- the host does not stall in the middle of the job
-            self._deferred_cull = (keep, culled)
+            # (the count travels to pinned host memory behind the validation on the same stream: whoever synchronises that
+            # stream later -- the sampler does, for its point count -- finds it there without another round trip)
+            host = ops._pinned_i64(cov.device, 1) if cov.device.type == "cuda" else None
+            if host is not None:
+                host.zero_()
+                host.view(torch.int32)[:1].copy_(culled, non_blocking=True)
+            self._deferred_cull = (keep, culled, host)
             self.last_validate_culled = False
             return keep
         self.last_validate_culled = culled > 0
@@ -152,8 +158,13 @@ class Gaussians():
         pending, self._deferred_cull = getattr(self, "_deferred_cull", None), None
         if pending is None:
             return False
-        keep, count = pending
-        if int(count.item()) == 0:
+        keep, count, host = pending
+        if host is not None:
+            torch.cuda.current_stream(count.device).synchronize()       # (normally idle already: the sampler has just waited for it)
+            culled = int(host.view(torch.int32)[0])
+        else:
+            culled = int(count.item())
+        if culled == 0:
             return False
         self.last_validate_culled = True
         self.add_gaussians_to_cull(keep)

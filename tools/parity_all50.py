@@ -37,30 +37,11 @@ for p in (os.path.join(ROOT, "3dgs-to-pc_amd"), os.path.dirname(os.path.abspath(
     if p not in sys.path:
         sys.path.insert(0, p)
 
-from parity_cfg2 import GOLDEN, _bits, k1_hash8, match_rows  # noqa: E402
+from parity_cfg2 import GOLDEN, _bits, k1_hash8, match_rows, explain_quota_flips  # noqa: E402
 
 
 def available(tag="1m_all50"):
     return os.path.isfile(os.path.join(GOLDEN, "render_py_cfg2_%s.npz" % tag))
-
-
-def explain_quota_flips(ppg, ref_ppg, mags, ref_contrib, contrib, num_points):
-    """Every point quota is round-half-even(x), x = size * num_points / sum(sizes) in float64 (gauss_to_pc.py:73-90), and a size
-    is proportional to its Gaussian's contribution.  A quota of ours may differ from the reference's only if OUR x and the
-    reference's lie on different sides of a half-integer, i.e. the reference's x is no farther from k + 1/2 than the two x can
-    differ: |dx| <= x * (|dc| / c + |dS| / S).  Returns (flips, explained, max |difference|, largest margin / bound ratio)."""
-    d = np.nonzero(ppg != ref_ppg)[0]
-    if d.size == 0:
-        return 0, 0, 0, 0.0
-    S = float(mags.sum())
-    x = mags * (float(num_points) / S)                      # OUR unrounded quotas (float64, as distribute_points forms them)
-    rel_c = np.abs(contrib.astype(np.float64) - ref_contrib.astype(np.float64)) / np.maximum(ref_contrib.astype(np.float64), 1e-30)
-    # the sum moves by at most the mean relative difference of its terms
-    rel_S = float((np.abs(contrib.astype(np.float64) - ref_contrib.astype(np.float64)) / np.maximum(ref_contrib, 1e-30) * mags).sum() / S)
-    bound = x[d] * (rel_c[d] + rel_S) + 1e-9
-    margin = np.abs(x[d] - (np.floor(x[d]) + 0.5))         # distance of our x from the rounding boundary
-    ok = (np.abs(ppg[d] - ref_ppg[d]) == 1) & (margin <= bound)
-    return int(d.size), int(ok.sum()), int(np.abs(ppg[d] - ref_ppg[d]).max()), float((margin / bound).max())
 
 
 def run(device="cuda:0", tag="1m_all50", sampler=True, t_floor=None):
