@@ -359,12 +359,18 @@ def convert_gaussians_to_pc(gaussians, transforms, intrinsics, mask_images, poin
                                    device=s.device, quiet=s.quiet, seed=seed,
                                    shard=(rank, world))
 
-    points, colours, normals = _generate()
+    early_error = None
+    try:
+        points, colours, normals = _generate()
+    except Exception as e:          # noqa: BLE001  (judged below: it may stem from rows the deferred cull removes)
+        early_error = e
     if gaussians.resolve_deferred_cull():
-        # rows WERE culled (ill-conditioned covariances): the cloud above came from the unfiltered set -- sample again
+        # rows WERE culled (ill-conditioned covariances): whatever came out above came from the unfiltered set -- sample again
         if total_gaussian_contributions is not None:
             total_gaussian_contributions = gaussians.select(total_gaussian_contributions)  # [invalid_gaussian_indices]
         points, colours, normals = _generate()
+    elif early_error is not None:
+        raise early_error
 
     total_point_cloud = PointCloudData(points=points, colours=colours, normals=normals)
     _stage("sample_ms")

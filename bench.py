@@ -756,6 +756,28 @@ def main():
             # and from our own render end to end (float64 closed-form eigenvalues here, float32 LAPACK there: a few quotas +-1)
             out["parity"]["ppg_equal_given_ref_contrib"] = full.get("ppg_mismatch_given_ref_contrib") == 0
             out["parity"]["ppg_equal_end_to_end"] = full.get("ppg_mismatch_end_to_end") == 0
+            # every end-to-end quota difference is a rounding-boundary case or it is not (tools/parity_cfg2.py::explain_quota_flips)
+            out["parity"]["ppg_flips_explained"] = full.get("ppg_flips_explained_end_to_end")
+            out["parity"]["ppg_flip_margin_over_bound"] = full.get("ppg_flip_margin_over_bound_end_to_end")
+        # ... and THE BENCHMARKED JOB ITSELF: all 50 cameras through the production path (convert_gaussians_to_pc: pipelined
+        # cameras, graph replays, deferred colour resolve -- what the timed loop above ran) against the untouched reference over
+        # the same 50 cameras (tests/golden/render_py_cfg2_1m_all50.npz; tools/parity_all50.py documents every key)
+        import parity_all50
+        tag50 = "mini_all6" if emulate else "1m_all50"
+        if "parity" in out and parity_all50.available(tag50) and (a.gaussians == 1_000_000 or emulate):
+            gauss_render.clear_context_pool()
+            r50 = parity_all50.run(str(device), tag=tag50)
+            gauss_render.clear_context_pool()
+            out["parity"]["all50"] = {k: r50.get(k) for k in (
+                "cameras", "path", "pipeline", "t_floor", "mask_flips", "near_threshold_1e-5", "visible", "contrib_max",
+                "contrib_frac_gt_1e-4", "contrib_compared", "winner_camera_mismatch", "winner_camera_compared", "colour_max",
+                "colour_max_same_winner", "colour_off_gaussians", "colour_compared_gaussians", "culled_equal", "keep_equal", "kept",
+                "ppg_mismatch_given_ref_contrib", "ppg_mismatch_end_to_end", "ppg_flips_explained", "ppg_max_abs_diff_end_to_end",
+                "ppg_flip_margin_over_bound_max", "sample_points", "sample_points_ref", "sample_rows_compared",
+                "sample_rows_unmatched", "sample_xyz_max", "sample_rgb_max", "sample_rows_order_shifted",
+                "cov3d_rows_differing", "camera_matrix_bits_differing", "reference_cpu_seconds_per_camera_mean",
+                "reference_cpu_threads", "oracle", "check_seconds")}
+            out["parity"]["cameras_all50"] = r50.get("cameras")
         # ... and the reference's DATA-DEPENDENT quad-tree (leaves over max_gaussians_per_tile split, gauss_render.py:319-335)
         # against outputs of the untouched reference on a scene that meets it: 150 000 Gaussians crowded into 160 x 96 pixels,
         # the same fixture tests/test_gpu_quadtree.py holds the renderer to (tests/render_checks.py::run_split_fixture)

@@ -20,5 +20,14 @@ for f in prims geom alloc sampler raster raster_cu clean project; do
   fi
   OBJS="$OBJS $O"
 done
-g++ -shared -fPIC $OBJS -o "$OUT"
+# relink only when an object is newer than the library, and atomically: several ranks of a torch.distributed test may call this
+# at once, and a loader must never meet a half-written file
+NEED=0
+[ -f "$OUT" ] || NEED=1
+for O in $OBJS; do [ "$O" -nt "$OUT" ] && NEED=1; done
+if [ "$NEED" = 1 ]; then
+  TMP="$OUT.$$.tmp"
+  g++ -shared -fPIC $OBJS -o "$TMP"
+  mv -f "$TMP" "$OUT"
+fi
 echo "$OUT"

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     lib.g2pc_abi_version.restype = ctypes.c_int
     from g2pc import _native as nv
-    assert lib.g2pc_abi_version() == nv.ABI_VERSION == 6
+    assert lib.g2pc_abi_version() == nv.ABI_VERSION == 7
 
 
 def test_library_exports_its_abi_and_nothing_else():

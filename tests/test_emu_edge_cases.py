@@ -168,3 +168,38 @@ def test_threshold_at_or_below_the_floor_takes_the_exact_blend(emu):
     there; the renderer drops its transmittance floor by itself whenever the threshold does not lie above it."""
     from render_checks import assert_hidden_behind_wall
     assert_hidden_behind_wall("cpu")
+
+
+def test_deferred_validate_cull_equals_the_eager_one(emu, monkeypatch):
+    """convert_gaussians_to_pc reads validate_covariances' culled-row count only after the sampling was queued
+    (DEFER_VALIDATE_CULL): when rows ARE culled (ill-conditioned covariances) the cloud is sampled again from the filtered set
+    and must equal the cloud of the eager order, row for row; and the magnitudes that reuse the validation's sqrt(area) must equal
+    the ones from a fresh eigen-decomposition bit for bit."""
+    import gauss_to_pc as g2p
+    from gauss_handler import Gaussians
+    sc = make_scene(600, 12, scale_lo=0.01, scale_hi=0.05)
+    # rows the clamp rounds cannot repair (a dynamic range of the spectrum beyond fp32: gauss_handler.py:142-166 culls them)
+    gen = torch.Generator().manual_seed(5)
+    bad = {}
+    for i in (5, 9, 17, 300, 599):
+        q, _ = torch.linalg.qr(torch.randn((3, 3), generator=gen))
+        m = q @ torch.diag(torch.tensor([1e5, 1e-3, -2e-3])) @ q.T
+        bad[i] = (m + m.T) * 0.5
+    s = g2p.GaussPointCloudSettings("python", 6000, True, 2.0, 0, False, 0.0, None, None, True, 0.0, True, None, 3, False,
+                                    0.05, None, False, True, "cpu")
+    clouds = []
+    for defer in (False, True):
+        monkeypatch.setattr(g2p, "DEFER_VALIDATE_CULL", defer)
+        G = Gaussians(sc.xyz, sc.scales, sc.rots, sc.colours.clone(), sc.opacities)
+        cov = G.covariances.clone()
+        for i, m in bad.items():
+            cov[i] = m
+        G.covariances = cov
+        cloud, _ = g2p.convert_gaussians_to_pc(G, None, None, None, s, seed=7)
+        assert G.last_validate_culled and G.xyz.shape[0] < 600           # rows really were culled
+        clouds.append((cloud.points.clone(), cloud.colours.clone(), G.xyz.shape[0]))
+        # the kept sqrt(area) against a fresh decomposition of the validated matrices
+        fresh = ops.gaussian_magnitudes(G.covariances, G.opacities)
+        assert torch.equal(G.get_gaussian_magnitudes(), fresh)
+    assert clouds[0][2] == clouds[1][2]
+    assert torch.equal(clouds[0][0], clouds[1][0]) and torch.equal(clouds[0][1], clouds[1][1])
