@@ -68,6 +68,10 @@ _PROTOS["g2pc_sampler_count_staged"] = (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, 
                                                   _vp, _vp, _vp, _vp, _vp])
 _PROTOS["g2pc_sampler_emit_rows_staged"] = (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _vp, _vp, _vp,
                                                       _i64, _vp, _vp, _vp, _vp, _vp, _vp])
+_PROTOS["g2pc_sampler_run_workspace"] = (_sz, [_i64, _i64, _i64, _i32, _i32, _i64, _i64])
+_PROTOS["g2pc_sampler_run_sections_offset"] = (_sz, [_i64, _i64, _i64, _i32, _i32, _i64, _i64])
+_PROTOS["g2pc_sampler_run"] = (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _i64, _i64, _i32, _i64, _i64,
+                                         _f32, _i32, _u64, _u64, C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp])
 _PROTOS["g2pc_eval_sh"] = (C.c_int, [_i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp])
 _PROTOS["g2pc_build_covariance_2d"] = (C.c_int, [_vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _vp, _vp])
 _PROTOS["g2pc_projection_ndc"] = (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp])

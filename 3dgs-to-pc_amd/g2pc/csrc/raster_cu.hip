@@ -128,29 +128,61 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_cu(Cam cam, int grid_x, int
                     float dx = x - campos.x, dy = y - campos.y, dz = z - campos.z;
                     float len = sqrtf(dx * dx + dy * dy + dz * dz);
                     dx /= len; dy /= len; dz /= len;
+                    // The Gaussian's coefficients [K][3] are one contiguous block (192 bytes at K = 16): read as 16-byte vectors when
+                    // the block is 16-byte aligned (K a multiple of 4) -- a quarter of the load instructions, each of which costs the
+                    // address unit one step per cache line it touches (until round 6: 48 single-dword loads, 64 lines apiece) --, band by
+                    // band, so that only one band's coefficients are live.  Per channel the sum runs left to right exactly as
+                    // computeColorFromSH writes it (forward.cu:22-73): bit-identical.
                     const float* sh = shs + (size_t)i * sh_coeffs * 3;
+#ifndef G2PC_CU_SH_VEC
+#define G2PC_CU_SH_VEC 1         // build-time A/B switch: 0 = single-dword loads, as until round 6
+#endif
+                    const bool vec = G2PC_CU_SH_VEC && ((sh_coeffs & 3) == 0) && ((((size_t)shs) & 15) == 0);
+                    float c[48];
+                    auto fetch = [&](int v0, int v1) {           // floats [4 v0, 4 v1) of the block
+                        if (vec) {
+#pragma unroll
+                            for (int v = v0; v < v1; ++v) {
+                                const float4 q = ((const float4*)sh)[v];
+                                c[4 * v] = q.x; c[4 * v + 1] = q.y; c[4 * v + 2] = q.z; c[4 * v + 3] = q.w;
+                            }
+                        } else {
+#pragma unroll
+                            for (int k = 4 * v0; k < 4 * v1; ++k) c[k] = k < sh_coeffs * 3 ? sh[k] : 0.0f;
+                        }
+                    };
                     float res[3];
+                    if (sh_degree > 0) fetch(0, 3); else fetch(0, 1);      // bands 0 (3 floats) and 1 (9); constant bounds: c[] stays in registers
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch) {
-                        float v = 0.28209479177387814f * sh[ch];
-                        if (sh_degree > 0) {
-                            v = v - 0.4886025119029199f * dy * sh[3 + ch] + 0.4886025119029199f * dz * sh[6 + ch] -
-                                0.4886025119029199f * dx * sh[9 + ch];
-                            if (sh_degree > 1) {
-                                float xx = dx * dx, yy = dy * dy, zz = dz * dz, xy = dx * dy, yz = dy * dz, xz = dx * dz;
-                                v = v + kSH_C2[0] * xy * sh[12 + ch] + kSH_C2[1] * yz * sh[15 + ch] +
-                                    kSH_C2[2] * (2.0f * zz - xx - yy) * sh[18 + ch] + kSH_C2[3] * xz * sh[21 + ch] +
-                                    kSH_C2[4] * (xx - yy) * sh[24 + ch];
-                                if (sh_degree > 2) {
-                                    v = v + kSH_C3[0] * dy * (3.0f * xx - yy) * sh[27 + ch] + kSH_C3[1] * xy * dz * sh[30 + ch] +
-                                        kSH_C3[2] * dy * (4.0f * zz - xx - yy) * sh[33 + ch] +
-                                        kSH_C3[3] * dz * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[36 + ch] +
-                                        kSH_C3[4] * dx * (4.0f * zz - xx - yy) * sh[39 + ch] +
-                                        kSH_C3[5] * dz * (xx - yy) * sh[42 + ch] + kSH_C3[6] * dx * (xx - 3.0f * yy) * sh[45 + ch];
-                                }
-                            }
+                        float v = 0.28209479177387814f * c[ch];
+                        if (sh_degree > 0)
+                            v = v - 0.4886025119029199f * dy * c[3 + ch] + 0.4886025119029199f * dz * c[6 + ch] -
+                                0.4886025119029199f * dx * c[9 + ch];
+                        res[ch] = v;
+                    }
+                    if (sh_degree > 1) {
+                        const float xx = dx * dx, yy = dy * dy, zz = dz * dz, xy = dx * dy, yz = dy * dz, xz = dx * dz;
+                        fetch(3, 7);                                       // floats 12 .. 27: band 2 (12 .. 26) and the first of band 3
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch)
+                            res[ch] = res[ch] + kSH_C2[0] * xy * c[12 + ch] + kSH_C2[1] * yz * c[15 + ch] +
+                                      kSH_C2[2] * (2.0f * zz - xx - yy) * c[18 + ch] + kSH_C2[3] * xz * c[21 + ch] +
+                                      kSH_C2[4] * (xx - yy) * c[24 + ch];
+                        if (sh_degree > 2) {
+                            fetch(7, 12);                                  // floats 28 .. 47
+#pragma unroll
+                            for (int ch = 0; ch < 3; ++ch)
+                                res[ch] = res[ch] + kSH_C3[0] * dy * (3.0f * xx - yy) * c[27 + ch] + kSH_C3[1] * xy * dz * c[30 + ch] +
+                                          kSH_C3[2] * dy * (4.0f * zz - xx - yy) * c[33 + ch] +
+                                          kSH_C3[3] * dz * (2.0f * zz - 3.0f * xx - 3.0f * yy) * c[36 + ch] +
+                                          kSH_C3[4] * dx * (4.0f * zz - xx - yy) * c[39 + ch] +
+                                          kSH_C3[5] * dz * (xx - yy) * c[42 + ch] + kSH_C3[6] * dx * (xx - 3.0f * yy) * c[45 + ch];
                         }
-                        v += 0.5f;
+                    }
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        const float v = res[ch] + 0.5f;
                         res[ch] = v < 0.0f ? 0.0f : v;
                     }
                     cr = res[0]; cg = res[1]; cb = res[2];
@@ -231,7 +263,11 @@ __global__ __launch_bounds__(CU_T) void k_blend_cu(int W, int H, int grid_x, int
             uint32_t g = inst_g[b + t] & gmask;
             const float4 r0 = rec[4 * (size_t)g], r1 = rec[4 * (size_t)g + 1], r3 = rec[4 * (size_t)g + 3];
             s_p0[t] = r0;
-            s_p1[t] = r1;
+            // .w: 1 / depth, formed ONCE per staged entry (the record's radius is not used by the blend).  The inverse-depth
+            // map accumulates contrib / depth per pixel (forward.cu:428-430): the quotient is the same for all 256 pixels, and an
+            // IEEE division is a 13-instruction sequence -- until round 6 every lane evaluated it on every visit, a third of
+            // the loop's VALU instructions.  Same operands, same operation: bit-identical.
+            s_p1[t] = make_float4(r1.x, r1.y, r1.z, 1.0f / r1.z);
             const float4 c3 = rec[4 * (size_t)g + 2];
             float gm = fmaxf(__uint_as_float(key_hi[2 * (size_t)g]), 1.17549435e-38f);
             s_p2[t] = make_float4(c3.x, c3.y, c3.z, gm);
@@ -273,7 +309,7 @@ __global__ __launch_bounds__(CU_T) void k_blend_cu(int W, int H, int grid_x, int
         const int cnt = (end - b) < (uint32_t)CU_T ? (int)(end - b) : CU_T;
         // wave-uniform early out inside the batch: nothing left to blend for these 64 pixels
         for (int i0 = 0; i0 < lcnt && !__all(done ? 1 : 0); i0 += 4) {
-            float alpha[4], power[4], dep[4];
+            float alpha[4], power[4], dep[4], idep[4];
             float4 cc[4];
             int kk[4];
 #pragma unroll
@@ -287,10 +323,11 @@ __global__ __launch_bounds__(CU_T) void k_blend_cu(int W, int H, int grid_x, int
                 power[u] = fmaf(dx, fmaf(a.w, dy, a.z * dx), (q.x * dy) * dy);
                 alpha[u] = fminf(0.99f, q.y * __builtin_amdgcn_exp2f(power[u]));
                 dep[u] = q.z;
+                idep[u] = q.w;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                G2PC_PIN(alpha[u]); G2PC_PIN(dep[u]);
+                G2PC_PIN(alpha[u]); G2PC_PIN(dep[u]); G2PC_PIN(idep[u]);
                 G2PC_PIN(cc[u].x); G2PC_PIN(cc[u].y); G2PC_PIN(cc[u].z); G2PC_PIN(cc[u].w);
             }
 #pragma unroll
@@ -306,7 +343,10 @@ __global__ __launch_bounds__(CU_T) void k_blend_cu(int W, int H, int grid_x, int
                 cr = fmaf(c.x, contrib, cr);
                 cg = fmaf(c.y, contrib, cg);
                 cb = fmaf(c.z, contrib, cb);
-                Ei = fmaf(1.0f / depth, contrib, Ei);
+#ifndef G2PC_CU_HOIST_IDEPTH
+#define G2PC_CU_HOIST_IDEPTH 1   // build-time A/B switch: 0 = 1 / depth by every lane on every visit, as until round 6
+#endif
+                Ei = fmaf(G2PC_CU_HOIST_IDEPTH ? idep[u] : 1.0f / depth, contrib, Ei);
                 E = fmaf(depth, contrib, E);
                 T = blend ? test_T : T;
                 if (__any(contrib >= c.w)) {

@@ -872,3 +872,88 @@ int g2pc_sample_mvn(const float* means, const float* cov9, int64_t g, int32_t n,
     return check_launch("g2pc_sample_mvn");
 }
 }
+
+extern "C" {
+/* The sampler's whole tail in ONE call (ABI 7): partition by bin -> staged count pass -> scans -> section table -> copying emission,
+ * everything it needs between them in ONE caller-provided workspace.  The launches are those of g2pc_sampler_partition,
+ * _stage_plan, _count_staged, _scan_counts, _sections and _emit_rows_staged in that order (bit-identical results); what the call
+ * removes is the host work between them -- a dozen interpreter-level calls and allocations per job, which pace a job whose kernels
+ * take 0.6 ms.  attempts <= 8 (the binned default runs 5; exact_num_points' 100 keep the chunked loop of the caller). */
+struct SamplerRunLayout { size_t perm, pbin, part_ws, part_bytes, added, dcount, hb, dscan, scan_ws, scan_bytes, sec_base, wrs, stage_t, stage_w, total; };
+static SamplerRunLayout sampler_run_layout(int64_t G, int64_t gv, int64_t p_wave, int32_t B, int32_t A, int64_t lane_planes, int64_t wave_rows) {
+    using namespace g2pc;
+    SamplerRunLayout l{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = align_up(off); off = o + bytes; return o; };
+    const size_t gvs = (size_t)(gv > 0 ? gv : 1);
+    l.perm = take((size_t)G * 4); l.pbin = take((size_t)G * 4);
+    l.part_bytes = g2pc_sampler_plan_workspace(G); l.part_ws = take(l.part_bytes);
+    l.added = take((gvs + 1) * 4);
+    l.dcount = take((size_t)A * gvs * 4); l.hb = take((size_t)A * gvs * 4); l.dscan = take((size_t)A * (gvs + 1) * 4);
+    l.scan_bytes = g2pc_sampler_scan_workspace(gv, A); l.scan_ws = take(l.scan_bytes);
+    l.sec_base = take(((size_t)(B > 0 ? B : 1) * (1 + A) + 1) * 8);
+    l.wrs = take(((size_t)B + 1) * 8);
+    l.stage_t = take((size_t)(lane_planes > 0 ? lane_planes : 0) * (size_t)(p_wave > 0 ? p_wave : 0) * 12 + 16);
+    l.stage_w = take((size_t)(wave_rows > 0 ? wave_rows : 0) * 12 + 16);
+    l.total = align_up(off) + 256;
+    return l;
+}
+size_t g2pc_sampler_run_workspace(int64_t g, int64_t gv, int64_t p_wave_begin, int32_t num_bins, int32_t attempts,
+                                  int64_t lane_planes, int64_t wave_rows) {
+    return sampler_run_layout(g, gv, p_wave_begin, num_bins, attempts, lane_planes, wave_rows).total;
+}
+/* byte offset of the section table (i64[num_bins * (1 + attempts) + 1]) inside the workspace -- diagnostics read it */
+size_t g2pc_sampler_run_sections_offset(int64_t g, int64_t gv, int64_t p_wave_begin, int32_t num_bins, int32_t attempts,
+                                        int64_t lane_planes, int64_t wave_rows) {
+    return sampler_run_layout(g, gv, p_wave_begin, num_bins, attempts, lane_planes, wave_rows).sec_base;
+}
+int g2pc_sampler_run(const float* means, const float* cov9, const float* colours, const float* normals, const int32_t* ppg,
+                     int64_t g, const int32_t* bin_of_ppg, int64_t lut_len, const int32_t* quota, const uint32_t* bin_start,
+                     int32_t num_bins, int64_t gv, int64_t p_wave_begin, int32_t wave_min_draws, int64_t lane_planes,
+                     int64_t wave_rows, float std_limit, int32_t attempts, uint64_t seed, uint64_t gid_base, int emit_means,
+                     int64_t rows_capacity, float* out_points, float* out_colours, float* out_normals, int32_t* out_gauss,
+                     int64_t* info_host, void* ws, size_t ws_bytes, void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(means && cov9 && colours && ppg && bin_of_ppg && quota && bin_start && ws && g > 0 &&
+                     (rows_capacity <= 0 || (out_points && out_colours)), G2PC_ERR_ARG, "bad arguments");
+    G2PC_REQUIRE(attempts >= 0 && attempts <= 8 && num_bins >= 0 && gv >= 0, G2PC_ERR_ARG, "bad sizes (attempts <= 8)");
+    if (p_wave_begin < 0 || p_wave_begin > gv) p_wave_begin = gv;
+    const SamplerRunLayout l = sampler_run_layout(g, gv, p_wave_begin, num_bins, attempts, lane_planes, wave_rows);
+    G2PC_REQUIRE(l.total <= ws_bytes, G2PC_ERR_WORKSPACE, "workspace too small");
+    char* b = (char*)ws;
+    uint32_t* perm = (uint32_t*)(b + l.perm); uint32_t* pbin = (uint32_t*)(b + l.pbin);
+    uint32_t* added = (uint32_t*)(b + l.added); uint32_t* dcount = (uint32_t*)(b + l.dcount); uint32_t* hb = (uint32_t*)(b + l.hb);
+    uint32_t* dscan = (uint32_t*)(b + l.dscan); int64_t* sec_base = (int64_t*)(b + l.sec_base);
+    uint64_t* wrs = (uint64_t*)(b + l.wrs);
+    const size_t gvs = (size_t)(gv > 0 ? gv : 1);
+    uint32_t* remaining = added + gvs;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = g2pc_sampler_partition(ppg, g, bin_of_ppg, lut_len, num_bins, perm, pbin, b + l.part_ws, l.part_bytes, stream);
+    if (rc) return rc;
+    hipMemsetAsync(added, 0, (gvs + 1) * 4, s);
+    G2pcSampleStage st{(float*)(b + l.stage_t), (float*)(b + l.stage_w), wrs};
+    const bool sampling = attempts > 0 && gv > 0;
+    if (sampling) {
+        if (p_wave_begin < gv) {
+            rc = g2pc_sampler_stage_plan(bin_start, quota, num_bins, wave_min_draws, wrs, stream);
+            if (rc) return rc;
+        }
+        rc = g2pc_sampler_count_staged(means, cov9, perm, pbin, quota, bin_start, gv, p_wave_begin, std_limit, 0, attempts, seed,
+                                       gid_base, added, dcount, hb, remaining, &st, stream);
+        if (rc) return rc;
+        rc = g2pc_sampler_scan_counts(dcount, dscan, gv, attempts, b + l.scan_ws, l.scan_bytes, stream);
+        if (rc) return rc;
+    }
+    const int A = sampling ? attempts : 0;
+    rc = g2pc_sampler_sections(bin_start, quota, num_bins, A, A ? dscan : nullptr, gv, emit_means, sec_base, info_host, remaining, stream);
+    if (rc) return rc;
+    if (rows_capacity > 0 && gv > 0 && num_bins > 0) {
+        rc = A ? g2pc_sampler_emit_rows_staged(means, cov9, colours, normals, perm, bin_start, quota, num_bins, A, gv, p_wave_begin, dscan,
+                                               hb, sec_base, rows_capacity, &st, out_points, out_colours, out_normals, out_gauss, stream)
+               : g2pc_sampler_emit_rows(means, cov9, colours, normals, perm, bin_start, num_bins, 0, 0, gv, seed, gid_base, nullptr,
+                                        sec_base, rows_capacity, out_points, out_colours, out_normals, out_gauss, stream);
+        if (rc) return rc;
+    }
+    return check_launch("g2pc_sampler_run");
+}
+}

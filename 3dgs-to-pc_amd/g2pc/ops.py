@@ -265,6 +265,7 @@ WAVE_MODE_MIN_DRAWS = 32   # quota-1 at and above which one Gaussian is sampled 
 HIST_GUESS = 8192          # histogram length used before max(points per Gaussian) is known on the host
 ATTEMPT_CHUNK = 8
 DRAW_ONCE = True           # the count pass keeps the points it may have to emit, the emission copies (G2pcSampleStage)
+ONE_CALL_TAIL = True       # partition .. emission through g2pc_sampler_run (one library call, one workspace)
 
 
 import ctypes as C  # noqa: E402
@@ -400,6 +401,38 @@ def sample_pointcloud(xyz: torch.Tensor, cov: torch.Tensor, colours: torch.Tenso
         rows_ub = means_rows + int(sum(members[b] * max(int(quota[b]) - 1, 0) for b in range(B)))
         lane_planes = max([int(quota[b]) - 1 for b in range(B) if members[b] > 0 and 0 < quota[b] - 1 < WAVE_MODE_MIN_DRAWS] or [0])
 
+    def outputs(rows):
+        pts = torch.empty((rows, 3), dtype=torch.float32, device=dev)
+        cols = torch.empty((rows, 3), dtype=torch.float32, device=dev)
+        nrm = torch.empty((rows, 3), dtype=torch.float32, device=dev) if normals is not None else None
+        gidx = torch.empty((rows,), dtype=torch.int32, device=dev) if want_index else None
+        return pts, cols, nrm, gidx
+
+    if ONE_CALL_TAIL and DRAW_ONCE and attempts <= ATTEMPT_CHUNK and G > 0:
+        # the whole tail -- partition, staged count, scans, section table, emission -- as ONE library call over ONE workspace
+        # (g2pc_sampler_run): the same launches without a dozen interpreter-level calls and allocations between them
+        A = attempts if (any_sampling and gv > 0) else 0
+        wave_rows = max(rows_ub - means_rows, 0) if p_wave < gv else 0
+        sizes = (G, gv, p_wave, B, A, max(int(lane_planes), 0), wave_rows)
+        wb = L.g2pc_sampler_run_workspace(*sizes)
+        ws = nv.workspace(wb, dev)
+        info = _pinned_i64(dev)
+        pts, cols, nrm, gidx = outputs(rows_ub)
+        with nv.region("sampler_run", dev):
+            nv.check(L.g2pc_sampler_run(nv.ptr(xyz), nv.ptr(cov), nv.ptr(colours), nv.ptr(normals), nv.ptr(ppg_i32), G,
+                                        nv.ptr(lut_d), lut_len, nv.ptr(quota_d), nv.ptr(bin_start), B, gv, p_wave,
+                                        WAVE_MODE_MIN_DRAWS, sizes[5], wave_rows, float(std), A, int(seed), int(gid_base),
+                                        1 if emit_means else 0, rows_ub, nv.ptr(pts), nv.ptr(cols), nv.ptr(nrm), nv.ptr(gidx),
+                                        C_void(info), nv.ptr(ws), wb, st), "sampler_run")
+        if dev.type == "cuda" and not nv.emulated():
+            torch.cuda.current_stream(dev).synchronize()             # round trip #2: how many points came out
+        M = int(info[0]) if B > 0 else 0
+        assert 0 <= M <= rows_ub, (M, rows_ub)
+        so = L.g2pc_sampler_run_sections_offset(*sizes)
+        sec_base = ws[so:so + (max(B, 1) * (1 + A) + 1) * 8].view(torch.int64)
+        return SampledCloud(pts[:M], cols[:M], nrm[:M] if nrm is not None else None, gidx[:M] if gidx is not None else None,
+                            bins, _LazyPerAttempt(sec_base, B, A))
+
     perm = torch.empty((G,), dtype=torch.int32, device=dev)
     pbin = torch.empty((G,), dtype=torch.int32, device=dev)
     ws_bytes = L.g2pc_sampler_plan_workspace(G)
@@ -409,13 +442,6 @@ def sample_pointcloud(xyz: torch.Tensor, cov: torch.Tensor, colours: torch.Tenso
     added = torch.zeros((max(gv, 1) + 1,), dtype=torch.int32, device=dev)        # [gv] = unfinished Gaussians ("remaining")
     remaining = added[max(gv, 1):]
     info = _pinned_i64(dev)
-
-    def outputs(rows):
-        pts = torch.empty((rows, 3), dtype=torch.float32, device=dev)
-        cols = torch.empty((rows, 3), dtype=torch.float32, device=dev)
-        nrm = torch.empty((rows, 3), dtype=torch.float32, device=dev) if normals is not None else None
-        gidx = torch.empty((rows,), dtype=torch.int32, device=dev) if want_index else None
-        return pts, cols, nrm, gidx
 
     def sync():
         if dev.type == "cuda" and not nv.emulated():

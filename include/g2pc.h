@@ -265,6 +265,24 @@ int g2pc_sampler_emit_rows_staged(const float* means, const float* cov9, const f
                                   const G2pcSampleStage* stage, float* out_points, float* out_colours, float* out_normals,
                                   int32_t* out_gauss, void* stream);
 
+/* The sampler's tail in ONE call: g2pc_sampler_partition -> _stage_plan -> _count_staged (attempts 0 .. attempts-1, <= 8) ->
+ * _scan_counts -> _sections -> _emit_rows_staged, with perm / pbin / counts / scans / section table / staging arrays all inside ONE
+ * workspace of g2pc_sampler_run_workspace() bytes (the section table at g2pc_sampler_run_sections_offset() for diagnostics).
+ * Same launches, same results; what it removes is the host work between them (create_new_gaussian_points' loop body is a
+ * dozen torch calls in the reference, gauss_to_pc.py:195-263).  bin_of_ppg / quota / bin_start as g2pc_sampler_bin_table
+ * leaves them; lane_planes / wave_rows size the staging (plan word 10; rows_ub - means_rows).  info_host: PINNED i64[2] <- {M,
+ * Gaussians still short}. */
+size_t g2pc_sampler_run_workspace(int64_t g, int64_t gv, int64_t p_wave_begin, int32_t num_bins, int32_t attempts,
+                                  int64_t lane_planes, int64_t wave_rows);
+size_t g2pc_sampler_run_sections_offset(int64_t g, int64_t gv, int64_t p_wave_begin, int32_t num_bins, int32_t attempts,
+                                        int64_t lane_planes, int64_t wave_rows);
+int g2pc_sampler_run(const float* means, const float* cov9, const float* colours, const float* normals, const int32_t* ppg,
+                     int64_t g, const int32_t* bin_of_ppg, int64_t lut_len, const int32_t* quota, const uint32_t* bin_start,
+                     int32_t num_bins, int64_t gv, int64_t p_wave_begin, int32_t wave_min_draws, int64_t lane_planes,
+                     int64_t wave_rows, float std_limit, int32_t attempts, uint64_t seed, uint64_t gid_base, int emit_means,
+                     int64_t rows_capacity, float* out_points, float* out_colours, float* out_normals, int32_t* out_gauss,
+                     int64_t* info_host, void* ws, size_t ws_bytes, void* stream);
+
 /* --- stand-alone helpers of the python renderer (the reference's public gauss_render functions) ------------------
  * eval_sh (gauss_render.py:43-99): sh f32[n, channels, coeffs] (coefficient index on the LAST axis, as the
  * reference indexes it), dirs f32[n,3] (may be NULL for degree 0), out f32[n, channels]; degree 0..4. */

@@ -35,10 +35,17 @@ def test_draw_once_equals_two_pass_sampling(emu, golden_dir, monkeypatch, name, 
     evaluates every keyed draw twice: the same cloud bit for bit, lane-mode and wave-mode staging, 5 and 100 attempts."""
     monkeypatch.setattr(ops, "WAVE_MODE_MIN_DRAWS", wave_min)
     monkeypatch.setattr(ops, "DRAW_ONCE", True)
+    monkeypatch.setattr(ops, "ONE_CALL_TAIL", False)
     _, _, _, a = run_sampler_case(golden_dir, name)
     monkeypatch.setattr(ops, "DRAW_ONCE", False)
     _, _, _, b = run_sampler_case(golden_dir, name)
     assert torch.equal(a.points, b.points) and torch.equal(a.colours, b.colours) and torch.equal(a.gauss_index, b.gauss_index)
+    # ... and the whole tail as ONE library call over one workspace (g2pc_sampler_run; the binned default's 5 attempts take it)
+    monkeypatch.setattr(ops, "DRAW_ONCE", True)
+    monkeypatch.setattr(ops, "ONE_CALL_TAIL", True)
+    _, _, _, c = run_sampler_case(golden_dir, name)
+    assert torch.equal(a.points, c.points) and torch.equal(a.colours, c.colours) and torch.equal(a.gauss_index, c.gauss_index)
+    assert list(a.emitted_per_attempt) == list(c.emitted_per_attempt)
 
 
 @pytest.mark.parametrize("seed,g,scale,exact", [(1, 5000, 30.0, False), (2, 20000, 300.0, False), (3, 3000, 3.0, False),

@@ -83,3 +83,32 @@ def test_wide_tile_field_and_its_shorter_camera_epoch():
         gauss_render.clear_context_pool()
     assert R.seq_bits == 14 and R.camera_epoch == 63 and R0.seq_bits == 14
     assert np.array_equal(k0 >> 32, k1 >> 32) and np.array_equal(c0, c1)
+
+
+@pytest.mark.parametrize("semantics", ["python", "cuda"])
+def test_one_and_a_half_million_gaussians_take_the_8192_bucket_instances(semantics):
+    """1 048 576 < n <= 2 097 152 Gaussians select k_bk_hist_w<BK_MAX> (8 192 depth buckets, 64 KB + 16 B of LDS: a
+    gfx950 size), the 32-buckets-per-thread loop of k_bk_scan and the 8 192-bucket emission; the 1.0 M fixtures take <4096>.
+    The fused camera call of both semantics at 1.5 M Gaussians against the two-call (radix) path: the same state bit for bit."""
+    import gauss_render
+    import camera_handler
+    from g2pc.synth import make_scene, make_cameras
+    from gauss_handler import Gaussians
+    gauss_render.clear_context_pool()
+    sc = make_scene(1_500_000, 31, device="cuda:0")
+    G = Gaussians(sc.xyz, sc.scales, sc.rots, sc.colours, sc.opacities)
+    tr, intr = make_cameras(6, width=640, height=360, focal=550.0)
+    res = []
+    for pipelined in (False, True):
+        R = gauss_render.get_renderer(semantics, G.xyz, G.opacities.unsqueeze(1), G.colours, G.covariances,
+                                      visible_gaussian_threshold=0.05)
+        for nm in sorted(tr):
+            R(camera_handler.get_camera(semantics, torch.tensor(tr[nm]), intr[nm]), return_image=not pipelined)
+        res.append((R.get_gaussian_colours().cpu().numpy(), R.get_total_gaussian_contributions().cpu().numpy(), R.rerendered))
+        if hasattr(R, "close"):
+            R.close()
+        del R
+    gauss_render.clear_context_pool()
+    assert int((res[0][1] > 0).sum()) > 100_000
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][0], res[1][0])
+    assert res[1][2] <= 1
