@@ -133,17 +133,22 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_cu(Cam cam, int grid_x, int
                     // address unit one step per cache line it touches (until round 6: 48 single-dword loads, 64 lines apiece) --, band by
                     // band, so that only one band's coefficients are live.  Per channel the sum runs left to right exactly as
                     // computeColorFromSH writes it (forward.cu:22-73): bit-identical.
+                    // sh_coeffs < 0: PLANE-MAJOR coefficients (g2pc_sh_planes: f32[3K/4][n][4], vector v of Gaussian i at v * n + i) --
+                    // the lanes of a wave then read 1 KB contiguous per vector instead of one 16-byte piece every 192 bytes; the scene
+                    // is static over a job's cameras, so the binding transposes once per job.
+                    const bool planes = sh_coeffs < 0;
+                    if (planes) sh_coeffs = -sh_coeffs;
                     const float* sh = shs + (size_t)i * sh_coeffs * 3;
 #ifndef G2PC_CU_SH_VEC
 #define G2PC_CU_SH_VEC 1         // build-time A/B switch: 0 = single-dword loads, as until round 6
 #endif
-                    const bool vec = G2PC_CU_SH_VEC && ((sh_coeffs & 3) == 0) && ((((size_t)shs) & 15) == 0);
+                    const bool vec = planes || (G2PC_CU_SH_VEC && ((sh_coeffs & 3) == 0) && ((((size_t)shs) & 15) == 0));
                     float c[48];
                     auto fetch = [&](int v0, int v1) {           // floats [4 v0, 4 v1) of the block
                         if (vec) {
 #pragma unroll
                             for (int v = v0; v < v1; ++v) {
-                                const float4 q = ((const float4*)sh)[v];
+                                const float4 q = planes ? ((const float4*)shs)[(size_t)v * (size_t)n + (size_t)i] : ((const float4*)sh)[v];
                                 c[4 * v] = q.x; c[4 * v + 1] = q.y; c[4 * v + 2] = q.z; c[4 * v + 3] = q.w;
                             }
                         } else {
@@ -205,6 +210,13 @@ __global__ __launch_bounds__(RA_T) void k_preprocess_cu(Cam cam, int grid_x, int
         __syncthreads();
         if (threadIdx.x < 2) atomicMax(&mm->partial[2 * (blockIdx.x % mm_slots) + threadIdx.x], s_mm[threadIdx.x]);
     }
+}
+// g2pc_sh_planes: shs f32[n][K][3] (the reference's layout, forward.cu:31) -> f32[3K/4][n][4]
+__global__ __launch_bounds__(RA_T) void k_sh_planes(const float4* __restrict__ in, long n, int vecs, float4* __restrict__ out) {
+    const long t = (long)blockIdx.x * RA_T + threadIdx.x;
+    if (t >= n * vecs) return;
+    const long v = t / n, i = t - v * n;                 // consecutive threads: consecutive Gaussians of one plane (coalesced stores)
+    out[t] = in[i * vecs + v];
 }
 // the depth bucket sort's header, cleared for the range notes of k_preprocess_cu
 __global__ void k_bucket_hdr_init_cu(BucketHdr* __restrict__ h, BucketPlan plan) { bucket_hdr_init(h, plan, threadIdx.x, blockDim.x); }
@@ -502,6 +514,15 @@ __global__ __launch_bounds__(RA_T) void k_init_camera_state_cu(unsigned long lon
 }  // namespace g2pc
 
 extern "C" {
+int g2pc_sh_planes(const float* shs, int64_t n, int32_t sh_coeffs, float* planes, void* stream) {
+    using namespace g2pc;
+    G2PC_REQUIRE(shs && planes && n > 0 && sh_coeffs > 0 && (sh_coeffs & 3) == 0 && (((size_t)shs | (size_t)planes) & 15) == 0,
+                 G2PC_ERR_ARG, "sh_coeffs must be a multiple of 4 and the arrays 16-byte aligned");
+    const int vecs = sh_coeffs * 3 / 4;
+    hipLaunchKernelGGL(k_sh_planes, dim3(cdiv((long)n * vecs, RA_T)), dim3(RA_T), 0, (hipStream_t)stream, (const float4*)shs, (long)n, vecs,
+                       (float4*)planes);
+    return check_launch("g2pc_sh_planes");
+}
 int g2pc_mark_visible(const float* means3D, int64_t n, const float* viewmatrix, uint8_t* present, void* stream) {
     using namespace g2pc;
     G2PC_REQUIRE(means3D && viewmatrix && present && n > 0, G2PC_ERR_ARG, "bad arguments");
@@ -522,8 +543,8 @@ static int front_cu_impl(const G2pcCamera* cam, const float* means3D, const floa
                  G2PC_ERR_ARG, "bad arguments");
     G2PC_REQUIRE((colours_precomp != nullptr) != (shs != nullptr), G2PC_ERR_ARG,
                  "provide exactly one of precomputed colours or SHs");       // __init__.py:42-43
-    G2PC_REQUIRE(!shs || (sh_degree >= 0 && sh_degree <= 3 && sh_coeffs >= (sh_degree + 1) * (sh_degree + 1)), G2PC_ERR_ARG,
-                 "SH degree / coefficient count mismatch");
+    G2PC_REQUIRE(!shs || (sh_degree >= 0 && sh_degree <= 3 && (sh_coeffs < 0 ? -sh_coeffs : sh_coeffs) >= (sh_degree + 1) * (sh_degree + 1) &&
+                          (sh_coeffs > 0 || ((-sh_coeffs) & 3) == 0)), G2PC_ERR_ARG, "SH degree / coefficient count mismatch");
     const int gx = (cam->width + 15) / 16, gy = (cam->height + 15) / 16;
     G2PC_REQUIRE(gx <= 65535 && gy <= 65535, G2PC_ERR_UNSUPPORTED, "image larger than 1048560 pixels per side");
     hipStream_t s = (hipStream_t)stream;
@@ -711,8 +732,8 @@ int g2pc_raster_camera_cu(const G2pcCamera* cam, const float* means3D, const flo
     G2PC_REQUIRE(cam && means3D && cov6 && opacity && campos && rec && rect && radii && cam_key && cam_surf && out_color &&
                      out_depth && out_invdepth && ws && n > 0 && capacity > 0, G2PC_ERR_ARG, "bad arguments");
     G2PC_REQUIRE((colours_precomp != nullptr) != (shs != nullptr), G2PC_ERR_ARG, "provide exactly one of precomputed colours or SHs");
-    G2PC_REQUIRE(!shs || (sh_degree >= 0 && sh_degree <= 3 && sh_coeffs >= (sh_degree + 1) * (sh_degree + 1)), G2PC_ERR_ARG,
-                 "SH degree / coefficient count mismatch");
+    G2PC_REQUIRE(!shs || (sh_degree >= 0 && sh_degree <= 3 && (sh_coeffs < 0 ? -sh_coeffs : sh_coeffs) >= (sh_degree + 1) * (sh_degree + 1) &&
+                          (sh_coeffs > 0 || ((-sh_coeffs) & 3) == 0)), G2PC_ERR_ARG, "SH degree / coefficient count mismatch");
     const int W = cam->width, H = cam->height;
     const int gx = (W + 15) / 16, gy = (H + 15) / 16, T = gx * gy;
     G2PC_REQUIRE(!cu_wide_grid(gx, gy) && bucket_emit_supported((long)n) && capacity < (1ll << 31), G2PC_ERR_UNSUPPORTED,

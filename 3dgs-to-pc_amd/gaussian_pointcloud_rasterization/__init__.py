@@ -55,6 +55,7 @@ nv._RASTER_PROTOS.update({
     "g2pc_raster_back_cu_dev": (C.c_int, [C.POINTER(_Camera), _vp, C.c_int64, C.c_int64] + [_vp] * 4 + [C.c_int] + [_vp] * 6 +
                                 [C.c_int32, C.c_int32, _vp, C.c_size_t, _vp]),
     "g2pc_mark_visible": (C.c_int, [_vp, C.c_int64, C.POINTER(C.c_float * 16), _vp, _vp]),
+    "g2pc_sh_planes": (C.c_int, [_vp, C.c_int64, C.c_int32, _vp, _vp]),
     "g2pc_raster_camera_cu_workspace": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32]),
     "g2pc_raster_camera_cu": (C.c_int, [C.POINTER(_Camera)] + [_vp] * 5 + [C.c_int32, C.c_int32, _vp, _vp, C.c_int64, C.c_int64] +
                               [_vp] * 3 + [C.c_int] + [_vp] * 6 + [C.c_int32, C.c_int32, _vp, C.c_size_t, _vp]),
@@ -68,6 +69,7 @@ FUSED_CAMERA_CALL = True          # pipelined cameras through g2pc_raster_camera
 PIPELINE_IN_EMULATOR = False      # tests: drive the no-read-back camera path through the CPU emulator too
 CAPACITY_HEADROOM = 1.25          # instance capacity of the pipelined cameras relative to the largest count seen so far
 MIN_CAPACITY = 1 << 16
+SH_PLANES = True                  # SH coefficients transposed once per renderer to plane-major (g2pc_sh_planes): coalesced reads per camera
 
 
 def mark_visible(means3D, viewmatrix, projmatrix=None):
@@ -161,6 +163,8 @@ class GaussianRasterizer(nn.Module):
         self._winner_cam = torch.full((n,), 1 << 30, dtype=torch.int32, device=dev)
         self._camera_counter = 0
         self.last = {}
+        self._sh()          # (the plane-major copy of the SH coefficients is made HERE, on the constructing stream: the camera
+        #                      streams are ordered behind it when the pipeline starts)
 
     # ---- one camera = front (async) / back (bin + blend) / ordered running-state update ------------------------------
     def _camera(self, rs):
@@ -177,9 +181,24 @@ class GaussianRasterizer(nn.Module):
     def _stream_ptr(self, sc):
         return C.c_void_p(sc.stream.cuda_stream) if sc.stream is not None else nv.stream_handle(self.device)
 
-    def _front(self, sc, cam, campos, sh_degree, count_host=True):
+    def _sh(self):
+        """(coefficients, count) as the rasteriser calls take them: PLANE-MAJOR (g2pc_sh_planes, count < 0) once per renderer when the
+        count is a multiple of 4 -- the scene is the same for every camera, and a wave then reads 1 KB contiguous per 16-byte
+        vector instead of 64 pieces 192 bytes apart (k_preprocess_cu was bound by the address unit, not by HBM) --, else as given."""
         shs = self.shs
-        coeffs = int(shs.shape[1]) if shs is not None else 0
+        if shs is None:
+            return None, 0
+        k = int(shs.shape[1])
+        if not SH_PLANES or k % 4 != 0:
+            return shs, k
+        if getattr(self, "_sh_planes", None) is None:
+            planes = torch.empty_like(shs)
+            nv.check(nv.lib().g2pc_sh_planes(nv.ptr(shs), self.n, k, nv.ptr(planes), nv.stream_handle(self.device)), "sh_planes")
+            self._sh_planes = planes
+        return self._sh_planes, -k
+
+    def _front(self, sc, cam, campos, sh_degree, count_host=True):
+        shs, coeffs = self._sh()
         with nv.region("raster_front", self.device, sc.stream):
             nv.check(nv.lib().g2pc_raster_front_cu(
                 C.byref(cam), nv.ptr(self.means3D), nv.ptr(self.cov3D_precomp), nv.ptr(self.opacities),
@@ -250,12 +269,12 @@ class GaussianRasterizer(nn.Module):
                 sc.invdepths = torch.empty((1, H, W), dtype=torch.float32, device=self.device)
         first, step = self.tile_shard if self.tile_shard is not None else (0, 1)
         if fused:
-            shs = self.shs
+            shs, coeffs = self._sh()
             with nv.region("raster_camera_cu", self.device, sc.stream):
                 rc = L.g2pc_raster_camera_cu(
                     C.byref(cam), nv.ptr(self.means3D), nv.ptr(self.cov3D_precomp), nv.ptr(self.opacities),
                     nv.ptr(self.colors_precomp), nv.ptr(shs), int(sh_degree) if shs is not None else 0,
-                    int(shs.shape[1]) if shs is not None else 0, C.cast(campos, C.c_void_p), nv.ptr(mask), self.n, capacity,
+                    coeffs, C.cast(campos, C.c_void_p), nv.ptr(mask), self.n, capacity,
                     nv.ptr(sc.rec), nv.ptr(sc.rect), nv.ptr(sc.radii), 1 if self.calculate_surface_distance else 0,
                     nv.ptr(sc.cam_key), nv.ptr(sc.cam_surf), nv.ptr(sc.colour), nv.ptr(sc.depths), nv.ptr(sc.invdepths),
                     C.c_void_p(sc.count_host.data_ptr()), int(first), int(step), nv.ptr(sc.back_ws), sc.back_bytes,

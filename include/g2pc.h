@@ -503,6 +503,11 @@ int g2pc_raster_rebase_keys(unsigned long long* best_key, int64_t n, void* strea
  * front: rec f32[n,16] (one 64-byte record per Gaussian: (x, y, conic a, b), (conic c, opacity, depth, radius), (r, g, b, -),
  * pad), rect u32[n] (u32[2n] for images beyond 4096 pixels a side: tile rectangles then take 16-bit coordinates, two
  * words per Gaussian), radii i32[n], sorted_idx u32[n], offsets u32[n+1] out. */
+/* ABI 7: sh_coeffs < 0 in g2pc_raster_front_cu / g2pc_raster_camera_cu = |sh_coeffs| coefficients per Gaussian in PLANE-MAJOR
+ * layout, f32[3K/4][n][4] (K a multiple of 4), as g2pc_sh_planes produces it from the reference's f32[n][K][3]: a wave reads
+ * 1 KB contiguous per 16-byte vector instead of 64 pieces 192 bytes apart.  The scene is static over a job's cameras
+ * (gauss_to_pc.py:437-454), so the binding transposes once per job; results are bit for bit the same. */
+int g2pc_sh_planes(const float* shs, int64_t n, int32_t sh_coeffs, float* planes, void* stream);
 int g2pc_raster_front_cu(const G2pcCamera* cam, const float* means3D, const float* cov6, const float* opacity,
                          const float* colours_precomp, const float* shs, int32_t sh_degree, int32_t sh_coeffs,
                          const float* campos, int64_t n, float* rec, uint32_t* rect, int32_t* radii,

@@ -477,7 +477,21 @@ def gen_render_all(ref, tag="1m_all50", n=1_000_000, num_points=10_000_000, widt
             secs = []
             prev = np.zeros(n, dtype=np.float32)
             winner = np.full(n, 255, dtype=np.uint8)
+            # resumable: the renderer's running state (contributions f32[n], colours f64[n,3]) and what was recorded so far are
+            # checkpointed after every camera (an hour-long run must survive the session that started it)
+            ckpt = os.path.join(HERE, "_build", "ckpt_render_%s.npz" % tag)
+            done = 0
+            if os.path.isfile(ckpt):
+                z = np.load(ckpt)
+                done = int(z["done"])
+                R.gaussian_max_contribution = torch.from_numpy(z["state_contrib"].copy())
+                R.gaussian_colours = torch.from_numpy(z["state_colours"].copy())
+                prev, winner, secs = z["state_contrib"].copy(), z["winner"].copy(), list(z["secs"])
+                raw.update({k: z[k] for k in z.files if k.startswith("cam")})
+                print("render_all: resuming after camera %d" % (done - 1), flush=True)
             for ci, name in enumerate(names):
+                if ci < done:
+                    continue
                 cam = ch.get_camera("python", torch.tensor(transforms[name]), intr[name], colour_resolution=width)
                 t0 = time.perf_counter()
                 img, _, _, _ = R(cam)
@@ -491,6 +505,10 @@ def gen_render_all(ref, tag="1m_all50", n=1_000_000, num_points=10_000_000, widt
                 raw["cam%d_image_s8" % ci] = _np(img).astype(np.float32)[::8, ::8].copy()
                 raw["cam%d_contrib_s16" % ci] = cur[::16].copy()
                 print("render_all: camera %d in %.1f s" % (ci, secs[-1]), flush=True)
+                os.makedirs(os.path.dirname(ckpt), exist_ok=True)
+                np.savez(ckpt + ".tmp.npz", done=ci + 1, state_contrib=cur, state_colours=_np(R.gaussian_colours), winner=winner,
+                         secs=np.array(secs), **{k: v for k, v in raw.items() if k.startswith("cam")})
+                os.replace(ckpt + ".tmp.npz", ckpt)
         colours = _np(R.get_gaussian_colours())
         visible = _np(R.get_visible_gaussians())
         c9 = _np(G.covariances).reshape(n, 9)
