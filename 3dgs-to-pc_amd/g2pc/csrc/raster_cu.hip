@@ -228,7 +228,12 @@ __global__ void k_bucket_hdr_init_cu(BucketHdr* __restrict__ h, BucketPlan plan)
 // for the surface distance, each guarded by a cheap "can any lane improve the staged value" ballot.
 constexpr int CU_T = 256;
 
-__global__ __launch_bounds__(CU_T) void k_blend_cu(int W, int H, int grid_x, int tile_first, int tile_step,
+#ifdef G2PC_CU_BLEND_WAVES          // build-time A/B switch: blocks per CU the register allocation is held to (5: 96 VGPRs, 14 spilled)
+#define G2PC_CU_BLEND_BOUNDS __launch_bounds__(CU_T, G2PC_CU_BLEND_WAVES)
+#else
+#define G2PC_CU_BLEND_BOUNDS __launch_bounds__(CU_T)
+#endif
+__global__ G2PC_CU_BLEND_BOUNDS void k_blend_cu(int W, int H, int grid_x, int tile_first, int tile_step,
                                                   const uint32_t* __restrict__ tile_start,
                                                   const uint32_t* __restrict__ inst_g, uint32_t gmask, const float4* __restrict__ rec,
                                                   const int32_t* __restrict__ mask, float3 bg, int calc_surf,
@@ -264,6 +269,26 @@ __global__ __launch_bounds__(CU_T) void k_blend_cu(int W, int H, int grid_x, int
         s_p2[CU_T] = make_float4(0.f, 0.f, 0.f, 3.0e38f);
         s_g[CU_T] = 0;
     }
+    // Build-time A/B switch, OFF: a software pipeline of the staging (instance ids two batches ahead, the records of the NEXT batch
+    // requested before the current one is walked -- every batch begins with two dependent round trips to memory that the four
+    // waves of the tile sit out behind the barrier; PMC: 55 % of a lone launch's wave life is waiting).  Bit-identical (the staged
+    // running maximum / surface distance are filters only), and SLOWER in the pipelined job: 27.2 - 27.5 ms against 24.9 - 25.3 on
+    // one box, alternating (profiles/r06i_cmd1.log) -- its 18 extra registers cost a block per CU (114 VGPRs: 4 waves per SIMD;
+    // held to 96 it spills 14 and is slower still), and with four cameras in flight other tiles already cover the wait.
+#ifndef G2PC_CU_BLEND_PREFETCH
+#define G2PC_CU_BLEND_PREFETCH 0
+#endif
+    bool v_cur = (start + t) < end, v_nxt = (start + CU_T + t) < end;
+    uint32_t g_cur = v_cur ? (inst_g[start + t] & gmask) : 0u;
+    uint32_t g_nxt = (G2PC_CU_BLEND_PREFETCH && v_nxt) ? (inst_g[start + CU_T + t] & gmask) : 0u;
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q3 = q0, qc = q0;
+    uint32_t qkey = 0u, qsurf = 0u;
+    auto request = [&](uint32_t g) {
+        q0 = rec[4 * (size_t)g]; q1 = rec[4 * (size_t)g + 1]; q3 = rec[4 * (size_t)g + 3]; qc = rec[4 * (size_t)g + 2];
+        qkey = key_hi[2 * (size_t)g];
+        if (calc_surf) qsurf = cam_surf[g];
+    };
+    if (G2PC_CU_BLEND_PREFETCH && v_cur) request(g_cur);
     for (uint32_t b = start; b < end; b += CU_T) {
         if (__syncthreads_and(done ? 1 : 0)) break;                       // forward.cu:373-375 (also: LDS is free again)
         // Stage entry t and decide, for each of the tile's four waves, whether this Gaussian's alpha can reach 1/255 on
@@ -271,20 +296,24 @@ __global__ __launch_bounds__(CU_T) void k_blend_cu(int W, int H, int grid_x, int
         // 411-413 `continue`), so a Gaussian that fails for all 64 pixels of a wave is not walked by that wave at all --
         // same results bit for bit, ~half the (pixel, Gaussian) pairs of a 16x16 tile never evaluated.
         bool keep[4] = {false, false, false, false};
-        if (b + t < end) {
-            uint32_t g = inst_g[b + t] & gmask;
-            const float4 r0 = rec[4 * (size_t)g], r1 = rec[4 * (size_t)g + 1], r3 = rec[4 * (size_t)g + 3];
+        if (!G2PC_CU_BLEND_PREFETCH) {
+            v_cur = b + t < end;
+            if (v_cur) { g_cur = inst_g[b + t] & gmask; request(g_cur); }
+        }
+        if (v_cur) {
+            const uint32_t g = g_cur;
+            const float4 r0 = q0, r1 = q1, r3 = q3;
             s_p0[t] = r0;
             // .w: 1 / depth, formed ONCE per staged entry (the record's radius is not used by the blend).  The inverse-depth
             // map accumulates contrib / depth per pixel (forward.cu:428-430): the quotient is the same for all 256 pixels, and an
-            // IEEE division is a 13-instruction sequence -- until round 6 every lane evaluated it on every visit, a third of
-            // the loop's VALU instructions.  Same operands, same operation: bit-identical.
+            // IEEE division is a 13-instruction sequence -- until round 6 every lane evaluated it on every visit.
+            // Same operands, same operation: bit-identical.
             s_p1[t] = make_float4(r1.x, r1.y, r1.z, 1.0f / r1.z);
-            const float4 c3 = rec[4 * (size_t)g + 2];
-            float gm = fmaxf(__uint_as_float(key_hi[2 * (size_t)g]), 1.17549435e-38f);
+            const float4 c3 = qc;
+            float gm = fmaxf(__uint_as_float(qkey), 1.17549435e-38f);
             s_p2[t] = make_float4(c3.x, c3.y, c3.z, gm);
             s_g[t] = g;
-            if (calc_surf) s_surf[t] = cam_surf[g];
+            if (calc_surf) s_surf[t] = qsurf;
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 const int wy0 = ty * 16 + 4 * w;
@@ -297,6 +326,12 @@ __global__ __launch_bounds__(CU_T) void k_blend_cu(int W, int H, int grid_x, int
             s_p2[t] = make_float4(0.f, 0.f, 0.f, 3.0e38f);
             s_g[t] = 0;
             s_surf[t] = 0;
+        }
+        if (G2PC_CU_BLEND_PREFETCH) {              // next batch's records (its ids arrived a batch ago), the ids of the one after
+            g_cur = g_nxt; v_cur = v_nxt;
+            v_nxt = (b + 2 * CU_T + t) < end;
+            g_nxt = v_nxt ? (inst_g[b + 2 * CU_T + t] & gmask) : 0u;
+            if (v_cur) request(g_cur);
         }
         unsigned long long kept[4];
 #pragma unroll
