@@ -278,6 +278,7 @@ __global__ G2PC_CU_BLEND_BOUNDS void k_blend_cu(int W, int H, int grid_x, int ti
 #ifndef G2PC_CU_BLEND_PREFETCH
 #define G2PC_CU_BLEND_PREFETCH 0
 #endif
+#if G2PC_CU_BLEND_PREFETCH
     bool v_cur = (start + t) < end, v_nxt = (start + CU_T + t) < end;
     uint32_t g_cur = v_cur ? (inst_g[start + t] & gmask) : 0u;
     uint32_t g_nxt = (G2PC_CU_BLEND_PREFETCH && v_nxt) ? (inst_g[start + CU_T + t] & gmask) : 0u;
@@ -289,6 +290,7 @@ __global__ G2PC_CU_BLEND_BOUNDS void k_blend_cu(int W, int H, int grid_x, int ti
         if (calc_surf) qsurf = cam_surf[g];
     };
     if (G2PC_CU_BLEND_PREFETCH && v_cur) request(g_cur);
+#endif
     for (uint32_t b = start; b < end; b += CU_T) {
         if (__syncthreads_and(done ? 1 : 0)) break;                       // forward.cu:373-375 (also: LDS is free again)
         // Stage entry t and decide, for each of the tile's four waves, whether this Gaussian's alpha can reach 1/255 on
@@ -296,6 +298,35 @@ __global__ G2PC_CU_BLEND_BOUNDS void k_blend_cu(int W, int H, int grid_x, int ti
         // 411-413 `continue`), so a Gaussian that fails for all 64 pixels of a wave is not walked by that wave at all --
         // same results bit for bit, ~half the (pixel, Gaussian) pairs of a 16x16 tile never evaluated.
         bool keep[4] = {false, false, false, false};
+#if !G2PC_CU_BLEND_PREFETCH
+        if (b + t < end) {
+            uint32_t g = inst_g[b + t] & gmask;
+            const float4 r0 = rec[4 * (size_t)g], r1 = rec[4 * (size_t)g + 1], r3 = rec[4 * (size_t)g + 3];
+            s_p0[t] = r0;
+            // .w: 1 / depth, formed ONCE per staged entry (the record's radius is not used by the blend).  The inverse-depth
+            // map accumulates contrib / depth per pixel (forward.cu:428-430): the quotient is the same for all 256 pixels, and an
+            // IEEE division is a 13-instruction sequence -- until round 6 every lane evaluated it on every visit.
+            // Same operands, same operation: bit-identical.
+            s_p1[t] = make_float4(r1.x, r1.y, r1.z, 1.0f / r1.z);
+            const float4 c3 = rec[4 * (size_t)g + 2];
+            float gm = fmaxf(__uint_as_float(key_hi[2 * (size_t)g]), 1.17549435e-38f);
+            s_p2[t] = make_float4(c3.x, c3.y, c3.z, gm);
+            s_g[t] = g;
+            if (calc_surf) s_surf[t] = cam_surf[g];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int wy0 = ty * 16 + 4 * w;
+                keep[w] = wy0 < H && rect_may_touch(r0.x, r0.y, r0.z, r0.w, r1.x, r3.x, r3.y, r3.z, rx0, rx1, (float)wy0,
+                                                    (float)min(wy0 + 3, H - 1));
+            }
+        } else {                                   // padding: opacity 0 -> alpha 0 < 1/255 -> skipped
+            s_p0[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            s_p1[t] = make_float4(0.f, 0.f, 1.f, 0.f);
+            s_p2[t] = make_float4(0.f, 0.f, 0.f, 3.0e38f);
+            s_g[t] = 0;
+            s_surf[t] = 0;
+        }
+#else
         if (!G2PC_CU_BLEND_PREFETCH) {
             v_cur = b + t < end;
             if (v_cur) { g_cur = inst_g[b + t] & gmask; request(g_cur); }
@@ -333,6 +364,7 @@ __global__ G2PC_CU_BLEND_BOUNDS void k_blend_cu(int W, int H, int grid_x, int ti
             g_nxt = v_nxt ? (inst_g[b + 2 * CU_T + t] & gmask) : 0u;
             if (v_cur) request(g_cur);
         }
+#endif
         unsigned long long kept[4];
 #pragma unroll
         for (int w = 0; w < 4; ++w) {

@@ -122,7 +122,7 @@ def algorithmic_bytes(workload, n, n_kept, m, cams, stats):
     return b
 
 
-ROCPROF_STATS_FILE = "profiles/r05fin_s1_kernel_stats.csv"   # rocprofv3 --kernel-trace --stats of `bench.py --streams 1 --no-parity --no-extra --no-cpu-baseline`
+ROCPROF_STATS_FILE = "profiles/r06fin_s1_kernel_stats.csv"   # rocprofv3 --kernel-trace --stats of `bench.py --streams 1 --no-parity --no-extra --no-cpu-baseline`
 
 
 def rocprof_kernel_avg(region):
@@ -138,8 +138,8 @@ def rocprof_kernel_avg(region):
     return None
 
 
-PMC_TRAFFIC_FILE = "profiles/r05fin_pmc_traffic.json"      # tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE passes of THIS command
-PMC_SQ_FILE = "profiles/r05fin_pmc_sq.json"               # tools/pmc_kernel.py: SQ counter pass of THIS command
+PMC_TRAFFIC_FILE = "profiles/r06fin_pmc_traffic.json"      # tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE passes of THIS command
+PMC_SQ_FILE = "profiles/r06fin_pmc_sq.json"               # tools/pmc_kernel.py: SQ counter pass of THIS command
 BLEND_KERNEL = "void g2pc::k_blend_py_dl<4>"
 
 
