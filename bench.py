@@ -774,8 +774,8 @@ def main():
                 "colour_max_same_winner", "colour_off_gaussians", "colour_compared_gaussians", "culled_equal", "keep_equal", "kept",
                 "ppg_mismatch_given_ref_contrib", "ppg_mismatch_end_to_end", "ppg_flips_explained", "ppg_max_abs_diff_end_to_end",
                 "ppg_flip_margin_over_bound_max", "sample_points", "sample_points_ref", "sample_rows_compared",
-                "sample_rows_unmatched", "sample_xyz_max", "sample_rgb_max", "sample_rows_order_shifted",
-                "cov3d_rows_differing", "camera_matrix_bits_differing", "reference_cpu_seconds_per_camera_mean",
+                "sample_rows_unmatched", "sample_xyz_max", "sample_rgb_max", "sample_rgb_rows_gt_1e-4", "sample_rows_order_shifted",
+                "ppg_flips_explained_given_ref_contrib", "cov3d_rows_differing", "camera_matrix_bits_differing", "reference_cpu_seconds_per_camera_mean",
                 "reference_cpu_threads", "oracle", "check_seconds")}
             out["parity"]["cameras_all50"] = r50.get("cameras")
         # ... and the reference's DATA-DEPENDENT quad-tree (leaves over max_gaussians_per_tile split, gauss_render.py:319-335)

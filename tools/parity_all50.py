@@ -163,6 +163,8 @@ def run(device="cuda:0", tag="1m_all50", sampler=True, t_floor=None):
         mags2 = G.get_gaussian_magnitudes(contributions=torch.from_numpy(rc).to(dev))
         ppg2 = ops.distribute_points(mags2, num_points)[1].cpu().numpy().astype(np.int64)
         out["ppg_mismatch_given_ref_contrib"] = int((ppg2 != ref_ppg).sum())
+        fl2, ex2, mx2, _ = explain_quota_flips(ppg2, ref_ppg, mags2.cpu().numpy().astype(np.float64), rc, rc, num_points)
+        out["ppg_flips_explained_given_ref_contrib"], out["ppg_max_abs_diff_given_ref_contrib"] = ex2, mx2
     # ---- the cloud the job returned -----------------------------------------------------------------------------------------
     if sampler:
         pts, rgb = cloud.points.cpu().numpy(), cloud.colours.cpu().numpy()

@@ -113,6 +113,8 @@ def match_rows(ours, ours_rgb, q, qc, rr, win=8, tol=1e-4):
     out["sample_xyz_max"] = float(np.abs(ours[match[found]] - q[found]).max()) if found.any() else None
     # a row's colour is its Gaussian's: an xyz match that belonged to another Gaussian would show here
     out["sample_rgb_max"] = float(np.abs(ours_rgb[match[found]] - qc[found]).max() / 255.0) if found.any() else None
+    # rows whose colour differs by more than 1e-4: their Gaussian's arg-max fell on the other pixel of a tie (colour_off_gaussians)
+    out["sample_rgb_rows_gt_1e-4"] = int((np.abs(ours_rgb[match[found]] - qc[found]).max(axis=1) / 255.0 > 1e-4).sum()) if found.any() else 0
     shifted = found & (match != rr)
     out["sample_rows_order_shifted"] = {
         "first_row": int(rr[np.nonzero(shifted)[0][0]]) if shifted.any() else None, "count": int(shifted.sum()),
