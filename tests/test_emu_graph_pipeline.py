@@ -185,7 +185,7 @@ def test_crowded_depth_bucket_within_its_room(emu, monkeypatch, variant):
         nv._LIB, nv._EMULATED = saved
 
 
-@pytest.mark.parametrize("semantics", ["python", "cuda"])
+@pytest.mark.parametrize("semantics", ["python"])      # (the native-semantics call at this size: tests/test_gpu_graph_pipeline.py, 1.5 M)
 def test_more_than_a_million_gaussians_take_the_8192_bucket_instances(emu, monkeypatch, semantics):
     """1 048 576 < n <= 2 097 152 Gaussians select k_bk_hist_w<BK_MAX> (8 192 depth buckets: 64 KB + 16 B of LDS, a
     gfx950-only size), the 32-buckets-per-thread loop of k_bk_scan and the 8 192-bucket emission -- no fixture reaches them
