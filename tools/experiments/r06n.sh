@@ -1,3 +1,5 @@
+# RECORD of a reverted experiment (profiles/r06n_lane_emit_ab.log): the 'rowemit' variant was built with -DG2PC_SAMPLER_LANE_EMIT=0 from a
+# sampler.hip that held the Gaussian-centric emission kernel; that kernel and its switch were removed after the measurement.
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 # lane emission (default) vs every row through the row-balanced kernel (rowemit), alternating, sampler workload and the 50-camera job
 bash tools/experiments/ab_round.sh "--workload sample --steps 50 --warmup 10" . rowemit . rowemit . rowemit
