@@ -559,7 +559,9 @@ def main():
     total_cameras, total_points = a.cameras * scale, a.points * scale
     scene_kw = dict(scale_lo=a.scene_scales[0], scale_hi=a.scene_scales[1]) if a.scene_scales else {}
     scene = make_scene(a.gaussians, 1234 + 3, device=device, with_sh=(workload == "render_cuda"), **scene_kw)
-    cams = make_cameras(total_cameras) if workload != "sample" else None
+    # (the emulator dry run renders miniature images: a 1280 x 720 camera is 921 600 emulated lanes per blend)
+    cam_kw = dict(width=128, height=72, focal=110.0) if emulate else {}
+    cams = make_cameras(total_cameras, **cam_kw) if workload != "sample" else None
     if cams is not None and a.camera_subset:
         keep = sorted(cams[0])[:a.camera_subset]              # profiling aid: first k of the SAME 50-camera rig
         cams = ({k: cams[0][k] for k in keep}, {k: cams[1][k] for k in keep})

@@ -6,7 +6,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = ["--gaussians", "3000", "--cameras", "4", "--points", "30000", "--steps", "1", "--warmup", "1",
+SMALL = ["--gaussians", "1000", "--cameras", "4", "--points", "10000", "--steps", "1", "--warmup", "1",
          "--no-parity", "--no-extra", "--no-cpu-baseline"]
 
 

@@ -8,7 +8,9 @@ from emu_util import emu, emu_exp  # noqa: F401
 
 def test_two_wave_blend_equals_single_wave_blend(emu_exp, golden_dir):
     from blend_variant_checks import run_variants, assert_variants_agree
-    assert_variants_agree(run_variants("cpu", golden_dir))
+    # (three of the six kernels of the experiments build -- single wave, two waves, dual list --: the product blends with the dual-list
+    # kernel only; all six against each other: tools/experiments/blend_variant_fuzz.py)
+    assert_variants_agree(run_variants("cpu", golden_dir, variants=(1, 3, 6)))
 
 
 @pytest.mark.parametrize("sub", [4, 1])

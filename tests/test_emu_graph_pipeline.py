@@ -205,8 +205,10 @@ def test_more_than_a_million_gaussians_take_the_8192_bucket_instances(emu, monke
     far = torch.arange(n) % 10 != 0
     xyz[far] = xyz[far] * 0.5 + torch.tensor([0.0, 0.0, 40.0])            # behind every camera of the rig below (and out of range)
     transforms, intr = make_cameras(24, width=96, height=54, focal=82.0)
-    names = [k for k in sorted(transforms) if transforms[k][2][3] > 2.0][:2]   # cameras on the +z side, looking down -z at the origin
-    assert len(names) == 2
+    # ONE camera on the +z side, looking down -z at the origin (the emulator walks 1.1 M fibres per head kernel: two cameras took
+    # 130 s of the CPU suite; tests/test_gpu_graph_pipeline.py renders 1.5 M Gaussians from several cameras in both semantics)
+    names = [k for k in sorted(transforms) if transforms[k][2][3] > 2.0][:1]
+    assert len(names) == 1
     G = Gaussians(xyz, sc.scales, sc.rots, sc.colours, sc.opacities)
     res = []
     for pipelined in (False, True):
@@ -221,7 +223,7 @@ def test_more_than_a_million_gaussians_take_the_8192_bucket_instances(emu, monke
         res.append((cols, contrib, R.rerendered))
         if hasattr(R, "close"):
             R.close()
-    assert int((res[0][1] > 0).sum()) > 20_000                           # the scene really was rendered
+    assert int((res[0][1] > 0).sum()) > 10_000                           # the scene really was rendered
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     assert res[1][2] <= 1                                                # (the first pipelined camera may learn the capacity)
     gauss_render.clear_context_pool()
